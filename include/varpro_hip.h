@@ -1,0 +1,277 @@
+/*
+ * varpro_hip.h -- C ABI of the MI355X-native batched variable-projection hot path.
+ *
+ * This header is the drop-in boundary.  The reference
+ * (geo-ant/varpro 0.13.3) has no FFI; its boundary is two Rust traits plus the
+ * builder/solver facade.  Every entry point below cites the reference item whose
+ * observable contract it replaces (paths relative to the reference repository).
+ * A Rust shim (bindings/rust/) implements
+ * `SeparableNonlinearModel` / `LeastSquaresProblem` on top of these calls.
+ *
+ * Conventions (the reference's own, src/lib.rs:42-87):
+ *   m  number of observations                  model.output_len()          src/model/mod.rs:263
+ *   n  number of basis functions               base_function_count()       src/model/mod.rs:259
+ *   q  number of nonlinear parameters alpha    parameter_count()           src/model/mod.rs:256
+ *   S  number of right-hand sides              Y_w.ncols()                 src/solvers/levmar/mod.rs:111
+ *   B  batch of independent problems (new; the reference solves one problem per call)
+ *
+ * Memory layouts (row index fastest == nalgebra column-major per problem):
+ *   t      [m]  (shared)   or [B][m]  with VP_FLAG_T_PER_PROBLEM
+ *   w      [m]  (shared)   or [B][m]  with VP_FLAG_W_PER_PROBLEM, NULL => Weights::Unit
+ *   Y, R   [B][S][m]       residual vector of problem b == vec(R_b) (src/util/mod.rs:101-106)
+ *   alpha  [B][q]
+ *   C      [B][S][n]
+ *   J      [B][q][S][m]    problem b: (m*S) x q column-major, RHS s at rows s*m.. (src/solvers/levmar/mod.rs:147-153)
+ *   Phi    [B][n][m]       dPhi [B][p][m], p = number of (basis,param) dependency pairs in model order
+ *
+ * All data pointers of one handle live in one address space chosen at creation:
+ * host (default; the library stages through hipMemcpyAsync) or device
+ * (VP_FLAG_DEVICE_PTRS; zero copies, everything enqueued on the handle's stream).
+ * One handle <-> one HIP stream; handles are independent and re-entrant, there is
+ * no global state (the reference is single-threaded and Clone, src/problem.rs:55).
+ *
+ * Return value of every call: 0 = ok, <0 = call-level error (vp_last_error()).
+ * Per-problem failures never abort a batch; they are latched in status[b]
+ * exactly like `cached = None` in the reference (src/solvers/levmar/mod.rs:61-72):
+ * status[b] != 0  <=>  residuals()/jacobian() would return None for problem b.
+ */
+#ifndef VARPRO_HIP_H
+#define VARPRO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VP_MAX_BASIS 8        /* n <= 8 */
+#define VP_MAX_PARAMS 8       /* q <= 8 */
+#define VP_MAX_BASIS_PARAMS 2 /* parameters one basis function may depend on */
+#define VP_MAX_PAIRS 16       /* p <= 16 non-zero (basis,param) derivative columns */
+
+/* scalar type of the problem == SeparableNonlinearModel::ScalarType (src/model/mod.rs:246) */
+enum { VP_F64 = 0, VP_F32 = 1 };
+
+/*
+ * Closed descriptor language for basis functions.  The reference
+ * accepts opaque Rust closures (src/model/model_basis_function.rs:11-12) which
+ * cannot run on a GPU; these kinds cover every model the reference's tests and
+ * benches use.  kind -> f(t, p0[, p1]) and its partial derivatives:
+ */
+enum {
+    VP_BASIS_CONST = 0,     /* 1                       invariant_function, shared_test_code/src/lib.rs:123     */
+    VP_BASIS_EXP_DECAY = 1, /* exp(-t/p0)              d/dp0 = exp(-t/p0)*t/p0^2   shared_test_code/src/lib.rs:101-114 */
+    VP_BASIS_EXP_RATE = 2,  /* exp(-p0*t)              d/dp0 = -t*exp(-p0*t)                                    */
+    VP_BASIS_EXP_COS = 3,   /* exp(-p0*t)*cos(p1*t)    d/dp0 = -t*f ; d/dp1 = -t*exp(-p0*t)*sin(p1*t)
+                               shared_test_code/src/models.rs:310-372 (O'Leary example)                         */
+    VP_BASIS_SIN_PHASE = 4  /* sin(p0*t+p1)            d/dp0 = t*cos(p0*t+p1) ; d/dp1 = cos(p0*t+p1)
+                               src/test_helpers/mod.rs:28-52                                                     */
+};
+
+/*
+ * Model descriptor == what SeparableModelBuilder::build() produces
+ * (src/model/builder/mod.rs:338-525): basis functions in insertion order
+ * (column j of Phi == basis j, src/model/builder/mod.rs:512-515) and, per basis
+ * function, which entries of alpha it depends on (the "Ind" table of
+ * matlab/examples/adaex.m:33-34; src/model/detail.rs:60-127).
+ * param[j][a] = index into alpha of argument a of basis j, or -1 if unused.
+ */
+typedef struct vp_model_desc {
+    int32_t n_basis;  /* n */
+    int32_t n_params; /* q */
+    int32_t kind[VP_MAX_BASIS];
+    int32_t param[VP_MAX_BASIS][VP_MAX_BASIS_PARAMS];
+} vp_model_desc;
+
+/* creation flags */
+enum {
+    VP_FLAG_DEVICE_PTRS = 1 << 0,   /* every data pointer passed for this handle is a device pointer */
+    VP_FLAG_T_PER_PROBLEM = 1 << 1, /* t is [B][m] instead of [m] */
+    VP_FLAG_W_PER_PROBLEM = 1 << 2  /* w is [B][m] instead of [m] */
+};
+
+/* per-problem status word (0 == the reference's `cached = Some(..)`) */
+enum {
+    VP_ST_OK = 0,
+    VP_ST_NONFINITE = 1,    /* Phi, C or R contains inf/nan (model error / SVD solve error path) */
+    VP_ST_NOT_EVALUATED = 2 /* residuals()/jacobian() before any set_params() */
+};
+
+/* call-level error codes */
+enum {
+    VP_ERR_OK = 0,
+    VP_ERR_INVALID = -1,     /* bad handle / argument / shape (builder errors, src/problem/builder.rs:15-46) */
+    VP_ERR_UNSUPPORTED = -2, /* shape or model outside what the kernels are instantiated for */
+    VP_ERR_HIP = -3,         /* HIP runtime failure */
+    VP_ERR_NO_DEVICE = -4    /* no gfx950 device / library built without device code */
+};
+
+/* builder validation errors mirror SeparableProblemBuilderError (src/problem/builder.rs:15-46);
+ * returned by vp_batch_create as VP_ERR_INVALID with one of these in vp_last_error_detail() */
+enum {
+    VP_BUILD_OK = 0,
+    VP_BUILD_Y_DATA_MISSING = 1,
+    VP_BUILD_INVALID_LENGTH_OF_DATA = 2,
+    VP_BUILD_ZERO_LENGTH_VECTOR = 3,
+    VP_BUILD_INVALID_PARAMETER_COUNT = 4,
+    VP_BUILD_INVALID_LENGTH_OF_WEIGHTS = 5
+};
+
+/*
+ * LM driver options == levenberg_marquardt::LevenbergMarquardt builder knobs
+ * reached through LevMarSolver::with_solver (src/solvers/levmar/mod.rs:221-223).
+ * Defaults (vp_lm_opts_default): ftol = xtol = gtol = 30*eps(dtype), stepbound = 100,
+ * patience = 100 (max evaluations = patience*(q+1)), scale_diag = 1.
+ */
+typedef struct vp_lm_opts {
+    double ftol;
+    double xtol;
+    double gtol;
+    double stepbound;
+    int32_t patience;
+    int32_t scale_diag;
+} vp_lm_opts;
+
+/* termination == levenberg_marquardt::TerminationReason; >0 <=> was_successful()
+ * (src/fit.rs:120-122, src/solvers/levmar/mod.rs:249-253) */
+enum {
+    VP_TERM_RESIDUALS_ZERO = 1,
+    VP_TERM_ORTHOGONAL = 2,
+    VP_TERM_CONVERGED_FTOL = 3,
+    VP_TERM_CONVERGED_XTOL = 4,
+    VP_TERM_CONVERGED_BOTH = 5,
+    VP_TERM_NOT_RUN = 0,
+    VP_TERM_USER = -1, /* residuals()/jacobian() returned None */
+    VP_TERM_NUMERICAL = -2,
+    VP_TERM_NO_IMPROVEMENT = -3,
+    VP_TERM_LOST_PATIENCE = -4,
+    VP_TERM_NO_PARAMETERS = -5,
+    VP_TERM_NO_RESIDUALS = -6,
+    VP_TERM_WRONG_DIMENSIONS = -7
+};
+
+/* == levenberg_marquardt::MinimizationReport (src/fit.rs:24-29) */
+typedef struct vp_report {
+    int32_t termination;
+    int32_t n_evals;  /* number_of_evaluations */
+    double objective; /* objective_function = 1/2 ||r||^2 */
+} vp_report;
+
+typedef struct vp_batch vp_batch;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/*
+ * == SeparableProblemBuilder::{new|mrhs, observations, weights, epsilon, build}
+ * (src/problem/builder.rs:116,194,142,220,261,246,278-324) for B problems at once.
+ * Validates shapes, stores Y_w = W*Y (src/problem/builder.rs:307), default epsilon
+ * = machine epsilon of dtype when svd_epsilon < 0 (src/problem/builder.rs:282).
+ * Unlike build() it does NOT run the initial set_params (there is no alpha yet);
+ * vp_set_params / vp_fit do.  `hip_stream` may be NULL (the library creates one).
+ */
+int vp_batch_create(vp_batch **h, const vp_model_desc *model, int dtype, int64_t m, int64_t S, int64_t B,
+                    const void *t, const void *Y, const void *w, double svd_epsilon, int flags, int device,
+                    void *hip_stream);
+
+/* == Drop of SeparableProblem */
+void vp_batch_destroy(vp_batch *h);
+
+/* ---- LeastSquaresProblem surface (src/solvers/levmar/mod.rs:22-202) --------------------- */
+
+/*
+ * == SeparableProblem::set_params (src/solvers/levmar/mod.rs:42-73) incl.
+ * model.set_params/eval (src/model/mod.rs:266-267,308) and the weighting
+ * (src/util/weights.rs:82-99): Phi_w = W Phi(alpha); solve min ||Y_w - Phi_w C||
+ * with singular values <= epsilon truncated; R = Y_w - Phi_w C.  Caches C, R,
+ * 1/2||R||^2 and status per problem (== CachedCalculations, src/problem.rs:88-107).
+ */
+int vp_set_params(vp_batch *h, const void *alpha);
+
+/* == LeastSquaresProblem::params (src/solvers/levmar/mod.rs:80-82) */
+int vp_params(vp_batch *h, void *alpha_out);
+
+/* == LeastSquaresProblem::residuals (src/solvers/levmar/mod.rs:91-95): r_b = vec(R_b).
+ * status may be NULL. */
+int vp_residuals(vp_batch *h, void *r_out, int32_t *status);
+
+/* == LeastSquaresProblem::jacobian (src/solvers/levmar/mod.rs:101-201): Kaufman
+ * Jacobian J[:,k] = -vec(P_perp W dPhi/dalpha_k C), incl. eval_partial_deriv
+ * (src/model/mod.rs:359-362).  status may be NULL. */
+int vp_jacobian(vp_batch *h, void *J_out, int32_t *status);
+
+/* == SeparableProblem::linear_coefficients (src/problem.rs:142-147,173-183) */
+int vp_linear_coeffs(vp_batch *h, void *C_out, int32_t *status);
+
+/* == SeparableProblem::weighted_data (src/problem.rs:154-156,189-196) */
+int vp_weighted_data(vp_batch *h, void *Yw_out);
+
+/* 1/2 ||vec R_b||^2 per problem, always f64 [B] (== MinimizationReport::objective_function) */
+int vp_cost(vp_batch *h, double *cost_out);
+
+/*
+ * Fused evaluation: set_params + any subset of {residuals, jacobian, coefficients,
+ * cost} in ONE kernel launch with Phi never leaving the chip.  NULL outputs are
+ * skipped.  Equivalent to the sequence of calls above (same cached state after).
+ */
+int vp_evaluate(vp_batch *h, const void *alpha, void *r_out, void *J_out, void *C_out, double *cost_out,
+                int32_t *status);
+
+/* ---- model surface -------------------------------------------------------------------- */
+
+/*
+ * == SeparableNonlinearModel::{set_params, eval, eval_partial_deriv}
+ * (src/model/mod.rs:266-267,308,359-362) for the whole batch, UNWEIGHTED:
+ * Phi_out[b][j][:] = basis j; dPhi_out[b][pair][:] = d basis_j / d alpha_k for the
+ * dependency pairs in model order (basis-major).  Either output may be NULL.
+ * flags: VP_BASIS_SKIP_INVARIANT omits VP_BASIS_CONST columns from Phi_out (then
+ * Phi_out is [B][n_alpha][m]); this is the stand-alone Phi kernel whose HBM
+ * roofline fraction BASELINE.json asks for.
+ */
+enum { VP_BASIS_SKIP_INVARIANT = 1 };
+int vp_basis(vp_batch *h, const void *alpha, void *Phi_out, void *dPhi_out, int flags);
+
+/* ---- solver surface ------------------------------------------------------------------- */
+
+void vp_lm_opts_default(vp_lm_opts *opts, int dtype);
+
+/*
+ * == LevMarSolver::fit (src/solvers/levmar/mod.rs:238-254), i.e.
+ * LevenbergMarquardt::minimize (third-party, call site :247) for every problem of
+ * the batch, device-resident.  alpha_inout: in = initial guess (the problem's
+ * current params), out = FitResult::nonlinear_parameters (src/fit.rs:113-115).
+ * C_out (may be NULL) = FitResult::linear_coefficients.  rep[b] (may be NULL) =
+ * MinimizationReport; rep[b].termination > 0 <=> fit returned Ok.  After the call
+ * the handle's cached state corresponds to the final parameters.
+ */
+int vp_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep);
+
+/* == FitResult::best_fit (src/fit.rs:55-59,87-91): UNWEIGHTED Phi(alpha) * C, [B][S][m] */
+int vp_best_fit(vp_batch *h, void *fit_out);
+
+/*
+ * Local batch aggregates for the multi-GPU cost reduction:
+ * out = { sum_b 1/2||r_b||^2 , #successful , #failed , sum_b n_evals } over this
+ * handle's problems (after vp_fit) -- always HOST doubles.  The cross-rank sum is one
+ * RCCL all-reduce of these 4 doubles, issued by the host layer.
+ */
+int vp_summary(vp_batch *h, double out[4]);
+
+/* ---- introspection --------------------------------------------------------------------- */
+
+/* duration in ms of the most recent launch of a kernel family on this handle, measured
+ * with hipEvents on the handle's stream (enabled by vp_set_timing(h,1)). */
+enum { VP_KERNEL_EVALUATE = 0, VP_KERNEL_BASIS = 1, VP_KERNEL_FIT = 2 };
+int vp_set_timing(vp_batch *h, int enable);
+int vp_last_kernel_ms(vp_batch *h, int which, float *ms);
+
+int vp_synchronize(vp_batch *h);
+const char *vp_last_error(void);
+int vp_last_error_detail(void);
+const char *vp_version(void);
+/* number of visible HIP devices (0 if none); never fails */
+int vp_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VARPRO_HIP_H */
