@@ -110,10 +110,10 @@ def make_desc(kinds, params, n_params):
 
 
 def desc_of(model):
-    """accepts an oracle ModelDesc, or any object with .kinds/.params/.n_params (e.g. varpro_amd.SeparableModel)"""
+    """accepts an oracle ModelDesc, or any object with .kinds/.param_indices/.n_params (duck-typed model)"""
     if isinstance(model, ModelDesc):
         return model
-    return make_desc(list(model.kinds), [tuple(p) for p in model.params], int(model.n_params))
+    return make_desc(list(model.kinds), [tuple(p) for p in model.param_indices], int(model.n_params))
 
 
 def _dp(a):

@@ -1,0 +1,305 @@
+"""BatchProblem: B independent separable problems (or B problems x S right-hand sides) on one GPU.
+
+This is the Python face of the ``vp_batch`` handle (include/varpro_hip.h).  It holds what the
+reference's ``SeparableProblem`` + ``CachedCalculations`` hold (src/problem.rs:57-107) for a whole
+batch, resident in HBM, and exposes the ``LeastSquaresProblem`` surface
+(src/solvers/levmar/mod.rs:22-202) batch-wise.
+
+Array conventions (row index fastest, i.e. each problem's slice is the reference's column-major
+matrix):  Y, R: (B, S, m) or (B, m) when S == 1;  alpha: (B, q);  C: (B, S, n) / (B, n);
+J: (B, q, S, m) / (B, q, m).
+
+Inputs may be numpy arrays (host-pointer mode: the library stages through HBM) or torch CUDA
+tensors (device-pointer mode: zero copies, results are torch tensors on the same device and the
+work is enqueued on torch's current stream).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+REPORT_DTYPE = np.dtype([("termination", np.int32), ("n_evals", np.int32), ("objective", np.float64)])
+
+STATUS_OK, STATUS_NONFINITE, STATUS_NOT_EVALUATED = 0, 1, 2
+
+
+def _is_torch(a):
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+class LevenbergMarquardt:
+    """mirrors ``levenberg_marquardt::LevenbergMarquardt`` builder knobs (reached in the reference via
+    ``LevMarSolver::with_solver``, src/solvers/levmar/mod.rs:221-223)."""
+
+    def __init__(self, dtype=np.float64):
+        eps = float(np.finfo(dtype).eps)
+        self.ftol = self.xtol = self.gtol = 30.0 * eps
+        self.stepbound = 100.0
+        self.patience = 100
+        self.scale_diag = True
+
+    @classmethod
+    def new(cls, dtype=np.float64):
+        return cls(dtype)
+
+    def with_ftol(self, v):
+        self.ftol = float(v)
+        return self
+
+    def with_xtol(self, v):
+        self.xtol = float(v)
+        return self
+
+    def with_gtol(self, v):
+        self.gtol = float(v)
+        return self
+
+    def with_tol(self, v):
+        self.ftol = self.xtol = self.gtol = float(v)
+        return self
+
+    def with_stepbound(self, v):
+        self.stepbound = float(v)
+        return self
+
+    def with_patience(self, v):
+        self.patience = int(v)
+        return self
+
+    def with_scale_diag(self, v):
+        self.scale_diag = bool(v)
+        return self
+
+    def _c(self):
+        o = _lib.LmOpts()
+        o.ftol, o.xtol, o.gtol, o.stepbound = self.ftol, self.xtol, self.gtol, self.stepbound
+        o.patience, o.scale_diag = self.patience, int(self.scale_diag)
+        return o
+
+
+class BatchProblem:
+    def __init__(self, model, Y, x=None, weights=None, epsilon=None, device=0):
+        """model: varpro_amd.SeparableModel; Y: (B, m) or (B, S, m); x: (m,) shared grid or (B, m)
+        per-problem grids (default: model.x); weights: None (unit), (m,) or (B, m)."""
+        self.lib = _lib.load()
+        self.model = model
+        self.n = model.base_function_count()
+        self.q = model.parameter_count()
+        self.p = len(model.pairs)
+        self.device_mode = _is_torch(Y)
+        if self.device_mode:
+            self._tdev = Y.device
+        self.np_dtype = np.dtype(model.dtype)
+        self.vp_dtype = _lib.VP_F64 if self.np_dtype == np.float64 else _lib.VP_F32
+        x = model.x if x is None else x
+        Y = self._as_array(Y)
+        if Y.ndim == 2:
+            self.single_rhs = True
+            B, m = Y.shape
+            S = 1
+        elif Y.ndim == 3:
+            self.single_rhs = False
+            B, S, m = Y.shape
+        else:
+            raise ValueError("Y must be (B, m) or (B, S, m)")
+        self.B, self.S, self.m = int(B), int(S), int(m)
+        x = self._as_array(x)
+        flags = 0
+        if self.device_mode:
+            flags |= _lib.VP_FLAG_DEVICE_PTRS
+        if x.ndim == 2:
+            flags |= _lib.VP_FLAG_T_PER_PROBLEM
+            if tuple(x.shape) != (self.B, self.m):
+                raise ValueError("per-problem grid must be (B, m)")
+        elif int(x.shape[0]) != self.m:
+            # SeparableProblemBuilderError::InvalidLengthOfData (src/problem/builder.rs:294-299)
+            raise ValueError("InvalidLengthOfData: x length = %d and y length = %d" % (int(x.shape[0]), self.m))
+        w = None
+        if weights is not None:
+            w = self._as_array(weights)
+            if w.ndim == 2:
+                flags |= _lib.VP_FLAG_W_PER_PROBLEM
+                if tuple(w.shape) != (self.B, self.m):
+                    raise ValueError("InvalidLengthOfWeights")
+            elif int(w.shape[0]) != self.m:
+                raise ValueError("InvalidLengthOfWeights")  # src/problem/builder.rs:300-303
+        self._keep = (x, Y, w)
+        stream = None
+        if self.device_mode:
+            device = Y.device.index if Y.device.index is not None else torch.cuda.current_device()
+            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        self.device = int(device)
+        h = C.c_void_p()
+        desc = model.desc()
+        eps = -1.0 if epsilon is None else abs(float(epsilon))
+        check(self.lib.vp_batch_create(C.byref(h), C.byref(desc), self.vp_dtype, self.m, self.S, self.B,
+                                       self._ptr(x), self._ptr(Y), self._ptr(w), eps, flags, self.device, stream))
+        self._h = h
+        self._keep = None  # the handle owns copies (Y_w = W*Y, t, w)
+
+    # ---- plumbing ----
+    def _as_array(self, a):
+        if self.device_mode:
+            if not _is_torch(a):
+                a = torch.as_tensor(np.asarray(a), device=self._torch_device())
+            tdt = torch.float64 if self.np_dtype == np.float64 else torch.float32
+            return a.to(dtype=tdt).contiguous()
+        return np.ascontiguousarray(a, dtype=self.np_dtype)
+
+    def _torch_device(self):
+        return getattr(self, "_tdev", None) or "cuda"
+
+    def _ptr(self, a):
+        if a is None:
+            return None
+        if _is_torch(a):
+            self._tdev = a.device
+            return C.c_void_p(a.data_ptr())
+        return C.c_void_p(a.ctypes.data)
+
+    def _empty(self, shape, dtype=None):
+        if self.device_mode:
+            if dtype is None:
+                tdt = torch.float64 if self.np_dtype == np.float64 else torch.float32
+            else:
+                tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.int32): torch.int32,
+                       np.dtype(np.uint8): torch.uint8}[np.dtype(dtype)]
+            return torch.empty(shape, dtype=tdt, device=self._torch_device())
+        return np.empty(shape, dtype=self.np_dtype if dtype is None else dtype)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vp_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _shape_rhs(self, *lead_trail):
+        return lead_trail
+
+    # ---- LeastSquaresProblem surface, batch-wise ----
+    def set_params(self, alpha):
+        """== SeparableProblem::set_params (src/solvers/levmar/mod.rs:42-73)"""
+        a = self._as_array(alpha).reshape(self.B, self.q)
+        check(self.lib.vp_set_params(self._h, self._ptr(a)))
+
+    def params(self):
+        out = self._empty((self.B, self.q))
+        check(self.lib.vp_params(self._h, self._ptr(out)))
+        return out
+
+    def status(self):
+        st = self._empty((self.B,), np.int32)
+        check(self.lib.vp_linear_coeffs(self._h, None, self._ptr(st)))
+        return st
+
+    def residuals(self, with_status=False):
+        """== residuals() (src/solvers/levmar/mod.rs:91-95): (B, S*m) column-stacked per problem"""
+        r = self._empty((self.B, self.S * self.m))
+        st = self._empty((self.B,), np.int32)
+        check(self.lib.vp_residuals(self._h, self._ptr(r), self._ptr(st)))
+        return (r, st) if with_status else r
+
+    def jacobian(self, with_status=False):
+        """== jacobian() (src/solvers/levmar/mod.rs:101-201): (B, q, S*m); J[b, k] is column k"""
+        J = self._empty((self.B, self.q, self.S * self.m))
+        st = self._empty((self.B,), np.int32)
+        check(self.lib.vp_jacobian(self._h, self._ptr(J), self._ptr(st)))
+        return (J, st) if with_status else J
+
+    def linear_coefficients(self):
+        """(B, n) for single RHS, (B, S, n) for MRHS (each [b] is the reference's n x S matrix, column-major)"""
+        Cm = self._empty((self.B, self.S, self.n))
+        check(self.lib.vp_linear_coeffs(self._h, self._ptr(Cm), None))
+        return Cm.reshape(self.B, self.n) if self.single_rhs else Cm
+
+    def weighted_data(self):
+        Yw = self._empty((self.B, self.S, self.m))
+        check(self.lib.vp_weighted_data(self._h, self._ptr(Yw)))
+        return Yw.reshape(self.B, self.m) if self.single_rhs else Yw
+
+    def cost(self):
+        c = self._empty((self.B,), np.float64)
+        check(self.lib.vp_cost(self._h, self._ptr(c)))
+        return c
+
+    def evaluate(self, alpha, want_residuals=True, want_jacobian=True):
+        """fused set_params + residuals + jacobian + coefficients + cost in one launch (vp_evaluate)"""
+        a = self._as_array(alpha).reshape(self.B, self.q)
+        r = self._empty((self.B, self.S * self.m)) if want_residuals else None
+        J = self._empty((self.B, self.q, self.S * self.m)) if want_jacobian else None
+        Cm = self._empty((self.B, self.S, self.n))
+        cost = self._empty((self.B,), np.float64)
+        st = self._empty((self.B,), np.int32)
+        check(self.lib.vp_evaluate(self._h, self._ptr(a), self._ptr(r), self._ptr(J), self._ptr(Cm), self._ptr(cost),
+                                   self._ptr(st)))
+        return dict(r=r, J=J, C=Cm.reshape(self.B, self.n) if self.single_rhs else Cm, cost=cost, status=st)
+
+    # ---- model surface ----
+    def basis(self, alpha, skip_invariant=False, want_phi=True, want_dphi=True, out_phi=None, out_dphi=None):
+        """== eval / eval_partial_deriv for the batch, UNWEIGHTED (vp_basis): Phi (B, n, m), dPhi (B, p, m)"""
+        a = self._as_array(alpha).reshape(self.B, self.q)
+        ncols = self.n - (sum(1 for k in self.model.kinds if k == 0) if skip_invariant else 0)
+        phi = out_phi if out_phi is not None else (self._empty((self.B, ncols, self.m)) if want_phi else None)
+        dphi = out_dphi if out_dphi is not None else (self._empty((self.B, self.p, self.m)) if want_dphi else None)
+        check(self.lib.vp_basis(self._h, self._ptr(a), self._ptr(phi), self._ptr(dphi),
+                                _lib.VP_BASIS_SKIP_INVARIANT if skip_invariant else 0))
+        return phi, dphi
+
+    # ---- solver surface ----
+    def fit(self, alpha0, solver=None, want_coefficients=True):
+        """== LevMarSolver::fit for every problem (vp_fit).  Returns (alpha, C, report) where report
+        is a structured numpy array (termination, n_evals, objective); termination > 0 <=> Ok."""
+        solver = solver or LevenbergMarquardt(self.np_dtype)
+        opts = solver._c()
+        a = self._as_array(alpha0).reshape(self.B, self.q)
+        a = a.clone() if _is_torch(a) else a.copy()
+        Cm = self._empty((self.B, self.n)) if want_coefficients else None
+        if self.device_mode:
+            rep_t = torch.empty((self.B, 16), dtype=torch.uint8, device=self._torch_device())
+            check(self.lib.vp_fit(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), self._ptr(rep_t)))
+            rep = rep_t  # raw bytes on device; use report_to_numpy() to decode
+        else:
+            rep = np.zeros(self.B, dtype=REPORT_DTYPE)
+            check(self.lib.vp_fit(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), C.c_void_p(rep.ctypes.data)))
+        return a, Cm, rep
+
+    @staticmethod
+    def report_to_numpy(rep):
+        if _is_torch(rep):
+            return rep.cpu().numpy().view(REPORT_DTYPE).reshape(-1)
+        return rep
+
+    def best_fit(self):
+        """== FitResult::best_fit (src/fit.rs:55-59, 87-91)"""
+        f = self._empty((self.B, self.S, self.m))
+        check(self.lib.vp_best_fit(self._h, self._ptr(f)))
+        return f.reshape(self.B, self.m) if self.single_rhs else f
+
+    def summary(self):
+        """local {sum cost, #successful, #failed, sum n_evals} after fit (vp_summary)"""
+        out = (C.c_double * 4)()
+        check(self.lib.vp_summary(self._h, out))
+        return np.array(list(out))
+
+    def set_timing(self, enable=True):
+        check(self.lib.vp_set_timing(self._h, int(enable)))
+
+    def last_kernel_ms(self, which):
+        ms = C.c_float(-1.0)
+        check(self.lib.vp_last_kernel_ms(self._h, int(which), C.byref(ms)))
+        return float(ms.value)
+
+    def synchronize(self):
+        check(self.lib.vp_synchronize(self._h))

@@ -1,0 +1,734 @@
+// vp_api.hip -- implementation of the C ABI declared in include/varpro_hip.h.
+// Host-side state management + dispatch into the kernel registry.  No fallbacks: every compute
+// entry point runs HIP kernels on a gfx950 device or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/varpro_hip.h"
+#include "vp_registry.hpp"
+
+using namespace vp;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local int g_detail = 0;
+
+int fail(int code, const std::string &msg, int detail = 0) {
+    g_err = msg;
+    g_detail = detail;
+    return code;
+}
+
+#define VP_HIP(expr)                                                                                                  \
+    do {                                                                                                              \
+        hipError_t e__ = (expr);                                                                                      \
+        if (e__ != hipSuccess)                                                                                        \
+            return fail(VP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                            \
+    } while (0)
+
+inline size_t tsize(int dtype) { return dtype == VP_F64 ? 8 : 4; }
+
+// ---- small utility kernels (dtype-generic plumbing, not the hot path) ------------------------------
+template <typename T>
+__global__ void weight_data_kernel(const T *__restrict__ Y, const T *__restrict__ w, T *__restrict__ Yw, int m,
+                                   int64_t cols_per_problem, int64_t w_stride, int64_t total) {
+    // Y_w = W * Y  (src/problem/builder.rs:307, src/util/mod.rs:86-95)
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t col = idx / m;
+        const int i = (int)(idx - col * m);
+        const int64_t b = col / cols_per_problem;
+        Yw[idx] = w ? (T)(w[b * w_stride + i] * Y[idx]) : Y[idx];
+    }
+}
+
+// per-problem reduction over the S right-hand sides: cost[b] = sum_s cost_bs ; status[b] = max_s status_bs
+__global__ void reduce_rhs_kernel(const double *__restrict__ cost_bs, const int32_t *__restrict__ status_bs,
+                                  double *__restrict__ cost_b, int32_t *__restrict__ status_b, int S, int64_t B) {
+    const int64_t b = blockIdx.x;
+    if (b >= B) return;
+    double acc = 0.0;
+    int st = 0;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        acc += cost_bs[b * S + s];
+        const int v = status_bs[b * S + s];
+        st = v > st ? v : st;
+    }
+    __shared__ double sh[256];
+    __shared__ int shs[256];
+    sh[threadIdx.x] = acc;
+    shs[threadIdx.x] = st;
+    __syncthreads();
+    for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sh[threadIdx.x] += sh[threadIdx.x + off];
+            shs[threadIdx.x] = shs[threadIdx.x] > shs[threadIdx.x + off] ? shs[threadIdx.x] : shs[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (cost_b) cost_b[b] = sh[0];
+        if (status_b) status_b[b] = shs[0];
+    }
+}
+
+// {sum cost, #successful, #failed, sum n_evals} over the batch
+__global__ void summary_kernel(const vp_report *__restrict__ rep, int64_t B, double *__restrict__ out4) {
+    double c = 0, ok = 0, bad = 0, ev = 0;
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+        const vp_report r = rep[b];
+        if (r.objective == r.objective) c += r.objective;
+        if (r.termination > 0) ok += 1.0;
+        else bad += 1.0;
+        ev += (double)r.n_evals;
+    }
+    __shared__ double sh[4][256];
+    sh[0][threadIdx.x] = c;
+    sh[1][threadIdx.x] = ok;
+    sh[2][threadIdx.x] = bad;
+    sh[3][threadIdx.x] = ev;
+    __syncthreads();
+    for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 4; ++k) atomicAdd(&out4[k], sh[k][0]);
+}
+
+} // namespace
+
+// ---- the handle ------------------------------------------------------------------------------------
+struct vp_batch {
+    vp_model_desc model;
+    int dtype;
+    int64_t m, S, B;
+    int n, q, p;
+    int flags;
+    int device;
+    double eps;
+    hipStream_t stream;
+    bool own_stream;
+    const KernelEntry *kern;
+    // device state (== SeparableProblem + CachedCalculations for the whole batch)
+    void *d_t, *d_w, *d_yw;
+    void *d_alpha;      // [B][q]
+    void *d_C;          // [B][S][n]
+    void *d_R;          // [B][S][m]  lazily allocated residual cache
+    double *d_cost_bs;  // [B*S]
+    int32_t *d_status_bs;
+    double *d_cost;     // [B]   (aliases d_cost_bs when S == 1)
+    int32_t *d_status;  // [B]
+    vp_report *d_report; // [B]
+    double *d_sum4;
+    bool have_params; // set_params/evaluate/fit has run
+    bool r_valid;     // d_R matches d_alpha
+    bool have_report;
+    // timing
+    bool timing;
+    hipEvent_t ev0, ev1;
+    float last_ms[3];
+};
+
+namespace {
+
+bool device_ptrs(const vp_batch *h) { return (h->flags & VP_FLAG_DEVICE_PTRS) != 0; }
+
+// input staging: user pointer -> device pointer usable on h->stream
+struct InBuf {
+    const void *dptr = nullptr;
+    void *tmp = nullptr;
+    int init(vp_batch *h, const void *user, size_t bytes) {
+        if (!user) {
+            dptr = nullptr;
+            return 0;
+        }
+        if (device_ptrs(h)) {
+            dptr = user;
+            return 0;
+        }
+        VP_HIP(hipMalloc(&tmp, bytes ? bytes : 1));
+        VP_HIP(hipMemcpyAsync(tmp, user, bytes, hipMemcpyHostToDevice, h->stream));
+        dptr = tmp;
+        return 0;
+    }
+    ~InBuf() {
+        if (tmp) {
+            (void)hipFree(tmp); // hipFree synchronises
+        }
+    }
+};
+
+// output staging: kernels write to dptr; finish() lands the bytes in the user's buffer
+struct OutBuf {
+    void *dptr = nullptr;
+    void *tmp = nullptr;
+    void *user = nullptr;
+    size_t bytes = 0;
+    int init(vp_batch *h, void *user_, size_t bytes_) {
+        user = user_;
+        bytes = bytes_;
+        if (!user) return 0;
+        if (device_ptrs(h)) {
+            dptr = user;
+            return 0;
+        }
+        VP_HIP(hipMalloc(&tmp, bytes ? bytes : 1));
+        dptr = tmp;
+        return 0;
+    }
+    int finish(vp_batch *h) {
+        if (tmp) {
+            VP_HIP(hipMemcpyAsync(user, tmp, bytes, hipMemcpyDeviceToHost, h->stream));
+            VP_HIP(hipStreamSynchronize(h->stream));
+        }
+        return 0;
+    }
+    ~OutBuf() {
+        if (tmp) (void)hipFree(tmp);
+    }
+};
+
+int copy_out(vp_batch *h, void *user, const void *dev, size_t bytes) {
+    if (!user) return 0;
+    if (device_ptrs(h)) {
+        VP_HIP(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        VP_HIP(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+        VP_HIP(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+void fill_params(vp_batch *h, LaunchParams &p) {
+    std::memset(&p, 0, sizeof(p));
+    p.model = &h->model;
+    p.t = h->d_t;
+    p.w = h->d_w;
+    p.yw = h->d_yw;
+    p.alpha = h->d_alpha;
+    p.m = (int)h->m;
+    p.S = (int)h->S;
+    p.B = h->B;
+    p.t_stride = (h->flags & VP_FLAG_T_PER_PROBLEM) ? h->m : 0;
+    p.w_stride = (h->flags & VP_FLAG_W_PER_PROBLEM) ? h->m : 0;
+    p.eps = h->eps;
+    p.stream = h->stream;
+}
+
+struct Timer {
+    vp_batch *h;
+    int which;
+    Timer(vp_batch *h_, int w) : h(h_), which(w) {
+        if (h->timing) (void)hipEventRecord(h->ev0, h->stream);
+    }
+    void stop() {
+        if (h->timing) {
+            (void)hipEventRecord(h->ev1, h->stream);
+            (void)hipEventSynchronize(h->ev1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+            h->last_ms[which] = ms;
+        }
+    }
+};
+
+int reduce_rhs(vp_batch *h) {
+    if (h->S == 1) return 0; // d_cost / d_status alias the per-(b,s) arrays
+    hipLaunchKernelGGL(reduce_rhs_kernel, dim3((unsigned)h->B), dim3(256), 0, h->stream, h->d_cost_bs,
+                       h->d_status_bs, h->d_cost, h->d_status, (int)h->S, h->B);
+    VP_HIP(hipGetLastError());
+    return 0;
+}
+
+int ensure_R(vp_batch *h) {
+    if (!h->d_R) VP_HIP(hipMalloc(&h->d_R, (size_t)h->B * h->S * h->m * tsize(h->dtype)));
+    return 0;
+}
+
+// run the evaluate kernel at h->d_alpha; any output may be null
+int run_evaluate(vp_batch *h, void *r_dev, void *J_dev, void *C_dev) {
+    LaunchParams p;
+    fill_params(h, p);
+    p.r_out = r_dev;
+    p.J_out = J_dev;
+    p.C_out = C_dev;
+    p.cost_out = h->d_cost_bs;
+    p.status = h->d_status_bs;
+    Timer tm(h, VP_KERNEL_EVALUATE);
+    int rc = h->kern->evaluate(p);
+    tm.stop();
+    if (rc != VP_ERR_OK) return fail(rc, "evaluate kernel launch failed");
+    return reduce_rhs(h);
+}
+
+int check_handle(vp_batch *h) {
+    if (!h) return fail(VP_ERR_INVALID, "null handle");
+    VP_HIP(hipSetDevice(h->device));
+    return 0;
+}
+
+} // namespace
+
+// ---- C ABI -------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *vp_last_error(void) { return g_err.c_str(); }
+int vp_last_error_detail(void) { return g_detail; }
+const char *vp_version(void) { return "varpro_hip 0.1.0 (gfx950)"; }
+
+int vp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+void vp_lm_opts_default(vp_lm_opts *o, int dtype) {
+    const double eps = dtype == VP_F32 ? (double)FLT_EPSILON : DBL_EPSILON;
+    o->ftol = 30.0 * eps;
+    o->xtol = 30.0 * eps;
+    o->gtol = 30.0 * eps;
+    o->stepbound = 100.0;
+    o->patience = 100;
+    o->scale_diag = 1;
+}
+
+int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64_t m, int64_t S, int64_t B,
+                    const void *t, const void *Y, const void *w, double svd_epsilon, int flags, int device,
+                    void *hip_stream) {
+    if (!out) return fail(VP_ERR_INVALID, "null output handle");
+    *out = nullptr;
+    if (!model) return fail(VP_ERR_INVALID, "null model");
+    if (dtype != VP_F64 && dtype != VP_F32) return fail(VP_ERR_INVALID, "bad dtype");
+    // builder validation (src/problem/builder.rs:278-302)
+    if (!Y) return fail(VP_ERR_INVALID, "Right hand side(s) not provided", VP_BUILD_Y_DATA_MISSING);
+    if (m <= 0 || S <= 0 || B <= 0 || !t)
+        return fail(VP_ERR_INVALID, "x or y must have nonzero number of elements.", VP_BUILD_ZERO_LENGTH_VECTOR);
+    if (model->n_basis <= 0 || model->n_basis > VP_MAX_BASIS || model->n_params < 0 ||
+        model->n_params > VP_MAX_PARAMS)
+        return fail(VP_ERR_INVALID, "model sizes out of range");
+    int fa, fb, fc, npairs;
+    if (classify_model(*model, fa, fb, fc, npairs) < 0) return fail(VP_ERR_INVALID, "malformed model descriptor");
+    if (npairs > VP_MAX_PAIRS) return fail(VP_ERR_INVALID, "too many dependency pairs");
+    if (m < model->n_basis) return fail(VP_ERR_UNSUPPORTED, "m < n (underdetermined linear sub-problem) unsupported");
+
+    int ndev = vp_device_count();
+    if (ndev <= 0) return fail(VP_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(VP_ERR_INVALID, "bad device index");
+    VP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    VP_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(VP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
+
+    const KernelEntry *kern = find_kernels(dtype, *model, m);
+    if (!kern)
+        return fail(VP_ERR_UNSUPPORTED, "no kernel instantiation for this (dtype, model, m); see DESIGN.md coverage table");
+
+    vp_batch *h = new vp_batch();
+    std::memset(h, 0, sizeof(*h));
+    h->model = *model;
+    h->dtype = dtype;
+    h->m = m;
+    h->S = S;
+    h->B = B;
+    h->n = model->n_basis;
+    h->q = model->n_params;
+    h->p = npairs;
+    h->flags = flags;
+    h->device = device;
+    const double meps = dtype == VP_F32 ? (double)FLT_EPSILON : DBL_EPSILON;
+    h->eps = svd_epsilon < 0 ? meps : std::fabs(svd_epsilon); // src/problem/builder.rs:246-251, 282
+    h->kern = kern;
+    if (hip_stream) {
+        h->stream = (hipStream_t)hip_stream;
+        h->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete h;
+            return fail(VP_ERR_HIP, "hipStreamCreate failed");
+        }
+        h->own_stream = true;
+    }
+    const size_t ts = tsize(dtype);
+    const size_t t_elems = (size_t)((flags & VP_FLAG_T_PER_PROBLEM) ? B * m : m);
+    const size_t w_elems = (size_t)((flags & VP_FLAG_W_PER_PROBLEM) ? B * m : m);
+    const size_t y_elems = (size_t)B * S * m;
+#define VP_TRY(expr)                                                                                                  \
+    do {                                                                                                              \
+        hipError_t e__ = (expr);                                                                                      \
+        if (e__ != hipSuccess) {                                                                                      \
+            std::string msg__ = std::string(#expr) + ": " + hipGetErrorString(e__);                                 \
+            vp_batch_destroy(h);                                                                                      \
+            return fail(VP_ERR_HIP, msg__);                                                                           \
+        }                                                                                                             \
+    } while (0)
+    const hipMemcpyKind kin = device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    VP_TRY(hipMalloc(&h->d_t, t_elems * ts));
+    VP_TRY(hipMemcpyAsync(h->d_t, t, t_elems * ts, kin, h->stream));
+    if (w) {
+        VP_TRY(hipMalloc(&h->d_w, w_elems * ts));
+        VP_TRY(hipMemcpyAsync(h->d_w, w, w_elems * ts, kin, h->stream));
+    }
+    VP_TRY(hipMalloc(&h->d_yw, y_elems * ts));
+    {
+        // Y_w = W * Y
+        void *ytmp = nullptr;
+        const void *ysrc = Y;
+        if (!device_ptrs(h)) {
+            VP_TRY(hipMalloc(&ytmp, y_elems * ts));
+            VP_TRY(hipMemcpyAsync(ytmp, Y, y_elems * ts, hipMemcpyHostToDevice, h->stream));
+            ysrc = ytmp;
+        }
+        const int64_t total = (int64_t)y_elems;
+        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 65536);
+        const int64_t wstride = (flags & VP_FLAG_W_PER_PROBLEM) ? m : 0;
+        if (dtype == VP_F64)
+            hipLaunchKernelGGL(weight_data_kernel<double>, dim3(grid), dim3(256), 0, h->stream, (const double *)ysrc,
+                               (const double *)h->d_w, (double *)h->d_yw, (int)m, S, wstride, total);
+        else
+            hipLaunchKernelGGL(weight_data_kernel<float>, dim3(grid), dim3(256), 0, h->stream, (const float *)ysrc,
+                               (const float *)h->d_w, (float *)h->d_yw, (int)m, S, wstride, total);
+        VP_TRY(hipGetLastError());
+        VP_TRY(hipStreamSynchronize(h->stream));
+        if (ytmp) (void)hipFree(ytmp);
+    }
+    VP_TRY(hipMalloc(&h->d_alpha, (size_t)std::max<int64_t>(1, B * h->q) * ts));
+    VP_TRY(hipMalloc(&h->d_C, (size_t)B * S * h->n * ts));
+    VP_TRY(hipMalloc((void **)&h->d_cost_bs, (size_t)B * S * sizeof(double)));
+    VP_TRY(hipMalloc((void **)&h->d_status_bs, (size_t)B * S * sizeof(int32_t)));
+    if (S == 1) {
+        h->d_cost = h->d_cost_bs;
+        h->d_status = h->d_status_bs;
+    } else {
+        VP_TRY(hipMalloc((void **)&h->d_cost, (size_t)B * sizeof(double)));
+        VP_TRY(hipMalloc((void **)&h->d_status, (size_t)B * sizeof(int32_t)));
+    }
+    VP_TRY(hipMalloc((void **)&h->d_report, (size_t)B * sizeof(vp_report)));
+    VP_TRY(hipMalloc((void **)&h->d_sum4, 4 * sizeof(double)));
+    VP_TRY(hipEventCreate(&h->ev0));
+    VP_TRY(hipEventCreate(&h->ev1));
+#undef VP_TRY
+    for (int k = 0; k < 3; ++k) h->last_ms[k] = -1.f;
+    *out = h;
+    return VP_ERR_OK;
+}
+
+void vp_batch_destroy(vp_batch *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->d_t);
+    (void)hipFree(h->d_w);
+    (void)hipFree(h->d_yw);
+    (void)hipFree(h->d_alpha);
+    (void)hipFree(h->d_C);
+    (void)hipFree(h->d_R);
+    (void)hipFree(h->d_cost_bs);
+    (void)hipFree(h->d_status_bs);
+    if (h->S != 1) {
+        (void)hipFree(h->d_cost);
+        (void)hipFree(h->d_status);
+    }
+    (void)hipFree(h->d_report);
+    (void)hipFree(h->d_sum4);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int vp_set_params(vp_batch *h, const void *alpha) {
+    if (int rc = check_handle(h)) return rc;
+    if (!alpha) return fail(VP_ERR_INVALID, "null alpha");
+    const size_t bytes = (size_t)h->B * h->q * tsize(h->dtype);
+    VP_HIP(hipMemcpyAsync(h->d_alpha, alpha, bytes, device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          h->stream));
+    if (int rc = ensure_R(h)) return rc;
+    if (int rc = run_evaluate(h, h->d_R, nullptr, h->d_C)) return rc;
+    h->have_params = true;
+    h->r_valid = true;
+    if (!device_ptrs(h)) VP_HIP(hipStreamSynchronize(h->stream));
+    return VP_ERR_OK;
+}
+
+int vp_params(vp_batch *h, void *alpha_out) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->have_params) return fail(VP_ERR_INVALID, "no parameters set yet");
+    return copy_out(h, alpha_out, h->d_alpha, (size_t)h->B * h->q * tsize(h->dtype));
+}
+
+static int copy_status(vp_batch *h, int32_t *status) {
+    if (!status) return 0;
+    if (!h->have_params) {
+        // residuals()/jacobian() before set_params: cached is None
+        std::vector<int32_t> tmp((size_t)h->B, VP_ST_NOT_EVALUATED);
+        if (device_ptrs(h)) {
+            VP_HIP(hipMemcpyAsync(status, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, h->stream));
+            VP_HIP(hipStreamSynchronize(h->stream));
+        } else {
+            std::memcpy(status, tmp.data(), tmp.size() * 4);
+        }
+        return 0;
+    }
+    return copy_out(h, status, h->d_status, (size_t)h->B * sizeof(int32_t));
+}
+
+int vp_residuals(vp_batch *h, void *r_out, int32_t *status) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->have_params) return copy_status(h, status) ? VP_ERR_HIP : VP_ERR_OK;
+    if (!h->r_valid) {
+        if (int rc = ensure_R(h)) return rc;
+        if (int rc = run_evaluate(h, h->d_R, nullptr, nullptr)) return rc;
+        h->r_valid = true;
+    }
+    if (int rc = copy_out(h, r_out, h->d_R, (size_t)h->B * h->S * h->m * tsize(h->dtype))) return rc;
+    return copy_status(h, status);
+}
+
+int vp_jacobian(vp_batch *h, void *J_out, int32_t *status) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->have_params) return copy_status(h, status) ? VP_ERR_HIP : VP_ERR_OK;
+    if (!J_out) return fail(VP_ERR_INVALID, "null J_out");
+    OutBuf J;
+    if (int rc = J.init(h, J_out, (size_t)h->B * h->q * h->S * h->m * tsize(h->dtype))) return rc;
+    if (int rc = run_evaluate(h, nullptr, J.dptr, nullptr)) return rc;
+    if (int rc = J.finish(h)) return rc;
+    return copy_status(h, status);
+}
+
+int vp_linear_coeffs(vp_batch *h, void *C_out, int32_t *status) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->have_params) return copy_status(h, status) ? VP_ERR_HIP : VP_ERR_OK;
+    if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * tsize(h->dtype))) return rc;
+    return copy_status(h, status);
+}
+
+int vp_weighted_data(vp_batch *h, void *Yw_out) {
+    if (int rc = check_handle(h)) return rc;
+    return copy_out(h, Yw_out, h->d_yw, (size_t)h->B * h->S * h->m * tsize(h->dtype));
+}
+
+int vp_cost(vp_batch *h, double *cost_out) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->have_params) return fail(VP_ERR_INVALID, "no parameters set yet");
+    return copy_out(h, cost_out, h->d_cost, (size_t)h->B * sizeof(double));
+}
+
+int vp_evaluate(vp_batch *h, const void *alpha, void *r_out, void *J_out, void *C_out, double *cost_out,
+                int32_t *status) {
+    if (int rc = check_handle(h)) return rc;
+    if (!alpha) return fail(VP_ERR_INVALID, "null alpha");
+    const size_t ts = tsize(h->dtype);
+    VP_HIP(hipMemcpyAsync(h->d_alpha, alpha, (size_t)h->B * h->q * ts,
+                          device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    OutBuf r, J;
+    if (int rc = r.init(h, r_out, (size_t)h->B * h->S * h->m * ts)) return rc;
+    if (int rc = J.init(h, J_out, (size_t)h->B * h->q * h->S * h->m * ts)) return rc;
+    if (int rc = run_evaluate(h, r.dptr, J.dptr, h->d_C)) return rc;
+    h->have_params = true;
+    h->r_valid = false;
+    if (int rc = r.finish(h)) return rc;
+    if (int rc = J.finish(h)) return rc;
+    if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
+    if (int rc = copy_out(h, cost_out, h->d_cost, (size_t)h->B * sizeof(double))) return rc;
+    return copy_status(h, status);
+}
+
+int vp_basis(vp_batch *h, const void *alpha, void *Phi_out, void *dPhi_out, int flags) {
+    if (int rc = check_handle(h)) return rc;
+    if (!alpha) return fail(VP_ERR_INVALID, "null alpha");
+    const size_t ts = tsize(h->dtype);
+    int ncols = 0;
+    for (int j = 0; j < h->n; ++j)
+        if (!((flags & VP_BASIS_SKIP_INVARIANT) && h->model.kind[j] == VP_BASIS_CONST)) ++ncols;
+    InBuf a;
+    if (int rc = a.init(h, alpha, (size_t)h->B * h->q * ts)) return rc;
+    OutBuf phi, dphi;
+    if (int rc = phi.init(h, Phi_out, (size_t)h->B * ncols * h->m * ts)) return rc;
+    if (int rc = dphi.init(h, dPhi_out, (size_t)h->B * h->p * h->m * ts)) return rc;
+    LaunchParams p;
+    fill_params(h, p);
+    p.alpha = a.dptr;
+    p.Phi_out = phi.dptr;
+    p.dPhi_out = dphi.dptr;
+    p.basis_flags = flags;
+    Timer tm(h, VP_KERNEL_BASIS);
+    int rc = h->kern->basis(p);
+    tm.stop();
+    if (rc != VP_ERR_OK) return fail(rc, "basis kernel launch failed");
+    if (int rc2 = phi.finish(h)) return rc2;
+    if (int rc2 = dphi.finish(h)) return rc2;
+    if (!device_ptrs(h)) VP_HIP(hipStreamSynchronize(h->stream));
+    return VP_ERR_OK;
+}
+
+int vp_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep) {
+    if (int rc = check_handle(h)) return rc;
+    if (!alpha_inout) return fail(VP_ERR_INVALID, "null alpha");
+    if (h->S != 1) return fail(VP_ERR_UNSUPPORTED, "vp_fit with S > 1 (MRHS global fit) is not built yet");
+    if (!h->kern->fit) return fail(VP_ERR_UNSUPPORTED, "no fit kernel for this model");
+    vp_lm_opts o;
+    if (opts) o = *opts;
+    else vp_lm_opts_default(&o, h->dtype);
+    const size_t ts = tsize(h->dtype);
+    VP_HIP(hipMemcpyAsync(h->d_alpha, alpha_inout, (size_t)h->B * h->q * ts,
+                          device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    LaunchParams p;
+    fill_params(h, p);
+    p.alpha_out = h->d_alpha;
+    p.C_out = h->d_C;
+    p.cost_out = h->d_cost_bs;
+    p.status = h->d_status_bs;
+    p.report = h->d_report;
+    p.opts = &o;
+    Timer tm(h, VP_KERNEL_FIT);
+    int rc = h->kern->fit(p);
+    tm.stop();
+    if (rc != VP_ERR_OK) return fail(rc, "fit kernel launch failed");
+    h->have_params = true;
+    h->r_valid = false;
+    h->have_report = true;
+    if (int rc2 = copy_out(h, alpha_inout, h->d_alpha, (size_t)h->B * h->q * ts)) return rc2;
+    if (int rc2 = copy_out(h, C_out, h->d_C, (size_t)h->B * h->n * ts)) return rc2;
+    if (int rc2 = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc2;
+    return VP_ERR_OK;
+}
+
+int vp_best_fit(vp_batch *h, void *fit_out) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->have_params) return fail(VP_ERR_INVALID, "no parameters set yet");
+    if (!h->kern->best_fit) return fail(VP_ERR_UNSUPPORTED, "no best_fit kernel for this model");
+    OutBuf f;
+    if (int rc = f.init(h, fit_out, (size_t)h->B * h->S * h->m * tsize(h->dtype))) return rc;
+    LaunchParams p;
+    fill_params(h, p);
+    p.C_out = h->d_C; // input here
+    p.r_out = f.dptr; // output
+    int rc = h->kern->best_fit(p);
+    if (rc != VP_ERR_OK) return fail(rc, "best_fit kernel launch failed");
+    return f.finish(h);
+}
+
+int vp_summary(vp_batch *h, double out[4]) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->have_report) return fail(VP_ERR_INVALID, "vp_summary requires a completed vp_fit");
+    VP_HIP(hipMemsetAsync(h->d_sum4, 0, 4 * sizeof(double), h->stream));
+    const unsigned grid = (unsigned)std::min<int64_t>((h->B + 255) / 256, 1024);
+    hipLaunchKernelGGL(summary_kernel, dim3(grid), dim3(256), 0, h->stream, h->d_report, h->B, h->d_sum4);
+    VP_HIP(hipGetLastError());
+    VP_HIP(hipMemcpyAsync(out, h->d_sum4, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    VP_HIP(hipStreamSynchronize(h->stream));
+    return VP_ERR_OK;
+}
+
+int vp_set_timing(vp_batch *h, int enable) {
+    if (!h) return fail(VP_ERR_INVALID, "null handle");
+    h->timing = enable != 0;
+    return VP_ERR_OK;
+}
+
+int vp_last_kernel_ms(vp_batch *h, int which, float *ms) {
+    if (!h || !ms || which < 0 || which > 2) return fail(VP_ERR_INVALID, "bad argument");
+    *ms = h->last_ms[which];
+    return VP_ERR_OK;
+}
+
+int vp_synchronize(vp_batch *h) {
+    if (int rc = check_handle(h)) return rc;
+    VP_HIP(hipStreamSynchronize(h->stream));
+    return VP_ERR_OK;
+}
+
+} // extern "C"
+
+// ---- registry ------------------------------------------------------------------------------------------
+namespace vp {
+
+std::vector<KernelEntry> &registry() {
+    static std::vector<KernelEntry> r;
+    return r;
+}
+
+static int kind_arity(int kind) {
+    switch (kind) {
+    case VP_BASIS_CONST: return 0;
+    case VP_BASIS_EXP_DECAY:
+    case VP_BASIS_EXP_RATE: return 1;
+    case VP_BASIS_EXP_COS:
+    case VP_BASIS_SIN_PHASE: return 2;
+    default: return -1;
+    }
+}
+
+int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out) {
+    int pairs = 0;
+    for (int j = 0; j < d.n_basis; ++j) {
+        const int ar = kind_arity(d.kind[j]);
+        if (ar < 0) return -1;
+        for (int k = 0; k < VP_MAX_BASIS_PARAMS; ++k) {
+            const int pi = d.param[j][k];
+            if (k < ar) {
+                if (pi < 0 || pi >= d.n_params) return -1;
+                ++pairs;
+            } else if (pi >= 0) {
+                return -1;
+            }
+        }
+    }
+    p_out = pairs;
+    // multi-exponential family: exp(-t/alpha_j) for j = 0..q-1 in order, optional trailing constant
+    bool multiexp = d.n_params >= 1 && (d.n_basis == d.n_params || d.n_basis == d.n_params + 1);
+    if (multiexp) {
+        for (int j = 0; j < d.n_params; ++j)
+            if (d.kind[j] != VP_BASIS_EXP_DECAY || d.param[j][0] != j) multiexp = false;
+        if (multiexp && d.n_basis == d.n_params + 1 && d.kind[d.n_params] != VP_BASIS_CONST) multiexp = false;
+    }
+    if (multiexp) {
+        a = d.n_params;
+        b = d.n_basis - d.n_params;
+        c = 0;
+        return FAMILY_MULTIEXP;
+    }
+    a = d.n_basis;
+    b = d.n_params;
+    c = pairs;
+    return FAMILY_RT;
+}
+
+const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m) {
+    int a, b, c, p;
+    const int fam = classify_model(d, a, b, c, p);
+    if (fam < 0) return nullptr;
+    const KernelEntry *best = nullptr;
+    for (int pass = 0; pass < 2 && !best; ++pass) {
+        // pass 0: exact family; pass 1: a multi-exponential model may also run on the runtime-model kernels
+        int f = fam, ka = a, kb = b, kc = c;
+        if (pass == 1) {
+            if (fam != FAMILY_MULTIEXP) break;
+            f = FAMILY_RT;
+            ka = d.n_basis;
+            kb = d.n_params;
+            kc = p;
+        }
+        for (const KernelEntry &e : registry()) {
+            if (e.dtype != dtype || e.family != f || e.a != ka || e.b != kb || e.c != kc) continue;
+            if ((int64_t)64 * e.R < m) continue;
+            if (!best || e.R < best->R) best = &e;
+        }
+    }
+    return best;
+}
+
+} // namespace vp

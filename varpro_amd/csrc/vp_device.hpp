@@ -1,0 +1,130 @@
+// vp_device.hpp -- gfx950 device primitives for the batched variable-projection kernels.
+//
+// Execution model: ONE 64-lane wavefront owns ONE separable problem.
+// The m observations are spread over the lanes, R = ceil(m/64) rows per lane, and every
+// column the algorithm touches (the basis columns of Phi, the data column y, the derivative
+// columns dPhi) lives in VGPRs for the whole evaluation -- Phi never exists in memory.
+// All reductions (column norms, Householder dot products) are wave-level: DPP inside the
+// 16-lane rows, v_readlane across the four rows.  No LDS traffic, no barriers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vp {
+
+template <typename T> struct num;
+template <> struct num<double> {
+    static constexpr double eps = 2.220446049250313e-16;
+    static constexpr double tiny = 2.2250738585072014e-308; // min positive normal
+};
+template <> struct num<float> {
+    static constexpr float eps = 1.1920929e-07f;
+    static constexpr float tiny = 1.17549435e-38f;
+};
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// make a wave-uniform predicate visible to the compiler as scalar so that branches on it are
+// s_cbranch (no exec-mask juggling around the DPP/readlane code below)
+__device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- lane <-> row mapping ---------------------------------------------------------------------
+// Rows are dealt to lanes in pairs so that a lane's global/LDS accesses are 16 B wide for fp64:
+// register r of lane l holds row ((r/VW)*64 + l)*VW + r%VW.
+template <int R> struct Layout {
+    static constexpr int VW = (R >= 2) ? 2 : 1;
+    static_assert(R == 1 || R % 2 == 0, "R must be 1 or even");
+    __device__ __forceinline__ static int row_of(int r, int lane) { return ((r / VW) * 64 + lane) * VW + (r % VW); }
+    // rows < 64*VW (all pivot rows) live in the first VW registers
+    __host__ __device__ static constexpr int reg_of_row(int row) { return row % VW; }
+    __host__ __device__ static constexpr int lane_of_row(int row) { return row / VW; }
+};
+
+// ---- cross-lane data movement -----------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ double dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ float dpp(float x) {
+    int v = __float_as_int(x);
+    v = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+    return __int_as_float(v);
+}
+__device__ __forceinline__ double readlane(double x, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane(float x, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+
+// DPP controls (GFX9): quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+// All-reduce (sum) of V independent values across the 64 lanes; every lane ends with the totals.
+// The V chains are interleaved step by step so their latencies overlap.
+template <int V, typename T> __device__ __forceinline__ void wave_allreduce(T (&x)[V]) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_XOR1>(x[v]);
+#pragma unroll
+    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_XOR2>(x[v]);
+#pragma unroll
+    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_HALF_MIRROR>(x[v]);
+#pragma unroll
+    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_MIRROR>(x[v]);
+    // every lane of a 16-lane row now holds its row sum; combine the four rows
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        T a = readlane(x[v], 0), b = readlane(x[v], 16), c = readlane(x[v], 32), d = readlane(x[v], 48);
+        x[v] = (a + b) + (c + d);
+    }
+}
+template <typename T> __device__ __forceinline__ T wave_sum(T x) {
+    T a[1] = {x};
+    wave_allreduce(a);
+    return a[0];
+}
+
+// element at (compile-time) row `row` of a register-resident column, broadcast to the wave
+template <int R, typename T> __device__ __forceinline__ T bcast_row(const T (&col)[R], int row) {
+    return readlane(col[Layout<R>::reg_of_row(row)], Layout<R>::lane_of_row(row));
+}
+
+// ---- tiny dynamically-indexed uniform arrays without scratch -----------------------------------
+template <int N, typename T> __device__ __forceinline__ T dyn_get(const T (&a)[N], int idx) {
+    T v = a[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) v = (idx == j) ? a[j] : v;
+    return v;
+}
+template <int N, typename T> __device__ __forceinline__ void dyn_set(T (&a)[N], int idx, T val) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) a[j] = (idx == j) ? val : a[j];
+}
+
+template <typename T> __device__ __forceinline__ bool is_finite(T x) { return (x - x) == T(0); }
+template <typename T> __device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }
+template <typename T> __device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
+__device__ __forceinline__ double tsqrt(double x) { return __builtin_sqrt(x); }
+__device__ __forceinline__ float tsqrt(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ double tabs(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float tabs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double tcopysign(double x, double s) { return __builtin_copysign(x, s); }
+__device__ __forceinline__ float tcopysign(float x, float s) { return __builtin_copysignf(x, s); }
+__device__ __forceinline__ double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// correctly rounded (to within the last bit in rare ties) quotient a/b given rb ~= 1/b:
+// one Newton correction of the product.  Replaces the 10+ instruction IEEE division sequence
+// for the per-row argument -t/tau; rb is computed once per problem.
+template <typename T> __device__ __forceinline__ T div_refined(T a, T b, T rb) {
+    T q0 = a * rb;
+    T rem = tfma(-q0, b, a);
+    return tfma(rem, rb, q0);
+}
+
+} // namespace vp

@@ -1,0 +1,306 @@
+// vp_kernels.hpp -- the __global__ kernels of the hot path (one wavefront == one problem).
+//
+//   evaluate_kernel : set_params (+ residuals + Jacobian + coefficients + cost) in one launch
+//                     == src/solvers/levmar/mod.rs:42-73, 91-95, 101-201 for a batch
+//   basis_kernel    : stand-alone Phi / dPhi evaluation (pure streaming writes; the kernel whose
+//                     HBM-roofline fraction BASELINE.json asks for) == src/model/mod.rs:308,359-362
+//   fit_kernel      : device-resident Levenberg-Marquardt over the VarPro functional (vp_fit.hpp)
+#pragma once
+#include "vp_core.hpp"
+
+namespace vp {
+
+// type-erased launch parameters (host side); every pointer is a device pointer
+struct LaunchParams {
+    const vp_model_desc *model;
+    const void *t;      // [m] or [B][m]
+    const void *w;      // NULL, [m] or [B][m]
+    const void *yw;     // [B][S][m] weighted data
+    const void *alpha;  // [B][q]
+    void *alpha_out;    // fit: [B][q]
+    void *r_out;        // [B][S][m] or NULL
+    void *J_out;        // [B][q][S][m] or NULL
+    void *C_out;        // [B][S][n] or NULL
+    double *cost_out;   // [B*S] partial costs (per problem and RHS) or NULL
+    int32_t *status;    // [B*S] or NULL
+    void *Phi_out;      // basis: [B][n or n_alpha][m]
+    void *dPhi_out;     // basis: [B][p][m]
+    vp_report *report;  // fit: [B]
+    const vp_lm_opts *opts;
+    int basis_flags;
+    int m;
+    int S;
+    int64_t B;
+    int64_t t_stride; // 0 (shared) or m
+    int64_t w_stride; // 0 (shared) or m
+    double eps;
+    hipStream_t stream;
+};
+
+// ---- row-distributed loads / stores ------------------------------------------------------------
+template <typename T, int R>
+__device__ __forceinline__ void load_rows(const T *__restrict__ base, const int m, const int lane, const bool vec_ok,
+                                          T (&out)[R]) {
+    using L = Layout<R>;
+    if constexpr (L::VW == 2) {
+        if (vec_ok) { // m even and base 2*sizeof(T)-aligned: one 2-element access per register pair
+#pragma unroll
+            for (int r = 0; r < R; r += 2) {
+                const int i = L::row_of(r, lane);
+                if (i < m) {
+                    using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+                    const V2 v = *reinterpret_cast<const V2 *>(base + i);
+                    out[r] = v.x;
+                    out[r + 1] = v.y;
+                } else {
+                    out[r] = T(0);
+                    out[r + 1] = T(0);
+                }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = L::row_of(r, lane);
+        out[r] = (i < m) ? base[i] : T(0);
+    }
+}
+
+template <typename T, int R>
+__device__ __forceinline__ void store_rows(T *__restrict__ base, const int m, const int lane, const bool vec_ok,
+                                           const T (&in)[R]) {
+    using L = Layout<R>;
+    if constexpr (L::VW == 2) {
+        if (vec_ok) {
+#pragma unroll
+            for (int r = 0; r < R; r += 2) {
+                const int i = L::row_of(r, lane);
+                if (i < m) {
+                    using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+                    V2 v;
+                    v.x = in[r];
+                    v.y = in[r + 1];
+                    *reinterpret_cast<V2 *>(base + i) = v;
+                }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = L::row_of(r, lane);
+        if (i < m) base[i] = in[r];
+    }
+}
+
+template <typename T> __device__ __forceinline__ bool vec_aligned(const void *p, int m) {
+    return ((m & 1) == 0) && ((reinterpret_cast<uintptr_t>(p) & (2 * sizeof(T) - 1)) == 0);
+}
+
+// scale[r] = w_i (or 1) for valid rows, 0 for padding rows
+template <typename T, int R>
+__device__ __forceinline__ void load_scale(const T *__restrict__ w, const int m, const int lane, T (&scale)[R]) {
+    using L = Layout<R>;
+    if (w != nullptr) {
+        load_rows<T, R>(w, m, lane, vec_aligned<T>(w, m), scale);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) scale[r] = (L::row_of(r, lane) < m) ? T(1) : T(0);
+    }
+}
+
+template <typename T, class M> struct EvalArgs {
+    M mdl;
+    const T *t;
+    const T *w;
+    const T *yw;
+    const T *alpha;
+    T *r_out;
+    T *J_out;
+    T *C_out;
+    double *cost_out;
+    int32_t *status;
+    int m;
+    int S;
+    int64_t nprob; // B*S
+    int64_t t_stride, w_stride;
+    T eps;
+};
+
+// MODE 0: coefficients/cost/status only; 1: + residuals; 2: + residuals + Jacobian
+template <typename T, class M, int R, int MODE>
+__global__ void __launch_bounds__(64) evaluate_kernel(const EvalArgs<T, M> a) {
+    constexpr int N = M::N, P = M::P, Q = M::Q;
+    const int lane = lane_id();
+    const int64_t prob = blockIdx.x; // problem * S + rhs
+    if (prob >= a.nprob) return;
+    const int64_t b = prob / a.S;
+    const int s = (int)(prob - b * a.S);
+    const int m = a.m;
+
+    T alpha[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
+
+    T t[R], scale[R], yw[R];
+    const T *tp = a.t + b * a.t_stride;
+    load_rows<T, R>(tp, m, lane, vec_aligned<T>(tp, m), t);
+    load_scale<T, R>(a.w ? a.w + b * a.w_stride : nullptr, m, lane, scale);
+    const T *yp = a.yw + prob * (int64_t)m;
+    const bool yvec = vec_aligned<T>(yp, m);
+    load_rows<T, R>(yp, m, lane, yvec, yw);
+
+    T A[N][R], X[1 + P][R];
+    EvalUniform<T, N> u;
+    evaluate_core<T, M, R>(a.mdl, alpha, t, scale, yw, a.eps, lane, A, X, u);
+
+    if (lane == 0) {
+        if (a.status) a.status[prob] = u.ok ? VP_ST_OK : VP_ST_NONFINITE;
+        if (a.cost_out) a.cost_out[prob] = 0.5 * (double)u.fn2;
+    }
+    if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(u.c, lane);
+
+    if constexpr (MODE >= 1) {
+        residual_qcoords<T, R, N>(X[0], u.e, lane);
+        if constexpr (MODE == 1) {
+            T Z[1][R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) Z[0][r] = X[0][r];
+            apply_q<T, R, N, 1>(A, u.tau, Z);
+            if (a.r_out) store_rows<T, R>(a.r_out + prob * (int64_t)m, m, lane, yvec, Z[0]);
+        } else {
+            T Z[1 + Q][R];
+            {
+                T ZJ[Q][R];
+                jacobian_qcoords<T, M, R>(a.mdl, X, u.c, ZJ, lane);
+#pragma unroll
+                for (int r = 0; r < R; ++r) Z[0][r] = X[0][r];
+#pragma unroll
+                for (int k = 0; k < Q; ++k)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) Z[1 + k][r] = ZJ[k][r];
+            }
+            apply_q<T, R, N, 1 + Q>(A, u.tau, Z);
+            if (a.r_out) store_rows<T, R>(a.r_out + prob * (int64_t)m, m, lane, yvec, Z[0]);
+            if (a.J_out) {
+                // J[b][k][s][m]
+#pragma unroll
+                for (int k = 0; k < Q; ++k) {
+                    T *jp = a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m;
+                    store_rows<T, R>(jp, m, lane, vec_aligned<T>(jp, m), Z[1 + k]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, class M> struct BasisArgs {
+    M mdl;
+    const T *t;
+    const T *alpha;
+    T *Phi_out;
+    T *dPhi_out;
+    int m;
+    int skip_invariant;
+    int n_phi_cols; // columns per problem in Phi_out
+    int64_t B;
+    int64_t t_stride;
+};
+
+// Stand-alone Phi/dPhi: reads q scalars (+ the shared grid from L2), writes (n + p) * m scalars per
+// problem with 16-byte-per-lane fully coalesced stores: HBM-write-bound by construction.
+template <typename T, class M, int R> __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs<T, M> a) {
+    constexpr int N = M::N, P = M::P, Q = M::Q;
+    using L = Layout<R>;
+    const int lane = lane_id();
+    const int64_t b = blockIdx.x;
+    if (b >= a.B) return;
+    const int m = a.m;
+    T alpha[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
+    T t[R], scale[R];
+    const T *tp = a.t + b * a.t_stride;
+    load_rows<T, R>(tp, m, lane, vec_aligned<T>(tp, m), t);
+#pragma unroll
+    for (int r = 0; r < R; ++r) scale[r] = (L::row_of(r, lane) < m) ? T(1) : T(0);
+    T A[N][R], D[P > 0 ? P : 1][R];
+    build_columns<T, M, R>(a.mdl, alpha, t, scale, A, D);
+    if (a.Phi_out) {
+        int col = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (a.skip_invariant && a.mdl.kind(j) == VP_BASIS_CONST) continue;
+            T *p = a.Phi_out + (b * a.n_phi_cols + col) * (int64_t)m;
+            store_rows<T, R>(p, m, lane, vec_aligned<T>(p, m), A[j]);
+            ++col;
+        }
+    }
+    if (a.dPhi_out) {
+#pragma unroll
+        for (int pidx = 0; pidx < P; ++pidx) {
+            T *p = a.dPhi_out + (b * P + pidx) * (int64_t)m;
+            store_rows<T, R>(p, m, lane, vec_aligned<T>(p, m), D[pidx]);
+        }
+    }
+}
+
+// ---- host-side launch templates ------------------------------------------------------------------
+template <class M> inline bool bind_model(const vp_model_desc &d, M &out) {
+    if constexpr (M::kStatic) {
+        (void)d;
+        (void)out;
+        return true;
+    } else {
+        return make_rt_model(d, out);
+    }
+}
+
+template <typename T, class M, int R> int launch_evaluate(const LaunchParams &p) {
+    EvalArgs<T, M> a;
+    if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+    a.t = (const T *)p.t;
+    a.w = (const T *)p.w;
+    a.yw = (const T *)p.yw;
+    a.alpha = (const T *)p.alpha;
+    a.r_out = (T *)p.r_out;
+    a.J_out = (T *)p.J_out;
+    a.C_out = (T *)p.C_out;
+    a.cost_out = p.cost_out;
+    a.status = p.status;
+    a.m = p.m;
+    a.S = p.S;
+    a.nprob = p.B * p.S;
+    a.t_stride = p.t_stride;
+    a.w_stride = p.w_stride;
+    a.eps = (T)p.eps;
+    if (a.nprob <= 0) return VP_ERR_OK;
+    dim3 grid((unsigned)a.nprob), block(64);
+    if (p.J_out) hipLaunchKernelGGL((evaluate_kernel<T, M, R, 2>), grid, block, 0, p.stream, a);
+    else if (p.r_out) hipLaunchKernelGGL((evaluate_kernel<T, M, R, 1>), grid, block, 0, p.stream, a);
+    else hipLaunchKernelGGL((evaluate_kernel<T, M, R, 0>), grid, block, 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+template <typename T, class M, int R> int launch_basis(const LaunchParams &p) {
+    BasisArgs<T, M> a;
+    if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+    a.t = (const T *)p.t;
+    a.alpha = (const T *)p.alpha;
+    a.Phi_out = (T *)p.Phi_out;
+    a.dPhi_out = (T *)p.dPhi_out;
+    a.m = p.m;
+    a.skip_invariant = (p.basis_flags & VP_BASIS_SKIP_INVARIANT) ? 1 : 0;
+    int ncols = 0;
+    for (int j = 0; j < p.model->n_basis; ++j)
+        if (!(a.skip_invariant && p.model->kind[j] == VP_BASIS_CONST)) ++ncols;
+    a.n_phi_cols = ncols;
+    a.B = p.B;
+    a.t_stride = p.t_stride;
+    if (a.B <= 0) return VP_ERR_OK;
+    hipLaunchKernelGGL((basis_kernel<T, M, R>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+} // namespace vp

@@ -1,0 +1,35 @@
+// vp_registry.hpp -- table of compiled kernel instantiations and its lookup.
+#pragma once
+#include <vector>
+
+#include "vp_kernels.hpp"
+
+namespace vp {
+
+typedef int (*launch_fn)(const LaunchParams &);
+
+enum { FAMILY_MULTIEXP = 1, FAMILY_RT = 2 };
+
+struct KernelEntry {
+    int dtype;  // VP_F64 / VP_F32
+    int family; // FAMILY_*
+    int a, b, c; // MULTIEXP: (nexp, offset, 0)   RT: (n, q, p)
+    int R;      // rows per lane; handles m <= 64*R
+    launch_fn evaluate;
+    launch_fn basis;
+    launch_fn fit;      // may be null
+    launch_fn best_fit; // may be null
+};
+
+std::vector<KernelEntry> &registry();
+
+struct Registrar {
+    explicit Registrar(const KernelEntry &e) { registry().push_back(e); }
+};
+
+// classify a public descriptor; returns family and its key (a,b,c); p_out = number of dependency pairs
+int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out);
+
+const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m);
+
+} // namespace vp

@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's model layer for the GPU path.
+
+Reference: ``SeparableModelBuilder`` (src/model/builder/mod.rs:252-272, methods :338-525, validity
+check :535-571), ``SeparableModel`` (src/model/mod.rs:367-517) and the plugin trait
+``SeparableNonlinearModel`` (src/model/mod.rs:239-363).
+
+The reference hands the solver opaque Rust closures; those cannot run on a GPU.  The
+drop-in replaces "closure" by "basis kind" from a closed descriptor language (``basis.*``), keeping
+the builder's call sequence, argument meaning and error variants: ``function(params, kind)`` /
+``partial_deriv(param)`` / ``invariant_function(kind)`` / ``independent_variable(x)`` /
+``initial_parameters(p)`` / ``build()``.  Derivatives are built into each kind; ``partial_deriv``
+only declares (and validates) that the derivative is provided, exactly where the reference takes
+the derivative closure.
+"""
+import numpy as np
+
+from . import _lib
+
+
+class basis:
+    """basis-function kinds (include/varpro_hip.h): f(t, p0[, p1])"""
+    CONST = 0       # 1                     (invariant_function)
+    EXP_DECAY = 1   # exp(-t/p0)            shared_test_code/src/lib.rs:101-114
+    EXP_RATE = 2    # exp(-p0 t)
+    EXP_COS = 3     # exp(-p0 t) cos(p1 t)  shared_test_code/src/models.rs:310-372
+    SIN_PHASE = 4   # sin(p0 t + p1)        src/test_helpers/mod.rs:28-52
+    ARITY = {CONST: 0, EXP_DECAY: 1, EXP_RATE: 1, EXP_COS: 2, SIN_PHASE: 2}
+    NAME = {CONST: "const", EXP_DECAY: "exp_decay", EXP_RATE: "exp_rate", EXP_COS: "exp_cos", SIN_PHASE: "sin_phase"}
+
+
+class ModelBuildError(ValueError):
+    """mirrors varpro::model::builder::error::ModelBuildError (src/model/builder/error.rs)"""
+
+    def __init__(self, variant, message):
+        super().__init__("%s: %s" % (variant, message))
+        self.variant = variant
+
+
+class ModelError(RuntimeError):
+    """mirrors varpro::model::errors::ModelError (derivative index out of bounds etc.)"""
+
+
+class SeparableModel:
+    """A separable model  f(x, alpha, c) = sum_j c_j phi_j(x, alpha)  described by basis kinds.
+
+    Implements the ``SeparableNonlinearModel`` surface: ``parameter_count``, ``base_function_count``,
+    ``output_len``, ``set_params``, ``params``, ``eval``, ``eval_partial_deriv`` (the last two run
+    the stand-alone Phi kernel, ``vp_basis``).
+    """
+
+    def __init__(self, parameter_names, kinds, params, x, initial_parameters, dtype=np.float64):
+        self.parameter_names = list(parameter_names)
+        self.kinds = [int(k) for k in kinds]
+        self.param_indices = [tuple(int(i) for i in p) for p in params]
+        self.n_params = len(self.parameter_names)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise TypeError("ScalarType must be float64 or float32")
+        self.x = np.ascontiguousarray(x, dtype=self.dtype).reshape(-1)
+        self._alpha = np.ascontiguousarray(initial_parameters, dtype=self.dtype).reshape(-1)
+        # dependency pairs in model order (basis-major): the layout of vp_basis' dPhi output
+        self.pairs = [(j, a, pi) for j, ps in enumerate(self.param_indices) for a, pi in enumerate(ps)]
+
+    # -- SeparableNonlinearModel surface (src/model/mod.rs:256-271) --
+    def parameter_count(self):
+        return self.n_params
+
+    def base_function_count(self):
+        return len(self.kinds)
+
+    def output_len(self):
+        return int(self.x.size)
+
+    def set_params(self, parameters):
+        p = np.ascontiguousarray(parameters, dtype=self.dtype).reshape(-1)
+        if p.size != self.n_params:
+            raise ModelError("IncorrectParameterCount: expected %d, got %d" % (self.n_params, p.size))
+        self._alpha = p.copy()
+
+    def params(self):
+        return self._alpha.copy()
+
+    def desc(self):
+        d = _lib.ModelDesc()
+        d.n_basis = len(self.kinds)
+        d.n_params = self.n_params
+        for j in range(_lib.VP_MAX_BASIS):
+            d.kind[j] = 0
+            for a in range(_lib.VP_MAX_BASIS_PARAMS):
+                d.param[j][a] = -1
+        for j, (k, ps) in enumerate(zip(self.kinds, self.param_indices)):
+            d.kind[j] = k
+            for a, pi in enumerate(ps):
+                d.param[j][a] = pi
+        return d
+
+    def _basis(self):
+        from .batch import BatchProblem
+        # a data-free handle is enough for the Phi kernel; y is a dummy column
+        bp = BatchProblem(self, np.zeros((1, self.x.size), dtype=self.dtype), x=self.x)
+        return bp.basis(self._alpha.reshape(1, -1))
+
+    def eval(self):
+        """Phi(alpha): (m, n) matrix, column j = basis j  (src/model/mod.rs:308)"""
+        phi, _ = self._basis()
+        return np.ascontiguousarray(phi[0].T)
+
+    def eval_partial_deriv(self, derivative_index):
+        """dPhi/dalpha_k: (m, n), zero columns for independent basis functions (src/model/mod.rs:359-362)"""
+        k = int(derivative_index)
+        if k < 0 or k >= self.n_params:
+            raise ModelError("DerivativeIndexOutOfBounds: %d" % k)
+        _, dphi = self._basis()
+        out = np.zeros((self.x.size, len(self.kinds)), dtype=self.dtype)
+        for p, (j, _a, pi) in enumerate(self.pairs):
+            if pi == k:
+                out[:, j] += dphi[0, p]
+        return out
+
+
+class SeparableModelBuilder:
+    """mirrors ``SeparableModelBuilder`` (src/model/builder/mod.rs:338-525)"""
+
+    def __init__(self, parameter_names, dtype=np.float64):
+        self._error = None
+        self._names = list(parameter_names)
+        self._dtype = dtype
+        self._functions = []  # dicts: params(list of names), kind, derivs(set)
+        self._x = None
+        self._initial = None
+        self._building = False  # state FunctionBuilding
+        if len(self._names) == 0:
+            self._fail("EmptyParameters", "A function or model parameter list is empty!")
+        elif len(set(self._names)) != len(self._names):
+            self._fail("DuplicateParameterNames", "Parameter list %r contains duplicates!" % (self._names,))
+        elif any("," in n for n in self._names):
+            self._fail("CommaInParameterNameNotAllowed", "Parameter names may not contain comma separator")
+
+    @classmethod
+    def new(cls, parameter_names, dtype=np.float64):
+        return cls(parameter_names, dtype)
+
+    def _fail(self, variant, msg):
+        if self._error is None:
+            self._error = ModelBuildError(variant, msg)
+        return self
+
+    def invariant_function(self, kind=basis.CONST):
+        if self._error:
+            return self
+        if basis.ARITY.get(kind) != 0:
+            return self._fail("IncorrectParameterCount", "invariant function takes no parameters")
+        self._functions.append(dict(params=[], kind=kind, derivs=set()))
+        self._building = False
+        return self
+
+    def function(self, function_params, kind):
+        if self._error:
+            return self
+        fp = list(function_params)
+        if len(fp) == 0:
+            return self._fail("EmptyParameters", "A function or model parameter list is empty!")
+        if len(set(fp)) != len(fp):
+            return self._fail("DuplicateParameterNames", "Parameter list %r contains duplicates!" % (fp,))
+        for p in fp:
+            if p not in self._names:
+                return self._fail("FunctionParameterNotInModel",
+                                  "Function parameter '%s' is not part of the model parameters." % p)
+        if kind not in basis.ARITY:
+            return self._fail("IncorrectParameterCount", "unknown basis kind %r" % (kind,))
+        if basis.ARITY[kind] != len(fp):
+            return self._fail("IncorrectParameterCount", "Incorrect number of parameters for function: expected %d, "
+                              "got %d" % (basis.ARITY[kind], len(fp)))
+        self._functions.append(dict(params=fp, kind=kind, derivs=set()))
+        self._building = True
+        return self
+
+    def partial_deriv(self, parameter, _derivative=None):
+        if self._error:
+            return self
+        if not self._building:
+            return self._fail("IllegalCallToPartialDeriv", "a call to this function can only follow a call to "
+                              "'function' or another call to 'partial_deriv'")
+        f = self._functions[-1]
+        if parameter not in f["params"]:
+            return self._fail("InvalidDerivative", "Parameter '%s' given for partial derivative does not exist in "
+                              "parameter list '%r'." % (parameter, f["params"]))
+        if parameter in f["derivs"]:
+            return self._fail("DuplicateDerivative", "Derivative for parameter '%s' was already provided!" % parameter)
+        f["derivs"].add(parameter)
+        return self
+
+    def independent_variable(self, x):
+        if self._error:
+            return self
+        self._x = np.asarray(x)
+        self._building = False
+        return self
+
+    def initial_parameters(self, initial):
+        if self._error:
+            return self
+        init = np.asarray(initial, dtype=np.float64).reshape(-1)
+        if init.size != len(self._names):
+            return self._fail("IncorrectParameterCount", "Incorrect number of parameters for function: expected %d, "
+                              "got %d" % (len(self._names), init.size))
+        self._initial = init
+        self._building = False
+        return self
+
+    def build(self):
+        if self._error:
+            raise self._error
+        if not self._functions:
+            raise ModelBuildError("EmptyModel", "Tried to construct model with no functions.")
+        for f in self._functions:
+            for p in f["params"]:
+                if p not in f["derivs"]:
+                    raise ModelBuildError("MissingDerivative", "Function with paramter list %r is missing derivative "
+                                          "for parametr '%s'." % (f["params"], p))
+        used = set(p for f in self._functions for p in f["params"])
+        for n in self._names:
+            if n not in used:
+                raise ModelBuildError("UnusedParameter", "Model depends on parameter '%s', but none of its functions "
+                                      "use it." % n)
+        if self._x is None:
+            raise ModelBuildError("MissingX", "Missing vector for independent variable x")
+        if self._initial is None:
+            raise ModelBuildError("MissingInitialParameters", "Missing initial guesses for model parameters")
+        if len(self._functions) > _lib.VP_MAX_BASIS or len(self._names) > _lib.VP_MAX_PARAMS:
+            raise ModelBuildError("IncorrectParameterCount", "model exceeds VP_MAX_BASIS/VP_MAX_PARAMS")
+        kinds = [f["kind"] for f in self._functions]
+        params = [tuple(self._names.index(p) for p in f["params"]) for f in self._functions]
+        return SeparableModel(self._names, kinds, params, self._x, self._initial, dtype=self._dtype)
+
+
+def multi_exponential_model(x, initial_taus, offset=True, dtype=np.float64):
+    """sum of exponential decays exp(-x/tau_j) (+ constant): the model family of every bench in the
+    reference (shared_test_code/src/lib.rs:119-135, shared_test_code/src/models.rs:16-156)."""
+    taus = list(np.asarray(initial_taus, dtype=np.float64).reshape(-1))
+    names = ["tau%d" % (i + 1) for i in range(len(taus))]
+    b = SeparableModelBuilder(names, dtype=dtype)
+    for nme in names:
+        b = b.function([nme], basis.EXP_DECAY).partial_deriv(nme)
+    if offset:
+        b = b.invariant_function(basis.CONST)
+    return b.independent_variable(x).initial_parameters(taus).build()
