@@ -87,7 +87,8 @@ typedef struct vp_model_desc {
 enum {
     VP_FLAG_DEVICE_PTRS = 1 << 0,   /* every data pointer passed for this handle is a device pointer */
     VP_FLAG_T_PER_PROBLEM = 1 << 1, /* t is [B][m] instead of [m] */
-    VP_FLAG_W_PER_PROBLEM = 1 << 2  /* w is [B][m] instead of [m] */
+    VP_FLAG_W_PER_PROBLEM = 1 << 2, /* w is [B][m] instead of [m] */
+    VP_FLAG_OWN_STREAM = 1 << 3     /* ignore hip_stream and run on a private non-blocking stream */
 };
 
 /* per-problem status word (0 == the reference's `cached = Some(..)`) */
@@ -167,7 +168,9 @@ typedef struct vp_batch vp_batch;
  * Validates shapes, stores Y_w = W*Y (src/problem/builder.rs:307), default epsilon
  * = machine epsilon of dtype when svd_epsilon < 0 (src/problem/builder.rs:282).
  * Unlike build() it does NOT run the initial set_params (there is no alpha yet);
- * vp_set_params / vp_fit do.  `hip_stream` may be NULL (the library creates one).
+ * vp_set_params / vp_fit do.  `hip_stream` is the hipStream_t all work of this handle is
+ * enqueued on; NULL means the HIP null (default) stream -- which is what PyTorch's default
+ * stream is -- unless VP_FLAG_OWN_STREAM asks for a private stream.
  */
 int vp_batch_create(vp_batch **h, const vp_model_desc *model, int dtype, int64_t m, int64_t S, int64_t B,
                     const void *t, const void *Y, const void *w, double svd_epsilon, int flags, int device,
@@ -244,6 +247,16 @@ void vp_lm_opts_default(vp_lm_opts *opts, int dtype);
  * the handle's cached state corresponds to the final parameters.
  */
 int vp_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep);
+
+/*
+ * Diagnostics for the per-iteration parity tests: vp_fit that additionally
+ * records, per problem, one row [alpha_trial(q), ||r(alpha_trial)||, ratio, delta, par] for every
+ * evaluation of the LM loop (row 0: the initial point, ratio = NaN) into
+ * trace_out [B][trace_rows][q+4] (f64; rows never written are NaN).  Same address space as the
+ * other pointers of the handle.
+ */
+int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep,
+                 double *trace_out, int trace_rows);
 
 /* == FitResult::best_fit (src/fit.rs:55-59,87-91): UNWEIGHTED Phi(alpha) * C, [B][S][m] */
 int vp_best_fit(vp_batch *h, void *fit_out);

@@ -70,6 +70,8 @@ def _load():
     lib.vpo_best_fit.argtypes = [C.c_void_p, dp]
     lib.vpo_best_fit.restype = C.c_int
     lib.vpo_fit.argtypes = [C.c_void_p, C.POINTER(LmOpts), C.POINTER(Report)]
+    lib.vpo_fit_trace.argtypes = [C.c_void_p, C.POINTER(LmOpts), C.POINTER(Report), dp, C.c_int]
+    lib.vpo_fit_trace.restype = C.c_int
     lib.vpo_thin_svd.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp]
     lib.vpo_enorm.argtypes = [C.c_int, dp]
     lib.vpo_enorm.restype = C.c_double
@@ -213,6 +215,14 @@ class Problem:
         rep = Report()
         lib().vpo_fit(self._h, C.byref(opts), C.byref(rep))
         return rep
+
+    def fit_trace(self, opts=None, max_rows=512):
+        """fit and return (report, trace[rows, q+4]) with rows [x_trial, ||r||, ratio, delta, par]"""
+        opts = opts or default_opts()
+        rep = Report()
+        tr = np.zeros((max_rows, self.q + 4))
+        n = lib().vpo_fit_trace(self._h, C.byref(opts), C.byref(rep), _dp(tr), max_rows)
+        return rep, tr[:n]
 
     def counters(self):
         st = self._struct()

@@ -627,7 +627,24 @@ void vpo_lm_opts_default(vp_lm_opts *o) {
     o->scale_diag = 1;
 }
 
-void vpo_fit(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep) {
+static void trace_row(double *trace, int max_rows, int *row, int n, const double *xt, double fnorm1, double ratio,
+                      double delta, double par) {
+    if (!trace || *row >= max_rows) return;
+    double *t = trace + (size_t)(*row) * (n + 4);
+    for (int j = 0; j < n; ++j) t[j] = xt[j];
+    t[n] = fnorm1;
+    t[n + 1] = ratio;
+    t[n + 2] = delta;
+    t[n + 3] = par;
+    ++*row;
+}
+
+void vpo_fit(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep) { vpo_fit_trace(p, opts, rep, NULL, 0); }
+
+/* same as vpo_fit; additionally records one row [x_trial(q), ||r(x_trial)||, ratio, delta, par] per
+ * evaluation (row 0: the initial point with ratio = NaN) -- used by the per-iteration parity tests */
+int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double *trace, int max_rows) {
+    int trow = 0;
     const int n = p->model.n_params;       /* LM "n" = number of parameters q */
     const int mr = p->m * p->S;            /* LM "m" = number of residuals */
     const double epsmch = DBL_EPSILON;
@@ -655,6 +672,7 @@ void vpo_fit(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep) {
     }
     fnorm = vpo_enorm(mr, fvec);
     report.objective = 0.5 * fnorm * fnorm;
+    trace_row(trace, max_rows, &trow, n, x, fnorm, NAN, 0.0, 0.0);
     if (mr == 0) {
         report.termination = VP_TERM_NO_RESIDUALS;
         goto done;
@@ -778,6 +796,7 @@ void vpo_fit(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep) {
                 par *= 0.5;
             }
             int good = ratio >= 1.0e-4;
+            trace_row(trace, max_rows, &trow, n, xt, fnorm1, ratio, delta, par);
             if (good) {
                 memcpy(x, xt, sizeof(double) * n);
                 if (opts->scale_diag) {
@@ -821,6 +840,7 @@ done:
     free(fjac);
     free(fwork);
     if (rep) *rep = report;
+    return trow;
 }
 
 /* ------------------------------------------------------------------------------------------- */

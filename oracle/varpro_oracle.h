@@ -81,6 +81,8 @@ int vpo_best_fit(const vpo_problem *p, double *fit_out);
 
 /* == LevMarSolver::fit -> LevenbergMarquardt::minimize (src/solvers/levmar/mod.rs:238-254) */
 void vpo_fit(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep);
+/* vpo_fit + per-evaluation trace rows [x_trial(q), ||r||, ratio, delta, par]; returns rows written */
+int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double *trace, int max_rows);
 
 /* thin SVD A (m x n, col-major, m >= n) = U diag(sigma) V^T, sigma descending */
 void vpo_thin_svd(int m, int n, const double *A, double *U, double *sigma, double *V);

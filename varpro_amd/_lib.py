@@ -20,7 +20,7 @@ VP_MAX_BASIS_PARAMS = 2
 VP_MAX_PAIRS = 16
 
 VP_F64, VP_F32 = 0, 1
-VP_FLAG_DEVICE_PTRS, VP_FLAG_T_PER_PROBLEM, VP_FLAG_W_PER_PROBLEM = 1, 2, 4
+VP_FLAG_DEVICE_PTRS, VP_FLAG_T_PER_PROBLEM, VP_FLAG_W_PER_PROBLEM, VP_FLAG_OWN_STREAM = 1, 2, 4, 8
 VP_BASIS_SKIP_INVARIANT = 1
 VP_KERNEL_EVALUATE, VP_KERNEL_BASIS, VP_KERNEL_FIT = 0, 1, 2
 
@@ -32,7 +32,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvarpro_hip.so")
 # every symbol include/varpro_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "vp_batch_create", "vp_batch_destroy", "vp_set_params", "vp_params", "vp_residuals", "vp_jacobian",
-    "vp_linear_coeffs", "vp_weighted_data", "vp_cost", "vp_evaluate", "vp_basis", "vp_lm_opts_default", "vp_fit",
+    "vp_linear_coeffs", "vp_weighted_data", "vp_cost", "vp_evaluate", "vp_basis", "vp_lm_opts_default", "vp_fit", "vp_fit_trace",
     "vp_best_fit", "vp_summary", "vp_set_timing", "vp_last_kernel_ms", "vp_synchronize", "vp_last_error",
     "vp_last_error_detail", "vp_version", "vp_device_count",
 ]
@@ -106,6 +106,7 @@ def load():
     lib.vp_lm_opts_default.argtypes = [C.POINTER(LmOpts), C.c_int]
     lib.vp_lm_opts_default.restype = None
     lib.vp_fit.argtypes = [vp, C.POINTER(LmOpts), vp, vp, vp]
+    lib.vp_fit_trace.argtypes = [vp, C.POINTER(LmOpts), vp, vp, vp, vp, C.c_int]
     lib.vp_best_fit.argtypes = [vp, vp]
     lib.vp_summary.argtypes = [vp, dp]
     lib.vp_set_timing.argtypes = [vp, C.c_int]

@@ -113,7 +113,9 @@ class BatchProblem:
         x = self._as_array(x)
         flags = 0
         if self.device_mode:
-            flags |= _lib.VP_FLAG_DEVICE_PTRS
+            flags |= _lib.VP_FLAG_DEVICE_PTRS  # work is enqueued on torch's current stream
+        else:
+            flags |= _lib.VP_FLAG_OWN_STREAM
         if x.ndim == 2:
             flags |= _lib.VP_FLAG_T_PER_PROBLEM
             if tuple(x.shape) != (self.B, self.m):
@@ -274,6 +276,20 @@ class BatchProblem:
             rep = np.zeros(self.B, dtype=REPORT_DTYPE)
             check(self.lib.vp_fit(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), C.c_void_p(rep.ctypes.data)))
         return a, Cm, rep
+
+    def fit_trace(self, alpha0, solver=None, max_rows=512):
+        """diagnostics (host mode only): fit + per-evaluation trace (B, max_rows, q+4) with rows
+        [alpha_trial, ||r||, ratio, delta, par]; unused rows are NaN"""
+        assert not self.device_mode
+        solver = solver or LevenbergMarquardt(self.np_dtype)
+        opts = solver._c()
+        a = self._as_array(alpha0).reshape(self.B, self.q).copy()
+        Cm = self._empty((self.B, self.n))
+        rep = np.zeros(self.B, dtype=REPORT_DTYPE)
+        tr = np.zeros((self.B, max_rows, self.q + 4))
+        check(self.lib.vp_fit_trace(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), C.c_void_p(rep.ctypes.data),
+                                    C.c_void_p(tr.ctypes.data), int(max_rows)))
+        return a, Cm, rep, tr
 
     @staticmethod
     def report_to_numpy(rep):

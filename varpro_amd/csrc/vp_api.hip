@@ -350,8 +350,8 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     const double meps = dtype == VP_F32 ? (double)FLT_EPSILON : DBL_EPSILON;
     h->eps = svd_epsilon < 0 ? meps : std::fabs(svd_epsilon); // src/problem/builder.rs:246-251, 282
     h->kern = kern;
-    if (hip_stream) {
-        h->stream = (hipStream_t)hip_stream;
+    if (!(flags & VP_FLAG_OWN_STREAM)) {
+        h->stream = (hipStream_t)hip_stream; // NULL == the null stream (PyTorch's default stream)
         h->own_stream = false;
     } else {
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -428,7 +428,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
 void vp_batch_destroy(vp_batch *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_t);
     (void)hipFree(h->d_w);
     (void)hipFree(h->d_yw);
@@ -575,6 +575,11 @@ int vp_basis(vp_batch *h, const void *alpha, void *Phi_out, void *dPhi_out, int 
 }
 
 int vp_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep) {
+    return vp_fit_trace(h, opts, alpha_inout, C_out, rep, nullptr, 0);
+}
+
+int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep,
+                 double *trace_out, int trace_rows) {
     if (int rc = check_handle(h)) return rc;
     if (!alpha_inout) return fail(VP_ERR_INVALID, "null alpha");
     if (h->S != 1) return fail(VP_ERR_UNSUPPORTED, "vp_fit with S > 1 (MRHS global fit) is not built yet");
@@ -593,6 +598,14 @@ int vp_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, 
     p.status = h->d_status_bs;
     p.report = h->d_report;
     p.opts = &o;
+    OutBuf tr;
+    const size_t tr_bytes = (size_t)h->B * (size_t)(trace_rows > 0 ? trace_rows : 0) * (h->q + 4) * sizeof(double);
+    if (trace_out && trace_rows > 0) {
+        if (int rc = tr.init(h, trace_out, tr_bytes)) return rc;
+        VP_HIP(hipMemsetAsync(tr.dptr, 0xFF, tr_bytes, h->stream)); // NaN-fill: unused rows read as NaN
+        p.trace = (double *)tr.dptr;
+        p.trace_rows = trace_rows;
+    }
     Timer tm(h, VP_KERNEL_FIT);
     int rc = h->kern->fit(p);
     tm.stop();
@@ -603,6 +616,7 @@ int vp_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, 
     if (int rc2 = copy_out(h, alpha_inout, h->d_alpha, (size_t)h->B * h->q * ts)) return rc2;
     if (int rc2 = copy_out(h, C_out, h->d_C, (size_t)h->B * h->n * ts)) return rc2;
     if (int rc2 = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc2;
+    if (int rc2 = tr.finish(h)) return rc2;
     return VP_ERR_OK;
 }
 

@@ -360,6 +360,8 @@ template <typename T, class M> struct FitArgs {
     T ftol, xtol, gtol, stepbound;
     int patience;
     int scale_diag;
+    double *trace;  // diagnostics (vp_fit_trace): [B][trace_rows][q+4] or null
+    int trace_rows;
 };
 
 template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_kernel(const FitArgs<T, M> a) {
@@ -415,6 +417,19 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_
     int st_best = VP_ST_NOT_EVALUATED;
     const int max_fev = a.patience * (Q + 1);
     const int mres = m; // number of residuals (S == 1)
+    int trow = 0;
+    auto trace_row = [&](const T(&xx)[Q], T fn, T ratio) {
+        if (a.trace && trow < a.trace_rows && lane == 0) {
+            double *tr = a.trace + ((size_t)b * a.trace_rows + trow) * (Q + 4);
+#pragma unroll
+            for (int k = 0; k < Q; ++k) tr[k] = (double)xx[k];
+            tr[Q] = (double)fn;
+            tr[Q + 1] = (double)ratio;
+            tr[Q + 2] = (double)delta;
+            tr[Q + 3] = (double)par;
+        }
+        ++trow;
+    };
 
     for (;;) {
         // ================= evaluate the VarPro functional at xt =================
@@ -439,6 +454,7 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_
             }
             fnorm = fnorm1;
             objective = T(0.5) * fnorm * fnorm;
+            trace_row(xt, fnorm1, T(0) / T(0));
 #pragma unroll
             for (int k = 0; k < N; ++k) cbest[k] = u.c[k];
             if (Q > mres) {
@@ -479,6 +495,7 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_
                 par = par * T(0.5);
             }
             const bool good = uni(ratio >= T(1.0e-4));
+            trace_row(xt, fnorm1, ratio);
             if (good) {
 #pragma unroll
                 for (int k = 0; k < Q; ++k) x[k] = xt[k];
@@ -637,6 +654,8 @@ template <typename T, class M, int R> int launch_fit(const LaunchParams &p) {
     a.stepbound = (T)p.opts->stepbound;
     a.patience = p.opts->patience;
     a.scale_diag = p.opts->scale_diag;
+    a.trace = p.trace;
+    a.trace_rows = p.trace_rows;
     if (a.B <= 0) return VP_ERR_OK;
     const size_t lds = (size_t)3 * 64 * R * sizeof(T);
     hipLaunchKernelGGL((fit_kernel<T, M, R>), dim3((unsigned)a.B), dim3(64), lds, p.stream, a);

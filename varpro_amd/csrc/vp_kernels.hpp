@@ -27,6 +27,8 @@ struct LaunchParams {
     void *dPhi_out;     // basis: [B][p][m]
     vp_report *report;  // fit: [B]
     const vp_lm_opts *opts;
+    double *trace;      // fit diagnostics: [B][trace_rows][q+4] or NULL
+    int trace_rows;
     int basis_flags;
     int m;
     int S;
