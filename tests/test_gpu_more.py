@@ -1,0 +1,264 @@
+"""More GPU parity coverage through the C ABI: multiple right-hand sides, other model families, per-problem
+grids/weights, failure latching, the alternative LM kernel, exp accuracy, device-pointer mode."""
+import os
+
+import numpy as np
+import pytest
+
+import refdata as rd
+import varpro_amd as vp
+from models import double_exp_builder_model, numpy_reference_eval
+from oracle import oracle as O
+from varpro_amd import basis, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def test_mrhs_trait_level_matches_oracle_both_branches():
+    # tests/integration_tests/main.rs:399-551 inputs: S=2 (branch S<=q) and S=3 (branch S>q of
+    # src/solvers/levmar/mod.rs:156-186); layout (m*S) x q column-major, RHS s at rows s*m..
+    x = synth.linspace_reference(0., 12.5, 20)
+    coeffs = {2: [(2., 4., 0.2), (5., 1., 9.)], 3: [(2., 4., 0.2), (10., 12., 18.), (5., 1., 9.)]}
+    for S, cs in coeffs.items():
+        Y = np.stack([a * np.exp(-x / 1.) + b * np.exp(-x / 3.) + c for a, b, c in cs], axis=1)  # m x S
+        mdl = double_exp_builder_model(x, [2.5, 6.5])
+        prob = vp.SeparableProblemBuilder.mrhs(mdl).observations(Y).build()
+        ref = O.Problem(mdl, x, Y.T.copy())
+        ref.set_params([2.5, 6.5])
+        C = prob.linear_coefficients()
+        assert C.shape == (3, S)
+        assert np.abs(C.T - ref.linear_coefficients()).max() <= TOL * np.abs(C).max()
+        r = prob.residuals()
+        assert r.shape == (20 * S,)
+        assert np.abs(r - ref.residuals()).max() <= TOL * np.abs(Y).max()
+        J = prob.jacobian()
+        assert J.shape == (20 * S, 2)
+        Jr = ref.jacobian()
+        for k in range(2):
+            assert np.abs(J[:, k] - Jr[k]).max() <= TOL * np.abs(Jr[k]).max()
+        assert np.allclose(prob.weighted_data(), Y)
+        prob.close()
+
+
+def test_mrhs_batch_cost_and_status_reduce_over_rhs():
+    rng = np.random.default_rng(3)
+    x = np.linspace(0, 10, 64)
+    B, S = 4, 5
+    mdl = double_exp_builder_model(x, [1.0, 4.0])
+    Y = rng.uniform(1, 2, (B, S, 1)) * np.exp(-x / 1.3) + rng.uniform(0, 1, (B, S, 1)) * np.exp(-x / 5.0) + 0.3
+    bp = vp.BatchProblem(mdl, Y, x=x)
+    alpha = np.tile([1.0, 4.0], (B, 1)) * (1 + 0.1 * rng.standard_normal((B, 2)))
+    ev = bp.evaluate(alpha)
+    for b in range(B):
+        ref = O.Problem(mdl, x, Y[b])
+        ref.set_params(alpha[b])
+        assert np.abs(ev["r"][b] - ref.residuals()).max() <= TOL * np.abs(Y[b]).max()
+        assert abs(ev["cost"][b] - 0.5 * (ref.residuals() ** 2).sum()) <= 1e-9 * ev["cost"][b]
+        assert np.abs(ev["C"][b] - ref.linear_coefficients()).max() <= TOL * np.abs(ev["C"][b]).max()
+    assert (ev["status"] == 0).all()
+    bp.close()
+
+
+@pytest.mark.parametrize("n_exp,offset,m", [(1, True, 100), (1, False, 1024), (2, False, 1024), (3, True, 1024),
+                                            (3, True, 57), (3, False, 64), (2, True, 2048)])
+def test_multiexp_family_evaluate_and_fit(n_exp, offset, m):
+    taus = [1.0, 3.0, 7.5][:n_exp]
+    d = synth.multi_exp_batch(12, n_exp, m, taus, noise=1e-3, spread=0.1, guess_spread=0.1)
+    if not offset:
+        d["Y"] = d["Y"] - d["c_true"][:, n_exp:n_exp + 1]
+    mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0], offset=offset)
+    bp = vp.BatchProblem(mdl, d["Y"], x=d["x"])
+    ev = bp.evaluate(d["tau_guess"])
+    ref = O.evaluate_batch(mdl, d["x"], d["Y"], d["tau_guess"], n_threads=4)
+    assert (ev["status"] == 0).all()
+    for b in range(12):
+        assert np.abs(ev["C"][b] - ref["C"][b]).max() <= 1e-9 * np.abs(ref["C"][b]).max()
+        assert np.abs(ev["r"][b] - ref["r"][b]).max() <= TOL * np.abs(d["Y"][b]).max()
+        for k in range(n_exp):
+            assert np.abs(ev["J"][b, k] - ref["J"][b, k]).max() <= 1e-9 * np.abs(ref["J"][b, k]).max()
+    alpha, C, rep = bp.fit(d["tau_guess"])
+    a_ref, C_ref, rep_ref, _ = O.fit_batch(mdl, d["x"], d["Y"], d["tau_guess"], n_threads=4)
+    ok = (rep_ref["termination"] > 0) & (rep["termination"] > 0)
+    assert ok.mean() >= 0.75
+    rel_o = np.abs(rep["objective"] - rep_ref["objective"])[ok] / rep_ref["objective"][ok]
+    assert np.median(rel_o) <= 1e-10
+    bp.close()
+
+
+def test_per_problem_grids_and_weights():
+    rng = np.random.default_rng(11)
+    B, m = 6, 200
+    X = np.sort(rng.uniform(0, 12, (B, m)), axis=1)
+    W = 0.5 + rng.random((B, m))
+    tau = np.stack([rng.uniform(0.5, 2, B), rng.uniform(3, 8, B)], 1)
+    Y = 3 * np.exp(-X / tau[:, :1]) + 2 * np.exp(-X / tau[:, 1:]) + 1 + 1e-3 * rng.standard_normal((B, m))
+    alpha = tau * 1.1
+    mdl = double_exp_builder_model(X[0], alpha[0])
+    bp = vp.BatchProblem(mdl, Y, x=X, weights=W)
+    ev = bp.evaluate(alpha)
+    a_fit, c_fit, rep = bp.fit(alpha)
+    for b in range(B):
+        ref = O.Problem(mdl, X[b], Y[b], w=W[b])
+        ref.set_params(alpha[b])
+        assert np.abs(ev["r"][b] - ref.residuals()).max() <= TOL * np.abs(Y[b] * W[b]).max()
+        assert np.abs(ev["C"][b] - ref.linear_coefficients()).max() <= TOL * np.abs(ev["C"][b]).max()
+        rr = ref.fit()
+        assert (rr.termination > 0) == (rep["termination"][b] > 0)
+        assert abs(rep["objective"][b] - rr.objective) <= 1e-8 * rr.objective
+    bp.close()
+
+
+def test_failures_are_latched_per_problem_and_do_not_abort_the_batch():
+    # == `cached = None` (src/solvers/levmar/mod.rs:61-72): one bad problem, the rest unaffected
+    d = synth.double_exp_batch(8, m=128, noise=1e-3)
+    Y = d["Y"].copy()
+    Y[3, 17] = np.nan
+    mdl = double_exp_builder_model(d["x"], d["tau_guess"][0])
+    bp = vp.BatchProblem(mdl, Y, x=d["x"])
+    alpha = d["tau_guess"].copy()
+    alpha[5] = [0.0, 3.0]  # exp(-t/0): non-finite basis column
+    ev = bp.evaluate(alpha)
+    assert ev["status"][3] != 0 and ev["status"][5] != 0
+    good = np.ones(8, bool)
+    good[[3, 5]] = False
+    assert (ev["status"][good] == 0).all()
+    ref = O.evaluate_batch(mdl, d["x"], Y, alpha, n_threads=2)
+    assert ((ref["status"] != 0) == (ev["status"] != 0)).all()
+    assert np.abs(ev["r"][good] - ref["r"][good]).max() <= TOL * np.abs(Y[good]).max()
+    bp.set_params(alpha)
+    _r, st = bp.residuals(with_status=True)
+    assert (np.asarray(st) != 0).tolist() == (~good).tolist()
+    a, c, rep = bp.fit(alpha)
+    assert rep["termination"][3] == -1 and rep["termination"][5] == -1  # TerminationReason::User
+    assert (rep["termination"][good] > 0).all()
+    # before any set_params the problem reports "not evaluated"
+    bp2 = vp.BatchProblem(mdl, Y, x=d["x"])
+    _r, st = bp2.residuals(with_status=True)
+    assert (np.asarray(st) == 2).all()
+    bp.close()
+    bp2.close()
+
+
+def test_multi_problem_per_wave_lm_kernel_agrees_with_default():
+    d = synth.double_exp_batch(200, m=1024, noise=1e-3)
+    mdl = double_exp_builder_model(d["x"], d["tau_guess"][0])
+    bp = vp.BatchProblem(mdl, d["Y"], x=d["x"])
+    a0, c0, r0 = bp.fit(d["tau_guess"])
+    try:
+        os.environ["VP_FIT_KERNEL"] = "mp"
+        for G in ("1", "7", "32"):
+            os.environ["VP_FIT_GROUP"] = G
+            a1, c1, r1 = bp.fit(d["tau_guess"])
+            assert (r1["termination"] > 0).tolist() == (r0["termination"] > 0).tolist()
+            ok = r0["termination"] > 0
+            rel = np.abs(r1["objective"] - r0["objective"])[ok] / r0["objective"][ok]
+            assert rel.max() <= 1e-6 and np.median(rel) <= 1e-12
+            assert abs(r1["n_evals"].mean() - r0["n_evals"].mean()) <= 0.1 * r0["n_evals"].mean()
+    finally:
+        os.environ.pop("VP_FIT_KERNEL", None)
+        os.environ.pop("VP_FIT_GROUP", None)
+    bp.close()
+
+
+def test_device_exp_accuracy_over_the_argument_range():
+    # exp(-t/tau) for arguments 0 .. -700: relative error <= 2 ulp against libm
+    m = 1024
+    x = np.linspace(0.0, 700.0, m)
+    mdl = (vp.SeparableModelBuilder(["tau"]).function(["tau"], basis.EXP_DECAY).partial_deriv("tau")
+           .independent_variable(x).initial_parameters([1.0]).build())
+    taus = np.array([[1.0], [0.37], [2.9], [123.456], [1e3]])
+    bp = vp.BatchProblem(mdl, np.zeros((taus.size, m)), x=x)
+    phi, dphi = bp.basis(taus)
+    for b, tau in enumerate(taus[:, 0]):
+        ref = np.exp(-x / tau)
+        nz = ref > 1e-300
+        rel = np.abs(phi[b, 0][nz] - ref[nz]) / ref[nz]
+        assert rel.max() <= 2 * 2.220446049250313e-16, (tau, rel.max())
+        refd = ref * x / (tau * tau)
+        assert np.abs(dphi[b, 0][nz] - refd[nz]).max() <= 4e-16 * np.abs(refd).max() + 4 * 2.3e-16 * np.abs(refd[nz]).max()
+    bp.close()
+
+
+def test_sin_phase_and_exp_rate_kinds():
+    rng = np.random.default_rng(2)
+    x = np.linspace(0, 4, 90)
+    mdl = (vp.SeparableModelBuilder(["omega", "phi", "k", "unused"])
+           .function(["omega", "phi"], basis.SIN_PHASE).partial_deriv("omega").partial_deriv("phi")
+           .function(["k"], basis.EXP_RATE).partial_deriv("k")
+           .function(["unused"], basis.EXP_DECAY).partial_deriv("unused")
+           .independent_variable(x).initial_parameters([2.0, 0.3, 0.7, 2.0]).build())
+    # n=3, q=4, p=4 -> RtModel<3,4,4> is not instantiated: must be reported, not silently mis-run
+    with pytest.raises(vp.VarproHipError) as e:
+        vp.BatchProblem(mdl, np.ones((1, 90)), x=x)
+    assert e.value.code == -2
+    mdl2 = (vp.SeparableModelBuilder(["omega", "phi", "k", "a"])
+            .function(["omega", "phi"], basis.SIN_PHASE).partial_deriv("omega").partial_deriv("phi")
+            .function(["k", "a"], basis.EXP_COS).partial_deriv("k").partial_deriv("a")
+            .independent_variable(x).initial_parameters([2.0, 0.3, 0.7, 1.1]).build())
+    y = 1.5 * np.sin(2.1 * x + 0.25) + 0.8 * np.exp(-0.6 * x) * np.cos(1.0 * x) + 0.01 * rng.standard_normal(x.size)
+    alpha = np.array([[2.0, 0.3, 0.7, 1.1]])
+    bp = vp.BatchProblem(mdl2, y[None, :], x=x)
+    ev = bp.evaluate(alpha)
+    c, r, J = numpy_reference_eval(mdl2, x, y, alpha[0])
+    assert np.abs(ev["C"][0] - c).max() <= 1e-9 * np.abs(c).max()
+    assert np.abs(ev["r"][0] - r).max() <= 1e-9 * np.abs(y).max()
+    for k in range(4):
+        assert np.abs(ev["J"][0, k] - J[k]).max() <= 1e-8 * np.abs(J[k]).max()
+    bp.close()
+
+
+def test_device_pointer_mode_with_torch_tensors():
+    import torch
+    d = synth.double_exp_batch(64, m=1024, noise=1e-3)
+    mdl = double_exp_builder_model(d["x"], d["tau_guess"][0])
+    dev = torch.device("cuda", 0)
+    Y = torch.from_numpy(d["Y"]).to(dev)
+    g = torch.from_numpy(d["tau_guess"]).to(dev)
+    bp_d = vp.BatchProblem(mdl, Y, x=torch.from_numpy(d["x"]).to(dev))
+    bp_h = vp.BatchProblem(mdl, d["Y"], x=d["x"])
+    ev_d = bp_d.evaluate(g)
+    ev_h = bp_h.evaluate(d["tau_guess"])
+    for k in ("r", "J", "C", "cost"):
+        assert isinstance(ev_d[k], torch.Tensor) and ev_d[k].is_cuda
+        assert np.array_equal(ev_d[k].cpu().numpy(), ev_h[k])
+    a_d, c_d, rep_d = bp_d.fit(g)
+    a_h, c_h, rep_h = bp_h.fit(d["tau_guess"])
+    assert np.array_equal(a_d.cpu().numpy(), a_h) and np.array_equal(c_d.cpu().numpy(), c_h)
+    rep_d = bp_d.report_to_numpy(rep_d)
+    assert np.array_equal(rep_d["n_evals"], rep_h["n_evals"])
+    assert np.allclose(bp_d.summary(), bp_h.summary(), rtol=1e-12)
+    bp_d.close()
+    bp_h.close()
+
+
+def test_large_batch_properties_at_full_size():
+    # BASELINE configs[1] at full size: size-independent properties instead of the (slow) oracle:
+    # P_perp idempotence/orthogonality:  r ⟂ range(Phi_w)  and  J_k ⟂ range(Phi_w);  cost = 1/2 |r|^2.
+    B, m = 4096, 1024
+    d = synth.double_exp_batch(B, m=m, noise=1e-3)
+    mdl = double_exp_builder_model(d["x"], d["tau_guess"][0])
+    bp = vp.BatchProblem(mdl, d["Y"], x=d["x"])
+    ev = bp.evaluate(d["tau_guess"])
+    phi, _ = bp.basis(d["tau_guess"])
+    assert (ev["status"] == 0).all()
+    ynorm = np.linalg.norm(d["Y"], axis=1)
+    pn = np.linalg.norm(phi, axis=2)  # (B, n)
+    ortho_r = np.abs(np.einsum("bjm,bm->bj", phi, ev["r"])) / (pn * ynorm[:, None])
+    assert ortho_r.max() <= 1e-12
+    jn = np.linalg.norm(ev["J"], axis=2)  # (B, q)
+    ortho_j = np.abs(np.einsum("bjm,bkm->bjk", phi, ev["J"])) / (pn[:, :, None] * jn[:, None, :])
+    assert ortho_j.max() <= 1e-9
+    assert np.abs(0.5 * (ev["r"] ** 2).sum(1) - ev["cost"]).max() <= 1e-12 * ev["cost"].max()
+    # y = Phi c + r exactly (linear sub-problem identity)
+    recon = np.einsum("bjm,bj->bm", phi, ev["C"]) + ev["r"]
+    assert np.abs(recon - d["Y"]).max() <= 1e-11 * np.abs(d["Y"]).max()
+    # the fit never increases the cost and converges for (nearly) all problems
+    a, c, rep = bp.fit(d["tau_guess"])
+    assert (rep["termination"] > 0).mean() > 0.99
+    ok = rep["termination"] > 0
+    assert (rep["objective"][ok] <= ev["cost"][ok] * (1 + 1e-12)).all()
+    s = bp.summary()
+    assert s[1] + s[2] == B and s[3] == rep["n_evals"].sum()
+    bp.close()

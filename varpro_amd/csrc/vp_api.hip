@@ -6,6 +6,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -583,7 +584,7 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
     if (int rc = check_handle(h)) return rc;
     if (!alpha_inout) return fail(VP_ERR_INVALID, "null alpha");
     if (h->S != 1) return fail(VP_ERR_UNSUPPORTED, "vp_fit with S > 1 (MRHS global fit) is not built yet");
-    if (!h->kern->fit) return fail(VP_ERR_UNSUPPORTED, "no fit kernel for this model");
+    if (!h->kern->fit && !h->kern->fit_single) return fail(VP_ERR_UNSUPPORTED, "no fit kernel for this model");
     vp_lm_opts o;
     if (opts) o = *opts;
     else vp_lm_opts_default(&o, h->dtype);
@@ -606,8 +607,15 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
         p.trace = (double *)tr.dptr;
         p.trace_rows = trace_rows;
     }
+    // The one-problem-per-wave kernel (vp_fit.hpp) is the default: measured 12.1 vs 8.5-9.8 Mfits/s for the
+    // multi-problem formulation (vp_fit_mp.hpp) on B = 65536 double-exponential fits.  Knobs for A/B runs:
+    // VP_FIT_KERNEL=mp selects the multi-problem kernel, VP_FIT_GROUP=<G> fixes its problems-per-wave.
+    launch_fn fit_fn = h->kern->fit_single ? h->kern->fit_single : h->kern->fit;
+    if (const char *e = std::getenv("VP_FIT_KERNEL"))
+        if (std::strcmp(e, "mp") == 0 && h->kern->fit) fit_fn = h->kern->fit;
+    if (const char *e = std::getenv("VP_FIT_GROUP")) p.fit_group = std::atoi(e);
     Timer tm(h, VP_KERNEL_FIT);
-    int rc = h->kern->fit(p);
+    int rc = fit_fn(p);
     tm.stop();
     if (rc != VP_ERR_OK) return fail(rc, "fit kernel launch failed");
     h->have_params = true;

@@ -10,22 +10,27 @@
 // path: if a cheap lower bound on sigma_min(R) does not clear epsilon, the n x n triangular
 // factor is decomposed with a one-sided Jacobi SVD and the truncated solve is applied.
 //
-// One fused sweep does all of it:  [Phi_w | y_w | D_1 .. D_P]  --Householder-->  R, Q^T y, Q^T D
-// (the dot products of a reflector with all remaining columns share ONE wave reduction round),
-// so per evaluation there are exactly 2n reduction rounds, independent of q.
+// All columns of one problem live in ONE register array  C[NC][R], NC = N + 1 + P:
+//     C[0..N)      W Phi          (overwritten by the Householder vectors)
+//     C[N]         y_w            (overwritten by Q^T y_w: rows >= N are the projected residual)
+//     C[N+1+p]     W dPhi_pair_p  (overwritten by Q^T W dPhi_p)
+// One fused sweep does everything: reflector k is applied to ALL remaining columns and their dot
+// products share ONE wave reduction round, so an evaluation costs 2N rounds regardless of Q.
 #pragma once
 #include "vp_device.hpp"
 #include "vp_model.hpp"
 
 namespace vp {
 
-// Householder QR of A (N columns) applied simultaneously to NX extra columns X.
-//   ROW0: first row the factorisation acts on (0 for Phi; N for the Jacobian living in rows >= N)
-// On return: A[k] holds reflector v_k (1 at row ROW0+k, 0 above); tau[k]; Rm = upper triangle
-// (row-major Rm[i][j], i <= j); xt[x][k] = (Q^T X_x)[ROW0+k]; X holds Q^T X in all rows.
-template <typename T, int R, int N, int NX, int ROW0>
-__device__ __forceinline__ void house_qr(T (&A)[N][R], T (&X)[NX][R], T (&tau)[N], T (&Rm)[N][N], T (&xt)[NX][N],
-                                         const int lane) {
+// Householder QR of the first N columns of C applied simultaneously to columns N..NC-1.
+//   ROW0: first row the factorisation acts on.
+// Reflector k is kept UNNORMALISED:  H_k = I + g_k v_k v_k^T  with v_k = a_k[prow:] except
+// v_k[prow] = alpha - beta, and g_k = 1/(beta (alpha - beta)) -- one reciprocal per reflector and no
+// scaling pass over the column.
+// On return: C[k] (k < N) holds v_k (0 above row ROW0+k); g[k]; Rm = upper triangle (Rm[i][j], i <= j);
+// qty[k] = (Q^T C[N])[ROW0+k]; columns >= N hold Q^T (.) in all rows.
+template <typename T, int R, int N, int NC, int ROW0>
+__device__ __forceinline__ void house_qr(T (&C)[NC][R], T (&g)[N], T (&Rm)[N][N], T (&qty)[N], const int lane) {
     using L = Layout<R>;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -34,65 +39,52 @@ __device__ __forceinline__ void house_qr(T (&A)[N][R], T (&X)[NX][R], T (&tau)[N
         T s = T(0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const T v = (L::row_of(r, lane) > prow) ? A[k][r] : T(0);
+            const T v = (r >= L::VW || L::row_of(r, lane) > prow) ? C[k][r] : T(0);
             s = tfma(v, v, s);
         }
         const T xn2 = wave_sum(s);
-        const T alpha = bcast_row<R>(A[k], prow);
-        T beta = alpha, tk = T(0), scal = T(0);
+        const T alpha = bcast_row<R>(C[k], prow);
+        T beta = alpha, gk = T(0), u = T(0);
         if (uni(xn2 != T(0))) {
             beta = -tcopysign(tsqrt(tfma(alpha, alpha, xn2)), alpha);
-            tk = (beta - alpha) / beta;
-            scal = T(1) / (alpha - beta);
+            u = alpha - beta;
+            gk = T(1) / (beta * u);
         }
-        tau[k] = tk;
+        g[k] = gk;
         Rm[k][k] = beta;
-        // v_k in place: rows > prow scaled, row prow = 1, rows < prow = 0 (makes the loops below mask-free)
+        // v_k in place: only the registers holding rows <= prow change (row prow := u, rows above := 0)
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < L::VW && r < R; ++r) {
             const int i = L::row_of(r, lane);
-            A[k][r] = (i > prow) ? A[k][r] * scal : ((i == prow) ? T(1) : T(0));
+            C[k][r] = (i > prow) ? C[k][r] : ((i == prow) ? u : T(0));
         }
         // w_c = v^T c for every remaining column: ONE reduction round for all of them
-        constexpr int NREM_MAX = (N - 1) + NX;
-        T w[NREM_MAX > 0 ? NREM_MAX : 1];
+        constexpr int NREM = NC - 1;
+        T w[NREM > 0 ? NREM : 1];
 #pragma unroll
-        for (int c = 0; c < NREM_MAX; ++c) w[c] = T(0);
+        for (int c = 0; c < NREM; ++c) w[c] = T(0);
 #pragma unroll
-        for (int j = k + 1; j < N; ++j) {
+        for (int j = k + 1; j < NC; ++j) {
             T acc = T(0);
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc = tfma(A[k][r], A[j][r], acc);
+            for (int r = 0; r < R; ++r) acc = tfma(C[k][r], C[j][r], acc);
             w[j - k - 1] = acc;
-        }
-#pragma unroll
-        for (int x = 0; x < NX; ++x) {
-            T acc = T(0);
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc = tfma(A[k][r], X[x][r], acc);
-            w[(N - 1 - k) + x] = acc;
         }
         wave_allreduce(w);
 #pragma unroll
-        for (int j = k + 1; j < N; ++j) {
-            const T f = -tk * w[j - k - 1];
+        for (int j = k + 1; j < NC; ++j) {
+            const T f = gk * w[j - k - 1];
 #pragma unroll
-            for (int r = 0; r < R; ++r) A[j][r] = tfma(f, A[k][r], A[j][r]);
-            Rm[k][j] = bcast_row<R>(A[j], prow);
-        }
-#pragma unroll
-        for (int x = 0; x < NX; ++x) {
-            const T f = -tk * w[(N - 1 - k) + x];
-#pragma unroll
-            for (int r = 0; r < R; ++r) X[x][r] = tfma(f, A[k][r], X[x][r]);
-            xt[x][k] = bcast_row<R>(X[x], prow);
+            for (int r = 0; r < R; ++r) C[j][r] = tfma(f, C[k][r], C[j][r]);
+            if (j < N) Rm[k][j] = bcast_row<R>(C[j], prow);
+            if (j == N) qty[k] = bcast_row<R>(C[j], prow);
         }
     }
 }
 
-// z <- Q z for NZ columns (Q = H_0 ... H_{N-1} from house_qr with the same ROW0)
-template <typename T, int R, int N, int NZ>
-__device__ __forceinline__ void apply_q(const T (&A)[N][R], const T (&tau)[N], T (&Z)[NZ][R]) {
+// z <- Q z for NZ columns (Q = H_0 ... H_{N-1}; V = the first N columns left by house_qr)
+template <typename T, int R, int N, int NC, int NZ>
+__device__ __forceinline__ void apply_q(const T (&V)[NC][R], const T (&g)[N], T (&Z)[NZ][R]) {
 #pragma unroll
     for (int k = N - 1; k >= 0; --k) {
         T w[NZ];
@@ -100,15 +92,15 @@ __device__ __forceinline__ void apply_q(const T (&A)[N][R], const T (&tau)[N], T
         for (int z = 0; z < NZ; ++z) {
             T acc = T(0);
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc = tfma(A[k][r], Z[z][r], acc);
+            for (int r = 0; r < R; ++r) acc = tfma(V[k][r], Z[z][r], acc);
             w[z] = acc;
         }
         wave_allreduce(w);
 #pragma unroll
         for (int z = 0; z < NZ; ++z) {
-            const T f = -tau[k] * w[z];
+            const T f = g[k] * w[z];
 #pragma unroll
-            for (int r = 0; r < R; ++r) Z[z][r] = tfma(f, A[k][r], Z[z][r]);
+            for (int r = 0; r < R; ++r) Z[z][r] = tfma(f, V[k][r], Z[z][r]);
         }
     }
 }
@@ -132,16 +124,16 @@ __device__ __noinline__ void truncated_solve(const T (&Rm)[N][N], const T (&qty)
         for (int p = 0; p < N - 1; ++p)
 #pragma unroll
             for (int q = p + 1; q < N; ++q) {
-                T a = 0, b = 0, g = 0;
+                T a = 0, b = 0, gg = 0;
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
                     a = tfma(W[p][i], W[p][i], a);
                     b = tfma(W[q][i], W[q][i], b);
-                    g = tfma(W[p][i], W[q][i], g);
+                    gg = tfma(W[p][i], W[q][i], gg);
                 }
-                if (g != T(0) && tabs(g) > num<T>::eps * T(0.25) * tsqrt(a * b)) {
+                if (gg != T(0) && tabs(gg) > num<T>::eps * T(0.25) * tsqrt(a * b)) {
                     rotated = true;
-                    const T zeta = (b - a) / (T(2) * g);
+                    const T zeta = (b - a) / (T(2) * gg);
                     const T tt = tcopysign(T(1), zeta) / (tabs(zeta) + tsqrt(T(1) + zeta * zeta));
                     const T cs = T(1) / tsqrt(T(1) + tt * tt), sn = cs * tt;
 #pragma unroll
@@ -184,17 +176,21 @@ __device__ __noinline__ void truncated_solve(const T (&Rm)[N][N], const T (&qty)
 }
 
 // c = R^{-1} qty by back substitution, guarded by a rank test equivalent to the reference's
-// "singular value <= eps" rule.  truncated != 0 => e (top part of the residual) is non-zero.
+// "singular value <= eps" rule.  truncated => e (top part of the residual) is non-zero.
+// Only N reciprocals (of the diagonal) are taken; everything else is multiply-add.
 template <typename T, int N>
 __device__ __forceinline__ void solve_coeffs(const T (&Rm)[N][N], const T (&qty)[N], T eps, T (&c)[N], T (&e)[N],
                                              bool &truncated) {
-    // sigma_min(R) >= 1/||R^{-1}||_F ; compute R^{-1} column by column (upper triangular)
     bool zero_diag = false;
 #pragma unroll
     for (int i = 0; i < N; ++i) zero_diag = zero_diag || (Rm[i][i] == T(0));
-    T inv_f2 = T(0);
     if (!uni(zero_diag)) {
-        T Ri[N][N]; // inverse, upper triangular
+        T d[N]; // reciprocals of the diagonal
+#pragma unroll
+        for (int i = 0; i < N; ++i) d[i] = T(1) / Rm[i][i];
+        // sigma_min(R) >= 1/||R^{-1}||_F : R^{-1} column by column (upper triangular)
+        T inv_f2 = T(0);
+        T Ri[N][N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
 #pragma unroll
@@ -206,7 +202,7 @@ __device__ __forceinline__ void solve_coeffs(const T (&Rm)[N][N], const T (&qty)
                 T acc = (i == j) ? T(1) : T(0);
 #pragma unroll
                 for (int l = i + 1; l <= j; ++l) acc = tfma(-Rm[i][l], Ri[l][j], acc);
-                Ri[i][j] = acc / Rm[i][i];
+                Ri[i][j] = acc * d[i];
                 inv_f2 = tfma(Ri[i][j], Ri[i][j], inv_f2);
             }
         }
@@ -217,7 +213,9 @@ __device__ __forceinline__ void solve_coeffs(const T (&Rm)[N][N], const T (&qty)
                 T acc = qty[i];
 #pragma unroll
                 for (int j = i + 1; j < N; ++j) acc = tfma(-Rm[i][j], c[j], acc);
-                c[i] = acc / Rm[i][i];
+                // (acc * d) corrected by one residual step == acc / R_ii to the last bit in practice
+                const T q0 = acc * d[i];
+                c[i] = tfma(tfma(-q0, Rm[i][i], acc), d[i], q0);
                 e[i] = T(0);
             }
             truncated = false;
@@ -230,45 +228,30 @@ __device__ __forceinline__ void solve_coeffs(const T (&Rm)[N][N], const T (&qty)
 
 // Everything one evaluation produces that is wave-uniform.
 template <typename T, int N> struct EvalUniform {
-    T c[N];      // linear coefficients
-    T e[N];      // range(Q)-part of the residual (non-zero only on the truncated path)
-    T tau[N];    // Householder scalars
-    T fn2;       // ||R||^2 (squared norm of the weighted residual)
-    bool ok;     // all finite
+    T c[N];   // linear coefficients
+    T e[N];   // range(Q)-part of the residual (non-zero only on the truncated path)
+    T g[N];   // Householder scalars g_k = 1/(beta_k u_k)
+    T fn2;    // ||R||^2 (squared norm of the weighted residual)
+    bool ok;  // all finite
 };
 
-// One full evaluation at `alpha`:
-//   A  <- Householder vectors of Phi_w
-//   X0 <- Q^T y_w  (rows >= N: the projected residual in Q-coordinates)
-//   D  <- Q^T (W dPhi_p)  for every dependency pair p
-template <typename T, class M, int R>
-__device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::Q], const T (&t)[R],
-                                              const T (&scale)[R], const T (&yw)[R], T eps, const int lane,
-                                              T (&A)[M::N][R], T (&X)[1 + M::P][R], EvalUniform<T, M::N> &u) {
-    constexpr int N = M::N, P = M::P;
+// One full evaluation at `alpha`: builds the columns (the data column C[N] must already hold y_w),
+// runs the fused sweep, solves for c and forms ||r||^2.
+template <typename T, class M, int R, int NC>
+__device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::Q], const RowSource<T, R> &src, T eps,
+                                              const int lane, T (&C)[NC][R], EvalUniform<T, M::N> &u) {
+    constexpr int N = M::N;
     using L = Layout<R>;
-    {
-        T D[P > 0 ? P : 1][R];
-        build_columns<T, M, R>(mdl, alpha, t, scale, A, D);
-#pragma unroll
-        for (int r = 0; r < R; ++r) X[0][r] = yw[r];
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int r = 0; r < R; ++r) X[1 + p][r] = D[p][r];
-    }
-    T Rm[N][N], xt[1 + P][N];
-    house_qr<T, R, N, 1 + P, 0>(A, X, u.tau, Rm, xt, lane);
-    T qty[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) qty[k] = xt[0][k];
+    build_columns<T, M, R, NC>(mdl, alpha, src, C);
+    T Rm[N][N], qty[N];
+    house_qr<T, R, N, NC, 0>(C, u.g, Rm, qty, lane);
     bool truncated;
     solve_coeffs<T, N>(Rm, qty, eps, u.c, u.e, truncated);
     // ||r||^2 = ||e||^2 + sum_{rows >= N} (Q^T y)^2
     T s = T(0);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const T v = (L::row_of(r, lane) >= N) ? X[0][r] : T(0);
+        const T v = (r >= L::VW || L::row_of(r, lane) >= N) ? C[N][r] : T(0);
         s = tfma(v, v, s);
     }
     T fn2 = wave_sum(s);
@@ -281,44 +264,58 @@ __device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::
     u.ok = uni(ok);
 }
 
-// Projected residual in Q-coordinates: rows < N <- e, rows >= N keep Q^T y.  (in place on X0)
+// Projected residual in Q-coordinates: rows < N <- e, rows >= N keep Q^T y.  (in place on the data column)
 template <typename T, int R, int N>
 __device__ __forceinline__ void residual_qcoords(T (&x0)[R], const T (&e)[N], const int lane) {
     using L = Layout<R>;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < L::VW && r < R; ++r) { // pivot rows live in the first VW registers
         const int i = L::row_of(r, lane);
-        if (r < L::VW) { // pivot rows live in the first VW registers
-            T v = x0[r];
+        T v = x0[r];
 #pragma unroll
-            for (int k = 0; k < N; ++k) v = (i == k) ? e[k] : v;
-            x0[r] = v;
-        }
+        for (int k = 0; k < N; ++k) v = (i == k) ? e[k] : v;
+        x0[r] = v;
     }
 }
 
 // Kaufman Jacobian columns in Q-coordinates:  Z_k = -(sum over pairs p of param k) c_{basis(p)} (Q^T D_p),
-// rows < N zeroed (that is the P_perp).  Z must not alias X.
-template <typename T, class M, int R>
-__device__ __forceinline__ void jacobian_qcoords(const M &mdl, const T (&X)[1 + M::P][R], const T (&c)[M::N],
-                                                 T (&Z)[M::Q][R], const int lane) {
+// rows < N zeroed (that is the P_perp).
+//   diagonal models (pair p == (basis p, param p)): done IN PLACE, Z_k is C[N+1+k];
+//   general models: written to the separate array Zs and the caller uses that.
+template <typename T, class M, int R, int NC>
+__device__ __forceinline__ void jacobian_qcoords(const M &mdl, T (&C)[NC][R], const T (&c)[M::N],
+                                                 T (&Zs)[M::kDiagonalPairs ? 1 : M::Q][R], const int lane) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
     using L = Layout<R>;
+    if constexpr (M::kDiagonalPairs) {
+        (void)Zs;
+        (void)mdl;
 #pragma unroll
-    for (int k = 0; k < Q; ++k) {
+        for (int k = 0; k < Q; ++k) {
+            const T ck = -c[k];
 #pragma unroll
-        for (int r = 0; r < R; ++r) Z[k][r] = T(0);
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            if (mdl.pair_param(p) == k) {
-                const T cj = -dyn_get<N>(c, mdl.pair_basis(p));
-#pragma unroll
-                for (int r = 0; r < R; ++r) Z[k][r] = tfma(cj, X[1 + p][r], Z[k][r]);
+            for (int r = 0; r < R; ++r) {
+                const bool top = (r < L::VW) && (L::row_of(r, lane) < N);
+                C[N + 1 + k][r] = top ? T(0) : ck * C[N + 1 + k][r];
             }
         }
+    } else {
 #pragma unroll
-        for (int r = 0; r < L::VW && r < R; ++r)
-            if (L::row_of(r, lane) < N) Z[k][r] = T(0);
+        for (int k = 0; k < Q; ++k) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) Zs[k][r] = T(0);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (mdl.pair_param(p) == k) {
+                    const T cj = -dyn_get<N>(c, mdl.pair_basis(p));
+#pragma unroll
+                    for (int r = 0; r < R; ++r) Zs[k][r] = tfma(cj, C[N + 1 + p][r], Zs[k][r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < L::VW && r < R; ++r)
+                if (L::row_of(r, lane) < N) Zs[k][r] = T(0);
+        }
     }
 }
 

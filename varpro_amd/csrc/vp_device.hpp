@@ -42,15 +42,17 @@ template <int R> struct Layout {
 };
 
 // ---- cross-lane data movement -----------------------------------------------------------------
-template <int CTRL> __device__ __forceinline__ double dpp(double x) {
+// DPP move: lanes of rows enabled in ROW_MASK receive the permuted value, all other lanes receive 0
+// (old = 0 and a fresh destination register: no tied-operand copies, 1 v_mov_b32_dpp per dword).
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ double dpp(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
     return __hiloint2double(hi, lo);
 }
-template <int CTRL> __device__ __forceinline__ float dpp(float x) {
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp(float x) {
     int v = __float_as_int(x);
-    v = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+    v = __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
     return __int_as_float(v);
 }
 __device__ __forceinline__ double readlane(double x, int lane) {
@@ -62,11 +64,16 @@ __device__ __forceinline__ float readlane(float x, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
 }
 
-// DPP controls (GFX9): quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror
+// DPP controls (GFX9): quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror,
+// row_bcast:15 (lane 15 of each row -> the next row), row_bcast:31 (lane 31 -> rows 2 and 3)
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+constexpr int DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
 
-// All-reduce (sum) of V independent values across the 64 lanes; every lane ends with the totals.
-// The V chains are interleaved step by step so their latencies overlap.
+// All-reduce (sum) of V independent values across the 64 lanes; every lane ends with the totals,
+// delivered through v_readlane (SGPRs), i.e. as genuinely scalar values.
+// 4 butterfly steps inside the 16-lane rows (every lane of a row then holds the row sum), 2 row
+// broadcast steps (row 3 then holds the wave sum), one v_readlane pair from lane 63: 20 instructions
+// per fp64 value.  The V chains are interleaved step by step so their latencies overlap.
 template <int V, typename T> __device__ __forceinline__ void wave_allreduce(T (&x)[V]) {
 #pragma unroll
     for (int v = 0; v < V; ++v) x[v] += dpp<DPP_XOR1>(x[v]);
@@ -76,12 +83,12 @@ template <int V, typename T> __device__ __forceinline__ void wave_allreduce(T (&
     for (int v = 0; v < V; ++v) x[v] += dpp<DPP_HALF_MIRROR>(x[v]);
 #pragma unroll
     for (int v = 0; v < V; ++v) x[v] += dpp<DPP_MIRROR>(x[v]);
-    // every lane of a 16-lane row now holds its row sum; combine the four rows
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-        T a = readlane(x[v], 0), b = readlane(x[v], 16), c = readlane(x[v], 32), d = readlane(x[v], 48);
-        x[v] = (a + b) + (c + d);
-    }
+    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_BCAST15, 0xA>(x[v]); // rows 1,3 += rows 0,2
+#pragma unroll
+    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_BCAST31, 0xC>(x[v]); // rows 2,3 += row 1 (= rows 0+1)
+#pragma unroll
+    for (int v = 0; v < V; ++v) x[v] = readlane(x[v], 63);
 }
 template <typename T> __device__ __forceinline__ T wave_sum(T x) {
     T a[1] = {x};
@@ -117,6 +124,42 @@ __device__ __forceinline__ double tcopysign(double x, double s) { return __built
 __device__ __forceinline__ float tcopysign(float x, float s) { return __builtin_copysignf(x, s); }
 __device__ __forceinline__ double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Fast wave-uniform scalar helpers for the LM bookkeeping (trust region, lmpar, Givens rotations).
+// v_rcp_f64 / v_rsq_f64 deliver ~26 good bits; two Newton steps bring them to the last 1-2 ulp at
+// 5-8 instructions instead of the 12-14 of the IEEE division / sqrt expansions.  They are NOT used
+// where parity is priced (Householder betas, the triangular solve for c, exp arguments).
+__device__ __forceinline__ double frcp(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ float frcp(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+}
+__device__ __forceinline__ double frsqrt(double h) {
+    double y = __builtin_amdgcn_rsq(h);
+    double e = __builtin_fma(-h * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    e = __builtin_fma(-h * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    return y;
+}
+__device__ __forceinline__ float frsqrt(float h) {
+    float y = __builtin_amdgcn_rsqf(h);
+    float e = __builtin_fmaf(-h * y, y, 1.0f);
+    return __builtin_fmaf(0.5f * y, e, y);
+}
+// sqrt for moderate-magnitude uniform scalars (0 -> 0; no denormal/huge rescaling)
+template <typename T> __device__ __forceinline__ T fsqrt(T h) {
+    if (!(h > T(0))) return tsqrt(h); // 0, negative or NaN: IEEE path
+    const T y = frsqrt(h);
+    T s = h * y;
+    s = tfma(tfma(-s, s, h), T(0.5) * y, s);
+    return s;
+}
 
 // correctly rounded (to within the last bit in rare ties) quotient a/b given rb ~= 1/b:
 // one Newton correction of the product.  Replaces the 10+ instruction IEEE division sequence

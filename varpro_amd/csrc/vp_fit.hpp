@@ -12,15 +12,52 @@
 // (vp_core.hpp), per accepted point additionally one pivoted QR of the q Jacobian columns.
 // The grid t, the row scale (weights) and the weighted data y_w of the problem stay in LDS for the
 // whole fit: HBM traffic per fit is m scalars in, q + n + report out.
+//
+// The wave-uniform bookkeeping (lmpar, qrsolv, trust-region update) runs on the vector ALU -- gfx950
+// has no scalar fp64 -- so every instruction of it costs as much as a 64-row vector instruction.
+// It is therefore written division-free where MINPACK divides repeatedly by the same quantity
+// (hoisted Newton-refined reciprocals, rsqrt-based Givens rotations).
 #pragma once
 #include "vp_kernels.hpp"
 
 namespace vp {
 
+// branch policy: U == true  -> the operands are wave-uniform, make the branch scalar (s_cbranch);
+//                U == false -> every lane runs its own problem (lane-parallel LM bookkeeping)
+template <bool U> __device__ __forceinline__ bool pol(bool c) {
+    if constexpr (U) return uni(c);
+    else return c;
+}
+template <bool U> __device__ __forceinline__ int pol(int v) {
+    if constexpr (U) return uni(v);
+    else return v;
+}
+
+// plain Euclidean norm of a wave-uniform q-vector; falls back to a scaled accumulation (the point of
+// MINPACK's enorm) only when the plain sum of squares over/underflows
+template <typename T, int Q, bool U = true> __device__ __forceinline__ T enorm_small(const T (&v)[Q]) {
+    T s = T(0);
+#pragma unroll
+    for (int j = 0; j < Q; ++j) s = tfma(v[j], v[j], s);
+    if (pol<U>(s > T(1e-280) && s < T(1e280))) return fsqrt(s);
+    T mx = T(0);
+#pragma unroll
+    for (int j = 0; j < Q; ++j) mx = tmax(mx, tabs(v[j]));
+    if (!(mx > T(0)) || !is_finite(mx)) return (s != s) ? s : mx; // 0, inf or nan
+    s = T(0);
+    const T inv = T(1) / mx;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        const T u = v[j] * inv;
+        s = tfma(u, u, s);
+    }
+    return mx * tsqrt(s);
+}
+
 // MINPACK qrsolv on wave-uniform registers.  r[row][col]: upper triangle incl. diagonal = R of the
 // pivoted QR; the strict lower triangle is scratch (receives S^T).  Solves
 // min || [R P^T; D] x - [qtb; 0] ||.
-template <typename T, int Q>
+template <typename T, int Q, bool U = true>
 __device__ __forceinline__ void qrsolv(T (&r)[Q][Q], const int (&ipvt)[Q], const T (&diag)[Q], const T (&qtb)[Q],
                                        T (&x)[Q], T (&sdiag)[Q]) {
     T wa[Q];
@@ -34,25 +71,21 @@ __device__ __forceinline__ void qrsolv(T (&r)[Q][Q], const int (&ipvt)[Q], const
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
         const T dl = dyn_get<Q>(diag, ipvt[j]);
-        if (uni(dl != T(0))) {
+        if (pol<U>(dl != T(0))) {
 #pragma unroll
             for (int k = j; k < Q; ++k) sdiag[k] = T(0);
             sdiag[j] = dl;
             T qtbpj = T(0);
 #pragma unroll
             for (int k = j; k < Q; ++k) {
-                if (uni(sdiag[k] == T(0))) continue;
-                T c, s;
-                if (uni(tabs(r[k][k]) < tabs(sdiag[k]))) {
-                    const T cotan = r[k][k] / sdiag[k];
-                    s = T(0.5) / tsqrt(T(0.25) + T(0.25) * (cotan * cotan));
-                    c = s * cotan;
-                } else {
-                    const T tn = sdiag[k] / r[k][k];
-                    c = T(0.5) / tsqrt(T(0.25) + T(0.25) * (tn * tn));
-                    s = c * tn;
-                }
-                r[k][k] = c * r[k][k] + s * sdiag[k];
+                if (pol<U>(sdiag[k] == T(0))) continue;
+                // Givens rotation (c, s) = sg * (r_kk, sdiag_k) / hypot, sg as in MINPACK's two branches
+                const T rk = r[k][k], sk = sdiag[k];
+                const T ih = frsqrt(tfma(rk, rk, sk * sk));
+                const T sg = (tabs(rk) < tabs(sk)) ? tcopysign(T(1), sk) : tcopysign(T(1), rk);
+                const T c = sg * rk * ih;
+                const T s = sg * sk * ih;
+                r[k][k] = c * rk + s * sk;
                 const T temp = c * wa[k] + s * qtbpj;
                 qtbpj = -s * wa[k] + c * qtbpj;
                 wa[k] = temp;
@@ -73,7 +106,7 @@ __device__ __forceinline__ void qrsolv(T (&r)[Q][Q], const int (&ipvt)[Q], const
         if (sdiag[j] == T(0) && nsing == Q) nsing = j;
         if (nsing < Q) wa[j] = T(0);
     }
-    nsing = uni(nsing);
+    nsing = pol<U>(nsing);
 #pragma unroll
     for (int k = 1; k <= Q; ++k) {
         const int j = Q - k; // only rows j < nsing participate
@@ -82,48 +115,34 @@ __device__ __forceinline__ void qrsolv(T (&r)[Q][Q], const int (&ipvt)[Q], const
 #pragma unroll
             for (int i = j + 1; i < Q; ++i)
                 if (i < nsing) sum = tfma(r[i][j], wa[i], sum);
-            wa[j] = (wa[j] - sum) / sdiag[j];
+            wa[j] = (wa[j] - sum) * frcp(sdiag[j]);
         }
     }
 #pragma unroll
     for (int j = 0; j < Q; ++j) dyn_set<Q>(x, ipvt[j], wa[j]);
 }
 
-template <typename T, int Q> __device__ __forceinline__ T enorm_small(const T (&v)[Q]) {
-    // uniform q-vector norm with a scale guard (the MINPACK enorm protects against overflow)
-    T mx = T(0);
-#pragma unroll
-    for (int j = 0; j < Q; ++j) mx = tmax(mx, tabs(v[j]));
-    if (!(mx > T(0)) || !is_finite(mx)) return mx; // 0, inf or nan
-    T s = T(0);
-    const T inv = T(1) / mx;
-#pragma unroll
-    for (int j = 0; j < Q; ++j) {
-        const T u = v[j] * inv;
-        s = tfma(u, u, s);
-    }
-    return mx * tsqrt(s);
-}
-
 // MINPACK lmpar.  Returns par; step = p (new point is x - p); dxnorm = ||diag .* p||.
-template <typename T, int Q>
+template <typename T, int Q, bool U = true>
 __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (&diag)[Q], const T (&qtb)[Q],
                                    const T delta, T par, T (&x)[Q], T &dxnorm_out) {
     const T p1 = T(0.1), p001 = T(0.001), dwarf = num<T>::tiny;
-    T wa1[Q], wa2[Q], sdiag[Q];
+    T wa1[Q], wa2[Q], sdiag[Q], rinv[Q], dperm[Q];
     int nsing = Q;
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
         wa1[j] = qtb[j];
         if (r[j][j] == T(0) && nsing == Q) nsing = j;
         if (nsing < Q) wa1[j] = T(0);
+        rinv[j] = (r[j][j] != T(0)) ? frcp(r[j][j]) : T(0);
+        dperm[j] = dyn_get<Q>(diag, ipvt[j]);
     }
-    nsing = uni(nsing);
+    nsing = pol<U>(nsing);
 #pragma unroll
     for (int k = 1; k <= Q; ++k) {
         const int j = Q - k;
         if (j < nsing) {
-            wa1[j] = wa1[j] / r[j][j];
+            wa1[j] = wa1[j] * rinv[j];
             const T temp = wa1[j];
 #pragma unroll
             for (int i = 0; i < j; ++i) wa1[i] = tfma(-r[i][j], temp, wa1[i]);
@@ -133,68 +152,69 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
     for (int j = 0; j < Q; ++j) dyn_set<Q>(x, ipvt[j], wa1[j]);
 #pragma unroll
     for (int j = 0; j < Q; ++j) wa2[j] = diag[j] * x[j];
-    T dxnorm = enorm_small<T, Q>(wa2);
+    T dxnorm = enorm_small<T, Q, U>(wa2);
     T fp = dxnorm - delta;
-    if (uni(fp <= p1 * delta)) {
+    if (pol<U>(fp <= p1 * delta)) {
         dxnorm_out = dxnorm;
         return T(0);
     }
+    const T idelta = frcp(delta);
     T parl = T(0);
     if (nsing >= Q) {
+        const T idx = frcp(dxnorm);
 #pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            const int l = ipvt[j];
-            wa1[j] = dyn_get<Q>(diag, l) * (dyn_get<Q>(wa2, l) / dxnorm);
-        }
+        for (int j = 0; j < Q; ++j) wa1[j] = dperm[j] * (dyn_get<Q>(wa2, ipvt[j]) * idx);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
             T sum = T(0);
 #pragma unroll
             for (int i = 0; i < j; ++i) sum = tfma(r[i][j], wa1[i], sum);
-            wa1[j] = (wa1[j] - sum) / r[j][j];
+            wa1[j] = (wa1[j] - sum) * rinv[j];
         }
-        const T temp = enorm_small<T, Q>(wa1);
-        parl = ((fp / delta) / temp) / temp;
+        T t2 = T(0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) t2 = tfma(wa1[j], wa1[j], t2);
+        parl = (fp * idelta) * frcp(t2); // ((fp/delta)/temp)/temp
     }
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
         T sum = T(0);
 #pragma unroll
         for (int i = 0; i <= j; ++i) sum = tfma(r[i][j], qtb[i], sum);
-        wa1[j] = sum / dyn_get<Q>(diag, ipvt[j]);
+        wa1[j] = sum * frcp(dperm[j]);
     }
-    const T gnorm = enorm_small<T, Q>(wa1);
-    T paru = gnorm / delta;
+    const T gnorm = enorm_small<T, Q, U>(wa1);
+    T paru = gnorm * idelta;
     if (paru == T(0)) paru = dwarf / tmin(delta, p1);
     par = tmax(par, parl);
     par = tmin(par, paru);
-    if (par == T(0)) par = gnorm / dxnorm;
+    if (par == T(0)) par = gnorm * frcp(dxnorm);
     for (int iter = 1;; ++iter) {
         if (par == T(0)) par = tmax(dwarf, p001 * paru);
-        const T sq = tsqrt(par);
+        const T sq = fsqrt(par);
 #pragma unroll
         for (int j = 0; j < Q; ++j) wa1[j] = sq * diag[j];
-        qrsolv<T, Q>(r, ipvt, wa1, qtb, x, sdiag);
+        qrsolv<T, Q, U>(r, ipvt, wa1, qtb, x, sdiag);
 #pragma unroll
         for (int j = 0; j < Q; ++j) wa2[j] = diag[j] * x[j];
-        dxnorm = enorm_small<T, Q>(wa2);
+        dxnorm = enorm_small<T, Q, U>(wa2);
         const T temp = fp;
         fp = dxnorm - delta;
-        if (uni(tabs(fp) <= p1 * delta || (parl == T(0) && fp <= temp && temp < T(0)) || iter == 10)) break;
+        if (pol<U>(tabs(fp) <= p1 * delta || (parl == T(0) && fp <= temp && temp < T(0)) || iter == 10)) break;
+        const T idx = frcp(dxnorm);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) wa1[j] = dperm[j] * (dyn_get<Q>(wa2, ipvt[j]) * idx);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            const int l = ipvt[j];
-            wa1[j] = dyn_get<Q>(diag, l) * (dyn_get<Q>(wa2, l) / dxnorm);
-        }
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            wa1[j] = wa1[j] / sdiag[j];
+            wa1[j] = wa1[j] * frcp(sdiag[j]);
             const T tj = wa1[j];
 #pragma unroll
             for (int i = j + 1; i < Q; ++i) wa1[i] = tfma(-r[i][j], tj, wa1[i]);
         }
-        const T tn = enorm_small<T, Q>(wa1);
-        const T parc = ((fp / delta) / tn) / tn;
+        T t2 = T(0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) t2 = tfma(wa1[j], wa1[j], t2);
+        const T parc = (fp * idelta) * frcp(t2);
         if (fp > T(0)) parl = tmax(parl, par);
         if (fp < T(0)) paru = tmin(paru, par);
         par = tmax(parl, par + parc);
@@ -205,6 +225,8 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
 
 // MINPACK qrfac (column pivoting, partial-norm downdating) of the Q Jacobian columns Z living in
 // rows >= ROW0, applied simultaneously to the residual column rv (-> qtf), as lmder does.
+// MINPACK's reflector  v = a/ajnorm + e_p,  H = I - v v^T / v_p  is applied in the equivalent
+// unnormalised form  H = I + g v' v'^T,  v' = a + ajnorm e_p,  g = -1/(ajnorm v'_p)  (one reciprocal).
 template <typename T, int R, int Q, int ROW0>
 __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q], T (&acnorm)[Q], int (&ipvt)[Q],
                                           T (&qtf)[Q], const int lane) {
@@ -268,7 +290,7 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
         T s = T(0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const T v = (L::row_of(r, lane) >= prow) ? Z[j][r] : T(0);
+            const T v = (r >= L::VW || L::row_of(r, lane) >= prow) ? Z[j][r] : T(0);
             s = tfma(v, v, s);
         }
         T ajnorm = tsqrt(wave_sum(s));
@@ -282,14 +304,13 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
         }
         const T piv = bcast_row<R>(Z[j], prow);
         if (piv < T(0)) ajnorm = -ajnorm;
-        const T inv = T(1) / ajnorm;
+        const T vp = piv + ajnorm;          // v'_p
+        const T gj = -T(1) / (ajnorm * vp); // H = I + gj v' v'^T
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
+        for (int r = 0; r < L::VW && r < R; ++r) {
             const int i = L::row_of(r, lane);
-            const T v = Z[j][r] * inv;
-            Z[j][r] = (i > prow) ? v : ((i == prow) ? v + T(1) : T(0));
+            Z[j][r] = (i > prow) ? Z[j][r] : ((i == prow) ? vp : T(0));
         }
-        const T vp = piv * inv + T(1); // v[prow]
         // dots with the remaining columns and with the residual column: one reduction round
         T w[Q]; // w[0..Q-j-2]: columns k > j ; w[Q-1]: residual
 #pragma unroll
@@ -310,9 +331,9 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
         wave_allreduce(w);
 #pragma unroll
         for (int k = j + 1; k < Q; ++k) {
-            const T temp = w[k - j - 1] / vp;
+            const T f = gj * w[k - j - 1];
 #pragma unroll
-            for (int r = 0; r < R; ++r) Z[k][r] = tfma(-temp, Z[j][r], Z[k][r]);
+            for (int r = 0; r < R; ++r) Z[k][r] = tfma(f, Z[j][r], Z[k][r]);
             const T akj = bcast_row<R>(Z[k], prow);
             Rj[j][k] = akj;
             if (uni(rdiag[k] != T(0))) {
@@ -323,7 +344,7 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
                     T s2 = T(0);
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const T v = (L::row_of(r, lane) > prow) ? Z[k][r] : T(0);
+                        const T v = (r >= L::VW || L::row_of(r, lane) > prow) ? Z[k][r] : T(0);
                         s2 = tfma(v, v, s2);
                     }
                     rdiag[k] = tsqrt(wave_sum(s2));
@@ -332,9 +353,9 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
             }
         }
         {
-            const T temp = -w[Q - 1] / vp;
+            const T f = gj * w[Q - 1];
 #pragma unroll
-            for (int r = 0; r < R; ++r) rv[r] = tfma(temp, Z[j][r], rv[r]);
+            for (int r = 0; r < R; ++r) rv[r] = tfma(f, Z[j][r], rv[r]);
             qtf[j] = bcast_row<R>(rv, prow);
         }
         rdiag[j] = -ajnorm;
@@ -364,32 +385,54 @@ template <typename T, class M> struct FitArgs {
     int trace_rows;
 };
 
-template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_kernel(const FitArgs<T, M> a) {
-    constexpr int N = M::N, P = M::P, Q = M::Q;
-    using L = Layout<R>;
+// Wave-uniform LM state.  It is PARKED in LDS while the fused QR sweep runs (lane 0 writes, every
+// lane re-reads afterwards): during the sweep -- the register-pressure peak, 2R VGPRs per column --
+// only the trial parameters stay in registers.
+template <typename T, int N, int Q> struct LmState {
+    T x[Q], diag[Q], qtf[Q], acnorm[Q], cbest[N];
+    T Rj[Q][Q];
+    T fnorm, delta, par, xnorm, gnorm, pnorm, prered, dirder, objective;
+    int ipvt[Q];
+    int flags; // bit0 first, bit1 first_tr, bit2 first_update
+    int nfev;
+};
+
+template <typename T, class M, int R> __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
+    constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
+    constexpr int MP = 64 * R;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *s_t = reinterpret_cast<T *>(smem_raw);
-    T *s_scale = s_t + 64 * R;
-    T *s_y = s_scale + 64 * R;
+    T *s_y = s_t + MP;
+    T *s_w = a.w ? s_y + MP : nullptr;
+    LmState<T, N, Q> *st = reinterpret_cast<LmState<T, N, Q> *>(s_y + MP + (a.w ? MP : 0));
     const int lane = lane_id();
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
     const int m = a.m;
-    constexpr int MP = 64 * R;
 
-    // stage the problem's grid, row scale and weighted data in LDS (row order, padding rows zero)
+    // stage the problem's grid, weights and weighted data in LDS (row order, padding rows zero)
     {
         T tmp[R];
         const T *tp = a.t + b * a.t_stride;
         load_rows<T, R>(tp, m, lane, vec_aligned<T>(tp, m), tmp);
         store_rows<T, R>(s_t, MP, lane, true, tmp);
-        load_scale<T, R>(a.w ? a.w + b * a.w_stride : nullptr, m, lane, tmp);
-        store_rows<T, R>(s_scale, MP, lane, true, tmp);
+        if (a.w) {
+            const T *wp = a.w + b * a.w_stride;
+            load_rows<T, R>(wp, m, lane, vec_aligned<T>(wp, m), tmp);
+            store_rows<T, R>(s_w, MP, lane, true, tmp);
+        }
         const T *yp = a.yw + b * (int64_t)m;
         load_rows<T, R>(yp, m, lane, vec_aligned<T>(yp, m), tmp);
         store_rows<T, R>(s_y, MP, lane, true, tmp);
     }
     __syncthreads(); // single wave: orders the LDS writes before the reads below
+    // the LDS copies are zero-padded to MP rows; valid rows are still i < m (scale 0 beyond)
+    RowSource<T, R> src;
+    src.t = s_t;
+    src.w = s_w;
+    src.m = m;
+    src.lane = lane;
+    src.vec = ((m & 1) == 0);
 
     // ---- LM state (wave-uniform) ----
     T x[Q], xt[Q], diag[Q], qtf[Q], step[Q], acnorm[Q], cbest[N];
@@ -432,16 +475,71 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_
     };
 
     for (;;) {
-        // ================= evaluate the VarPro functional at xt =================
-        T A[N][R], X[1 + P][R];
-        EvalUniform<T, N> u;
-        {
-            T t[R], scale[R], yw[R];
-            load_rows<T, R>(s_t, MP, lane, true, t);
-            load_rows<T, R>(s_scale, MP, lane, true, scale);
-            load_rows<T, R>(s_y, MP, lane, true, yw);
-            evaluate_core<T, M, R>(a.mdl, xt, t, scale, yw, a.eps, lane, A, X, u);
+        // ---- park the LM state in LDS for the duration of the sweep ----
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                st->x[k] = x[k];
+                st->diag[k] = diag[k];
+                st->qtf[k] = qtf[k];
+                st->acnorm[k] = acnorm[k];
+                st->ipvt[k] = ipvt[k];
+#pragma unroll
+                for (int j = 0; j < Q; ++j) st->Rj[k][j] = Rj[k][j];
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) st->cbest[k] = cbest[k];
+            st->fnorm = fnorm;
+            st->delta = delta;
+            st->par = par;
+            st->xnorm = xnorm;
+            st->gnorm = gnorm;
+            st->pnorm = pnorm;
+            st->prered = prered;
+            st->dirder = dirder;
+            st->objective = objective;
+            st->flags = (first ? 1 : 0) | (first_tr ? 2 : 0) | (first_update ? 4 : 0);
+            st->nfev = nfev;
         }
+        asm volatile("" ::: "memory");
+
+        // ================= evaluate the VarPro functional at xt =================
+        T C[NC][R];
+        EvalUniform<T, N> u;
+        load_rows<T, R>(s_y, MP, lane, true, C[N]);
+        evaluate_core<T, M, R, NC>(a.mdl, xt, src, a.eps, lane, C, u);
+
+        asm volatile("" ::: "memory");
+        // ---- un-park ----
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            x[k] = st->x[k];
+            diag[k] = st->diag[k];
+            qtf[k] = st->qtf[k];
+            acnorm[k] = st->acnorm[k];
+            ipvt[k] = uni(st->ipvt[k]);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) Rj[k][j] = st->Rj[k][j];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) cbest[k] = st->cbest[k];
+        fnorm = st->fnorm;
+        delta = st->delta;
+        par = st->par;
+        xnorm = st->xnorm;
+        gnorm = st->gnorm;
+        pnorm = st->pnorm;
+        prered = st->prered;
+        dirder = st->dirder;
+        objective = st->objective;
+        {
+            const int fl = uni(st->flags);
+            first = (fl & 1) != 0;
+            first_tr = (fl & 2) != 0;
+            first_update = (fl & 4) != 0;
+            nfev = uni(st->nfev);
+        }
+
         const T fnorm1 = tsqrt(u.fn2);
         bool need_jac = false;
         if (first) {
@@ -461,11 +559,11 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_
                 term = VP_TERM_WRONG_DIMENSIONS;
                 break;
             }
-            if (!is_finite(fnorm)) {
+            if (uni(!is_finite(fnorm))) {
                 term = VP_TERM_NUMERICAL;
                 break;
             }
-            if (fnorm <= num<T>::tiny) {
+            if (uni(fnorm <= num<T>::tiny)) {
                 term = VP_TERM_RESIDUALS_ZERO;
                 break;
             }
@@ -482,16 +580,16 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_
                 st_best = VP_ST_NONFINITE;
                 break;
             }
-            const T q1 = fnorm1 / fnorm;
+            const T q1 = fnorm1 * frcp(fnorm);
             const T actred = (fnorm1 * T(0.1) < fnorm) ? T(1) - q1 * q1 : T(-1);
-            const T ratio = (prered == T(0)) ? T(0) : actred / prered;
+            const T ratio = (prered == T(0)) ? T(0) : actred * frcp(prered);
             if (ratio <= T(0.25)) {
-                T temp = !(actred < T(0)) ? T(0.5) : T(0.5) * dirder / (dirder + T(0.5) * actred);
+                T temp = !(actred < T(0)) ? T(0.5) : T(0.5) * dirder * frcp(dirder + T(0.5) * actred);
                 if (fnorm1 * T(0.1) >= fnorm || temp < T(0.1)) temp = T(0.1);
                 delta = temp * tmin(delta, pnorm * T(10));
-                par = par / temp;
+                par = par * frcp(temp);
             } else if (par == T(0) || ratio >= T(0.75)) {
-                delta = pnorm / T(0.5);
+                delta = pnorm * T(2);
                 par = par * T(0.5);
             }
             const bool good = uni(ratio >= T(1.0e-4));
@@ -507,7 +605,7 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_
                 xnorm = enorm_small<T, Q>(tmpv);
                 fnorm = fnorm1;
                 objective = T(0.5) * fnorm1 * fnorm1;
-                if (!is_finite(xnorm)) {
+                if (uni(!is_finite(xnorm))) {
                     term = VP_TERM_NUMERICAL;
                     break;
                 }
@@ -537,13 +635,18 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_
 
         if (need_jac) {
             // ================= Jacobian in Q-coordinates, pivoted QR, Q_J^T r =================
-            T Z[Q][R];
-            jacobian_qcoords<T, M, R>(a.mdl, X, u.c, Z, lane);
-            residual_qcoords<T, R, N>(X[0], u.e, lane);
-            jac_qrfac<T, R, Q, N>(Z, X[0], Rj, acnorm, ipvt, qtf, lane);
+            T Zs[M::kDiagonalPairs ? 1 : Q][R];
+            jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, lane);
+            residual_qcoords<T, R, N>(C[N], u.e, lane);
+            if constexpr (M::kDiagonalPairs) {
+                jac_qrfac<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[N + 1]), C[N], Rj, acnorm, ipvt, qtf, lane);
+            } else {
+                jac_qrfac<T, R, Q, N>(Zs, C[N], Rj, acnorm, ipvt, qtf, lane);
+            }
             // norm of the scaled gradient
-            T g = T(0);
+            T gmax = T(0);
             bool degenerate = false;
+            const T ifn = frcp(fnorm);
 #pragma unroll
             for (int j = 0; j < Q; ++j) {
                 const T an = dyn_get<Q>(acnorm, ipvt[j]);
@@ -551,12 +654,12 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_
                     T sum = T(0);
 #pragma unroll
                     for (int i = 0; i <= j; ++i) sum = tfma(Rj[i][j], qtf[i], sum);
-                    const T temp = tabs(sum / (an * fnorm));
+                    const T temp = tabs(sum * frcp(an) * ifn);
                     if (temp != temp) degenerate = true;
-                    g = tmax(g, temp);
+                    gmax = tmax(gmax, temp);
                 }
             }
-            gnorm = g;
+            gnorm = gmax;
             if (uni(degenerate)) {
                 term = VP_TERM_NUMERICAL;
                 break;
@@ -601,15 +704,16 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) fit_
 #pragma unroll
                 for (int i = 0; i <= j; ++i) wa[i] = tfma(Rj[i][j], pj, wa[i]);
             }
-            const T t1 = enorm_small<T, Q>(wa) / fnorm;
+            const T ifn = frcp(fnorm);
+            const T t1 = enorm_small<T, Q>(wa) * ifn;
             const T temp1 = t1 * t1;
-            const T t2 = (tsqrt(par) * pnorm) / fnorm;
+            const T t2 = (fsqrt(par) * pnorm) * ifn;
             const T temp2 = t2 * t2;
             if (uni(!is_finite(temp1) || !is_finite(temp2))) {
                 term = VP_TERM_NUMERICAL;
                 break;
             }
-            prered = temp1 + temp2 / T(0.5);
+            prered = temp1 + temp2 * T(2);
             dirder = -(temp1 + temp2);
         }
         if (first_tr && pnorm < delta) delta = pnorm;
@@ -657,7 +761,7 @@ template <typename T, class M, int R> int launch_fit(const LaunchParams &p) {
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
     if (a.B <= 0) return VP_ERR_OK;
-    const size_t lds = (size_t)3 * 64 * R * sizeof(T);
+    const size_t lds = (size_t)(p.w ? 3 : 2) * 64 * R * sizeof(T) + sizeof(LmState<T, M::N, M::Q>);
     hipLaunchKernelGGL((fit_kernel<T, M, R>), dim3((unsigned)a.B), dim3(64), lds, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
@@ -675,8 +779,7 @@ template <typename T, class M> struct BestFitArgs {
 };
 
 template <typename T, class M, int R> __global__ void __launch_bounds__(64) best_fit_kernel(const BestFitArgs<T, M> a) {
-    constexpr int N = M::N, P = M::P, Q = M::Q;
-    using L = Layout<R>;
+    constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     const int lane = lane_id();
     const int64_t prob = blockIdx.x;
     if (prob >= a.nprob) return;
@@ -687,19 +790,15 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) best
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
 #pragma unroll
     for (int k = 0; k < N; ++k) c[k] = a.C[prob * N + k];
-    T t[R], scale[R];
-    const T *tp = a.t + b * a.t_stride;
-    load_rows<T, R>(tp, m, lane, vec_aligned<T>(tp, m), t);
-#pragma unroll
-    for (int r = 0; r < R; ++r) scale[r] = (L::row_of(r, lane) < m) ? T(1) : T(0);
-    T A[N][R], D[P > 0 ? P : 1][R];
-    build_columns<T, M, R>(a.mdl, alpha, t, scale, A, D);
+    const RowSource<T, R> src = make_row_source<T, R>(a.t + b * a.t_stride, (const T *)nullptr, m, lane);
+    T C[NC][R];
+    build_columns<T, M, R, NC>(a.mdl, alpha, src, C);
     T f[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < N; ++j) acc = tfma(A[j][r], c[j], acc);
+        for (int j = 0; j < N; ++j) acc = tfma(C[j][r], c[j], acc);
         f[r] = acc;
     }
     T *op = a.out + prob * (int64_t)m;

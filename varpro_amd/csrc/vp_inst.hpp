@@ -1,6 +1,6 @@
 // vp_inst.hpp -- macros that instantiate one (dtype, model, R) kernel set and register it.
 #pragma once
-#include "vp_fit.hpp"
+#include "vp_fit_mp.hpp"
 #include "vp_registry.hpp"
 
 #define VP_CAT_(a, b) a##b
@@ -10,11 +10,13 @@
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
         DT, ::vp::FAMILY_MULTIEXP, NEXP, OFF, 0, RR, &::vp::launch_evaluate<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>, \
         &::vp::launch_basis<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                            \
+        &::vp::launch_fit_mp<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                           \
         &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                              \
         &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>});
 
 #define VP_REGISTER_RT(T, DT, NN, QQ, PP, RR)                                                                          \
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
         DT, ::vp::FAMILY_RT, NN, QQ, PP, RR, &::vp::launch_evaluate<T, ::vp::RtModel<NN, QQ, PP>, RR>,                \
-        &::vp::launch_basis<T, ::vp::RtModel<NN, QQ, PP>, RR>, &::vp::launch_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>,   \
+        &::vp::launch_basis<T, ::vp::RtModel<NN, QQ, PP>, RR>, &::vp::launch_fit_mp<T, ::vp::RtModel<NN, QQ, PP>, RR>, \
+        &::vp::launch_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                          \
         &::vp::launch_best_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>});

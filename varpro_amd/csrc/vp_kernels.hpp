@@ -10,6 +10,12 @@
 
 namespace vp {
 
+// Minimum waves per SIMD the register allocator must leave room for (2 <=> 256 VGPRs per lane, 1 <=> 512),
+// chosen from the register footprint of the NC resident columns (R rows x sizeof(T)/4 VGPRs each).
+template <typename T, int R, int NC> constexpr int waves_for() {
+    return (NC * R * (int)(sizeof(T) / 4) <= 200) ? 2 : 1;
+}
+
 // type-erased launch parameters (host side); every pointer is a device pointer
 struct LaunchParams {
     const vp_model_desc *model;
@@ -29,6 +35,7 @@ struct LaunchParams {
     const vp_lm_opts *opts;
     double *trace;      // fit diagnostics: [B][trace_rows][q+4] or NULL
     int trace_rows;
+    int fit_group;      // fit: problems per wave (0 = automatic)
     int basis_flags;
     int m;
     int S;
@@ -100,16 +107,15 @@ template <typename T> __device__ __forceinline__ bool vec_aligned(const void *p,
     return ((m & 1) == 0) && ((reinterpret_cast<uintptr_t>(p) & (2 * sizeof(T) - 1)) == 0);
 }
 
-// scale[r] = w_i (or 1) for valid rows, 0 for padding rows
 template <typename T, int R>
-__device__ __forceinline__ void load_scale(const T *__restrict__ w, const int m, const int lane, T (&scale)[R]) {
-    using L = Layout<R>;
-    if (w != nullptr) {
-        load_rows<T, R>(w, m, lane, vec_aligned<T>(w, m), scale);
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) scale[r] = (L::row_of(r, lane) < m) ? T(1) : T(0);
-    }
+__device__ __forceinline__ RowSource<T, R> make_row_source(const T *t, const T *w, int m, int lane) {
+    RowSource<T, R> s;
+    s.t = t;
+    s.w = w;
+    s.m = m;
+    s.lane = lane;
+    s.vec = vec_aligned<T>(t, m) && (w == nullptr || vec_aligned<T>(w, m));
+    return s;
 }
 
 template <typename T, class M> struct EvalArgs {
@@ -132,8 +138,8 @@ template <typename T, class M> struct EvalArgs {
 
 // MODE 0: coefficients/cost/status only; 1: + residuals; 2: + residuals + Jacobian
 template <typename T, class M, int R, int MODE>
-__global__ void __launch_bounds__(64) evaluate_kernel(const EvalArgs<T, M> a) {
-    constexpr int N = M::N, P = M::P, Q = M::Q;
+__global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) evaluate_kernel(const EvalArgs<T, M> a) {
+    constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     const int lane = lane_id();
     const int64_t prob = blockIdx.x; // problem * S + rhs
     if (prob >= a.nprob) return;
@@ -145,17 +151,15 @@ __global__ void __launch_bounds__(64) evaluate_kernel(const EvalArgs<T, M> a) {
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
 
-    T t[R], scale[R], yw[R];
-    const T *tp = a.t + b * a.t_stride;
-    load_rows<T, R>(tp, m, lane, vec_aligned<T>(tp, m), t);
-    load_scale<T, R>(a.w ? a.w + b * a.w_stride : nullptr, m, lane, scale);
+    const RowSource<T, R> src =
+        make_row_source<T, R>(a.t + b * a.t_stride, a.w ? a.w + b * a.w_stride : nullptr, m, lane);
+    T C[NC][R];
     const T *yp = a.yw + prob * (int64_t)m;
     const bool yvec = vec_aligned<T>(yp, m);
-    load_rows<T, R>(yp, m, lane, yvec, yw);
+    load_rows<T, R>(yp, m, lane, yvec, C[N]);
 
-    T A[N][R], X[1 + P][R];
     EvalUniform<T, N> u;
-    evaluate_core<T, M, R>(a.mdl, alpha, t, scale, yw, a.eps, lane, A, X, u);
+    evaluate_core<T, M, R, NC>(a.mdl, alpha, src, a.eps, lane, C, u);
 
     if (lane == 0) {
         if (a.status) a.status[prob] = u.ok ? VP_ST_OK : VP_ST_NONFINITE;
@@ -164,26 +168,29 @@ __global__ void __launch_bounds__(64) evaluate_kernel(const EvalArgs<T, M> a) {
     if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(u.c, lane);
 
     if constexpr (MODE >= 1) {
-        residual_qcoords<T, R, N>(X[0], u.e, lane);
+        residual_qcoords<T, R, N>(C[N], u.e, lane);
         if constexpr (MODE == 1) {
             T Z[1][R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) Z[0][r] = X[0][r];
-            apply_q<T, R, N, 1>(A, u.tau, Z);
+            for (int r = 0; r < R; ++r) Z[0][r] = C[N][r];
+            apply_q<T, R, N, NC, 1>(C, u.g, Z);
             if (a.r_out) store_rows<T, R>(a.r_out + prob * (int64_t)m, m, lane, yvec, Z[0]);
         } else {
             T Z[1 + Q][R];
             {
-                T ZJ[Q][R];
-                jacobian_qcoords<T, M, R>(a.mdl, X, u.c, ZJ, lane);
+                T Zs[M::kDiagonalPairs ? 1 : Q][R];
+                jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, lane);
 #pragma unroll
-                for (int r = 0; r < R; ++r) Z[0][r] = X[0][r];
+                for (int r = 0; r < R; ++r) Z[0][r] = C[N][r];
 #pragma unroll
                 for (int k = 0; k < Q; ++k)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) Z[1 + k][r] = ZJ[k][r];
+                    for (int r = 0; r < R; ++r) {
+                        if constexpr (M::kDiagonalPairs) Z[1 + k][r] = C[N + 1 + k][r];
+                        else Z[1 + k][r] = Zs[k][r];
+                    }
             }
-            apply_q<T, R, N, 1 + Q>(A, u.tau, Z);
+            apply_q<T, R, N, NC, 1 + Q>(C, u.g, Z);
             if (a.r_out) store_rows<T, R>(a.r_out + prob * (int64_t)m, m, lane, yvec, Z[0]);
             if (a.J_out) {
                 // J[b][k][s][m]
@@ -213,8 +220,7 @@ template <typename T, class M> struct BasisArgs {
 // Stand-alone Phi/dPhi: reads q scalars (+ the shared grid from L2), writes (n + p) * m scalars per
 // problem with 16-byte-per-lane fully coalesced stores: HBM-write-bound by construction.
 template <typename T, class M, int R> __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs<T, M> a) {
-    constexpr int N = M::N, P = M::P, Q = M::Q;
-    using L = Layout<R>;
+    constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     const int lane = lane_id();
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
@@ -222,20 +228,16 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) basi
     T alpha[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
-    T t[R], scale[R];
-    const T *tp = a.t + b * a.t_stride;
-    load_rows<T, R>(tp, m, lane, vec_aligned<T>(tp, m), t);
-#pragma unroll
-    for (int r = 0; r < R; ++r) scale[r] = (L::row_of(r, lane) < m) ? T(1) : T(0);
-    T A[N][R], D[P > 0 ? P : 1][R];
-    build_columns<T, M, R>(a.mdl, alpha, t, scale, A, D);
+    const RowSource<T, R> src = make_row_source<T, R>(a.t + b * a.t_stride, (const T *)nullptr, m, lane);
+    T C[NC][R];
+    build_columns<T, M, R, NC>(a.mdl, alpha, src, C);
     if (a.Phi_out) {
         int col = 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             if (a.skip_invariant && a.mdl.kind(j) == VP_BASIS_CONST) continue;
             T *p = a.Phi_out + (b * a.n_phi_cols + col) * (int64_t)m;
-            store_rows<T, R>(p, m, lane, vec_aligned<T>(p, m), A[j]);
+            store_rows<T, R>(p, m, lane, vec_aligned<T>(p, m), C[j]);
             ++col;
         }
     }
@@ -243,7 +245,7 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) basi
 #pragma unroll
         for (int pidx = 0; pidx < P; ++pidx) {
             T *p = a.dPhi_out + (b * P + pidx) * (int64_t)m;
-            store_rows<T, R>(p, m, lane, vec_aligned<T>(p, m), D[pidx]);
+            store_rows<T, R>(p, m, lane, vec_aligned<T>(p, m), C[N + 1 + pidx]);
         }
     }
 }

@@ -23,12 +23,14 @@ template <int NEXP, bool OFFSET> struct MultiExpModel {
     __host__ __device__ constexpr int pair_basis(int p) const { return p; }
     __host__ __device__ constexpr int pair_arg(int) const { return 0; }
     __host__ __device__ constexpr int pair_param(int p) const { return p; }
+    static constexpr bool kDiagonalPairs = true; // pair p <-> (basis p, param p), P == Q
 };
 
 // ---- runtime model with compile-time sizes: any mix of kinds / shared parameters ---------------
 template <int N_, int Q_, int P_> struct RtModel {
     static constexpr int N = N_, Q = Q_, P = P_;
     static constexpr bool kStatic = false;
+    static constexpr bool kDiagonalPairs = false;
     int32_t kind_[N_];
     int32_t par_[N_][VP_MAX_BASIS_PARAMS];
     int32_t pb_[P_], pa_[P_], pp_[P_];
@@ -39,21 +41,89 @@ template <int N_, int Q_, int P_> struct RtModel {
     __host__ __device__ int pair_param(int p) const { return pp_[p]; }
 };
 
-__device__ __forceinline__ double texp(double x) { return __ocml_exp_f64(x); }
+// fp64 exp for the basis columns: 2*m of these per evaluation dominate the vector work, so it is
+// written out: k = rint(x log2 e); r = x - k ln2 (two FMAs, hi/lo split); degree-13 Taylor polynomial on
+// |r| <= ln2/2 (truncation 6e-18 relative); ldexp.  19 instructions, < 1 ulp + 1 ulp of Horner rounding;
+// no range-check selects: v_ldexp_f64 saturates to inf / flushes to 0 by itself, NaN propagates.
+__device__ __forceinline__ double texp(double x) {
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(-k, 6.93147180559945286227e-01, x);
+    r = __builtin_fma(-k, 2.31904681384629955842e-17, r);
+    double p = 1.6059043836821613e-10;                 // 1/13!
+    p = __builtin_fma(p, r, 2.0876756987868100e-09);   // 1/12!
+    p = __builtin_fma(p, r, 2.5052108385441720e-08);   // 1/11!
+    p = __builtin_fma(p, r, 2.7557319223985893e-07);   // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985888e-06);   // 1/9!
+    p = __builtin_fma(p, r, 2.4801587301587302e-05);   // 1/8!
+    p = __builtin_fma(p, r, 1.9841269841269841e-04);   // 1/7!
+    p = __builtin_fma(p, r, 1.3888888888888889e-03);   // 1/6!
+    p = __builtin_fma(p, r, 8.3333333333333332e-03);   // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);   // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);   // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
 __device__ __forceinline__ float texp(float x) { return __ocml_exp_f32(x); }
 __device__ __forceinline__ double tsin(double x) { return __ocml_sin_f64(x); }
 __device__ __forceinline__ float tsin(float x) { return __ocml_sin_f32(x); }
 __device__ __forceinline__ double tcos(double x) { return __ocml_cos_f64(x); }
 __device__ __forceinline__ float tcos(float x) { return __ocml_cos_f32(x); }
 
-// Build the (weighted) basis columns A[N][R] and derivative columns D[P][R] of one problem.
-//   t[r]      grid value of the lane's row r
-//   scale[r]  w_i for rows i < m (1 for unit weights) and 0 for padding rows i >= m
-// Padding rows come out exactly zero in every column, so they drop out of all later reductions.
-template <typename T, class M, int R>
-__device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::Q], const T (&t)[R],
-                                              const T (&scale)[R], T (&A)[M::N][R], T (&D)[M::P > 0 ? M::P : 1][R]) {
+// ---- row sources: where the grid value t_i and the row scale of a lane's rows come from -----------
+// scale_i = w_i for rows i < m (1 for unit weights) and 0 for padding rows i >= m, so that padding
+// rows are exactly zero in every column and drop out of all later reductions.
+// Values are fetched per register PAIR right where they are consumed (short live ranges: the grid is
+// never held in 2R VGPRs across the whole column build).
+template <typename T, int R> struct RowSource {
+    const T *t;  // grid, indexed by row (LDS or global)
+    const T *w;  // weights indexed by row, or nullptr for unit weights
+    int m;       // rows >= m are padding
+    int lane;
+    bool vec;    // 2-element aligned accesses allowed
+    using L = Layout<R>;
+    __device__ __forceinline__ void get(int r0, T (&tt)[2], T (&sc)[2]) const {
+        // r0 even (or R == 1): registers r0, r0+1 hold rows i, i+1
+        const int i = L::row_of(r0, lane);
+        if constexpr (L::VW == 2) {
+            using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+            if (vec) {
+                if (i < m) { // m even when vec: i+1 < m too
+                    const V2 v = *reinterpret_cast<const V2 *>(t + i);
+                    tt[0] = v.x;
+                    tt[1] = v.y;
+                    if (w) {
+                        const V2 u = *reinterpret_cast<const V2 *>(w + i);
+                        sc[0] = u.x;
+                        sc[1] = u.y;
+                    } else {
+                        sc[0] = T(1);
+                        sc[1] = T(1);
+                    }
+                } else {
+                    tt[0] = tt[1] = sc[0] = sc[1] = T(0);
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < L::VW; ++e) {
+            const bool in = (i + e) < m;
+            tt[e] = in ? t[i + e] : T(0);
+            sc[e] = in ? (w ? w[i + e] : T(1)) : T(0);
+        }
+    }
+};
+
+// Build the (weighted) basis columns and derivative columns of one problem into the unified column
+// array C:  C[j] = W phi_j  (j < N),  C[N] is left alone (data column),  C[N+1+p] = W dphi_pair_p.
+template <typename T, class M, int R, int NC>
+__device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::Q], const RowSource<T, R> &src,
+                                              T (&C)[NC][R]) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
+    constexpr int VW = Layout<R>::VW;
+    static_assert(NC >= N + 1 + P, "column array too small");
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int kind = mdl.kind(j);
@@ -69,56 +139,45 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                 else s1 = p;
             }
         }
-        T d0[R], d1[R];
-        if (kind == VP_BASIS_CONST) {
+        const T rt = (kind == VP_BASIS_EXP_DECAY) ? T(1) / p0 : T(0);
+        const T rt2 = (kind == VP_BASIS_EXP_DECAY) ? T(1) / (p0 * p0) : T(0);
 #pragma unroll
-            for (int r = 0; r < R; ++r) A[j][r] = scale[r];
-        } else if (kind == VP_BASIS_EXP_DECAY) {
-            // exp(-t/tau);  d/dtau = exp(-t/tau) * t / tau^2     (shared_test_code/src/lib.rs:101-114)
-            const T rt = T(1) / p0;
-            const T rt2 = T(1) / (p0 * p0);
+        for (int r0 = 0; r0 < R; r0 += VW) {
+            T tt[2], sc[2];
+            src.get(r0, tt, sc);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const T e = texp(-div_refined(t[r], p0, rt)) * scale[r];
-                A[j][r] = e;
-                d0[r] = (e * t[r]) * rt2;
-            }
-        } else if (kind == VP_BASIS_EXP_RATE) {
+            for (int e = 0; e < VW; ++e) {
+                const int r = r0 + e;
+                const T t = tt[e], scl = sc[e];
+                T f, d0 = T(0), d1 = T(0);
+                if (kind == VP_BASIS_CONST) {
+                    f = scl;
+                } else if (kind == VP_BASIS_EXP_DECAY) {
+                    // exp(-t/tau);  d/dtau = exp(-t/tau) * t / tau^2   (shared_test_code/src/lib.rs:101-114)
+                    f = texp(-div_refined(t, p0, rt)) * scl;
+                    d0 = (f * t) * rt2;
+                } else if (kind == VP_BASIS_EXP_RATE) {
+                    f = texp(-p0 * t) * scl;
+                    d0 = -t * f;
+                } else if (kind == VP_BASIS_EXP_COS) {
+                    // exp(-a t) cos(b t)   (shared_test_code/src/models.rs:313-314, 349-372)
+                    const T ex = texp(-p0 * t) * scl;
+                    f = ex * tcos(p1 * t);
+                    d0 = f * (-t);
+                    d1 = -t * ex * tsin(p1 * t);
+                } else { // VP_BASIS_SIN_PHASE   (src/test_helpers/mod.rs:28-52)
+                    const T ph = p0 * t + p1;
+                    const T cs = tcos(ph) * scl;
+                    f = tsin(ph) * scl;
+                    d0 = t * cs;
+                    d1 = cs;
+                }
+                C[j][r] = f;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const T e = texp(-p0 * t[r]) * scale[r];
-                A[j][r] = e;
-                d0[r] = -t[r] * e;
-            }
-        } else if (kind == VP_BASIS_EXP_COS) {
-            // exp(-a t) cos(b t)   (shared_test_code/src/models.rs:313-314, 349-372)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const T ex = texp(-p0 * t[r]) * scale[r];
-                const T f = ex * tcos(p1 * t[r]);
-                A[j][r] = f;
-                d0[r] = f * (-t[r]);
-                d1[r] = -t[r] * ex * tsin(p1 * t[r]);
-            }
-        } else { // VP_BASIS_SIN_PHASE   (src/test_helpers/mod.rs:28-52)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const T ph = p0 * t[r] + p1;
-                const T cs = tcos(ph) * scale[r];
-                A[j][r] = tsin(ph) * scale[r];
-                d0[r] = t[r] * cs;
-                d1[r] = cs;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            if (p == s0) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) D[p][r] = d0[r];
-            }
-            if (p == s1) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) D[p][r] = d1[r];
+                for (int p = 0; p < P; ++p) {
+                    if (p == s0) C[N + 1 + p][r] = d0;
+                    if (p == s1) C[N + 1 + p][r] = d1;
+                }
             }
         }
     }

@@ -17,7 +17,8 @@ struct KernelEntry {
     int R;      // rows per lane; handles m <= 64*R
     launch_fn evaluate;
     launch_fn basis;
-    launch_fn fit;      // may be null
+    launch_fn fit;      // multi-problem-per-wave LM (vp_fit_mp.hpp); may be null
+    launch_fn fit_single; // one-problem-per-wave LM (vp_fit.hpp), kept for A/B and diagnostics
     launch_fn best_fit; // may be null
 };
 
