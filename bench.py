@@ -36,7 +36,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU (configs[1] = 4096)")
+    ap.add_argument("--batch", type=int, default=65536,
+                    help="problems per GPU: 65536 = BASELINE configs[3]'s per-GPU shard (524288 over 8 GPUs) and the "
+                         "north_star 1-GPU headline size; configs[1] (4096) is measured alongside on rank 0")
     ap.add_argument("--m", type=int, default=1024)
     ap.add_argument("--noise", type=float, default=1e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,6 +144,32 @@ def main():
         #   jacobian QR ~ 2m*2*3 per accepted step (~ evaluations)
         flops_eval = 2 * m * 28 + 4 * m * (5 + 4 + 3) + 12 * m
         tflops_fit = B * evals_per_fit * flops_eval / (fit_ms * 1e-3) / 1e12
+        # BASELINE configs[1] (B = 4096 on one GPU) alongside: same generator, first 4096 problems
+        cfg1 = None
+        if B >= 4096 and world == 1:
+            bp1 = vp.BatchProblem(mdl, Y[:4096].contiguous(), x=x)
+            g1 = guess[:4096].contiguous()
+            for _ in range(3):
+                bp1.fit(g1, want_coefficients=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n1 = max(args.steps, 10)
+            for _ in range(n1):
+                bp1.fit(g1, want_coefficients=False)
+                bp1.summary()
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / n1
+            cfg1 = {"workload": "BASELINE configs[1]: 4096 fits on 1 GPU (tail-latency bound: the slowest fit "
+                                "needs >100 LM evaluations)", "fits_per_s": 4096 / dt1, "ms_per_step": dt1 * 1e3}
+            bp1.close()
+        # HBM traffic of the Phi kernel from the committed rocprofv3 PMC passes (profiles/), per launch
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pj.get("batch") == B and pj.get("m") == m:
+                traffic = pj["basis_kernel"]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "independent fits/sec (double-exp, m=%d, fp64)" % m,
             "value": value,
@@ -156,8 +184,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: %d independent double-exponential+offset fits per GPU, m=%d, n=3, "
-                            "q=2, fp64, noise %.0e, full LM fit to convergence per step" % (B, m, args.noise),
+                "workload": "BASELINE configs[3] per-GPU shard (= north_star 1-GPU headline): %d independent "
+                            "double-exponential+offset fits per GPU, m=%d, n=3, q=2, fp64, noise %.0e, full LM fit to "
+                            "convergence per step" % (B, m, args.noise),
                 "batch_per_gpu": B, "m": m, "parallelism": "batch-sharded x%d" % world,
                 "mean_evaluations_per_fit": evals_per_fit, "fits_successful": n_ok, "fits_failed": n_bad,
                 "sum_cost": sum_cost,
@@ -165,9 +194,10 @@ def main():
             "roofline": {
                 "kernel": "basis_kernel (vp_basis: stand-alone Phi/dPhi evaluation)",
                 "bound": "hbm", "achieved": gbs_phi, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs_phi / HBM_PEAK_GBS, "traffic": None,
+                "frac": gbs_phi / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_launch": bytes_phi, "avg_launch_ms": basis_ms,
             },
+            "configs1": cfg1,
             "roofline_fit": {
                 "kernel": "fit_kernel (vp_fit: device-resident LM, dominant kernel of the timed step)",
                 "bound": "fp64_valu", "achieved": tflops_fit, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -105,6 +105,30 @@ __device__ __forceinline__ void apply_q(const T (&V)[NC][R], const T (&g)[N], T 
     }
 }
 
+// in-place variant: columns [C0, C1) of the unified array <- Q (.)   (C0 >= N)
+template <typename T, int R, int N, int NC, int C0, int C1>
+__device__ __forceinline__ void apply_q_cols(T (&C)[NC][R], const T (&g)[N]) {
+    constexpr int NZ = C1 - C0;
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+        T w[NZ];
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc = tfma(C[k][r], C[C0 + z][r], acc);
+            w[z] = acc;
+        }
+        wave_allreduce(w);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) {
+            const T f = g[k] * w[z];
+#pragma unroll
+            for (int r = 0; r < R; ++r) C[C0 + z][r] = tfma(f, C[k][r], C[C0 + z][r]);
+        }
+    }
+}
+
 // Slow path of the linear solve: truncated SVD of the N x N triangular factor (absolute threshold
 // eps, as nalgebra's SVD::solve at src/solvers/levmar/mod.rs:52-54).  All arithmetic wave-uniform.
 // Returns the minimum-norm c and e = qty - Rm c (the part of the residual that lives in range(Q)).
@@ -237,12 +261,12 @@ template <typename T, int N> struct EvalUniform {
 
 // One full evaluation at `alpha`: builds the columns (the data column C[N] must already hold y_w),
 // runs the fused sweep, solves for c and forms ||r||^2.
-template <typename T, class M, int R, int NC>
-__device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::Q], const RowSource<T, R> &src, T eps,
+template <typename T, class M, int R, int NC, class Src>
+__device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::Q], const Src &src, T eps,
                                               const int lane, T (&C)[NC][R], EvalUniform<T, M::N> &u) {
     constexpr int N = M::N;
     using L = Layout<R>;
-    build_columns<T, M, R, NC>(mdl, alpha, src, C);
+    build_columns<T, M, R, NC, Src>(mdl, alpha, src, C);
     T Rm[N][N], qty[N];
     house_qr<T, R, N, NC, 0>(C, u.g, Rm, qty, lane);
     bool truncated;

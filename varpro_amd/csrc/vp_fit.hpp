@@ -397,14 +397,15 @@ template <typename T, int N, int Q> struct LmState {
     int nfev;
 };
 
-template <typename T, class M, int R> __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
+template <typename T, class M, int R, bool WEIGHTED>
+__global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     constexpr int MP = 64 * R;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *s_t = reinterpret_cast<T *>(smem_raw);
     T *s_y = s_t + MP;
-    T *s_w = a.w ? s_y + MP : nullptr;
-    LmState<T, N, Q> *st = reinterpret_cast<LmState<T, N, Q> *>(s_y + MP + (a.w ? MP : 0));
+    T *s_w = WEIGHTED ? s_y + MP : nullptr;
+    LmState<T, N, Q> *st = reinterpret_cast<LmState<T, N, Q> *>(s_y + MP + (WEIGHTED ? MP : 0));
     const int lane = lane_id();
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
@@ -416,7 +417,7 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64, (wav
         const T *tp = a.t + b * a.t_stride;
         load_rows<T, R>(tp, m, lane, vec_aligned<T>(tp, m), tmp);
         store_rows<T, R>(s_t, MP, lane, true, tmp);
-        if (a.w) {
+        if constexpr (WEIGHTED) {
             const T *wp = a.w + b * a.w_stride;
             load_rows<T, R>(wp, m, lane, vec_aligned<T>(wp, m), tmp);
             store_rows<T, R>(s_w, MP, lane, true, tmp);
@@ -427,12 +428,13 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64, (wav
     }
     __syncthreads(); // single wave: orders the LDS writes before the reads below
     // the LDS copies are zero-padded to MP rows; valid rows are still i < m (scale 0 beyond)
-    RowSource<T, R> src;
+    using Src = RowSource<T, R, true, WEIGHTED ? 1 : 0>;
+    Src src;
     src.t = s_t;
     src.w = s_w;
     src.m = m;
     src.lane = lane;
-    src.vec = ((m & 1) == 0);
+    src.vec = true;
 
     // ---- LM state (wave-uniform) ----
     T x[Q], xt[Q], diag[Q], qtf[Q], step[Q], acnorm[Q], cbest[N];
@@ -507,7 +509,7 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64, (wav
         T C[NC][R];
         EvalUniform<T, N> u;
         load_rows<T, R>(s_y, MP, lane, true, C[N]);
-        evaluate_core<T, M, R, NC>(a.mdl, xt, src, a.eps, lane, C, u);
+        evaluate_core<T, M, R, NC, Src>(a.mdl, xt, src, a.eps, lane, C, u);
 
         asm volatile("" ::: "memory");
         // ---- un-park ----
@@ -762,7 +764,8 @@ template <typename T, class M, int R> int launch_fit(const LaunchParams &p) {
     a.trace_rows = p.trace_rows;
     if (a.B <= 0) return VP_ERR_OK;
     const size_t lds = (size_t)(p.w ? 3 : 2) * 64 * R * sizeof(T) + sizeof(LmState<T, M::N, M::Q>);
-    hipLaunchKernelGGL((fit_kernel<T, M, R>), dim3((unsigned)a.B), dim3(64), lds, p.stream, a);
+    if (p.w) hipLaunchKernelGGL((fit_kernel<T, M, R, true>), dim3((unsigned)a.B), dim3(64), lds, p.stream, a);
+    else hipLaunchKernelGGL((fit_kernel<T, M, R, false>), dim3((unsigned)a.B), dim3(64), lds, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
@@ -792,7 +795,7 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) best
     for (int k = 0; k < N; ++k) c[k] = a.C[prob * N + k];
     const RowSource<T, R> src = make_row_source<T, R>(a.t + b * a.t_stride, (const T *)nullptr, m, lane);
     T C[NC][R];
-    build_columns<T, M, R, NC>(a.mdl, alpha, src, C);
+    build_columns<T, M, R, NC, RowSource<T, R>>(a.mdl, alpha, src, C);
     T f[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {

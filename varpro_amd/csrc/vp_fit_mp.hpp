@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_
                 const T *yp = a.yw + prob * (int64_t)m;
                 load_rows<T, R>(yp, m, lane, vec_aligned<T>(yp, m), C[N]);
             }
-            evaluate_core<T, M, R, NC>(a.mdl, alpha, src, a.eps, lane, C, u);
+            evaluate_core<T, M, R, NC, RowSource<T, R>>(a.mdl, alpha, src, a.eps, lane, C, u);
 
             const T fnorm1 = tsqrt(u.fn2);
             T actred = T(0), ratio = T(0);

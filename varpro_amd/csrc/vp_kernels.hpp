@@ -6,6 +6,8 @@
 //                     HBM-roofline fraction BASELINE.json asks for) == src/model/mod.rs:308,359-362
 //   fit_kernel      : device-resident Levenberg-Marquardt over the VarPro functional (vp_fit.hpp)
 #pragma once
+#include <initializer_list>
+
 #include "vp_core.hpp"
 
 namespace vp {
@@ -47,6 +49,7 @@ struct LaunchParams {
 };
 
 // ---- row-distributed loads / stores ------------------------------------------------------------
+// branch-free: rows >= m read element 0 and are zeroed by a select
 template <typename T, int R>
 __device__ __forceinline__ void load_rows(const T *__restrict__ base, const int m, const int lane, const bool vec_ok,
                                           T (&out)[R]) {
@@ -56,15 +59,11 @@ __device__ __forceinline__ void load_rows(const T *__restrict__ base, const int 
 #pragma unroll
             for (int r = 0; r < R; r += 2) {
                 const int i = L::row_of(r, lane);
-                if (i < m) {
-                    using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
-                    const V2 v = *reinterpret_cast<const V2 *>(base + i);
-                    out[r] = v.x;
-                    out[r + 1] = v.y;
-                } else {
-                    out[r] = T(0);
-                    out[r + 1] = T(0);
-                }
+                const bool in = i < m;
+                using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+                const V2 v = *reinterpret_cast<const V2 *>(base + (in ? i : 0));
+                out[r] = in ? v.x : T(0);
+                out[r + 1] = in ? v.y : T(0);
             }
             return;
         }
@@ -72,7 +71,9 @@ __device__ __forceinline__ void load_rows(const T *__restrict__ base, const int 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = L::row_of(r, lane);
-        out[r] = (i < m) ? base[i] : T(0);
+        const bool in = i < m;
+        const T v = base[in ? i : 0];
+        out[r] = in ? v : T(0);
     }
 }
 
@@ -137,8 +138,11 @@ template <typename T, class M> struct EvalArgs {
 };
 
 // MODE 0: coefficients/cost/status only; 1: + residuals; 2: + residuals + Jacobian
-template <typename T, class M, int R, int MODE>
-__global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) evaluate_kernel(const EvalArgs<T, M> a) {
+// ALIGNED: m even and every array 16-byte aligned (checked on the host) -> 2-element accesses only
+// WEIGHTED: weights present (decided on the host)
+template <typename T, class M, int R, int MODE, bool ALIGNED, bool WEIGHTED>
+__global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>()))
+    evaluate_kernel(const EvalArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     const int lane = lane_id();
     const int64_t prob = blockIdx.x; // problem * S + rhs
@@ -151,15 +155,20 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) eval
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
 
-    const RowSource<T, R> src =
-        make_row_source<T, R>(a.t + b * a.t_stride, a.w ? a.w + b * a.w_stride : nullptr, m, lane);
+    using Src = RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0>;
+    Src src;
+    src.t = a.t + b * a.t_stride;
+    src.w = WEIGHTED ? a.w + b * a.w_stride : nullptr;
+    src.m = m;
+    src.lane = lane;
+    src.vec = ALIGNED;
     T C[NC][R];
     const T *yp = a.yw + prob * (int64_t)m;
-    const bool yvec = vec_aligned<T>(yp, m);
+    constexpr bool yvec = ALIGNED;
     load_rows<T, R>(yp, m, lane, yvec, C[N]);
 
     EvalUniform<T, N> u;
-    evaluate_core<T, M, R, NC>(a.mdl, alpha, src, a.eps, lane, C, u);
+    evaluate_core<T, M, R, NC, Src>(a.mdl, alpha, src, a.eps, lane, C, u);
 
     if (lane == 0) {
         if (a.status) a.status[prob] = u.ok ? VP_ST_OK : VP_ST_NONFINITE;
@@ -169,35 +178,43 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) eval
 
     if constexpr (MODE >= 1) {
         residual_qcoords<T, R, N>(C[N], u.e, lane);
+        T *rp = a.r_out ? a.r_out + prob * (int64_t)m : nullptr;
         if constexpr (MODE == 1) {
-            T Z[1][R];
+            // r = Q r~ : back-sweep on the data column only, in place
+            apply_q_cols<T, R, N, NC, N, N + 1>(C, u.g);
+            if (rp) store_rows<T, R>(rp, m, lane, yvec, C[N]);
+        } else if constexpr (M::kDiagonalPairs) {
+            // J~_k = -c_k (Q^T D_k) in place, then ONE back-sweep over [r~ | J~_1 .. J~_q] in place
+            T Zs[1][R];
+            jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, lane);
+            apply_q_cols<T, R, N, NC, N, NC>(C, u.g);
+            if (rp) store_rows<T, R>(rp, m, lane, yvec, C[N]);
+            if (a.J_out) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) Z[0][r] = C[N][r];
-            apply_q<T, R, N, NC, 1>(C, u.g, Z);
-            if (a.r_out) store_rows<T, R>(a.r_out + prob * (int64_t)m, m, lane, yvec, Z[0]);
+                for (int k = 0; k < Q; ++k) { // J[b][k][s][m]
+                    T *jp = a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m;
+                    store_rows<T, R>(jp, m, lane, ALIGNED, C[N + 1 + k]);
+                }
+            }
         } else {
             T Z[1 + Q][R];
             {
-                T Zs[M::kDiagonalPairs ? 1 : Q][R];
+                T Zs[Q][R];
                 jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, lane);
 #pragma unroll
                 for (int r = 0; r < R; ++r) Z[0][r] = C[N][r];
 #pragma unroll
                 for (int k = 0; k < Q; ++k)
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if constexpr (M::kDiagonalPairs) Z[1 + k][r] = C[N + 1 + k][r];
-                        else Z[1 + k][r] = Zs[k][r];
-                    }
+                    for (int r = 0; r < R; ++r) Z[1 + k][r] = Zs[k][r];
             }
             apply_q<T, R, N, NC, 1 + Q>(C, u.g, Z);
-            if (a.r_out) store_rows<T, R>(a.r_out + prob * (int64_t)m, m, lane, yvec, Z[0]);
+            if (rp) store_rows<T, R>(rp, m, lane, yvec, Z[0]);
             if (a.J_out) {
-                // J[b][k][s][m]
 #pragma unroll
-                for (int k = 0; k < Q; ++k) {
+                for (int k = 0; k < Q; ++k) { // J[b][k][s][m]
                     T *jp = a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m;
-                    store_rows<T, R>(jp, m, lane, vec_aligned<T>(jp, m), Z[1 + k]);
+                    store_rows<T, R>(jp, m, lane, ALIGNED, Z[1 + k]);
                 }
             }
         }
@@ -219,7 +236,8 @@ template <typename T, class M> struct BasisArgs {
 
 // Stand-alone Phi/dPhi: reads q scalars (+ the shared grid from L2), writes (n + p) * m scalars per
 // problem with 16-byte-per-lane fully coalesced stores: HBM-write-bound by construction.
-template <typename T, class M, int R> __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs<T, M> a) {
+template <typename T, class M, int R, bool ALIGNED>
+__global__ void __launch_bounds__(64) basis_kernel(const BasisArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     const int lane = lane_id();
     const int64_t b = blockIdx.x;
@@ -228,16 +246,22 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) basi
     T alpha[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
-    const RowSource<T, R> src = make_row_source<T, R>(a.t + b * a.t_stride, (const T *)nullptr, m, lane);
+    using Src = RowSource<T, R, false, 0, ALIGNED ? 1 : 0>;
+    Src src;
+    src.t = a.t + b * a.t_stride;
+    src.w = nullptr;
+    src.m = m;
+    src.lane = lane;
+    src.vec = ALIGNED;
     T C[NC][R];
-    build_columns<T, M, R, NC>(a.mdl, alpha, src, C);
+    build_columns<T, M, R, NC, Src>(a.mdl, alpha, src, C);
     if (a.Phi_out) {
         int col = 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             if (a.skip_invariant && a.mdl.kind(j) == VP_BASIS_CONST) continue;
             T *p = a.Phi_out + (b * a.n_phi_cols + col) * (int64_t)m;
-            store_rows<T, R>(p, m, lane, vec_aligned<T>(p, m), C[j]);
+            store_rows<T, R>(p, m, lane, ALIGNED, C[j]);
             ++col;
         }
     }
@@ -245,12 +269,21 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) basi
 #pragma unroll
         for (int pidx = 0; pidx < P; ++pidx) {
             T *p = a.dPhi_out + (b * P + pidx) * (int64_t)m;
-            store_rows<T, R>(p, m, lane, vec_aligned<T>(p, m), C[N + 1 + pidx]);
+            store_rows<T, R>(p, m, lane, ALIGNED, C[N + 1 + pidx]);
         }
     }
 }
 
 // ---- host-side launch templates ------------------------------------------------------------------
+// every per-problem / per-column slice starts at a multiple of m elements from its base: with m even and
+// 16-byte aligned bases all 2-element accesses are aligned
+template <typename T> inline bool host_aligned(int m, std::initializer_list<const void *> ptrs) {
+    if (m & 1) return false;
+    for (const void *q : ptrs)
+        if (q && (reinterpret_cast<uintptr_t>(q) & (2 * sizeof(T) - 1)) != 0) return false;
+    return true;
+}
+
 template <class M> inline bool bind_model(const vp_model_desc &d, M &out) {
     if constexpr (M::kStatic) {
         (void)d;
@@ -281,9 +314,19 @@ template <typename T, class M, int R> int launch_evaluate(const LaunchParams &p)
     a.eps = (T)p.eps;
     if (a.nprob <= 0) return VP_ERR_OK;
     dim3 grid((unsigned)a.nprob), block(64);
-    if (p.J_out) hipLaunchKernelGGL((evaluate_kernel<T, M, R, 2>), grid, block, 0, p.stream, a);
-    else if (p.r_out) hipLaunchKernelGGL((evaluate_kernel<T, M, R, 1>), grid, block, 0, p.stream, a);
-    else hipLaunchKernelGGL((evaluate_kernel<T, M, R, 0>), grid, block, 0, p.stream, a);
+    const bool aligned = host_aligned<T>(p.m, {p.t, p.w, p.yw, p.r_out, p.J_out});
+    const int mode = p.J_out ? 2 : (p.r_out ? 1 : 0);
+    const int variant = mode * 4 + (aligned ? 2 : 0) + (p.w ? 1 : 0);
+#define VP_EV(MODE_, AL_, W_)                                                                                          \
+    case (MODE_) * 4 + (AL_) * 2 + (W_):                                                                               \
+        hipLaunchKernelGGL((evaluate_kernel<T, M, R, MODE_, (AL_) != 0, (W_) != 0>), grid, block, 0, p.stream, a);    \
+        break;
+    switch (variant) {
+        VP_EV(0, 0, 0) VP_EV(0, 0, 1) VP_EV(0, 1, 0) VP_EV(0, 1, 1)
+        VP_EV(1, 0, 0) VP_EV(1, 0, 1) VP_EV(1, 1, 0) VP_EV(1, 1, 1)
+        VP_EV(2, 0, 0) VP_EV(2, 0, 1) VP_EV(2, 1, 0) VP_EV(2, 1, 1)
+    }
+#undef VP_EV
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
@@ -303,7 +346,9 @@ template <typename T, class M, int R> int launch_basis(const LaunchParams &p) {
     a.B = p.B;
     a.t_stride = p.t_stride;
     if (a.B <= 0) return VP_ERR_OK;
-    hipLaunchKernelGGL((basis_kernel<T, M, R>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+    if (host_aligned<T>(p.m, {p.t, p.Phi_out, p.dPhi_out}))
+        hipLaunchKernelGGL((basis_kernel<T, M, R, true>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+    else hipLaunchKernelGGL((basis_kernel<T, M, R, false>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 

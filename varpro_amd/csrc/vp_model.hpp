@@ -9,6 +9,10 @@
 #include "../../include/varpro_hip.h"
 #include "vp_device.hpp"
 
+#ifndef VP_BUILD_CHUNK
+#define VP_BUILD_CHUNK 8
+#endif
+
 namespace vp {
 
 // ---- static (compile-time) model: sum of NEXP exponential decays + optional constant offset ----
@@ -76,33 +80,42 @@ __device__ __forceinline__ float tcos(float x) { return __ocml_cos_f32(x); }
 // rows are exactly zero in every column and drop out of all later reductions.
 // Values are fetched per register PAIR right where they are consumed (short live ranges: the grid is
 // never held in 2R VGPRs across the whole column build).
-template <typename T, int R> struct RowSource {
+//   PADDED : the arrays are 16-byte aligned and zero-padded to 64*R rows (the LDS copies of the fit
+//            kernel): always 2-element accesses, no bounds clamp on the address
+//   WMODE  : 0 = unit weights (compile time), 1 = weights present (compile time), 2 = decide by w != nullptr
+//   VMODE  : 0 = scalar accesses only, 1 = 2-element aligned accesses (compile time), 2 = decide by `vec`
+template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2> struct RowSource {
     const T *t;  // grid, indexed by row (LDS or global)
     const T *w;  // weights indexed by row, or nullptr for unit weights
     int m;       // rows >= m are padding
     int lane;
-    bool vec;    // 2-element aligned accesses allowed
+    bool vec;    // (!PADDED only) 2-element aligned accesses allowed
     using L = Layout<R>;
+    __device__ __forceinline__ bool weighted() const {
+        if constexpr (WMODE == 0) return false;
+        else if constexpr (WMODE == 1) return true;
+        else return w != nullptr;
+    }
+    // BRANCH-FREE per row pair: out-of-range rows read a valid element and are zeroed by selects, so the
+    // R row pairs of a column stay in one basic block.
     __device__ __forceinline__ void get(int r0, T (&tt)[2], T (&sc)[2]) const {
         // r0 even (or R == 1): registers r0, r0+1 hold rows i, i+1
         const int i = L::row_of(r0, lane);
         if constexpr (L::VW == 2) {
             using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
-            if (vec) {
-                if (i < m) { // m even when vec: i+1 < m too
-                    const V2 v = *reinterpret_cast<const V2 *>(t + i);
-                    tt[0] = v.x;
-                    tt[1] = v.y;
-                    if (w) {
-                        const V2 u = *reinterpret_cast<const V2 *>(w + i);
-                        sc[0] = u.x;
-                        sc[1] = u.y;
-                    } else {
-                        sc[0] = T(1);
-                        sc[1] = T(1);
-                    }
+            if (PADDED || VMODE == 1 || (VMODE == 2 && vec)) {
+                const bool in0 = i < m, in1 = (i + 1) < m; // !PADDED: m even, in1 == in0
+                const int ic = PADDED ? i : (in0 ? i : 0);
+                const V2 v = *reinterpret_cast<const V2 *>(t + ic);
+                tt[0] = in0 ? v.x : T(0);
+                tt[1] = in1 ? v.y : T(0);
+                if (weighted()) {
+                    const V2 u = *reinterpret_cast<const V2 *>(w + ic);
+                    sc[0] = in0 ? u.x : T(0);
+                    sc[1] = in1 ? u.y : T(0);
                 } else {
-                    tt[0] = tt[1] = sc[0] = sc[1] = T(0);
+                    sc[0] = in0 ? T(1) : T(0);
+                    sc[1] = in1 ? T(1) : T(0);
                 }
                 return;
             }
@@ -110,17 +123,23 @@ template <typename T, int R> struct RowSource {
 #pragma unroll
         for (int e = 0; e < L::VW; ++e) {
             const bool in = (i + e) < m;
-            tt[e] = in ? t[i + e] : T(0);
-            sc[e] = in ? (w ? w[i + e] : T(1)) : T(0);
+            const int ic = in ? (i + e) : 0;
+            const T tv = t[ic];
+            tt[e] = in ? tv : T(0);
+            if (weighted()) {
+                const T wv = w[ic];
+                sc[e] = in ? wv : T(0);
+            } else {
+                sc[e] = in ? T(1) : T(0);
+            }
         }
     }
 };
 
 // Build the (weighted) basis columns and derivative columns of one problem into the unified column
 // array C:  C[j] = W phi_j  (j < N),  C[N] is left alone (data column),  C[N+1+p] = W dphi_pair_p.
-template <typename T, class M, int R, int NC>
-__device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::Q], const RowSource<T, R> &src,
-                                              T (&C)[NC][R]) {
+template <typename T, class M, int R, int NC, class Src>
+__device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::Q], const Src &src, T (&C)[NC][R]) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
     constexpr int VW = Layout<R>::VW;
     static_assert(NC >= N + 1 + P, "column array too small");
@@ -143,6 +162,10 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
         const T rt2 = (kind == VP_BASIS_EXP_DECAY) ? T(1) / (p0 * p0) : T(0);
 #pragma unroll
         for (int r0 = 0; r0 < R; r0 += VW) {
+            // keep at most VP_BUILD_CHUNK rows of the transcendental pipeline in flight: without the fence the
+            // scheduler interleaves all R rows of a column (R x ~4 fp64 temporaries) and spills
+            if constexpr (R > VP_BUILD_CHUNK)
+                if (r0 % VP_BUILD_CHUNK == 0 && r0 != 0) __builtin_amdgcn_sched_barrier(0);
             T tt[2], sc[2];
             src.get(r0, tt, sc);
 #pragma unroll
