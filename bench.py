@@ -49,7 +49,8 @@ def main():
     import torch.distributed as dist
 
     import varpro_amd as vp
-    from varpro_amd import _lib, synth
+    from varpro_amd import distributed as vd
+    from varpro_amd import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -70,7 +71,6 @@ def main():
     x = torch.from_numpy(d["x"]).to(dev)
     guess = torch.from_numpy(d["tau_guess"]).to(dev)
     bp = vp.BatchProblem(mdl, Y, x=x)  # device-pointer mode on torch's current stream
-    red = torch.zeros(4, dtype=torch.float64, device=dev)
 
     def barrier():
         if world > 1:
@@ -79,11 +79,8 @@ def main():
     def step():
         alpha, _c, _rep = bp.fit(guess, want_coefficients=False)
         s = bp.summary()  # local {sum cost, #ok, #failed, sum evals} (host doubles)
-        if world > 1:
-            red.copy_(torch.from_numpy(s))
-            dist.all_reduce(red, op=dist.ReduceOp.SUM)  # RCCL over xGMI: the scalar LM cost reduction
-            return red
-        return s
+        # RCCL over xGMI: the scalar LM cost reduction (one 32-byte sum all-reduce per step)
+        return vd.allreduce_summary(s, device=dev)
 
     for _ in range(args.warmup):
         step()
@@ -102,7 +99,6 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        last = last.cpu().numpy()
     total_fits = float(world) * B * args.steps
     value = total_fits / dt
     sum_cost, n_ok, n_bad, n_evals = [float(v) for v in last]

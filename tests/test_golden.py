@@ -1,0 +1,58 @@
+"""The 1e-10 contract pinned against the independent 50-digit (mpmath) golden vectors of
+tests/golden/make_golden.py: CPU tier checks the oracle, GPU tier checks the HIP path (C ABI)."""
+import os
+
+import numpy as np
+import pytest
+
+import varpro_amd as vp
+from models import double_exp_builder_model, oleary_model
+from oracle import oracle as O
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_eval.npz"))
+CASES = ["cfg0_guess", "cfg0_near", "cfg1w", "oleary"]
+TOL = 1e-10
+
+
+def _case(tag):
+    x, y, alpha = G[tag + "_x"], G[tag + "_y"], G[tag + "_alpha"]
+    w = G[tag + "_w"] if (tag + "_w") in G.files else None
+    mdl = oleary_model(x, alpha) if tag == "oleary" else double_exp_builder_model(x, alpha)
+    return mdl, x, y, alpha, w, G[tag + "_c"], G[tag + "_r"], G[tag + "_J"]
+
+
+def _check(c, r, J, cg, rg, Jg, yw, dkc_scale):
+    assert np.abs(c - cg).max() <= TOL * np.abs(cg).max()
+    assert np.abs(r - rg).max() <= TOL * np.abs(yw).max()
+    for k in range(Jg.shape[0]):
+        # |dJ_k| <= 1e-10 max|J_k|, floor: rounding of the un-projected column
+        assert np.abs(J[k] - Jg[k]).max() <= TOL * np.abs(Jg[k]).max() + 1e-13 * dkc_scale[k]
+
+
+def _dkc_scale(mdl, x, alpha, c, w):
+    out = []
+    for k in range(mdl.n_params):
+        dk = (O.eval_dphi(mdl, x, alpha, k) * c[:, None]).sum(0) * (1.0 if w is None else w)
+        out.append(np.abs(dk).max())
+    return out
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_oracle_matches_high_precision_golden(tag):
+    mdl, x, y, alpha, w, cg, rg, Jg = _case(tag)
+    p = O.Problem(mdl, x, y, w=w)
+    p.set_params(alpha)
+    yw = y if w is None else y * w
+    _check(p.linear_coefficients(), p.residuals(), p.jacobian(), cg, rg, Jg, yw, _dkc_scale(mdl, x, alpha, cg, w))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_gpu_matches_high_precision_golden(tag):
+    mdl, x, y, alpha, w, cg, rg, Jg = _case(tag)
+    bp = vp.BatchProblem(mdl, y[None, :], x=x, weights=w)
+    ev = bp.evaluate(alpha[None, :])
+    assert ev["status"][0] == 0
+    yw = y if w is None else y * w
+    _check(ev["C"][0], ev["r"][0], ev["J"][0], cg, rg, Jg, yw, _dkc_scale(mdl, x, alpha, cg, w))
+    bp.close()
