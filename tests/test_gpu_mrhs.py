@@ -1,0 +1,112 @@
+"""Multiple right-hand sides (global fit) on the GPU: factor-once + streaming kernels and the device LM over
+J^T J / J^T r, against the CPU oracle (which materialises the (m S) x q Jacobian as the reference does)."""
+import numpy as np
+import pytest
+
+import varpro_amd as vp
+from models import double_exp_builder_model
+from oracle import oracle as O
+from varpro_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _triple(x, guess):
+    return vp.multi_exponential_model(x, guess, offset=True)
+
+
+@pytest.mark.parametrize("S,m", [(2, 20), (3, 20), (40, 256), (300, 1024)])
+def test_mrhs_evaluate_matches_oracle(S, m):
+    rng = np.random.default_rng(S)
+    x = 12.5 * np.arange(m) / (m - 1)
+    Cm = rng.uniform(0, 100, (S, 3))
+    Y = Cm[:, 0:1] * np.exp(-x / 1.0) + Cm[:, 1:2] * np.exp(-x / 3.0) + Cm[:, 2:3]
+    Y = Y + 1e-3 * np.abs(Y).max() * rng.standard_normal(Y.shape)
+    mdl = double_exp_builder_model(x, [1.4, 4.1])
+    bp = vp.BatchProblem(mdl, Y[None], x=x)
+    ev = bp.evaluate(np.array([[1.4, 4.1]]))
+    ref = O.Problem(mdl, x, Y)
+    ref.set_params([1.4, 4.1])
+    assert ev["status"][0] == 0
+    assert np.abs(ev["C"][0] - ref.linear_coefficients()).max() <= TOL * np.abs(ref.linear_coefficients()).max()
+    assert np.abs(ev["r"][0] - ref.residuals()).max() <= TOL * np.abs(Y).max()
+    Jr = ref.jacobian()
+    for k in range(2):
+        assert np.abs(ev["J"][0, k] - Jr[k]).max() <= TOL * np.abs(Jr[k]).max()
+    assert abs(ev["cost"][0] - 0.5 * (ref.residuals() ** 2).sum()) <= 1e-10 * ev["cost"][0]
+    bp.close()
+
+
+def test_mrhs_reference_fits_recover_truth():
+    # tests/integration_tests/main.rs:399-463 (S=2) and :467-551 (S=3): tau=(1,3) and all coefficients to 1e-8
+    x = synth.linspace_reference(0., 12.5, 20)
+    coeffs = {2: [(2., 4., 0.2), (5., 1., 9.)], 3: [(2., 4., 0.2), (10., 12., 18.), (5., 1., 9.)]}
+    for S, cs in coeffs.items():
+        Y = np.stack([a * np.exp(-x / 1.) + b * np.exp(-x / 3.) + c for a, b, c in cs], axis=1)  # m x S
+        mdl = double_exp_builder_model(x, [2.5, 6.5])
+        prob = vp.SeparableProblemBuilder.mrhs(mdl).observations(Y).build()
+        res = vp.LevMarSolver.default().fit(prob)
+        assert res.was_successful()
+        tau = res.nonlinear_parameters()
+        i1, i2 = (0, 1) if tau[0] < tau[1] else (1, 0)
+        assert abs(tau[i1] - 1.) < 1e-8 and abs(tau[i2] - 3.) < 1e-8
+        C = res.linear_coefficients()  # n x S
+        for s, (a, b, c) in enumerate(cs):
+            assert abs(C[i1, s] - a) < 1e-8 and abs(C[i2, s] - b) < 1e-8 and abs(C[2, s] - c) < 1e-8
+        assert np.abs(res.best_fit() - Y).max() < 1e-5
+        prob.close()
+
+
+@pytest.mark.parametrize("S,m,noise", [(64, 256, 1e-3), (500, 1024, 1e-3), (64, 1024, 0.0)])
+def test_mrhs_fit_matches_oracle(S, m, noise):
+    rng = np.random.default_rng(S + m)
+    x = 12.5 * np.arange(m) / (m - 1)
+    Cm = rng.uniform(0, 100, (S, 3))
+    Y = Cm[:, 0:1] * np.exp(-x / 1.0) + Cm[:, 1:2] * np.exp(-x / 3.0) + Cm[:, 2:3]
+    if noise:
+        Y = Y + noise * np.abs(Y).max() * rng.standard_normal(Y.shape)
+    guess = np.array([[1.5, 4.5]])
+    mdl = double_exp_builder_model(x, guess[0])
+    bp = vp.BatchProblem(mdl, Y[None], x=x)
+    alpha, C, rep, tr = bp.fit_trace(guess, max_rows=12)
+    ref = O.Problem(mdl, x, Y)
+    ref.set_params(guess[0])
+    rr, tr_ref = ref.fit_trace(max_rows=12)
+    assert rep["termination"][0] > 0 and rr.termination > 0
+    # same trajectory for the leading evaluations (Gram-based LM step vs the oracle's QR of the tall J)
+    for i in range(min(5, len(tr_ref), int(rep["n_evals"][0]))):
+        if tr_ref[i, 2] < 1e-6 * tr_ref[0, 2]:
+            break
+        assert np.abs(tr[0, i, :2] - tr_ref[i, :2]).max() <= 1e-6 * np.abs(tr_ref[i, :2]).max(), i
+        assert abs(tr[0, i, 2] - tr_ref[i, 2]) <= 1e-6 * tr_ref[i, 2], i
+    if noise:
+        assert abs(rep["objective"][0] - rr.objective) <= 1e-8 * rr.objective
+        assert np.abs(alpha[0] - ref.params()).max() <= 1e-6 * np.abs(ref.params()).max()
+    else:
+        assert np.abs(alpha[0] - [1.0, 3.0]).max() < 1e-8
+        assert np.abs(C[0] - Cm).max() < 1e-6
+    # handle state after the fit: coefficients, residual cache and cost belong to the final parameters
+    assert np.array_equal(np.asarray(bp.params()), alpha)
+    r = bp.residuals()
+    assert abs(0.5 * (r ** 2).sum() - rep["objective"][0]) <= 1e-9 * max(rep["objective"][0], 1e-12 * (Y ** 2).sum())
+    bp.close()
+
+
+def test_mrhs_triple_exponential_config2_shape_small():
+    # BASELINE configs[2] model (3 exponentials + offset, n=4, q=3) at reduced S/m: evaluation parity + fit
+    d = synth.mrhs_triple_exp(S=200, m=512)
+    mdl = _triple(d["x"], d["tau_guess"])
+    bp = vp.BatchProblem(mdl, d["Y"][None], x=d["x"])
+    ev = bp.evaluate(d["tau_guess"][None])
+    ref = O.Problem(mdl, d["x"], d["Y"])
+    ref.set_params(d["tau_guess"])
+    assert np.abs(ev["r"][0] - ref.residuals()).max() <= TOL * np.abs(d["Y"]).max()
+    Jr = ref.jacobian()
+    for k in range(3):
+        assert np.abs(ev["J"][0, k] - Jr[k]).max() <= 1e-9 * np.abs(Jr[k]).max()
+    alpha, C, rep = bp.fit(d["tau_guess"][None])
+    assert rep["termination"][0] > 0
+    assert np.abs(np.sort(alpha[0]) - d["tau_true"]).max() < 1e-6
+    assert np.abs(C[0] - d["C_true"]).max() < 1e-4 * np.abs(d["C_true"]).max()
+    bp.close()

@@ -267,14 +267,19 @@ class BatchProblem:
         opts = solver._c()
         a = self._as_array(alpha0).reshape(self.B, self.q)
         a = a.clone() if _is_torch(a) else a.copy()
-        Cm = self._empty((self.B, self.n)) if want_coefficients else None
+        Cm = self._empty((self.B, self.S, self.n)) if want_coefficients else None
         if self.device_mode:
             rep_t = torch.empty((self.B, 16), dtype=torch.uint8, device=self._torch_device())
             check(self.lib.vp_fit(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), self._ptr(rep_t)))
             rep = rep_t  # raw bytes on device; use report_to_numpy() to decode
+            if Cm is not None and self.single_rhs:
+                Cm = Cm.reshape(self.B, self.n)
+            return a, Cm, rep
         else:
             rep = np.zeros(self.B, dtype=REPORT_DTYPE)
             check(self.lib.vp_fit(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), C.c_void_p(rep.ctypes.data)))
+        if Cm is not None and self.single_rhs:
+            Cm = Cm.reshape(self.B, self.n)
         return a, Cm, rep
 
     def fit_trace(self, alpha0, solver=None, max_rows=512):
@@ -284,11 +289,13 @@ class BatchProblem:
         solver = solver or LevenbergMarquardt(self.np_dtype)
         opts = solver._c()
         a = self._as_array(alpha0).reshape(self.B, self.q).copy()
-        Cm = self._empty((self.B, self.n))
+        Cm = self._empty((self.B, self.S, self.n))
         rep = np.zeros(self.B, dtype=REPORT_DTYPE)
         tr = np.zeros((self.B, max_rows, self.q + 4))
         check(self.lib.vp_fit_trace(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), C.c_void_p(rep.ctypes.data),
                                     C.c_void_p(tr.ctypes.data), int(max_rows)))
+        if self.single_rhs:
+            Cm = Cm.reshape(self.B, self.n)
         return a, Cm, rep, tr
 
     @staticmethod

@@ -12,6 +12,7 @@
 
 #include "../../include/varpro_hip.h"
 #include "vp_registry.hpp"
+#include "vp_mrhs.hpp"
 
 using namespace vp;
 
@@ -136,6 +137,9 @@ struct vp_batch {
     bool timing;
     hipEvent_t ev0, ev1;
     float last_ms[3];
+    // multiple-right-hand-side path (S > 1): factor/stream/LM-step kernels + their workspace
+    bool have_mrhs;
+    MrhsWs mrhs;
 };
 
 namespace {
@@ -264,7 +268,16 @@ int run_evaluate(vp_batch *h, void *r_dev, void *J_dev, void *C_dev) {
     p.cost_out = h->d_cost_bs;
     p.status = h->d_status_bs;
     Timer tm(h, VP_KERNEL_EVALUATE);
-    int rc = h->kern->evaluate(p);
+    int rc;
+    if (h->have_mrhs) {
+        // S > 1: factor Phi once per problem, then ONE streaming pass over the S data columns
+        p.mrhs_ws = &h->mrhs;
+        p.mrhs_mode = 1;
+        rc = h->kern->mrhs_factor(p);
+        if (rc == VP_ERR_OK) rc = h->kern->mrhs_stream(p);
+    } else {
+        rc = h->kern->evaluate(p);
+    }
     tm.stop();
     if (rc != VP_ERR_OK) return fail(rc, "evaluate kernel launch failed");
     return reduce_rhs(h);
@@ -274,6 +287,66 @@ int check_handle(vp_batch *h) {
     if (!h) return fail(VP_ERR_INVALID, "null handle");
     VP_HIP(hipSetDevice(h->device));
     return 0;
+}
+
+// == LevMarSolver::fit for problems with multiple right-hand sides (global fit): host-stepped loop of
+// {factor, streaming reduction over Y, LM step} launches; all LM state stays on the device, the host only
+// reads back one int (number of still-active problems) per iteration.
+int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep, double *trace_out,
+             int trace_rows) {
+    if (!h->have_mrhs) return fail(VP_ERR_UNSUPPORTED, "no MRHS kernels for this (model, m)");
+    vp_lm_opts o;
+    if (opts) o = *opts;
+    else vp_lm_opts_default(&o, h->dtype);
+    const size_t ts = tsize(h->dtype);
+    const hipMemcpyKind kin = device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    VP_HIP(hipMemcpyAsync(h->d_alpha, alpha_inout, (size_t)h->B * h->q * ts, kin, h->stream));
+    LaunchParams p;
+    fill_params(h, p);
+    p.mrhs_ws = &h->mrhs;
+    p.opts = &o;
+    OutBuf tr;
+    const size_t tr_bytes = (size_t)h->B * (size_t)(trace_rows > 0 ? trace_rows : 0) * (h->q + 4) * sizeof(double);
+    if (trace_out && trace_rows > 0) {
+        if (int rc = tr.init(h, trace_out, tr_bytes)) return rc;
+        VP_HIP(hipMemsetAsync(tr.dptr, 0xFF, tr_bytes, h->stream));
+        p.trace = (double *)tr.dptr;
+        p.trace_rows = trace_rows;
+    }
+    VP_HIP(hipMemsetAsync(h->mrhs.nactive, 0, sizeof(int32_t), h->stream));
+    VP_HIP(hipMemsetAsync(h->mrhs.acc, 0, (size_t)h->B * (1 + h->n * h->n + h->p) * sizeof(double), h->stream));
+    Timer tm(h, VP_KERNEL_FIT);
+    p.mrhs_init = 1;
+    p.alpha = h->d_alpha;
+    if (int rc = h->kern->mrhs_lm(p)) return fail(rc, "mrhs_lm (init) launch failed");
+    p.mrhs_init = 0;
+    const int max_iter = o.patience * (h->q + 1) + 2;
+    for (int it = 0; it < max_iter; ++it) {
+        p.alpha = h->mrhs.alpha_trial;
+        p.mrhs_mode = 0;
+        if (int rc = h->kern->mrhs_factor(p)) return fail(rc, "mrhs_factor launch failed");
+        if (int rc = h->kern->mrhs_stream(p)) return fail(rc, "mrhs_stream launch failed");
+        if (int rc = h->kern->mrhs_lm(p)) return fail(rc, "mrhs_lm launch failed");
+        int32_t nact = 0;
+        VP_HIP(hipMemcpyAsync(&nact, h->mrhs.nactive, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        VP_HIP(hipStreamSynchronize(h->stream));
+        if (nact <= 0) break;
+    }
+    // final parameters + reports, then one trait-level evaluation at the final point (C, cost, status, R cache)
+    p.alpha_out = h->d_alpha;
+    p.report = h->d_report;
+    if (int rc = h->kern->mrhs_finish(p)) return fail(rc, "mrhs_finish launch failed");
+    tm.stop();
+    if (int rc = ensure_R(h)) return rc;
+    if (int rc = run_evaluate(h, h->d_R, nullptr, h->d_C)) return rc;
+    h->have_params = true;
+    h->r_valid = true;
+    h->have_report = true;
+    if (int rc = copy_out(h, alpha_inout, h->d_alpha, (size_t)h->B * h->q * ts)) return rc;
+    if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
+    if (int rc = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc;
+    if (int rc = tr.finish(h)) return rc;
+    return VP_ERR_OK;
 }
 
 } // namespace
@@ -420,6 +493,18 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     VP_TRY(hipMalloc((void **)&h->d_sum4, 4 * sizeof(double)));
     VP_TRY(hipEventCreate(&h->ev0));
     VP_TRY(hipEventCreate(&h->ev1));
+    if (S > 1 && kern->mrhs_factor && kern->mrhs_stream && kern->mrhs_lm && kern->mrhs_finish) {
+        const int n_ = h->n, p_ = h->p, q_ = h->q;
+        VP_TRY(hipMalloc(&h->mrhs.qthin, (size_t)B * n_ * m * ts));
+        VP_TRY(hipMalloc(&h->mrhs.g, (size_t)B * std::max(1, p_) * m * ts));
+        VP_TRY(hipMalloc((void **)&h->mrhs.small, (size_t)B * (n_ * n_ + p_ * p_) * sizeof(double)));
+        VP_TRY(hipMalloc((void **)&h->mrhs.statusA, (size_t)B * sizeof(int32_t)));
+        VP_TRY(hipMalloc((void **)&h->mrhs.acc, (size_t)B * (1 + n_ * n_ + p_) * sizeof(double)));
+        VP_TRY(hipMalloc(&h->mrhs.lm_state, (size_t)B * kern->mrhs_state_bytes));
+        VP_TRY(hipMalloc((void **)&h->mrhs.nactive, sizeof(int32_t)));
+        VP_TRY(hipMalloc(&h->mrhs.alpha_trial, (size_t)std::max<int64_t>(1, B * q_) * ts));
+        h->have_mrhs = true;
+    }
 #undef VP_TRY
     for (int k = 0; k < 3; ++k) h->last_ms[k] = -1.f;
     *out = h;
@@ -444,6 +529,16 @@ void vp_batch_destroy(vp_batch *h) {
     }
     (void)hipFree(h->d_report);
     (void)hipFree(h->d_sum4);
+    if (h->have_mrhs) {
+        (void)hipFree(h->mrhs.qthin);
+        (void)hipFree(h->mrhs.g);
+        (void)hipFree(h->mrhs.small);
+        (void)hipFree(h->mrhs.statusA);
+        (void)hipFree(h->mrhs.acc);
+        (void)hipFree(h->mrhs.lm_state);
+        (void)hipFree(h->mrhs.nactive);
+        (void)hipFree(h->mrhs.alpha_trial);
+    }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -583,7 +678,7 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
                  double *trace_out, int trace_rows) {
     if (int rc = check_handle(h)) return rc;
     if (!alpha_inout) return fail(VP_ERR_INVALID, "null alpha");
-    if (h->S != 1) return fail(VP_ERR_UNSUPPORTED, "vp_fit with S > 1 (MRHS global fit) is not built yet");
+    if (h->S != 1) return mrhs_fit(h, opts, alpha_inout, C_out, rep, trace_out, trace_rows);
     if (!h->kern->fit && !h->kern->fit_single) return fail(VP_ERR_UNSUPPORTED, "no fit kernel for this model");
     vp_lm_opts o;
     if (opts) o = *opts;

@@ -29,7 +29,8 @@ namespace vp {
 // scaling pass over the column.
 // On return: C[k] (k < N) holds v_k (0 above row ROW0+k); g[k]; Rm = upper triangle (Rm[i][j], i <= j);
 // qty[k] = (Q^T C[N])[ROW0+k]; columns >= N hold Q^T (.) in all rows.
-template <typename T, int R, int N, int NC, int ROW0>
+//   HAS_Y: column N is a data column whose top entries are returned in qty
+template <typename T, int R, int N, int NC, int ROW0, bool HAS_Y = true>
 __device__ __forceinline__ void house_qr(T (&C)[NC][R], T (&g)[N], T (&Rm)[N][N], T (&qty)[N], const int lane) {
     using L = Layout<R>;
 #pragma unroll
@@ -77,7 +78,7 @@ __device__ __forceinline__ void house_qr(T (&C)[NC][R], T (&g)[N], T (&Rm)[N][N]
 #pragma unroll
             for (int r = 0; r < R; ++r) C[j][r] = tfma(f, C[k][r], C[j][r]);
             if (j < N) Rm[k][j] = bcast_row<R>(C[j], prow);
-            if (j == N) qty[k] = bcast_row<R>(C[j], prow);
+            if (HAS_Y && j == N) qty[k] = bcast_row<R>(C[j], prow);
         }
     }
 }

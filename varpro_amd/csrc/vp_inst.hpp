@@ -1,6 +1,7 @@
 // vp_inst.hpp -- macros that instantiate one (dtype, model, R) kernel set and register it.
 #pragma once
 #include "vp_fit_mp.hpp"
+#include "vp_mrhs.hpp"
 #include "vp_registry.hpp"
 
 #define VP_CAT_(a, b) a##b
@@ -12,11 +13,19 @@
         &::vp::launch_basis<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                            \
         &::vp::launch_fit_mp<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                           \
         &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                              \
-        &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>});
+        &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                         \
+        &::vp::launch_mrhs_factor<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                      \
+        &::vp::launch_mrhs_stream<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                      \
+        &::vp::launch_mrhs_lm<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                          \
+        &::vp::launch_mrhs_finish<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                      \
+        ::vp::mrhs_state_bytes<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>>()});
 
 #define VP_REGISTER_RT(T, DT, NN, QQ, PP, RR)                                                                          \
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
         DT, ::vp::FAMILY_RT, NN, QQ, PP, RR, &::vp::launch_evaluate<T, ::vp::RtModel<NN, QQ, PP>, RR>,                \
         &::vp::launch_basis<T, ::vp::RtModel<NN, QQ, PP>, RR>, &::vp::launch_fit_mp<T, ::vp::RtModel<NN, QQ, PP>, RR>, \
         &::vp::launch_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                          \
-        &::vp::launch_best_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>});
+        &::vp::launch_best_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                     \
+        &::vp::launch_mrhs_factor<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                  \
+        &::vp::launch_mrhs_stream<T, ::vp::RtModel<NN, QQ, PP>, RR>, &::vp::launch_mrhs_lm<T, ::vp::RtModel<NN, QQ, PP>, RR>, \
+        &::vp::launch_mrhs_finish<T, ::vp::RtModel<NN, QQ, PP>, RR>, ::vp::mrhs_state_bytes<T, ::vp::RtModel<NN, QQ, PP>>()});

@@ -38,6 +38,9 @@ struct LaunchParams {
     double *trace;      // fit diagnostics: [B][trace_rows][q+4] or NULL
     int trace_rows;
     int fit_group;      // fit: problems per wave (0 = automatic)
+    const void *mrhs_ws; // MRHS path: pointer to the handle's MrhsWs
+    int mrhs_mode;      // MRHS stream: 0 = reduced quantities (fit), 1 = trait-level outputs
+    int mrhs_init;      // MRHS LM step: 1 = initialise the state
     int basis_flags;
     int m;
     int S;

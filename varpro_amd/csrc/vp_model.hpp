@@ -138,11 +138,12 @@ template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2> 
 
 // Build the (weighted) basis columns and derivative columns of one problem into the unified column
 // array C:  C[j] = W phi_j  (j < N),  C[N] is left alone (data column),  C[N+1+p] = W dphi_pair_p.
-template <typename T, class M, int R, int NC, class Src>
+//   DOFF: index of the first derivative column (N + 1 with a data column at N; N without one)
+template <typename T, class M, int R, int NC, class Src, int DOFF = M::N + 1>
 __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::Q], const Src &src, T (&C)[NC][R]) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
     constexpr int VW = Layout<R>::VW;
-    static_assert(NC >= N + 1 + P, "column array too small");
+    static_assert(NC >= DOFF + P, "column array too small");
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int kind = mdl.kind(j);
@@ -198,8 +199,8 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                 C[j][r] = f;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    if (p == s0) C[N + 1 + p][r] = d0;
-                    if (p == s1) C[N + 1 + p][r] = d1;
+                    if (p == s0) C[DOFF + p][r] = d0;
+                    if (p == s1) C[DOFF + p][r] = d1;
                 }
             }
         }

@@ -1,0 +1,523 @@
+// vp_mrhs.hpp -- multiple right-hand sides: one alpha shared by S data columns ("global fit").
+//
+// == SeparableProblemBuilder::mrhs + the S > 1 paths of set_params / residuals / jacobian / fit
+//    (src/problem/builder.rs:194-225, src/solvers/levmar/mod.rs:42-73, 101-201 branch B :172-186).
+//
+// Phi depends on alpha only, so an evaluation splits into
+//   FACTOR  (one wavefront per problem, negligible): Phi_w = Q R by the register-resident Householder sweep;
+//           writes the explicit thin Q (m x n), R^{-1}, and  G_p = P_perp (W dPhi_p)  (m x P, original
+//           coordinates) -- the reference's  A = U (U^T D_k) - D_k  of branch B, up to sign -- plus G^T G.
+//   STREAM  (HBM-bound, one pass over Y): per column s, entirely in registers with Q and G staged in LDS:
+//           T = Q^T y_s (one reduction round), c_s = R^{-1} T, r_s = y_s - Q T,
+//           trait outputs:   R, C, and J_k[:, s] = - sum_{p in k} c_{j(p), s} G_p   (no reductions at all)
+//           fit (reduced):   ||r_s||^2, u_s = G^T r_s -> accumulates  sum ||r||^2,  sum_s c_s c_s^T,  sum_s c_s o u_s,
+//                            from which  J^T J = (sum c c^T) o (G^T G)  and  J^T r  follow WITHOUT ever
+//                            materialising the (m S) x q Jacobian (768 MiB per evaluation at configs[2]).
+//   LM STEP (one wavefront per problem): the MINPACK bookkeeping of vp_lm_core.hpp on J^T J / J^T r.
+//
+// Algorithmic HBM bytes per evaluation (T = 8): trait level  T m S (2 + q) + ... (read Y, write R and J);
+// fit level  T m S  (read Y once).  Deviation from the reference, documented in DESIGN.md: the LM step uses
+// the Gram matrix (normal equations of the q x q trust-region subproblem) instead of a QR of the tall J; the
+// linear sub-problem itself stays Householder-based.  A rank-deficient Phi_w (SVD truncation path) is reported
+// as a failed evaluation on this path.
+#pragma once
+#include "vp_lm_core.hpp"
+
+namespace vp {
+
+enum { VP_ST_SINGULAR = 3 }; // MRHS fast path: Phi_w numerically rank deficient (no truncated solve here)
+
+// device workspace of the MRHS path (owned by the handle)
+struct MrhsWs {
+    void *qthin;      // [B][N][m]  T
+    void *g;          // [B][P][m]  T
+    double *small;    // [B][N*N + P*P]   R^{-1} (row-major), G^T G
+    int32_t *statusA; // [B]
+    double *acc;      // [B][1 + N*N + P]  sum ||r||^2, sum c c^T, sum c_{j(p)} u_p   (zeroed per evaluation)
+    void *lm_state;   // [B] LmVars
+    int32_t *nactive; // [1]
+    void *alpha_trial; // [B][q] T
+    int32_t *nevals;  // unused
+};
+
+template <typename T, class M> struct MrhsFactorArgs {
+    M mdl;
+    const T *t;
+    const T *w;
+    const T *alpha; // [B][q] trial parameters
+    MrhsWs ws;
+    int m;
+    int64_t B;
+    int64_t t_stride, w_stride;
+    T eps;
+};
+
+template <typename T, class M, int R>
+__global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T, M> a) {
+    constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + P;
+    using L = Layout<R>;
+    const int lane = lane_id();
+    const int64_t b = blockIdx.x;
+    if (b >= a.B) return;
+    const int m = a.m;
+    T alpha[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
+    RowSource<T, R> src;
+    src.t = a.t + b * a.t_stride;
+    src.w = a.w ? a.w + b * a.w_stride : nullptr;
+    src.m = m;
+    src.lane = lane;
+    src.vec = false;
+    T C[NC][R];
+    build_columns<T, M, R, NC, RowSource<T, R>, N>(a.mdl, alpha, src, C);
+    T g[N], Rm[N][N], qdummy[N];
+    house_qr<T, R, N, NC, 0, false>(C, g, Rm, qdummy, lane);
+    // R^{-1} (upper triangular) and the rank test of solve_coeffs
+    double *small = a.ws.small + b * (N * N + P * P);
+    int st = VP_ST_OK;
+    bool zero_diag = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) zero_diag = zero_diag || !(tabs(Rm[i][i]) > T(0)) || !is_finite(Rm[i][i]);
+    T Ri[N][N];
+    if (!uni(zero_diag)) {
+        T inv_f2 = T(0);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int i = N - 1; i >= 0; --i) {
+                if (i > j) {
+                    Ri[i][j] = T(0);
+                    continue;
+                }
+                T acc = (i == j) ? T(1) : T(0);
+#pragma unroll
+                for (int l = i + 1; l <= j; ++l) acc = tfma(-Rm[i][l], Ri[l][j], acc);
+                Ri[i][j] = acc / Rm[i][i];
+                inv_f2 = tfma(Ri[i][j], Ri[i][j], inv_f2);
+            }
+        if (!uni(inv_f2 * a.eps * a.eps < T(1))) st = VP_ST_SINGULAR;
+        if (!uni(is_finite(inv_f2))) st = VP_ST_NONFINITE;
+    } else {
+        st = VP_ST_SINGULAR;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) Ri[i][j] = T(0);
+    }
+    if (lane == 0) {
+        a.ws.statusA[b] = st;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) small[i * N + j] = (double)Ri[i][j];
+    }
+    // G_p = Q [0; (Q^T W dPhi_p)_{>= N}]  in place on the derivative columns
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < L::VW && r < R; ++r)
+            if (L::row_of(r, lane) < N) C[N + p][r] = T(0);
+    if constexpr (P > 0) {
+        apply_q_cols<T, R, N, NC, N, NC>(C, g);
+        T gg[P * P];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int p2 = 0; p2 < P; ++p2) {
+                T acc = T(0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc = tfma(C[N + p][r], C[N + p2][r], acc);
+                gg[p * P + p2] = acc;
+            }
+        wave_allreduce(gg);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < P * P; ++i) small[N * N + i] = (double)gg[i];
+        }
+        T *gout = (T *)a.ws.g + b * (int64_t)P * m;
+#pragma unroll
+        for (int p = 0; p < P; ++p) store_rows<T, R>(gout + (int64_t)p * m, m, lane, false, C[N + p]);
+    }
+    // explicit thin Q: column j = Q e_j
+    T *qout = (T *)a.ws.qthin + b * (int64_t)N * m;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        T Z[1][R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) Z[0][r] = (L::row_of(r, lane) == j) ? T(1) : T(0);
+        apply_q<T, R, N, NC, 1>(C, g, Z);
+        store_rows<T, R>(qout + (int64_t)j * m, m, lane, false, Z[0]);
+    }
+}
+
+template <typename T, int N, int P> struct MrhsStreamArgs {
+    const T *yw;   // [B][S][m]
+    MrhsWs ws;
+    T *r_out;      // MODE 1: [B][S][m] or null
+    T *J_out;      // MODE 1: [B][q][S][m] or null
+    T *C_out;      // MODE 1: [B][S][n] or null
+    double *cost_bs;  // MODE 1
+    int32_t *status_bs;
+    int pb[P > 0 ? P : 1], pp[P > 0 ? P : 1]; // pair -> basis, pair -> parameter
+    int q;
+    int m;
+    int S;
+    int64_t B;
+};
+
+// MODE 0: reduced quantities for the LM loop; MODE 1: trait-level outputs
+template <typename T, int N, int P, int R, int MODE>
+__global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArgs<T, N, P> a) {
+    constexpr int MP = 64 * R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *s_q = reinterpret_cast<T *>(smem_raw); // [N][MP]
+    T *s_g = s_q + N * MP;                    // [P][MP]
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6), nwave = (int)(blockDim.x >> 6);
+    const int64_t b = blockIdx.y;
+    const int m = a.m;
+    const T *qsrc = (const T *)a.ws.qthin + b * (int64_t)N * m;
+    const T *gsrc = (const T *)a.ws.g + b * (int64_t)P * m;
+    for (int idx = threadIdx.x; idx < (N + P) * MP; idx += blockDim.x) {
+        const int col = idx / MP, row = idx - col * MP;
+        T v = T(0);
+        if (row < m) v = (col < N) ? qsrc[(int64_t)col * m + row] : gsrc[(int64_t)(col - N) * m + row];
+        s_q[idx] = v;
+    }
+    const double *small = a.ws.small + b * (N * N + P * P);
+    T Ri[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) Ri[i][j] = (T)small[i * N + j];
+    const int stA = a.ws.statusA[b];
+    __syncthreads();
+
+    using L = Layout<R>;
+    T acc_cost = T(0), acc_cc[N][N], acc_v[P > 0 ? P : 1];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc_cc[i][j] = T(0);
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc_v[p] = T(0);
+
+    const int64_t gw = (int64_t)blockIdx.x * nwave + wave, nw = (int64_t)gridDim.x * nwave;
+    for (int64_t s = gw; s < a.S; s += nw) {
+        const int64_t prob = b * a.S + s;
+        const T *yp = a.yw + prob * (int64_t)m;
+        const bool yvec = vec_aligned<T>(yp, m);
+        T y[R];
+        load_rows<T, R>(yp, m, lane, yvec, y);
+        // T = Q^T y
+        T tq[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int r0 = 0; r0 < R; r0 += L::VW) {
+                const int i = L::row_of(r0, lane);
+#pragma unroll
+                for (int e = 0; e < L::VW; ++e) acc = tfma(s_q[j * MP + i + e], y[r0 + e], acc);
+            }
+            tq[j] = acc;
+        }
+        wave_allreduce(tq);
+        // r = y - Q T  (in place)
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int r0 = 0; r0 < R; r0 += L::VW) {
+                const int i = L::row_of(r0, lane);
+#pragma unroll
+                for (int e = 0; e < L::VW; ++e) y[r0 + e] = tfma(-tq[j], s_q[j * MP + i + e], y[r0 + e]);
+            }
+        // c = R^{-1} T
+        T c[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = i; j < N; ++j) acc = tfma(Ri[i][j], tq[j], acc);
+            c[i] = acc;
+        }
+        // ||r||^2 and u = G^T r
+        T red[1 + P];
+        {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc = tfma(y[r], y[r], acc);
+            red[0] = acc;
+        }
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                T acc = T(0);
+#pragma unroll
+                for (int r0 = 0; r0 < R; r0 += L::VW) {
+                    const int i = L::row_of(r0, lane);
+#pragma unroll
+                    for (int e = 0; e < L::VW; ++e) acc = tfma(s_g[p * MP + i + e], y[r0 + e], acc);
+                }
+                red[1 + p] = acc;
+            }
+            wave_allreduce(red);
+            acc_cost += red[0];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) acc_cc[i][j] = tfma(c[i], c[j], acc_cc[i][j]);
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc_v[p] = tfma(dyn_get<N>(c, a.pb[p]), red[1 + p], acc_v[p]);
+        } else {
+            T r1[1] = {red[0]};
+            wave_allreduce(r1);
+            bool ok = is_finite(r1[0]) && stA == VP_ST_OK;
+#pragma unroll
+            for (int i = 0; i < N; ++i) ok = ok && is_finite(c[i]);
+            if (lane == 0) {
+                if (a.cost_bs) a.cost_bs[prob] = 0.5 * (double)r1[0];
+                if (a.status_bs) a.status_bs[prob] = ok ? VP_ST_OK : (stA != VP_ST_OK ? stA : VP_ST_NONFINITE);
+            }
+            if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(c, lane);
+            if (a.r_out) store_rows<T, R>(a.r_out + prob * (int64_t)m, m, lane, yvec, y);
+            if (a.J_out) {
+                for (int k = 0; k < a.q; ++k) {
+                    T jk[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) jk[r] = T(0);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        if (a.pp[p] == k) {
+                            const T cj = -dyn_get<N>(c, a.pb[p]);
+#pragma unroll
+                            for (int r0 = 0; r0 < R; r0 += L::VW) {
+                                const int i = L::row_of(r0, lane);
+#pragma unroll
+                                for (int e = 0; e < L::VW; ++e) jk[r0 + e] = tfma(cj, s_g[p * MP + i + e], jk[r0 + e]);
+                            }
+                        }
+                    }
+                    T *jp = a.J_out + ((b * a.q + k) * (int64_t)a.S + s) * (int64_t)m;
+                    store_rows<T, R>(jp, m, lane, vec_aligned<T>(jp, m), jk);
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 0) {
+        if (lane == 0) {
+            double *acc = a.ws.acc + b * (1 + N * N + P);
+            atomicAdd(&acc[0], (double)acc_cost);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) atomicAdd(&acc[1 + i * N + j], (double)acc_cc[i][j]);
+#pragma unroll
+            for (int p = 0; p < P; ++p) atomicAdd(&acc[1 + N * N + p], (double)acc_v[p]);
+        }
+    }
+}
+
+template <typename T, int N, int Q, int P> struct MrhsLmArgs {
+    MrhsWs ws;
+    LmOpts<T> opts;
+    const T *alpha0;   // init only
+    int pb[P > 0 ? P : 1], pp[P > 0 ? P : 1];
+    int m, S;
+    int64_t B;
+    int init;          // 1: initialise the state from alpha0 and publish the first trial point
+    double *trace;     // [B][trace_rows][q+4] or null
+    int trace_rows;
+};
+
+// one wavefront per problem; wave-uniform arithmetic
+template <typename T, int N, int Q, int P>
+__global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P> a) {
+    const int64_t b = blockIdx.x;
+    if (b >= a.B) return;
+    const int lane = lane_id();
+    using Vars = LmVars<T, N, Q>;
+    Vars *gs = reinterpret_cast<Vars *>(a.ws.lm_state) + b;
+    T *trial = (T *)a.ws.alpha_trial + b * Q;
+    double *acc = a.ws.acc + b * (1 + N * N + P);
+    Vars s;
+    if (a.init) {
+        T a0[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) a0[k] = a.alpha0[b * Q + k];
+        lm_init<T, N, Q>(s, a0);
+        if (lane == 0) {
+            *gs = s;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) trial[k] = s.xt[k];
+            atomicAdd(a.ws.nactive, 1);
+        }
+        return;
+    }
+    s = *gs;
+    if (s.term != 0) return; // finished earlier
+    const int stA = a.ws.statusA[b];
+    const T cost2 = (T)acc[0];
+    const bool ok = uni(stA == VP_ST_OK && is_finite(cost2));
+    const T fnorm1 = tsqrt(cost2);
+    const bool need_jac = lm_after_eval<T, N, Q, true>(s, a.opts, fnorm1, ok, (long)a.m * a.S);
+    if (a.trace && lane == 0 && s.nfev - 1 < a.trace_rows) {
+        double *tr = a.trace + ((size_t)b * a.trace_rows + (s.nfev - 1)) * (Q + 4);
+        for (int k = 0; k < Q; ++k) tr[k] = (double)s.xt[k];
+        tr[Q] = (double)fnorm1;
+        tr[Q + 1] = 0.0 / 0.0;
+        tr[Q + 2] = (double)s.delta;
+        tr[Q + 3] = (double)s.par;
+    }
+    if (need_jac) {
+        const double *small = a.ws.small + b * (N * N + P * P);
+        T A[Q][Q], bv[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            bv[k] = T(0);
+#pragma unroll
+            for (int l = 0; l < Q; ++l) A[k][l] = T(0);
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int kp = a.pp[p], jp = a.pb[p];
+            dyn_set<Q>(bv, kp, dyn_get<Q>(bv, kp) - (T)acc[1 + N * N + p]);
+#pragma unroll
+            for (int p2 = 0; p2 < P; ++p2) {
+                const int kp2 = a.pp[p2], jp2 = a.pb[p2];
+                const T contrib = (T)acc[1 + jp * N + jp2] * (T)small[N * N + p * P + p2];
+#pragma unroll
+                for (int k = 0; k < Q; ++k)
+#pragma unroll
+                    for (int l = 0; l < Q; ++l)
+                        if (k == kp && l == kp2) A[k][l] += contrib;
+            }
+        }
+        gram_to_qr<T, Q>(A, bv, s.Rj, s.acnorm, s.ipvt, s.qtf);
+    }
+    lm_next_step<T, N, Q, true>(s, a.opts, need_jac);
+    if (lane == 0) {
+        *gs = s;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) trial[k] = s.xt[k];
+        for (int i = 0; i < 1 + N * N + P; ++i) acc[i] = 0.0;
+        if (s.term != 0) atomicAdd(a.ws.nactive, -1);
+    }
+}
+
+} // namespace vp
+
+// ---- host-side launchers ---------------------------------------------------------------------------
+namespace vp {
+
+template <class M> inline void pair_maps(const vp_model_desc &d, int (&pb)[M::P > 0 ? M::P : 1], int (&pp)[M::P > 0 ? M::P : 1]) {
+    int p = 0;
+    for (int j = 0; j < d.n_basis; ++j)
+        for (int a = 0; a < VP_MAX_BASIS_PARAMS; ++a)
+            if (d.param[j][a] >= 0 && p < M::P) {
+                pb[p] = j;
+                pp[p] = d.param[j][a];
+                ++p;
+            }
+}
+
+template <typename T, class M, int R> int launch_mrhs_factor(const LaunchParams &p) {
+    MrhsFactorArgs<T, M> a;
+    if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+    a.t = (const T *)p.t;
+    a.w = (const T *)p.w;
+    a.alpha = (const T *)p.alpha;
+    a.ws = *reinterpret_cast<const MrhsWs *>(p.mrhs_ws);
+    a.m = p.m;
+    a.B = p.B;
+    a.t_stride = p.t_stride;
+    a.w_stride = p.w_stride;
+    a.eps = (T)p.eps;
+    hipLaunchKernelGGL((mrhs_factor_kernel<T, M, R>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams &p) {
+    constexpr int N = M::N, P = M::P;
+    MrhsStreamArgs<T, N, P> a;
+    a.yw = (const T *)p.yw;
+    a.ws = *reinterpret_cast<const MrhsWs *>(p.mrhs_ws);
+    a.r_out = (T *)p.r_out;
+    a.J_out = (T *)p.J_out;
+    a.C_out = (T *)p.C_out;
+    a.cost_bs = p.cost_out;
+    a.status_bs = p.status;
+    pair_maps<M>(*p.model, a.pb, a.pp);
+    a.q = M::Q;
+    a.m = p.m;
+    a.S = p.S;
+    a.B = p.B;
+    const size_t lds = (size_t)(N + P) * 64 * R * sizeof(T);
+    const int waves_per_wg = 8;
+    int64_t gx = (p.S + waves_per_wg - 1) / waves_per_wg;
+    if (gx > 256) gx = 256; // one persistent workgroup per CU (its LDS copy of Q and G is ~100 KiB)
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)p.B), block(64 * waves_per_wg);
+    hipError_t e;
+    if (p.mrhs_mode == 0) {
+        e = hipFuncSetAttribute((const void *)mrhs_stream_kernel<T, N, P, R, 0>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return VP_ERR_HIP;
+        hipLaunchKernelGGL((mrhs_stream_kernel<T, N, P, R, 0>), grid, block, lds, p.stream, a);
+    } else {
+        e = hipFuncSetAttribute((const void *)mrhs_stream_kernel<T, N, P, R, 1>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return VP_ERR_HIP;
+        hipLaunchKernelGGL((mrhs_stream_kernel<T, N, P, R, 1>), grid, block, lds, p.stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+template <typename T, class M, int R> int launch_mrhs_lm(const LaunchParams &p) {
+    constexpr int N = M::N, P = M::P, Q = M::Q;
+    MrhsLmArgs<T, N, Q, P> a;
+    a.ws = *reinterpret_cast<const MrhsWs *>(p.mrhs_ws);
+    a.opts.ftol = (T)p.opts->ftol;
+    a.opts.xtol = (T)p.opts->xtol;
+    a.opts.gtol = (T)p.opts->gtol;
+    a.opts.stepbound = (T)p.opts->stepbound;
+    a.opts.patience = p.opts->patience;
+    a.opts.scale_diag = p.opts->scale_diag;
+    a.alpha0 = (const T *)p.alpha;
+    pair_maps<M>(*p.model, a.pb, a.pp);
+    a.m = p.m;
+    a.S = p.S;
+    a.B = p.B;
+    a.init = p.mrhs_init;
+    a.trace = p.trace;
+    a.trace_rows = p.trace_rows;
+    hipLaunchKernelGGL((mrhs_lm_kernel<T, N, Q, P>), dim3((unsigned)p.B), dim3(64), 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+// bytes of one LmVars record (the handle allocates B of them) and final-state extraction
+template <typename T, class M> size_t mrhs_state_bytes() { return sizeof(LmVars<T, M::N, M::Q>); }
+
+template <typename T, int N, int Q>
+__global__ void mrhs_finish_kernel(const LmVars<T, N, Q> *st, int64_t B, T *alpha_out, vp_report *rep) {
+    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const LmVars<T, N, Q> s = st[b];
+    for (int k = 0; k < Q; ++k) alpha_out[b * Q + k] = s.x[k];
+    vp_report r;
+    r.termination = s.term;
+    r.n_evals = s.nfev;
+    r.objective = (double)s.objective;
+    rep[b] = r;
+}
+
+template <typename T, class M, int R> int launch_mrhs_finish(const LaunchParams &p) {
+    const MrhsWs &ws = *reinterpret_cast<const MrhsWs *>(p.mrhs_ws);
+    const unsigned grid = (unsigned)((p.B + 63) / 64);
+    hipLaunchKernelGGL((mrhs_finish_kernel<T, M::N, M::Q>), dim3(grid), dim3(64), 0, p.stream,
+                       (const LmVars<T, M::N, M::Q> *)ws.lm_state, p.B, (T *)p.alpha_out, p.report);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+} // namespace vp

@@ -20,6 +20,9 @@ struct KernelEntry {
     launch_fn fit;      // multi-problem-per-wave LM (vp_fit_mp.hpp); may be null
     launch_fn fit_single; // one-problem-per-wave LM (vp_fit.hpp), kept for A/B and diagnostics
     launch_fn best_fit; // may be null
+    // multiple-right-hand-side path (vp_mrhs.hpp); all null if not instantiated
+    launch_fn mrhs_factor, mrhs_stream, mrhs_lm, mrhs_finish;
+    size_t mrhs_state_bytes;
 };
 
 std::vector<KernelEntry> &registry();
