@@ -314,7 +314,6 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         p.trace_rows = trace_rows;
     }
     VP_HIP(hipMemsetAsync(h->mrhs.nactive, 0, sizeof(int32_t), h->stream));
-    VP_HIP(hipMemsetAsync(h->mrhs.acc, 0, (size_t)h->B * (1 + h->n * h->n + h->p) * sizeof(double), h->stream));
     Timer tm(h, VP_KERNEL_FIT);
     p.mrhs_init = 1;
     p.alpha = h->d_alpha;
@@ -499,7 +498,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         VP_TRY(hipMalloc(&h->mrhs.g, (size_t)B * std::max(1, p_) * m * ts));
         VP_TRY(hipMalloc((void **)&h->mrhs.small, (size_t)B * (n_ * n_ + p_ * p_) * sizeof(double)));
         VP_TRY(hipMalloc((void **)&h->mrhs.statusA, (size_t)B * sizeof(int32_t)));
-        VP_TRY(hipMalloc((void **)&h->mrhs.acc, (size_t)B * (1 + n_ * n_ + p_) * sizeof(double)));
+        VP_TRY(hipMalloc((void **)&h->mrhs.acc, (size_t)B * 256 * (1 + n_ * n_ + p_) * sizeof(double)));
         VP_TRY(hipMalloc(&h->mrhs.lm_state, (size_t)B * kern->mrhs_state_bytes));
         VP_TRY(hipMalloc((void **)&h->mrhs.nactive, sizeof(int32_t)));
         VP_TRY(hipMalloc(&h->mrhs.alpha_trial, (size_t)std::max<int64_t>(1, B * q_) * ts));

@@ -33,7 +33,7 @@ struct MrhsWs {
     void *g;          // [B][P][m]  T
     double *small;    // [B][N*N + P*P]   R^{-1} (row-major), G^T G
     int32_t *statusA; // [B]
-    double *acc;      // [B][1 + N*N + P]  sum ||r||^2, sum c c^T, sum c_{j(p)} u_p   (zeroed per evaluation)
+    double *acc;      // [B][gx][1 + N*N + P]  per-workgroup partials of sum ||r||^2, sum c c^T, sum c_{j(p)} u_p
     void *lm_state;   // [B] LmVars
     int32_t *nactive; // [1]
     void *alpha_trial; // [B][q] T
@@ -210,29 +210,41 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
         const bool yvec = vec_aligned<T>(yp, m);
         T y[R];
         load_rows<T, R>(yp, m, lane, yvec, y);
+        // All row loops are processed in chunks of CH rows separated by scheduling fences: without them the
+        // scheduler hoists the LDS reads of every (column, row) ahead (7 columns x R rows) and spills.
+        constexpr int CH = (R > 8) ? 8 : R;
         // T = Q^T y
         T tq[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            T acc = T(0);
+        for (int j = 0; j < N; ++j) tq[j] = T(0);
 #pragma unroll
-            for (int r0 = 0; r0 < R; r0 += L::VW) {
-                const int i = L::row_of(r0, lane);
+        for (int c0 = 0; c0 < R; c0 += CH) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < L::VW; ++e) acc = tfma(s_q[j * MP + i + e], y[r0 + e], acc);
-            }
-            tq[j] = acc;
+            for (int j = 0; j < N; ++j)
+#pragma unroll
+                for (int r0 = c0; r0 < c0 + CH; r0 += L::VW) {
+                    const int i = L::row_of(r0, lane);
+#pragma unroll
+                    for (int e = 0; e < L::VW; ++e) tq[j] = tfma(s_q[j * MP + i + e], y[r0 + e], tq[j]);
+                }
         }
+        __builtin_amdgcn_sched_barrier(0);
         wave_allreduce(tq);
         // r = y - Q T  (in place)
 #pragma unroll
-        for (int j = 0; j < N; ++j)
+        for (int c0 = 0; c0 < R; c0 += CH) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r0 = 0; r0 < R; r0 += L::VW) {
-                const int i = L::row_of(r0, lane);
+            for (int j = 0; j < N; ++j)
 #pragma unroll
-                for (int e = 0; e < L::VW; ++e) y[r0 + e] = tfma(-tq[j], s_q[j * MP + i + e], y[r0 + e]);
-            }
+                for (int r0 = c0; r0 < c0 + CH; r0 += L::VW) {
+                    const int i = L::row_of(r0, lane);
+#pragma unroll
+                    for (int e = 0; e < L::VW; ++e) y[r0 + e] = tfma(-tq[j], s_q[j * MP + i + e], y[r0 + e]);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // c = R^{-1} T
         T c[N];
 #pragma unroll
@@ -252,16 +264,21 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
         }
         if constexpr (MODE == 0) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                T acc = T(0);
+            for (int p = 0; p < P; ++p) red[1 + p] = T(0);
 #pragma unroll
-                for (int r0 = 0; r0 < R; r0 += L::VW) {
-                    const int i = L::row_of(r0, lane);
+            for (int c0 = 0; c0 < R; c0 += CH) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int e = 0; e < L::VW; ++e) acc = tfma(s_g[p * MP + i + e], y[r0 + e], acc);
-                }
-                red[1 + p] = acc;
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int r0 = c0; r0 < c0 + CH; r0 += L::VW) {
+                        const int i = L::row_of(r0, lane);
+#pragma unroll
+                        for (int e = 0; e < L::VW; ++e)
+                            red[1 + p] = tfma(s_g[p * MP + i + e], y[r0 + e], red[1 + p]);
+                    }
             }
+            __builtin_amdgcn_sched_barrier(0);
             wave_allreduce(red);
             acc_cost += red[0];
 #pragma unroll
@@ -306,15 +323,26 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
         }
     }
     if constexpr (MODE == 0) {
+        // workgroup-level reduction of the per-wave partial sums, then ONE plain store per workgroup into its
+        // own slot acc[b][blockIdx.x][:] (no atomics: 2048 waves x 20 same-address atomics cost ~0.5 ms)
+        constexpr int NACC = 1 + N * N + P;
+        __syncthreads(); // everyone is done reading s_q / s_g: reuse the front of the LDS as scratch
+        double *s_part = reinterpret_cast<double *>(smem_raw);
         if (lane == 0) {
-            double *acc = a.ws.acc + b * (1 + N * N + P);
-            atomicAdd(&acc[0], (double)acc_cost);
+            double *mine = s_part + wave * NACC;
+            mine[0] = (double)acc_cost;
 #pragma unroll
             for (int i = 0; i < N; ++i)
 #pragma unroll
-                for (int j = 0; j < N; ++j) atomicAdd(&acc[1 + i * N + j], (double)acc_cc[i][j]);
+                for (int j = 0; j < N; ++j) mine[1 + i * N + j] = (double)acc_cc[i][j];
 #pragma unroll
-            for (int p = 0; p < P; ++p) atomicAdd(&acc[1 + N * N + p], (double)acc_v[p]);
+            for (int p = 0; p < P; ++p) mine[1 + N * N + p] = (double)acc_v[p];
+        }
+        __syncthreads();
+        if (threadIdx.x < NACC) {
+            double tot = 0.0;
+            for (int w = 0; w < nwave; ++w) tot += s_part[w * NACC + threadIdx.x];
+            a.ws.acc[(b * gridDim.x + blockIdx.x) * NACC + threadIdx.x] = tot;
         }
     }
 }
@@ -327,6 +355,7 @@ template <typename T, int N, int Q, int P> struct MrhsLmArgs {
     int m, S;
     int64_t B;
     int init;          // 1: initialise the state from alpha0 and publish the first trial point
+    int gx;            // workgroups per problem of the streaming kernel (partial-sum slots)
     double *trace;     // [B][trace_rows][q+4] or null
     int trace_rows;
 };
@@ -340,7 +369,8 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
     using Vars = LmVars<T, N, Q>;
     Vars *gs = reinterpret_cast<Vars *>(a.ws.lm_state) + b;
     T *trial = (T *)a.ws.alpha_trial + b * Q;
-    double *acc = a.ws.acc + b * (1 + N * N + P);
+    constexpr int NACC = 1 + N * N + P;
+    static_assert(NACC <= 64, "one lane per accumulator");
     Vars s;
     if (a.init) {
         T a0[Q];
@@ -357,6 +387,19 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
     }
     s = *gs;
     if (s.term != 0) return; // finished earlier
+    // total the per-workgroup partial sums: lane i owns accumulator i, then broadcast
+    double acc[NACC];
+    {
+        // lanes stride over the gx partial records (independent loads in flight), then wave all-reduce
+        const double *part = a.ws.acc + (size_t)b * a.gx * NACC;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+        for (int g = lane; g < a.gx; g += 64) {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] += part[(size_t)g * NACC + i];
+        }
+        wave_allreduce(acc);
+    }
     const int stA = a.ws.statusA[b];
     const T cost2 = (T)acc[0];
     const bool ok = uni(stA == VP_ST_OK && is_finite(cost2));
@@ -401,7 +444,6 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
         *gs = s;
 #pragma unroll
         for (int k = 0; k < Q; ++k) trial[k] = s.xt[k];
-        for (int i = 0; i < 1 + N * N + P; ++i) acc[i] = 0.0;
         if (s.term != 0) atomicAdd(a.ws.nactive, -1);
     }
 }
@@ -420,6 +462,15 @@ template <class M> inline void pair_maps(const vp_model_desc &d, int (&pb)[M::P 
                 pp[p] = d.param[j][a];
                 ++p;
             }
+}
+
+// workgroups per problem of the streaming kernel: one persistent 8-wave workgroup per CU at most (its LDS copy
+// of Q and G is ~100 KiB)
+inline int mrhs_gx(int64_t S) {
+    int64_t gx = (S + 7) / 8;
+    if (gx > 256) gx = 256;
+    if (gx < 1) gx = 1;
+    return (int)gx;
 }
 
 template <typename T, class M, int R> int launch_mrhs_factor(const LaunchParams &p) {
@@ -455,9 +506,7 @@ template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams 
     a.B = p.B;
     const size_t lds = (size_t)(N + P) * 64 * R * sizeof(T);
     const int waves_per_wg = 8;
-    int64_t gx = (p.S + waves_per_wg - 1) / waves_per_wg;
-    if (gx > 256) gx = 256; // one persistent workgroup per CU (its LDS copy of Q and G is ~100 KiB)
-    if (gx < 1) gx = 1;
+    const int gx = mrhs_gx(p.S);
     dim3 grid((unsigned)gx, (unsigned)p.B), block(64 * waves_per_wg);
     hipError_t e;
     if (p.mrhs_mode == 0) {
@@ -490,6 +539,7 @@ template <typename T, class M, int R> int launch_mrhs_lm(const LaunchParams &p) 
     a.S = p.S;
     a.B = p.B;
     a.init = p.mrhs_init;
+    a.gx = mrhs_gx(p.S);
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
     hipLaunchKernelGGL((mrhs_lm_kernel<T, N, Q, P>), dim3((unsigned)p.B), dim3(64), 0, p.stream, a);
