@@ -840,8 +840,9 @@ const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m) {
         }
         for (const KernelEntry &e : registry()) {
             if (e.dtype != dtype || e.family != f || e.a != ka || e.b != kb || e.c != kc) continue;
-            if ((int64_t)64 * e.R < m) continue;
-            if (!best || e.R < best->R) best = &e;
+            if ((int64_t)64 * e.R * e.W < m) continue;
+            // smallest capacity first; among equal capacities the fewest waves per problem
+            if (!best || e.R * e.W < best->R * best->W || (e.R * e.W == best->R * best->W && e.W < best->W)) best = &e;
         }
     }
     return best;

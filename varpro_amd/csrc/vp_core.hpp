@@ -30,9 +30,10 @@ namespace vp {
 // On return: C[k] (k < N) holds v_k (0 above row ROW0+k); g[k]; Rm = upper triangle (Rm[i][j], i <= j);
 // qty[k] = (Q^T C[N])[ROW0+k]; columns >= N hold Q^T (.) in all rows.
 //   HAS_Y: column N is a data column whose top entries are returned in qty
-template <typename T, int R, int N, int NC, int ROW0, bool HAS_Y = true>
-__device__ __forceinline__ void house_qr(T (&C)[NC][R], T (&g)[N], T (&Rm)[N][N], T (&qty)[N], const int lane) {
-    using L = Layout<R>;
+template <typename T, int R, int N, int NC, int ROW0, bool HAS_Y = true, class G>
+__device__ __forceinline__ void house_qr(T (&C)[NC][R], T (&g)[N], T (&Rm)[N][N], T (&qty)[N], G &grp) {
+    using L = Layout<R, G::W>;
+    const int lane = grp.gl;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const int prow = ROW0 + k;
@@ -43,8 +44,8 @@ __device__ __forceinline__ void house_qr(T (&C)[NC][R], T (&g)[N], T (&Rm)[N][N]
             const T v = (r >= L::VW || L::row_of(r, lane) > prow) ? C[k][r] : T(0);
             s = tfma(v, v, s);
         }
-        const T xn2 = wave_sum(s);
-        const T alpha = bcast_row<R>(C[k], prow);
+        const T xn2 = group_sum(grp, s);
+        const T alpha = group_row<R>(grp, C[k], prow);
         T beta = alpha, gk = T(0), u = T(0);
         if (uni(xn2 != T(0))) {
             beta = -tcopysign(tsqrt(tfma(alpha, alpha, xn2)), alpha);
@@ -71,21 +72,32 @@ __device__ __forceinline__ void house_qr(T (&C)[NC][R], T (&g)[N], T (&Rm)[N][N]
             for (int r = 0; r < R; ++r) acc = tfma(C[k][r], C[j][r], acc);
             w[j - k - 1] = acc;
         }
-        wave_allreduce(w);
+        group_allreduce(grp, w);
 #pragma unroll
         for (int j = k + 1; j < NC; ++j) {
             const T f = gk * w[j - k - 1];
 #pragma unroll
             for (int r = 0; r < R; ++r) C[j][r] = tfma(f, C[k][r], C[j][r]);
-            if (j < N) Rm[k][j] = bcast_row<R>(C[j], prow);
-            if (HAS_Y && j == N) qty[k] = bcast_row<R>(C[j], prow);
+        }
+        // row prow of the updated columns: R entries of the factor columns, Q^T y entry of the data column
+        constexpr int NTOP = HAS_Y ? N : N - 1; // last column index whose top entry is needed
+        T top[NTOP > 0 ? NTOP : 1];
+#pragma unroll
+        for (int j = 0; j < (NTOP > 0 ? NTOP : 1); ++j) top[j] = T(0);
+#pragma unroll
+        for (int j = k + 1; j <= NTOP; ++j) top[j - 1] = C[j][L::reg_of_row(prow)];
+        if (k + 1 <= NTOP) group_bcast<(NTOP > 0 ? NTOP : 1)>(grp, top, L::lane_of_row(prow));
+#pragma unroll
+        for (int j = k + 1; j <= NTOP; ++j) {
+            if (j < N) Rm[k][j] = top[j - 1];
+            if (HAS_Y && j == N) qty[k] = top[j - 1];
         }
     }
 }
 
 // z <- Q z for NZ columns (Q = H_0 ... H_{N-1}; V = the first N columns left by house_qr)
-template <typename T, int R, int N, int NC, int NZ>
-__device__ __forceinline__ void apply_q(const T (&V)[NC][R], const T (&g)[N], T (&Z)[NZ][R]) {
+template <typename T, int R, int N, int NC, int NZ, class G>
+__device__ __forceinline__ void apply_q(const T (&V)[NC][R], const T (&g)[N], T (&Z)[NZ][R], G &grp) {
 #pragma unroll
     for (int k = N - 1; k >= 0; --k) {
         T w[NZ];
@@ -96,7 +108,7 @@ __device__ __forceinline__ void apply_q(const T (&V)[NC][R], const T (&g)[N], T 
             for (int r = 0; r < R; ++r) acc = tfma(V[k][r], Z[z][r], acc);
             w[z] = acc;
         }
-        wave_allreduce(w);
+        group_allreduce(grp, w);
 #pragma unroll
         for (int z = 0; z < NZ; ++z) {
             const T f = g[k] * w[z];
@@ -107,8 +119,8 @@ __device__ __forceinline__ void apply_q(const T (&V)[NC][R], const T (&g)[N], T 
 }
 
 // in-place variant: columns [C0, C1) of the unified array <- Q (.)   (C0 >= N)
-template <typename T, int R, int N, int NC, int C0, int C1>
-__device__ __forceinline__ void apply_q_cols(T (&C)[NC][R], const T (&g)[N]) {
+template <typename T, int R, int N, int NC, int C0, int C1, class G>
+__device__ __forceinline__ void apply_q_cols(T (&C)[NC][R], const T (&g)[N], G &grp) {
     constexpr int NZ = C1 - C0;
 #pragma unroll
     for (int k = N - 1; k >= 0; --k) {
@@ -120,7 +132,7 @@ __device__ __forceinline__ void apply_q_cols(T (&C)[NC][R], const T (&g)[N]) {
             for (int r = 0; r < R; ++r) acc = tfma(C[k][r], C[C0 + z][r], acc);
             w[z] = acc;
         }
-        wave_allreduce(w);
+        group_allreduce(grp, w);
 #pragma unroll
         for (int z = 0; z < NZ; ++z) {
             const T f = g[k] * w[z];
@@ -262,14 +274,15 @@ template <typename T, int N> struct EvalUniform {
 
 // One full evaluation at `alpha`: builds the columns (the data column C[N] must already hold y_w),
 // runs the fused sweep, solves for c and forms ||r||^2.
-template <typename T, class M, int R, int NC, class Src>
-__device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::Q], const Src &src, T eps,
-                                              const int lane, T (&C)[NC][R], EvalUniform<T, M::N> &u) {
+template <typename T, class M, int R, int NC, class Src, class G>
+__device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::Q], const Src &src, T eps, G &grp,
+                                              T (&C)[NC][R], EvalUniform<T, M::N> &u) {
     constexpr int N = M::N;
-    using L = Layout<R>;
+    using L = Layout<R, G::W>;
+    const int lane = grp.gl;
     build_columns<T, M, R, NC, Src>(mdl, alpha, src, C);
     T Rm[N][N], qty[N];
-    house_qr<T, R, N, NC, 0>(C, u.g, Rm, qty, lane);
+    house_qr<T, R, N, NC, 0, true, G>(C, u.g, Rm, qty, grp);
     bool truncated;
     solve_coeffs<T, N>(Rm, qty, eps, u.c, u.e, truncated);
     // ||r||^2 = ||e||^2 + sum_{rows >= N} (Q^T y)^2
@@ -279,7 +292,7 @@ __device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::
         const T v = (r >= L::VW || L::row_of(r, lane) >= N) ? C[N][r] : T(0);
         s = tfma(v, v, s);
     }
-    T fn2 = wave_sum(s);
+    T fn2 = group_sum(grp, s);
 #pragma unroll
     for (int k = 0; k < N; ++k) fn2 = tfma(u.e[k], u.e[k], fn2);
     u.fn2 = fn2;
@@ -290,9 +303,10 @@ __device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::
 }
 
 // Projected residual in Q-coordinates: rows < N <- e, rows >= N keep Q^T y.  (in place on the data column)
-template <typename T, int R, int N>
-__device__ __forceinline__ void residual_qcoords(T (&x0)[R], const T (&e)[N], const int lane) {
-    using L = Layout<R>;
+template <typename T, int R, int N, class G>
+__device__ __forceinline__ void residual_qcoords(T (&x0)[R], const T (&e)[N], const G &grp) {
+    using L = Layout<R, G::W>;
+    const int lane = grp.gl;
 #pragma unroll
     for (int r = 0; r < L::VW && r < R; ++r) { // pivot rows live in the first VW registers
         const int i = L::row_of(r, lane);
@@ -307,11 +321,12 @@ __device__ __forceinline__ void residual_qcoords(T (&x0)[R], const T (&e)[N], co
 // rows < N zeroed (that is the P_perp).
 //   diagonal models (pair p == (basis p, param p)): done IN PLACE, Z_k is C[N+1+k];
 //   general models: written to the separate array Zs and the caller uses that.
-template <typename T, class M, int R, int NC>
+template <typename T, class M, int R, int NC, class G>
 __device__ __forceinline__ void jacobian_qcoords(const M &mdl, T (&C)[NC][R], const T (&c)[M::N],
-                                                 T (&Zs)[M::kDiagonalPairs ? 1 : M::Q][R], const int lane) {
+                                                 T (&Zs)[M::kDiagonalPairs ? 1 : M::Q][R], const G &grp) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
-    using L = Layout<R>;
+    using L = Layout<R, G::W>;
+    const int lane = grp.gl;
     if constexpr (M::kDiagonalPairs) {
         (void)Zs;
         (void)mdl;

@@ -30,15 +30,41 @@ __device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstl
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---- lane <-> row mapping ---------------------------------------------------------------------
-// Rows are dealt to lanes in pairs so that a lane's global/LDS accesses are 16 B wide for fp64:
-// register r of lane l holds row ((r/VW)*64 + l)*VW + r%VW.
-template <int R> struct Layout {
+// A problem is owned by a GROUP of W wavefronts (W = 1: one wavefront; W > 1: one workgroup of W waves for
+// problems whose columns do not fit the registers of one wave).  Rows are dealt to the 64*W group lanes in
+// pairs so that a lane's global/LDS accesses are 16 B wide for fp64: register r of group lane gl holds
+// row ((r/VW)*64*W + gl)*VW + r%VW.
+template <int R, int W = 1> struct Layout {
     static constexpr int VW = (R >= 2) ? 2 : 1;
     static_assert(R == 1 || R % 2 == 0, "R must be 1 or even");
-    __device__ __forceinline__ static int row_of(int r, int lane) { return ((r / VW) * 64 + lane) * VW + (r % VW); }
-    // rows < 64*VW (all pivot rows) live in the first VW registers
+    __device__ __forceinline__ static int row_of(int r, int gl) { return ((r / VW) * (64 * W) + gl) * VW + (r % VW); }
+    // rows < 64*W*VW (all pivot rows) live in the first VW registers
     __host__ __device__ static constexpr int reg_of_row(int row) { return row % VW; }
-    __host__ __device__ static constexpr int lane_of_row(int row) { return row / VW; }
+    __host__ __device__ static constexpr int lane_of_row(int row) { return row / VW; } // group lane
+};
+
+// exchange area of a multi-wave group in LDS: two phases of all-reduce slots + two phases of broadcast slots
+constexpr int VP_XV = 16; // max values per group all-reduce
+constexpr int VP_XB = 16; // max values per group broadcast
+template <int W> constexpr int group_xch_bytes() { return W > 1 ? (2 * W * VP_XV + 2 * VP_XB) * 8 : 0; }
+
+// the group a lane belongs to
+template <int W_> struct Grp {
+    static constexpr int W = W_;
+    int lane;           // lane within the wave (0..63)
+    int wave;           // wave within the group (0..W-1)
+    int gl;             // group lane = wave*64 + lane: the index used by Layout::row_of
+    unsigned char *xch; // LDS exchange area (W > 1), group_xch_bytes<W>() bytes, 8-byte aligned
+    int phase;          // toggles between the two buffers of each area on every exchange
+    __device__ __forceinline__ static Grp make(unsigned char *xch_) {
+        Grp g;
+        g.lane = (int)(threadIdx.x & 63u);
+        g.wave = (W_ > 1) ? (int)(threadIdx.x >> 6) : 0;
+        g.gl = g.wave * 64 + g.lane;
+        g.xch = xch_;
+        g.phase = 0;
+        return g;
+    }
 };
 
 // ---- cross-lane data movement -----------------------------------------------------------------
@@ -96,9 +122,61 @@ template <typename T> __device__ __forceinline__ T wave_sum(T x) {
     return a[0];
 }
 
-// element at (compile-time) row `row` of a register-resident column, broadcast to the wave
-template <int R, typename T> __device__ __forceinline__ T bcast_row(const T (&col)[R], int row) {
-    return readlane(col[Layout<R>::reg_of_row(row)], Layout<R>::lane_of_row(row));
+// All-reduce over the whole group.  W == 1: the wave all-reduce.  W > 1: wave all-reduce, lane 0 of every
+// wave posts its V sums in LDS, ONE barrier, every lane adds the W partials in the same fixed order (so all
+// waves hold bit-identical totals and take identical control-flow decisions).  Double-buffered by g.phase:
+// one barrier per exchange is enough.
+template <int V, typename T, class G> __device__ __forceinline__ void group_allreduce(G &g, T (&x)[V]) {
+    wave_allreduce(x);
+    if constexpr (G::W > 1) {
+        static_assert(V <= VP_XV, "too many values in one group all-reduce");
+        T *buf = reinterpret_cast<T *>(g.xch + (size_t)g.phase * (G::W * VP_XV * 8));
+        if (g.lane == 0) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) buf[g.wave * VP_XV + v] = x[v];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            T s = buf[v];
+#pragma unroll
+            for (int w = 1; w < G::W; ++w) s += buf[w * VP_XV + v];
+            x[v] = s;
+        }
+        g.phase ^= 1;
+    }
+}
+template <typename T, class G> __device__ __forceinline__ T group_sum(G &g, T x) {
+    T a[1] = {x};
+    group_allreduce(g, a);
+    return a[0];
+}
+
+// Broadcast NV values held by group lane `owner_gl` (compile-time after unrolling) to the whole group.
+template <int NV, typename T, class G> __device__ __forceinline__ void group_bcast(G &g, T (&v)[NV], int owner_gl) {
+    if constexpr (G::W == 1) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = readlane(v[i], owner_gl);
+    } else {
+        static_assert(NV <= VP_XB, "too many values in one group broadcast");
+        T *buf = reinterpret_cast<T *>(g.xch + (size_t)(2 * G::W * VP_XV * 8) + (size_t)g.phase * (VP_XB * 8));
+        if (g.gl == owner_gl) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) buf[i] = v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = buf[i];
+        g.phase ^= 1;
+    }
+}
+
+// element at (compile-time) row `row` of a register-resident column, broadcast to the group
+template <int R, typename T, class G> __device__ __forceinline__ T group_row(G &g, const T (&col)[R], int row) {
+    using L = Layout<R, G::W>;
+    T v[1] = {col[L::reg_of_row(row)]};
+    group_bcast<1>(g, v, L::lane_of_row(row));
+    return v[0];
 }
 
 // ---- tiny dynamically-indexed uniform arrays without scratch -----------------------------------

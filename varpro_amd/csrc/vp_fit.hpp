@@ -227,10 +227,11 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
 // rows >= ROW0, applied simultaneously to the residual column rv (-> qtf), as lmder does.
 // MINPACK's reflector  v = a/ajnorm + e_p,  H = I - v v^T / v_p  is applied in the equivalent
 // unnormalised form  H = I + g v' v'^T,  v' = a + ajnorm e_p,  g = -1/(ajnorm v'_p)  (one reciprocal).
-template <typename T, int R, int Q, int ROW0>
+template <typename T, int R, int Q, int ROW0, class G>
 __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q], T (&acnorm)[Q], int (&ipvt)[Q],
-                                          T (&qtf)[Q], const int lane) {
-    using L = Layout<R>;
+                                          T (&qtf)[Q], G &grp) {
+    using L = Layout<R, G::W>;
+    const int lane = grp.gl;
     T rdiag[Q], wa[Q];
     {
         T s[Q];
@@ -241,7 +242,7 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
             for (int r = 0; r < R; ++r) acc = tfma(Z[j][r], Z[j][r], acc);
             s[j] = acc;
         }
-        wave_allreduce(s);
+        group_allreduce(grp, s);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
             acnorm[j] = tsqrt(s[j]);
@@ -293,16 +294,16 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
             const T v = (r >= L::VW || L::row_of(r, lane) >= prow) ? Z[j][r] : T(0);
             s = tfma(v, v, s);
         }
-        T ajnorm = tsqrt(wave_sum(s));
+        T ajnorm = tsqrt(group_sum(grp, s));
         if (uni(ajnorm == T(0))) {
             rdiag[j] = T(0);
             // remaining columns untouched: their row-prow entries are the R entries
 #pragma unroll
-            for (int k = j + 1; k < Q; ++k) Rj[j][k] = bcast_row<R>(Z[k], prow);
-            qtf[j] = bcast_row<R>(rv, prow);
+            for (int k = j + 1; k < Q; ++k) Rj[j][k] = group_row<R>(grp, Z[k], prow);
+            qtf[j] = group_row<R>(grp, rv, prow);
             continue;
         }
-        const T piv = bcast_row<R>(Z[j], prow);
+        const T piv = group_row<R>(grp, Z[j], prow);
         if (piv < T(0)) ajnorm = -ajnorm;
         const T vp = piv + ajnorm;          // v'_p
         const T gj = -T(1) / (ajnorm * vp); // H = I + gj v' v'^T
@@ -328,13 +329,13 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
             for (int r = 0; r < R; ++r) acc = tfma(Z[j][r], rv[r], acc);
             w[Q - 1] = acc;
         }
-        wave_allreduce(w);
+        group_allreduce(grp, w);
 #pragma unroll
         for (int k = j + 1; k < Q; ++k) {
             const T f = gj * w[k - j - 1];
 #pragma unroll
             for (int r = 0; r < R; ++r) Z[k][r] = tfma(f, Z[j][r], Z[k][r]);
-            const T akj = bcast_row<R>(Z[k], prow);
+            const T akj = group_row<R>(grp, Z[k], prow);
             Rj[j][k] = akj;
             if (uni(rdiag[k] != T(0))) {
                 const T tq = akj / rdiag[k];
@@ -347,7 +348,7 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
                         const T v = (r >= L::VW || L::row_of(r, lane) > prow) ? Z[k][r] : T(0);
                         s2 = tfma(v, v, s2);
                     }
-                    rdiag[k] = tsqrt(wave_sum(s2));
+                    rdiag[k] = tsqrt(group_sum(grp, s2));
                     wa[k] = rdiag[k];
                 }
             }
@@ -356,7 +357,7 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
             const T f = gj * w[Q - 1];
 #pragma unroll
             for (int r = 0; r < R; ++r) rv[r] = tfma(f, Z[j][r], rv[r]);
-            qtf[j] = bcast_row<R>(rv, prow);
+            qtf[j] = group_row<R>(grp, rv, prow);
         }
         rdiag[j] = -ajnorm;
     }
@@ -397,16 +398,23 @@ template <typename T, int N, int Q> struct LmState {
     int nfev;
 };
 
-template <typename T, class M, int R, bool WEIGHTED>
-__global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
+// W = waves per problem (the workgroup is one group): W > 1 spreads the rows of one problem over W*64 lanes.
+// Every wave of a group runs the identical wave-uniform LM bookkeeping on bit-identical inputs (the group
+// all-reduce delivers the same totals to all waves), so no LM state is ever exchanged between waves.
+template <typename T, class M, int R, int W, bool WEIGHTED>
+__global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
-    constexpr int MP = 64 * R;
+    constexpr int MP = 64 * R * W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *s_t = reinterpret_cast<T *>(smem_raw);
     T *s_y = s_t + MP;
     T *s_w = WEIGHTED ? s_y + MP : nullptr;
-    LmState<T, N, Q> *st = reinterpret_cast<LmState<T, N, Q> *>(s_y + MP + (WEIGHTED ? MP : 0));
-    const int lane = lane_id();
+    unsigned char *s_after = reinterpret_cast<unsigned char *>(s_y + MP + (WEIGHTED ? MP : 0));
+    using G = Grp<W>;
+    G grp = G::make(s_after); // exchange area first (8-byte aligned), then one LmState per wave
+    LmState<T, N, Q> *st =
+        reinterpret_cast<LmState<T, N, Q> *>(s_after + ((group_xch_bytes<W>() + 15) / 16) * 16) + grp.wave;
+    const int lane = grp.gl; // group lane: row ownership; LDS park / result writes use grp.lane / grp.wave
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
     const int m = a.m;
@@ -415,20 +423,20 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_
     {
         T tmp[R];
         const T *tp = a.t + b * a.t_stride;
-        load_rows<T, R>(tp, m, lane, vec_aligned<T>(tp, m), tmp);
-        store_rows<T, R>(s_t, MP, lane, true, tmp);
+        load_rows<T, R, W>(tp, m, lane, vec_aligned<T>(tp, m), tmp);
+        store_rows<T, R, W>(s_t, MP, lane, true, tmp);
         if constexpr (WEIGHTED) {
             const T *wp = a.w + b * a.w_stride;
-            load_rows<T, R>(wp, m, lane, vec_aligned<T>(wp, m), tmp);
-            store_rows<T, R>(s_w, MP, lane, true, tmp);
+            load_rows<T, R, W>(wp, m, lane, vec_aligned<T>(wp, m), tmp);
+            store_rows<T, R, W>(s_w, MP, lane, true, tmp);
         }
         const T *yp = a.yw + b * (int64_t)m;
-        load_rows<T, R>(yp, m, lane, vec_aligned<T>(yp, m), tmp);
-        store_rows<T, R>(s_y, MP, lane, true, tmp);
+        load_rows<T, R, W>(yp, m, lane, vec_aligned<T>(yp, m), tmp);
+        store_rows<T, R, W>(s_y, MP, lane, true, tmp);
     }
-    __syncthreads(); // single wave: orders the LDS writes before the reads below
+    __syncthreads(); // orders the LDS writes before the reads below (every lane re-reads only its own rows)
     // the LDS copies are zero-padded to MP rows; valid rows are still i < m (scale 0 beyond)
-    using Src = RowSource<T, R, true, WEIGHTED ? 1 : 0>;
+    using Src = RowSource<T, R, true, WEIGHTED ? 1 : 0, 1, W>;
     Src src;
     src.t = s_t;
     src.w = s_w;
@@ -464,7 +472,7 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_
     const int mres = m; // number of residuals (S == 1)
     int trow = 0;
     auto trace_row = [&](const T(&xx)[Q], T fn, T ratio) {
-        if (a.trace && trow < a.trace_rows && lane == 0) {
+        if (a.trace && trow < a.trace_rows && lane == 0) { // group lane 0 only
             double *tr = a.trace + ((size_t)b * a.trace_rows + trow) * (Q + 4);
 #pragma unroll
             for (int k = 0; k < Q; ++k) tr[k] = (double)xx[k];
@@ -477,8 +485,8 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_
     };
 
     for (;;) {
-        // ---- park the LM state in LDS for the duration of the sweep ----
-        if (lane == 0) {
+        // ---- park the LM state in LDS for the duration of the sweep (each wave parks its own copy) ----
+        if (grp.lane == 0) {
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
                 st->x[k] = x[k];
@@ -508,8 +516,8 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_
         // ================= evaluate the VarPro functional at xt =================
         T C[NC][R];
         EvalUniform<T, N> u;
-        load_rows<T, R>(s_y, MP, lane, true, C[N]);
-        evaluate_core<T, M, R, NC, Src>(a.mdl, xt, src, a.eps, lane, C, u);
+        load_rows<T, R, W>(s_y, MP, lane, true, C[N]);
+        evaluate_core<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, C, u);
 
         asm volatile("" ::: "memory");
         // ---- un-park ----
@@ -638,12 +646,12 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_
         if (need_jac) {
             // ================= Jacobian in Q-coordinates, pivoted QR, Q_J^T r =================
             T Zs[M::kDiagonalPairs ? 1 : Q][R];
-            jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, lane);
-            residual_qcoords<T, R, N>(C[N], u.e, lane);
+            jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, grp);
+            residual_qcoords<T, R, N>(C[N], u.e, grp);
             if constexpr (M::kDiagonalPairs) {
-                jac_qrfac<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[N + 1]), C[N], Rj, acnorm, ipvt, qtf, lane);
+                jac_qrfac<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[N + 1]), C[N], Rj, acnorm, ipvt, qtf, grp);
             } else {
-                jac_qrfac<T, R, Q, N>(Zs, C[N], Rj, acnorm, ipvt, qtf, lane);
+                jac_qrfac<T, R, Q, N>(Zs, C[N], Rj, acnorm, ipvt, qtf, grp);
             }
             // norm of the scaled gradient
             T gmax = T(0);
@@ -738,7 +746,7 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_
     if (a.C_out && lane < N) a.C_out[b * N + lane] = dyn_get<N>(cbest, lane);
 }
 
-template <typename T, class M, int R> int launch_fit(const LaunchParams &p) {
+template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchParams &p) {
     FitArgs<T, M> a;
     if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
     a.t = (const T *)p.t;
@@ -763,9 +771,10 @@ template <typename T, class M, int R> int launch_fit(const LaunchParams &p) {
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
     if (a.B <= 0) return VP_ERR_OK;
-    const size_t lds = (size_t)(p.w ? 3 : 2) * 64 * R * sizeof(T) + sizeof(LmState<T, M::N, M::Q>);
-    if (p.w) hipLaunchKernelGGL((fit_kernel<T, M, R, true>), dim3((unsigned)a.B), dim3(64), lds, p.stream, a);
-    else hipLaunchKernelGGL((fit_kernel<T, M, R, false>), dim3((unsigned)a.B), dim3(64), lds, p.stream, a);
+    const size_t lds = (size_t)(p.w ? 3 : 2) * 64 * R * W * sizeof(T) + ((group_xch_bytes<W>() + 15) / 16) * 16 +
+                       (size_t)W * sizeof(LmState<T, M::N, M::Q>);
+    if (p.w) hipLaunchKernelGGL((fit_kernel<T, M, R, W, true>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
+    else hipLaunchKernelGGL((fit_kernel<T, M, R, W, false>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
@@ -781,9 +790,10 @@ template <typename T, class M> struct BestFitArgs {
     int64_t t_stride;
 };
 
-template <typename T, class M, int R> __global__ void __launch_bounds__(64) best_fit_kernel(const BestFitArgs<T, M> a) {
+template <typename T, class M, int R, int W>
+__global__ void __launch_bounds__(64 * W) best_fit_kernel(const BestFitArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
-    const int lane = lane_id();
+    const int lane = (int)threadIdx.x; // group lane
     const int64_t prob = blockIdx.x;
     if (prob >= a.nprob) return;
     const int64_t b = prob / a.S;
@@ -793,9 +803,15 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) best
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
 #pragma unroll
     for (int k = 0; k < N; ++k) c[k] = a.C[prob * N + k];
-    const RowSource<T, R> src = make_row_source<T, R>(a.t + b * a.t_stride, (const T *)nullptr, m, lane);
+    using Src = RowSource<T, R, false, 0, 0, W>;
+    Src src;
+    src.t = a.t + b * a.t_stride;
+    src.w = nullptr;
+    src.m = m;
+    src.lane = lane;
+    src.vec = false;
     T C[NC][R];
-    build_columns<T, M, R, NC, RowSource<T, R>>(a.mdl, alpha, src, C);
+    build_columns<T, M, R, NC, Src>(a.mdl, alpha, src, C);
     T f[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -805,10 +821,10 @@ template <typename T, class M, int R> __global__ void __launch_bounds__(64) best
         f[r] = acc;
     }
     T *op = a.out + prob * (int64_t)m;
-    store_rows<T, R>(op, m, lane, vec_aligned<T>(op, m), f);
+    store_rows<T, R, W>(op, m, lane, vec_aligned<T>(op, m), f);
 }
 
-template <typename T, class M, int R> int launch_best_fit(const LaunchParams &p) {
+template <typename T, class M, int R, int W = 1> int launch_best_fit(const LaunchParams &p) {
     BestFitArgs<T, M> a;
     if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
     a.t = (const T *)p.t;
@@ -820,7 +836,7 @@ template <typename T, class M, int R> int launch_best_fit(const LaunchParams &p)
     a.nprob = p.B * p.S;
     a.t_stride = p.t_stride;
     if (a.nprob <= 0) return VP_ERR_OK;
-    hipLaunchKernelGGL((best_fit_kernel<T, M, R>), dim3((unsigned)a.nprob), dim3(64), 0, p.stream, a);
+    hipLaunchKernelGGL((best_fit_kernel<T, M, R, W>), dim3((unsigned)a.nprob), dim3(64 * W), 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 

@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_
     auto rec = [&](int p) -> State * { return reinterpret_cast<State *>(s_state + (size_t)p * SW); };
 
     const int lane = lane_id();
+    Grp<1> grp = Grp<1>::make(nullptr);
     const int64_t p0 = (int64_t)blockIdx.x * G;
     if (p0 >= a.B) return;
     const int count = (int)((a.B - p0) < G ? (a.B - p0) : G);
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_
                 const T *yp = a.yw + prob * (int64_t)m;
                 load_rows<T, R>(yp, m, lane, vec_aligned<T>(yp, m), C[N]);
             }
-            evaluate_core<T, M, R, NC, RowSource<T, R>>(a.mdl, alpha, src, a.eps, lane, C, u);
+            evaluate_core<T, M, R, NC, RowSource<T, R>, Grp<1>>(a.mdl, alpha, src, a.eps, grp, C, u);
 
             const T fnorm1 = tsqrt(u.fn2);
             T actred = T(0), ratio = T(0);
@@ -158,12 +159,12 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P>())) fit_
             int ipvt[Q];
             if (need_jac) {
                 T Zs[M::kDiagonalPairs ? 1 : Q][R];
-                jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, lane);
-                residual_qcoords<T, R, N>(C[N], u.e, lane);
+                jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, grp);
+                residual_qcoords<T, R, N>(C[N], u.e, grp);
                 if constexpr (M::kDiagonalPairs) {
-                    jac_qrfac<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[N + 1]), C[N], Rj, acnorm, ipvt, qtf, lane);
+                    jac_qrfac<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[N + 1]), C[N], Rj, acnorm, ipvt, qtf, grp);
                 } else {
-                    jac_qrfac<T, R, Q, N>(Zs, C[N], Rj, acnorm, ipvt, qtf, lane);
+                    jac_qrfac<T, R, Q, N>(Zs, C[N], Rj, acnorm, ipvt, qtf, grp);
                 }
             }
             if (lane == 0) {

@@ -9,7 +9,7 @@
 
 #define VP_REGISTER_MULTIEXP(T, DT, NEXP, OFF, RR)                                                                     \
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
-        DT, ::vp::FAMILY_MULTIEXP, NEXP, OFF, 0, RR, &::vp::launch_evaluate<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>, \
+        DT, ::vp::FAMILY_MULTIEXP, NEXP, OFF, 0, RR, 1, &::vp::launch_evaluate<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>, \
         &::vp::launch_basis<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                            \
         &::vp::launch_fit_mp<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                           \
         &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                              \
@@ -22,10 +22,19 @@
 
 #define VP_REGISTER_RT(T, DT, NN, QQ, PP, RR)                                                                          \
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
-        DT, ::vp::FAMILY_RT, NN, QQ, PP, RR, &::vp::launch_evaluate<T, ::vp::RtModel<NN, QQ, PP>, RR>,                \
+        DT, ::vp::FAMILY_RT, NN, QQ, PP, RR, 1, &::vp::launch_evaluate<T, ::vp::RtModel<NN, QQ, PP>, RR>,             \
         &::vp::launch_basis<T, ::vp::RtModel<NN, QQ, PP>, RR>, &::vp::launch_fit_mp<T, ::vp::RtModel<NN, QQ, PP>, RR>, \
         &::vp::launch_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                          \
         &::vp::launch_best_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                     \
         &::vp::launch_mrhs_factor<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                  \
         &::vp::launch_mrhs_stream<T, ::vp::RtModel<NN, QQ, PP>, RR>, &::vp::launch_mrhs_lm<T, ::vp::RtModel<NN, QQ, PP>, RR>, \
         &::vp::launch_mrhs_finish<T, ::vp::RtModel<NN, QQ, PP>, RR>, ::vp::mrhs_state_bytes<T, ::vp::RtModel<NN, QQ, PP>>()});
+
+// multi-wave groups (WW waves per problem): problems whose columns do not fit the registers of one wave
+#define VP_REGISTER_MULTIEXP_W(T, DT, NEXP, OFF, RR, WW)                                                               \
+    static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
+        DT, ::vp::FAMILY_MULTIEXP, NEXP, OFF, 0, RR, WW,                                                               \
+        &::vp::launch_evaluate<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                     \
+        &::vp::launch_basis<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr,                               \
+        &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                          \
+        &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0});

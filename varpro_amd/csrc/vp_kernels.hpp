@@ -17,6 +17,10 @@ namespace vp {
 template <typename T, int R, int NC> constexpr int waves_for() {
     return (NC * R * (int)(sizeof(T) / 4) <= 200) ? 2 : 1;
 }
+// launch bound (2nd argument = waves per SIMD) for a kernel whose workgroup is one group of W waves
+template <typename T, int R, int NC, int W> constexpr int group_waves_per_eu() {
+    return W >= 4 ? ((waves_for<T, R, NC>() * W) / 4 > 0 ? (waves_for<T, R, NC>() * W) / 4 : 1) : waves_for<T, R, NC>();
+}
 
 // type-erased launch parameters (host side); every pointer is a device pointer
 struct LaunchParams {
@@ -53,10 +57,10 @@ struct LaunchParams {
 
 // ---- row-distributed loads / stores ------------------------------------------------------------
 // branch-free: rows >= m read element 0 and are zeroed by a select
-template <typename T, int R>
+template <typename T, int R, int W = 1>
 __device__ __forceinline__ void load_rows(const T *__restrict__ base, const int m, const int lane, const bool vec_ok,
                                           T (&out)[R]) {
-    using L = Layout<R>;
+    using L = Layout<R, W>;
     if constexpr (L::VW == 2) {
         if (vec_ok) { // m even and base 2*sizeof(T)-aligned: one 2-element access per register pair
 #pragma unroll
@@ -80,10 +84,10 @@ __device__ __forceinline__ void load_rows(const T *__restrict__ base, const int 
     }
 }
 
-template <typename T, int R>
+template <typename T, int R, int W = 1>
 __device__ __forceinline__ void store_rows(T *__restrict__ base, const int m, const int lane, const bool vec_ok,
                                            const T (&in)[R]) {
-    using L = Layout<R>;
+    using L = Layout<R, W>;
     if constexpr (L::VW == 2) {
         if (vec_ok) {
 #pragma unroll
@@ -143,11 +147,14 @@ template <typename T, class M> struct EvalArgs {
 // MODE 0: coefficients/cost/status only; 1: + residuals; 2: + residuals + Jacobian
 // ALIGNED: m even and every array 16-byte aligned (checked on the host) -> 2-element accesses only
 // WEIGHTED: weights present (decided on the host)
-template <typename T, class M, int R, int MODE, bool ALIGNED, bool WEIGHTED>
-__global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>()))
+template <typename T, class M, int R, int W, int MODE, bool ALIGNED, bool WEIGHTED>
+__global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>()))
     evaluate_kernel(const EvalArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
-    const int lane = lane_id();
+    __shared__ __attribute__((aligned(16))) unsigned char s_xch[group_xch_bytes<W>() > 0 ? group_xch_bytes<W>() : 16];
+    using G = Grp<W>;
+    G grp = G::make(s_xch);
+    const int lane = grp.gl; // group lane: row ownership
     const int64_t prob = blockIdx.x; // problem * S + rhs
     if (prob >= a.nprob) return;
     const int64_t b = prob / a.S;
@@ -158,7 +165,7 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P + ((MODE 
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
 
-    using Src = RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0>;
+    using Src = RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0, W>;
     Src src;
     src.t = a.t + b * a.t_stride;
     src.w = WEIGHTED ? a.w + b * a.w_stride : nullptr;
@@ -168,10 +175,10 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P + ((MODE 
     T C[NC][R];
     const T *yp = a.yw + prob * (int64_t)m;
     constexpr bool yvec = ALIGNED;
-    load_rows<T, R>(yp, m, lane, yvec, C[N]);
+    load_rows<T, R, W>(yp, m, lane, yvec, C[N]);
 
     EvalUniform<T, N> u;
-    evaluate_core<T, M, R, NC, Src>(a.mdl, alpha, src, a.eps, lane, C, u);
+    evaluate_core<T, M, R, NC, Src, G>(a.mdl, alpha, src, a.eps, grp, C, u);
 
     if (lane == 0) {
         if (a.status) a.status[prob] = u.ok ? VP_ST_OK : VP_ST_NONFINITE;
@@ -180,30 +187,30 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P + ((MODE 
     if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(u.c, lane);
 
     if constexpr (MODE >= 1) {
-        residual_qcoords<T, R, N>(C[N], u.e, lane);
+        residual_qcoords<T, R, N>(C[N], u.e, grp);
         T *rp = a.r_out ? a.r_out + prob * (int64_t)m : nullptr;
         if constexpr (MODE == 1) {
             // r = Q r~ : back-sweep on the data column only, in place
-            apply_q_cols<T, R, N, NC, N, N + 1>(C, u.g);
-            if (rp) store_rows<T, R>(rp, m, lane, yvec, C[N]);
+            apply_q_cols<T, R, N, NC, N, N + 1>(C, u.g, grp);
+            if (rp) store_rows<T, R, W>(rp, m, lane, yvec, C[N]);
         } else if constexpr (M::kDiagonalPairs) {
             // J~_k = -c_k (Q^T D_k) in place, then ONE back-sweep over [r~ | J~_1 .. J~_q] in place
             T Zs[1][R];
-            jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, lane);
-            apply_q_cols<T, R, N, NC, N, NC>(C, u.g);
-            if (rp) store_rows<T, R>(rp, m, lane, yvec, C[N]);
+            jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, grp);
+            apply_q_cols<T, R, N, NC, N, NC>(C, u.g, grp);
+            if (rp) store_rows<T, R, W>(rp, m, lane, yvec, C[N]);
             if (a.J_out) {
 #pragma unroll
                 for (int k = 0; k < Q; ++k) { // J[b][k][s][m]
                     T *jp = a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m;
-                    store_rows<T, R>(jp, m, lane, ALIGNED, C[N + 1 + k]);
+                    store_rows<T, R, W>(jp, m, lane, ALIGNED, C[N + 1 + k]);
                 }
             }
         } else {
             T Z[1 + Q][R];
             {
                 T Zs[Q][R];
-                jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, lane);
+                jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, grp);
 #pragma unroll
                 for (int r = 0; r < R; ++r) Z[0][r] = C[N][r];
 #pragma unroll
@@ -211,13 +218,13 @@ __global__ void __launch_bounds__(64, (waves_for<T, R, M::N + 1 + M::P + ((MODE 
 #pragma unroll
                     for (int r = 0; r < R; ++r) Z[1 + k][r] = Zs[k][r];
             }
-            apply_q<T, R, N, NC, 1 + Q>(C, u.g, Z);
-            if (rp) store_rows<T, R>(rp, m, lane, yvec, Z[0]);
+            apply_q<T, R, N, NC, 1 + Q>(C, u.g, Z, grp);
+            if (rp) store_rows<T, R, W>(rp, m, lane, yvec, Z[0]);
             if (a.J_out) {
 #pragma unroll
                 for (int k = 0; k < Q; ++k) { // J[b][k][s][m]
                     T *jp = a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m;
-                    store_rows<T, R>(jp, m, lane, ALIGNED, Z[1 + k]);
+                    store_rows<T, R, W>(jp, m, lane, ALIGNED, Z[1 + k]);
                 }
             }
         }
@@ -239,17 +246,17 @@ template <typename T, class M> struct BasisArgs {
 
 // Stand-alone Phi/dPhi: reads q scalars (+ the shared grid from L2), writes (n + p) * m scalars per
 // problem with 16-byte-per-lane fully coalesced stores: HBM-write-bound by construction.
-template <typename T, class M, int R, bool ALIGNED>
-__global__ void __launch_bounds__(64) basis_kernel(const BasisArgs<T, M> a) {
+template <typename T, class M, int R, int W, bool ALIGNED>
+__global__ void __launch_bounds__(64 * W) basis_kernel(const BasisArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
-    const int lane = lane_id();
+    const int lane = (int)threadIdx.x; // group lane
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
     const int m = a.m;
     T alpha[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
-    using Src = RowSource<T, R, false, 0, ALIGNED ? 1 : 0>;
+    using Src = RowSource<T, R, false, 0, ALIGNED ? 1 : 0, W>;
     Src src;
     src.t = a.t + b * a.t_stride;
     src.w = nullptr;
@@ -264,7 +271,7 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs<T, M> a) {
         for (int j = 0; j < N; ++j) {
             if (a.skip_invariant && a.mdl.kind(j) == VP_BASIS_CONST) continue;
             T *p = a.Phi_out + (b * a.n_phi_cols + col) * (int64_t)m;
-            store_rows<T, R>(p, m, lane, ALIGNED, C[j]);
+            store_rows<T, R, W>(p, m, lane, ALIGNED, C[j]);
             ++col;
         }
     }
@@ -272,7 +279,7 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs<T, M> a) {
 #pragma unroll
         for (int pidx = 0; pidx < P; ++pidx) {
             T *p = a.dPhi_out + (b * P + pidx) * (int64_t)m;
-            store_rows<T, R>(p, m, lane, ALIGNED, C[N + 1 + pidx]);
+            store_rows<T, R, W>(p, m, lane, ALIGNED, C[N + 1 + pidx]);
         }
     }
 }
@@ -297,7 +304,7 @@ template <class M> inline bool bind_model(const vp_model_desc &d, M &out) {
     }
 }
 
-template <typename T, class M, int R> int launch_evaluate(const LaunchParams &p) {
+template <typename T, class M, int R, int W = 1> int launch_evaluate(const LaunchParams &p) {
     EvalArgs<T, M> a;
     if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
     a.t = (const T *)p.t;
@@ -316,13 +323,13 @@ template <typename T, class M, int R> int launch_evaluate(const LaunchParams &p)
     a.w_stride = p.w_stride;
     a.eps = (T)p.eps;
     if (a.nprob <= 0) return VP_ERR_OK;
-    dim3 grid((unsigned)a.nprob), block(64);
+    dim3 grid((unsigned)a.nprob), block(64 * W);
     const bool aligned = host_aligned<T>(p.m, {p.t, p.w, p.yw, p.r_out, p.J_out});
     const int mode = p.J_out ? 2 : (p.r_out ? 1 : 0);
     const int variant = mode * 4 + (aligned ? 2 : 0) + (p.w ? 1 : 0);
 #define VP_EV(MODE_, AL_, W_)                                                                                          \
     case (MODE_) * 4 + (AL_) * 2 + (W_):                                                                               \
-        hipLaunchKernelGGL((evaluate_kernel<T, M, R, MODE_, (AL_) != 0, (W_) != 0>), grid, block, 0, p.stream, a);    \
+        hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, MODE_, (AL_) != 0, (W_) != 0>), grid, block, 0, p.stream, a); \
         break;
     switch (variant) {
         VP_EV(0, 0, 0) VP_EV(0, 0, 1) VP_EV(0, 1, 0) VP_EV(0, 1, 1)
@@ -333,7 +340,7 @@ template <typename T, class M, int R> int launch_evaluate(const LaunchParams &p)
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
-template <typename T, class M, int R> int launch_basis(const LaunchParams &p) {
+template <typename T, class M, int R, int W = 1> int launch_basis(const LaunchParams &p) {
     BasisArgs<T, M> a;
     if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
     a.t = (const T *)p.t;
@@ -350,8 +357,8 @@ template <typename T, class M, int R> int launch_basis(const LaunchParams &p) {
     a.t_stride = p.t_stride;
     if (a.B <= 0) return VP_ERR_OK;
     if (host_aligned<T>(p.m, {p.t, p.Phi_out, p.dPhi_out}))
-        hipLaunchKernelGGL((basis_kernel<T, M, R, true>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
-    else hipLaunchKernelGGL((basis_kernel<T, M, R, false>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+        hipLaunchKernelGGL((basis_kernel<T, M, R, W, true>), dim3((unsigned)a.B), dim3(64 * W), 0, p.stream, a);
+    else hipLaunchKernelGGL((basis_kernel<T, M, R, W, false>), dim3((unsigned)a.B), dim3(64 * W), 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 

@@ -84,13 +84,13 @@ __device__ __forceinline__ float tcos(float x) { return __ocml_cos_f32(x); }
 //            kernel): always 2-element accesses, no bounds clamp on the address
 //   WMODE  : 0 = unit weights (compile time), 1 = weights present (compile time), 2 = decide by w != nullptr
 //   VMODE  : 0 = scalar accesses only, 1 = 2-element aligned accesses (compile time), 2 = decide by `vec`
-template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2> struct RowSource {
+template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2, int W = 1> struct RowSource {
     const T *t;  // grid, indexed by row (LDS or global)
     const T *w;  // weights indexed by row, or nullptr for unit weights
     int m;       // rows >= m are padding
-    int lane;
+    int lane;    // GROUP lane (wave*64 + lane for multi-wave groups)
     bool vec;    // (!PADDED only) 2-element aligned accesses allowed
-    using L = Layout<R>;
+    using L = Layout<R, W>;
     __device__ __forceinline__ bool weighted() const {
         if constexpr (WMODE == 0) return false;
         else if constexpr (WMODE == 1) return true;

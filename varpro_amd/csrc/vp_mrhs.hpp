@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T,
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + P;
     using L = Layout<R>;
     const int lane = lane_id();
+    Grp<1> grp = Grp<1>::make(nullptr);
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
     const int m = a.m;
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T,
     T C[NC][R];
     build_columns<T, M, R, NC, RowSource<T, R>, N>(a.mdl, alpha, src, C);
     T g[N], Rm[N][N], qdummy[N];
-    house_qr<T, R, N, NC, 0, false>(C, g, Rm, qdummy, lane);
+    house_qr<T, R, N, NC, 0, false, Grp<1>>(C, g, Rm, qdummy, grp);
     // R^{-1} (upper triangular) and the rank test of solve_coeffs
     double *small = a.ws.small + b * (N * N + P * P);
     int st = VP_ST_OK;
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T,
         for (int r = 0; r < L::VW && r < R; ++r)
             if (L::row_of(r, lane) < N) C[N + p][r] = T(0);
     if constexpr (P > 0) {
-        apply_q_cols<T, R, N, NC, N, NC>(C, g);
+        apply_q_cols<T, R, N, NC, N, NC>(C, g, grp);
         T gg[P * P];
 #pragma unroll
         for (int p = 0; p < P; ++p)
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T,
         T Z[1][R];
 #pragma unroll
         for (int r = 0; r < R; ++r) Z[0][r] = (L::row_of(r, lane) == j) ? T(1) : T(0);
-        apply_q<T, R, N, NC, 1>(C, g, Z);
+        apply_q<T, R, N, NC, 1>(C, g, Z, grp);
         store_rows<T, R>(qout + (int64_t)j * m, m, lane, false, Z[0]);
     }
 }

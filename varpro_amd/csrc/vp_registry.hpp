@@ -14,7 +14,8 @@ struct KernelEntry {
     int dtype;  // VP_F64 / VP_F32
     int family; // FAMILY_*
     int a, b, c; // MULTIEXP: (nexp, offset, 0)   RT: (n, q, p)
-    int R;      // rows per lane; handles m <= 64*R
+    int R;      // rows per lane
+    int W;      // waves per problem; handles m <= 64*R*W
     launch_fn evaluate;
     launch_fn basis;
     launch_fn fit;      // multi-problem-per-wave LM (vp_fit_mp.hpp); may be null
