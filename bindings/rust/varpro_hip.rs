@@ -1,0 +1,191 @@
+//! Reference-side shim over `libvarpro_hip.so` (SOURCE ONLY: there is no rustc/cargo in the build image, so this
+//! file has never been compiled; it is the binding a varpro maintainer would add).
+//!
+//! It implements the reference's own traits on top of the C ABI of `include/varpro_hip.h`:
+//!   * `levenberg_marquardt::LeastSquaresProblem` for `GpuSeparableProblem`
+//!     (replaces `impl LeastSquaresProblem for SeparableProblem`, src/solvers/levmar/mod.rs:22-202)
+//!   * `varpro::model::SeparableNonlinearModel` for `GpuModel` (src/model/mod.rs:239-363)
+//! so that the unchanged `LevMarSolver::fit` (src/solvers/levmar/mod.rs:238-254) drives the GPU kernels, and adds
+//! `fit_batch`, the device-resident batched fit (`vp_fit`).
+#![allow(non_camel_case_types)]
+use std::ffi::{c_char, c_void, CStr};
+use std::ptr::null_mut;
+
+use levenberg_marquardt::LeastSquaresProblem;
+use nalgebra::storage::Owned;
+use nalgebra::{DMatrix, DVector, Dyn};
+use varpro::model::SeparableNonlinearModel;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct vp_model_desc {
+    pub n_basis: i32,
+    pub n_params: i32,
+    pub kind: [i32; 8],
+    pub param: [[i32; 2]; 8],
+}
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct vp_lm_opts {
+    pub ftol: f64,
+    pub xtol: f64,
+    pub gtol: f64,
+    pub stepbound: f64,
+    pub patience: i32,
+    pub scale_diag: i32,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct vp_report {
+    pub termination: i32,
+    pub n_evals: i32,
+    pub objective: f64,
+}
+pub enum vp_batch {}
+
+pub const VP_BASIS_CONST: i32 = 0;
+pub const VP_BASIS_EXP_DECAY: i32 = 1;
+pub const VP_BASIS_EXP_RATE: i32 = 2;
+pub const VP_BASIS_EXP_COS: i32 = 3;
+pub const VP_BASIS_SIN_PHASE: i32 = 4;
+pub const VP_F64: i32 = 0;
+pub const VP_FLAG_OWN_STREAM: i32 = 8;
+
+#[link(name = "varpro_hip")]
+extern "C" {
+    pub fn vp_batch_create(h: *mut *mut vp_batch, model: *const vp_model_desc, dtype: i32, m: i64, s: i64, b: i64,
+        t: *const c_void, y: *const c_void, w: *const c_void, svd_epsilon: f64, flags: i32, device: i32,
+        hip_stream: *mut c_void) -> i32;
+    pub fn vp_batch_destroy(h: *mut vp_batch);
+    pub fn vp_set_params(h: *mut vp_batch, alpha: *const c_void) -> i32;
+    pub fn vp_params(h: *mut vp_batch, alpha_out: *mut c_void) -> i32;
+    pub fn vp_residuals(h: *mut vp_batch, r_out: *mut c_void, status: *mut i32) -> i32;
+    pub fn vp_jacobian(h: *mut vp_batch, j_out: *mut c_void, status: *mut i32) -> i32;
+    pub fn vp_linear_coeffs(h: *mut vp_batch, c_out: *mut c_void, status: *mut i32) -> i32;
+    pub fn vp_weighted_data(h: *mut vp_batch, yw_out: *mut c_void) -> i32;
+    pub fn vp_cost(h: *mut vp_batch, cost_out: *mut f64) -> i32;
+    pub fn vp_evaluate(h: *mut vp_batch, alpha: *const c_void, r: *mut c_void, j: *mut c_void, c: *mut c_void,
+        cost: *mut f64, status: *mut i32) -> i32;
+    pub fn vp_basis(h: *mut vp_batch, alpha: *const c_void, phi: *mut c_void, dphi: *mut c_void, flags: i32) -> i32;
+    pub fn vp_lm_opts_default(o: *mut vp_lm_opts, dtype: i32);
+    pub fn vp_fit(h: *mut vp_batch, opts: *const vp_lm_opts, alpha_inout: *mut c_void, c_out: *mut c_void,
+        rep: *mut vp_report) -> i32;
+    pub fn vp_best_fit(h: *mut vp_batch, fit_out: *mut c_void) -> i32;
+    pub fn vp_summary(h: *mut vp_batch, out: *mut f64) -> i32;
+    pub fn vp_last_error() -> *const c_char;
+}
+
+fn last_error() -> String {
+    unsafe { CStr::from_ptr(vp_last_error()).to_string_lossy().into_owned() }
+}
+
+/// One separable problem (S right-hand sides) whose state lives on the GPU.
+pub struct GpuSeparableProblem {
+    h: *mut vp_batch,
+    m: usize,
+    s: usize,
+    n: usize,
+    q: usize,
+    alpha: DVector<f64>,
+}
+
+impl GpuSeparableProblem {
+    /// == SeparableProblemBuilder::{new|mrhs, observations, weights, epsilon, build}
+    pub fn build(desc: vp_model_desc, x: &DVector<f64>, y: &DMatrix<f64>, w: Option<&DVector<f64>>, eps: Option<f64>,
+                 initial: DVector<f64>) -> Result<Self, String> {
+        let (m, s) = (y.nrows(), y.ncols());
+        let mut h: *mut vp_batch = null_mut();
+        let rc = unsafe {
+            vp_batch_create(&mut h, &desc, VP_F64, m as i64, s as i64, 1, x.as_ptr() as *const c_void,
+                y.as_ptr() as *const c_void, w.map_or(std::ptr::null(), |w| w.as_ptr() as *const c_void),
+                eps.unwrap_or(-1.0), VP_FLAG_OWN_STREAM, 0, null_mut())
+        };
+        if rc != 0 { return Err(last_error()); }
+        let mut p = Self { h, m, s, n: desc.n_basis as usize, q: desc.n_params as usize, alpha: initial.clone() };
+        p.set_params(&initial); // build() runs the first evaluation (src/problem/builder.rs:321)
+        Ok(p)
+    }
+    /// == SeparableProblem::linear_coefficients (n x S, column-major)
+    pub fn linear_coefficients(&self) -> Option<DMatrix<f64>> {
+        let mut c = DMatrix::<f64>::zeros(self.n, self.s);
+        let mut st = 0i32;
+        let rc = unsafe { vp_linear_coeffs(self.h, c.as_mut_ptr() as *mut c_void, &mut st) };
+        (rc == 0 && st == 0).then_some(c)
+    }
+}
+
+impl Drop for GpuSeparableProblem {
+    fn drop(&mut self) { unsafe { vp_batch_destroy(self.h) } }
+}
+
+impl LeastSquaresProblem<f64, Dyn, Dyn> for GpuSeparableProblem {
+    type ResidualStorage = Owned<f64, Dyn>;
+    type JacobianStorage = Owned<f64, Dyn, Dyn>;
+    type ParameterStorage = Owned<f64, Dyn>;
+
+    fn set_params(&mut self, p: &DVector<f64>) {
+        self.alpha = p.clone();
+        // failures are latched per problem in the handle, exactly like `cached = None`
+        unsafe { vp_set_params(self.h, p.as_ptr() as *const c_void); }
+    }
+    fn params(&self) -> DVector<f64> { self.alpha.clone() }
+    fn residuals(&self) -> Option<DVector<f64>> {
+        let mut r = DVector::<f64>::zeros(self.m * self.s);
+        let mut st = 0i32;
+        let rc = unsafe { vp_residuals(self.h, r.as_mut_ptr() as *mut c_void, &mut st) };
+        (rc == 0 && st == 0).then_some(r)
+    }
+    fn jacobian(&self) -> Option<DMatrix<f64>> {
+        // [q][S][m] in memory == (m*S) x q column-major (src/solvers/levmar/mod.rs:147-153)
+        let mut j = DMatrix::<f64>::zeros(self.m * self.s, self.q);
+        let mut st = 0i32;
+        let rc = unsafe { vp_jacobian(self.h, j.as_mut_ptr() as *mut c_void, &mut st) };
+        (rc == 0 && st == 0).then_some(j)
+    }
+}
+
+/// The model plugin over the descriptor language (replaces closures).
+pub struct GpuModel { pub desc: vp_model_desc, pub x: DVector<f64>, pub alpha: DVector<f64>, h: *mut vp_batch }
+
+#[derive(Debug, thiserror::Error)]
+#[error("varpro_hip: {0}")]
+pub struct GpuModelError(String);
+
+impl SeparableNonlinearModel for GpuModel {
+    type ScalarType = f64;
+    type Error = GpuModelError;
+    fn parameter_count(&self) -> usize { self.desc.n_params as usize }
+    fn base_function_count(&self) -> usize { self.desc.n_basis as usize }
+    fn output_len(&self) -> usize { self.x.len() }
+    fn set_params(&mut self, p: DVector<f64>) -> Result<(), Self::Error> { self.alpha = p; Ok(()) }
+    fn params(&self) -> DVector<f64> { self.alpha.clone() }
+    fn eval(&self) -> Result<DMatrix<f64>, Self::Error> {
+        let mut phi = DMatrix::<f64>::zeros(self.x.len(), self.desc.n_basis as usize);
+        let rc = unsafe { vp_basis(self.h, self.alpha.as_ptr() as *const c_void, phi.as_mut_ptr() as *mut c_void, null_mut(), 0) };
+        if rc != 0 { return Err(GpuModelError(last_error())); }
+        Ok(phi)
+    }
+    fn eval_partial_deriv(&self, k: usize) -> Result<DMatrix<f64>, Self::Error> {
+        // dPhi comes back as one column per (basis, parameter) dependency pair in model order; scatter the pairs
+        // of parameter k into a zero m x n matrix (zero columns for independent basis functions)
+        let (m, n) = (self.x.len(), self.desc.n_basis as usize);
+        let pairs: Vec<(usize, usize)> = (0..n).flat_map(|j| (0..2).filter_map(move |a| Some((j, a))))
+            .filter(|&(j, a)| self.desc.param[j][a] >= 0).collect();
+        let mut dphi = DMatrix::<f64>::zeros(m, pairs.len());
+        let rc = unsafe { vp_basis(self.h, self.alpha.as_ptr() as *const c_void, null_mut(), dphi.as_mut_ptr() as *mut c_void, 0) };
+        if rc != 0 { return Err(GpuModelError(last_error())); }
+        let mut out = DMatrix::<f64>::zeros(m, n);
+        for (p, &(j, a)) in pairs.iter().enumerate() {
+            if self.desc.param[j][a] as usize == k { out.column_mut(j).axpy(1.0, &dphi.column(p), 1.0); }
+        }
+        Ok(out)
+    }
+}
+
+/// Device-resident batched fit: B independent problems, alpha [B][q] in/out, returns one report per problem.
+/// `termination > 0`  <=>  `TerminationReason::was_successful()` (src/fit.rs:120-122).
+pub fn fit_batch(h: *mut vp_batch, opts: &vp_lm_opts, alpha: &mut [f64], c_out: &mut [f64], b: usize) -> Vec<vp_report> {
+    let mut rep = vec![vp_report::default(); b];
+    unsafe { vp_fit(h, opts, alpha.as_mut_ptr() as *mut c_void, c_out.as_mut_ptr() as *mut c_void, rep.as_mut_ptr()); }
+    rep
+}

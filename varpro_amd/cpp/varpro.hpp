@@ -1,0 +1,381 @@
+// varpro.hpp -- C++17 host-side mirror of the reference's public surface over the C ABI (include/varpro_hip.h).
+//
+// The reference (geo-ant/varpro) is compiled code (Rust); its toolchain is absent from the build image, so the
+// host side above the C ABI is written in C++ (header-only) with the reference's names, argument meaning and
+// error behaviour:
+//
+//   varpro::SeparableModelBuilder / SeparableModel      src/model/builder/mod.rs:252-571, src/model/mod.rs:239-517
+//   varpro::SeparableProblemBuilder / SeparableProblem  src/problem/builder.rs:116-324, src/problem.rs:57-212,
+//                                                        impl LeastSquaresProblem: src/solvers/levmar/mod.rs:22-202
+//   varpro::LevMarSolver / FitResult / MinimizationReport / LevenbergMarquardt
+//                                                        src/solvers/levmar/mod.rs:204-315, src/fit.rs
+//   varpro::BatchProblem                                 new: B independent problems per launch
+//
+// Rust's `Result<T, E>` / `Option<T>` map to exceptions / std::optional; matrices are column-major
+// std::vector<double> exactly as nalgebra stores them.  Closures are replaced by basis kinds.
+// Link with -lvarpro_hip (varpro_amd/lib).  No CPU fallback: without a gfx950 device every compute call throws.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/varpro_hip.h"
+
+namespace varpro {
+
+enum class Basis : int32_t {
+    Const = VP_BASIS_CONST,
+    ExpDecay = VP_BASIS_EXP_DECAY,
+    ExpRate = VP_BASIS_EXP_RATE,
+    ExpCos = VP_BASIS_EXP_COS,
+    SinPhase = VP_BASIS_SIN_PHASE
+};
+inline int arity(Basis k) {
+    switch (k) {
+    case Basis::Const: return 0;
+    case Basis::ExpDecay:
+    case Basis::ExpRate: return 1;
+    default: return 2;
+    }
+}
+
+// == ModelBuildError (src/model/builder/error.rs): `variant` is the Rust enum variant name
+struct ModelBuildError : std::runtime_error {
+    std::string variant;
+    ModelBuildError(std::string v, const std::string &msg) : std::runtime_error(v + ": " + msg), variant(std::move(v)) {}
+};
+// == SeparableProblemBuilderError (src/problem/builder.rs:15-46)
+struct SeparableProblemBuilderError : std::runtime_error {
+    std::string variant;
+    SeparableProblemBuilderError(std::string v, const std::string &msg)
+        : std::runtime_error(v + ": " + msg), variant(std::move(v)) {}
+};
+// call-level failure of the C ABI (VP_ERR_*)
+struct HipError : std::runtime_error {
+    int code;
+    HipError(int c, const std::string &msg) : std::runtime_error("varpro_hip error " + std::to_string(c) + ": " + msg), code(c) {}
+};
+inline void check(int rc) {
+    if (rc != 0) throw HipError(rc, vp_last_error());
+}
+
+// == SeparableModel: the descriptor the builder produces + the SeparableNonlinearModel trait surface
+class SeparableModel {
+  public:
+    std::vector<std::string> parameter_names;
+    vp_model_desc desc{};
+    std::vector<double> x;
+    std::vector<double> alpha;
+
+    size_t parameter_count() const { return (size_t)desc.n_params; }      // src/model/mod.rs:256
+    size_t base_function_count() const { return (size_t)desc.n_basis; }   // :259
+    size_t output_len() const { return x.size(); }                        // :263
+    void set_params(const std::vector<double> &p) {                       // :266-267
+        if (p.size() != parameter_count()) throw std::invalid_argument("IncorrectParameterCount");
+        alpha = p;
+    }
+    const std::vector<double> &params() const { return alpha; }           // :271
+};
+
+// == SeparableModelBuilder (src/model/builder/mod.rs:338-525); errors are latched and reported by build()
+class SeparableModelBuilder {
+    struct Fn {
+        std::vector<std::string> params;
+        Basis kind;
+        std::vector<std::string> derivs;
+    };
+    std::vector<std::string> names_;
+    std::vector<Fn> fns_;
+    std::vector<double> x_, init_;
+    bool have_x_ = false, have_init_ = false, building_ = false;
+    std::optional<ModelBuildError> err_;
+    void fail(const char *v, const std::string &m) {
+        if (!err_) err_.emplace(v, m);
+    }
+    static bool contains(const std::vector<std::string> &v, const std::string &s) {
+        for (auto &e : v)
+            if (e == s) return true;
+        return false;
+    }
+
+  public:
+    explicit SeparableModelBuilder(std::vector<std::string> parameter_names) : names_(std::move(parameter_names)) {
+        if (names_.empty()) fail("EmptyParameters", "A function or model parameter list is empty!");
+        for (size_t i = 0; i < names_.size(); ++i) {
+            if (names_[i].find(',') != std::string::npos) fail("CommaInParameterNameNotAllowed", names_[i]);
+            for (size_t j = i + 1; j < names_.size(); ++j)
+                if (names_[i] == names_[j]) fail("DuplicateParameterNames", "Parameter list contains duplicates!");
+        }
+    }
+    SeparableModelBuilder &invariant_function(Basis kind = Basis::Const) {
+        if (err_) return *this;
+        if (arity(kind) != 0) fail("IncorrectParameterCount", "invariant function takes no parameters");
+        else fns_.push_back({{}, kind, {}});
+        building_ = false;
+        return *this;
+    }
+    SeparableModelBuilder &function(std::vector<std::string> params, Basis kind) {
+        if (err_) return *this;
+        if (params.empty()) return fail("EmptyParameters", "A function or model parameter list is empty!"), *this;
+        for (size_t i = 0; i < params.size(); ++i) {
+            for (size_t j = i + 1; j < params.size(); ++j)
+                if (params[i] == params[j]) return fail("DuplicateParameterNames", "duplicates in function parameters"), *this;
+            if (!contains(names_, params[i]))
+                return fail("FunctionParameterNotInModel", "Function parameter '" + params[i] + "' is not part of the model parameters."), *this;
+        }
+        if ((size_t)arity(kind) != params.size()) return fail("IncorrectParameterCount", "Incorrect number of parameters for function"), *this;
+        fns_.push_back({std::move(params), kind, {}});
+        building_ = true;
+        return *this;
+    }
+    SeparableModelBuilder &partial_deriv(const std::string &parameter) {
+        if (err_) return *this;
+        if (!building_) return fail("IllegalCallToPartialDeriv", "can only follow 'function' or 'partial_deriv'"), *this;
+        Fn &f = fns_.back();
+        if (!contains(f.params, parameter)) return fail("InvalidDerivative", "Parameter '" + parameter + "' does not exist in parameter list"), *this;
+        if (contains(f.derivs, parameter)) return fail("DuplicateDerivative", "Derivative for parameter '" + parameter + "' was already provided!"), *this;
+        f.derivs.push_back(parameter);
+        return *this;
+    }
+    SeparableModelBuilder &independent_variable(std::vector<double> x) {
+        x_ = std::move(x);
+        have_x_ = true;
+        building_ = false;
+        return *this;
+    }
+    SeparableModelBuilder &initial_parameters(std::vector<double> p) {
+        if (err_) return *this;
+        if (p.size() != names_.size()) return fail("IncorrectParameterCount", "wrong number of initial parameters"), *this;
+        init_ = std::move(p);
+        have_init_ = true;
+        building_ = false;
+        return *this;
+    }
+    SeparableModel build() const {
+        if (err_) throw *err_;
+        if (fns_.empty()) throw ModelBuildError("EmptyModel", "Tried to construct model with no functions.");
+        for (auto &f : fns_)
+            for (auto &p : f.params)
+                if (!contains(f.derivs, p)) throw ModelBuildError("MissingDerivative", "missing derivative for parameter '" + p + "'");
+        for (auto &n : names_) {
+            bool used = false;
+            for (auto &f : fns_) used = used || contains(f.params, n);
+            if (!used) throw ModelBuildError("UnusedParameter", "Model depends on parameter '" + n + "', but none of its functions use it.");
+        }
+        if (!have_x_) throw ModelBuildError("MissingX", "Missing vector for independent variable x");
+        if (!have_init_) throw ModelBuildError("MissingInitialParameters", "Missing initial guesses for model parameters");
+        if (fns_.size() > VP_MAX_BASIS || names_.size() > VP_MAX_PARAMS) throw ModelBuildError("IncorrectParameterCount", "model exceeds VP_MAX_BASIS/VP_MAX_PARAMS");
+        SeparableModel m;
+        m.parameter_names = names_;
+        m.x = x_;
+        m.alpha = init_;
+        m.desc.n_basis = (int32_t)fns_.size();
+        m.desc.n_params = (int32_t)names_.size();
+        for (int j = 0; j < VP_MAX_BASIS; ++j) {
+            m.desc.kind[j] = 0;
+            for (int a = 0; a < VP_MAX_BASIS_PARAMS; ++a) m.desc.param[j][a] = -1;
+        }
+        for (size_t j = 0; j < fns_.size(); ++j) {
+            m.desc.kind[j] = (int32_t)fns_[j].kind;
+            for (size_t a = 0; a < fns_[j].params.size(); ++a)
+                for (size_t k = 0; k < names_.size(); ++k)
+                    if (names_[k] == fns_[j].params[a]) m.desc.param[j][a] = (int32_t)k;
+        }
+        return m;
+    }
+};
+
+// == levenberg_marquardt::LevenbergMarquardt builder knobs (src/solvers/levmar/mod.rs:221-223)
+struct LevenbergMarquardt {
+    vp_lm_opts o;
+    LevenbergMarquardt() { vp_lm_opts_default(&o, VP_F64); }
+    LevenbergMarquardt &with_ftol(double v) { return o.ftol = v, *this; }
+    LevenbergMarquardt &with_xtol(double v) { return o.xtol = v, *this; }
+    LevenbergMarquardt &with_gtol(double v) { return o.gtol = v, *this; }
+    LevenbergMarquardt &with_stepbound(double v) { return o.stepbound = v, *this; }
+    LevenbergMarquardt &with_patience(int v) { return o.patience = v, *this; }
+    LevenbergMarquardt &with_scale_diag(bool v) { return o.scale_diag = v ? 1 : 0, *this; }
+};
+
+// B independent problems x S right-hand sides on one GPU (host-pointer mode; fp64)
+class BatchProblem {
+    vp_batch *h_ = nullptr;
+
+  public:
+    int64_t m = 0, S = 1, B = 0;
+    int n = 0, q = 0;
+    BatchProblem() = default;
+    BatchProblem(const SeparableModel &model, const std::vector<double> &Y, int64_t B_, int64_t S_,
+                 const std::vector<double> *weights = nullptr, double epsilon = -1.0, int device = 0) {
+        m = (int64_t)model.output_len();
+        B = B_;
+        S = S_;
+        n = model.desc.n_basis;
+        q = model.desc.n_params;
+        if ((int64_t)Y.size() != B * S * m) throw std::invalid_argument("Y must hold B*S*m values");
+        check(vp_batch_create(&h_, &model.desc, VP_F64, m, S, B, model.x.data(), Y.data(), weights ? weights->data() : nullptr,
+                              epsilon, VP_FLAG_OWN_STREAM, device, nullptr));
+    }
+    BatchProblem(const BatchProblem &) = delete;
+    BatchProblem &operator=(const BatchProblem &) = delete;
+    BatchProblem(BatchProblem &&o) noexcept { *this = std::move(o); }
+    BatchProblem &operator=(BatchProblem &&o) noexcept {
+        std::swap(h_, o.h_);
+        m = o.m, S = o.S, B = o.B, n = o.n, q = o.q;
+        return *this;
+    }
+    ~BatchProblem() {
+        if (h_) vp_batch_destroy(h_);
+    }
+    vp_batch *handle() const { return h_; }
+    void set_params(const std::vector<double> &alpha) { check(vp_set_params(h_, alpha.data())); }
+    std::vector<int32_t> status() const {
+        std::vector<int32_t> st((size_t)B);
+        check(vp_linear_coeffs(h_, nullptr, st.data()));
+        return st;
+    }
+    std::vector<double> residuals() const {
+        std::vector<double> r((size_t)(B * S * m));
+        check(vp_residuals(h_, r.data(), nullptr));
+        return r;
+    }
+    std::vector<double> jacobian() const {
+        std::vector<double> J((size_t)(B * q * S * m));
+        check(vp_jacobian(h_, J.data(), nullptr));
+        return J;
+    }
+    std::vector<double> linear_coefficients() const {
+        std::vector<double> C((size_t)(B * S * n));
+        check(vp_linear_coeffs(h_, C.data(), nullptr));
+        return C;
+    }
+    std::vector<double> best_fit() const {
+        std::vector<double> f((size_t)(B * S * m));
+        check(vp_best_fit(h_, f.data()));
+        return f;
+    }
+    std::vector<vp_report> fit(std::vector<double> &alpha_inout, const LevenbergMarquardt &solver = LevenbergMarquardt()) {
+        std::vector<vp_report> rep((size_t)B);
+        check(vp_fit(h_, &solver.o, alpha_inout.data(), nullptr, rep.data()));
+        return rep;
+    }
+};
+
+// == SeparableProblem (single problem, S right-hand sides); `None` of the reference == std::nullopt
+class SeparableProblem {
+    SeparableModel model_;
+    BatchProblem batch_;
+    std::optional<std::vector<double>> weights_;
+
+  public:
+    SeparableProblem(SeparableModel model, const std::vector<double> &Y, int64_t S, std::optional<std::vector<double>> weights,
+                     double epsilon)
+        : model_(std::move(model)), batch_(model_, Y, 1, S, weights ? &*weights : nullptr, epsilon), weights_(std::move(weights)) {
+        set_params(model_.params()); // build(): initial set_params (src/problem/builder.rs:321)
+    }
+    void set_params(const std::vector<double> &p) { // src/solvers/levmar/mod.rs:42-73
+        model_.set_params(p);
+        batch_.set_params(p);
+    }
+    const std::vector<double> &params() const { return model_.params(); } // :80-82
+    std::optional<std::vector<double>> residuals() const {               // :91-95
+        if (batch_.status()[0] != VP_ST_OK) return std::nullopt;
+        return batch_.residuals();
+    }
+    std::optional<std::vector<double>> jacobian() const { // :101-201  (m*S) x q column-major
+        if (batch_.status()[0] != VP_ST_OK) return std::nullopt;
+        return batch_.jacobian();
+    }
+    std::optional<std::vector<double>> linear_coefficients() const { // src/problem.rs:142-183  n x S column-major
+        if (batch_.status()[0] != VP_ST_OK) return std::nullopt;
+        return batch_.linear_coefficients();
+    }
+    const SeparableModel &model() const { return model_; }
+    SeparableModel &model_mut() { return model_; }
+    BatchProblem &batch() { return batch_; }
+    const BatchProblem &batch() const { return batch_; }
+};
+
+// == SeparableProblemBuilder::{new, mrhs, observations, weights, epsilon, build}
+class SeparableProblemBuilder {
+    SeparableModel model_;
+    bool mrhs_;
+    std::optional<std::vector<double>> Y_;
+    int64_t S_ = 1;
+    std::optional<std::vector<double>> weights_;
+    double eps_ = -1.0;
+    SeparableProblemBuilder(SeparableModel m, bool mrhs) : model_(std::move(m)), mrhs_(mrhs) {}
+
+  public:
+    static SeparableProblemBuilder new_(SeparableModel m) { return SeparableProblemBuilder(std::move(m), false); }
+    static SeparableProblemBuilder mrhs(SeparableModel m) { return SeparableProblemBuilder(std::move(m), true); }
+    // single RHS: y (m values);  MRHS: Y column-major m x S
+    SeparableProblemBuilder &observations(std::vector<double> Y, int64_t S = 1) {
+        Y_ = std::move(Y);
+        S_ = mrhs_ ? S : 1;
+        return *this;
+    }
+    SeparableProblemBuilder &weights(std::vector<double> w) { return weights_ = std::move(w), *this; }
+    SeparableProblemBuilder &epsilon(double e) { return eps_ = std::fabs(e), *this; }
+    SeparableProblem build() {
+        if (!Y_) throw SeparableProblemBuilderError("YDataMissing", "Right hand side(s) not provided");
+        const size_t xlen = model_.output_len();
+        if (xlen == 0 || Y_->empty()) throw SeparableProblemBuilderError("ZeroLengthVector", "x or y must have nonzero number of elements.");
+        if (Y_->size() != xlen * (size_t)S_)
+            throw SeparableProblemBuilderError("InvalidLengthOfData", "Vectors x and y must have same lengths.");
+        if (weights_ && weights_->size() != xlen)
+            throw SeparableProblemBuilderError("InvalidLengthOfWeights", "The weights must have the same length as the data y.");
+        return SeparableProblem(model_, *Y_, S_, weights_, eps_);
+    }
+};
+
+// == MinimizationReport / FitResult (src/fit.rs)
+struct MinimizationReport {
+    int termination;
+    int number_of_evaluations;
+    double objective_function;
+    bool was_successful() const { return termination > 0; }
+};
+struct FitResult {
+    SeparableProblem problem;
+    MinimizationReport minimization_report;
+    const std::vector<double> &nonlinear_parameters() const { return problem.model().params(); } // src/fit.rs:113-115
+    std::optional<std::vector<double>> linear_coefficients() const { return problem.linear_coefficients(); }
+    std::optional<std::vector<double>> best_fit() const { // unweighted Phi C (src/fit.rs:55-59, 87-91)
+        if (!problem.linear_coefficients()) return std::nullopt;
+        return problem.batch().best_fit();
+    }
+    bool was_successful() const { return minimization_report.was_successful(); } // :120-122
+};
+// the Err(FitResult) arm of LevMarSolver::fit (src/solvers/levmar/mod.rs:248-253)
+struct FitError : std::runtime_error {
+    FitResult result;
+    explicit FitError(FitResult r) : std::runtime_error("fit did not terminate successfully"), result(std::move(r)) {}
+};
+
+class LevMarSolver {
+    LevenbergMarquardt solver_;
+
+  public:
+    LevMarSolver() = default;
+    static LevMarSolver with_solver(LevenbergMarquardt s) {
+        LevMarSolver l;
+        l.solver_ = s;
+        return l;
+    }
+    // consumes the problem; returns the FitResult on success, throws FitError(result) otherwise
+    FitResult fit(SeparableProblem problem) const {
+        std::vector<double> alpha = problem.params();
+        std::vector<vp_report> rep = problem.batch().fit(alpha, solver_);
+        problem.model_mut().set_params(alpha);
+        FitResult res{std::move(problem), MinimizationReport{rep[0].termination, rep[0].n_evals, rep[0].objective}};
+        if (!res.was_successful()) throw FitError(std::move(res));
+        return res;
+    }
+};
+
+} // namespace varpro
