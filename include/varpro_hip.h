@@ -262,6 +262,19 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
 int vp_best_fit(vp_batch *h, void *fit_out);
 
 /*
+ * == FitStatistics::try_calculate (src/statistics/mod.rs:352-441) for every problem of a single-RHS batch at
+ * the handle's current parameters (after vp_fit / vp_set_params); what fit_with_statistics
+ * (src/solvers/levmar/mod.rs:275-304) adds to fit.
+ *   cov_out            [B][(n+q)][(n+q)]  sigma^2 (H^T H)^-1, H = W [Phi, (dPhi/dalpha_k c)_k]; ordering
+ *                      [linear coefficients, nonlinear parameters] (covariance_matrix(), :129)
+ *   reduced_chi2_out   [B] f64            ||r_w||^2 / (m - n - q)  (reduced_chi2(), :183)
+ *   conf_sigma_out     [B][m] or NULL     sqrt(j_i^T Cov j_i): multiply by the Student-t quantile
+ *                                         t_ppf((p+1)/2, m-n-q) to get confidence_band_radius(p) (:271-304)
+ *   status             [B] or NULL        0 ok; 4 = Underdetermined / MatrixInversion (the reference's Err)
+ */
+int vp_statistics(vp_batch *h, void *cov_out, double *reduced_chi2_out, void *conf_sigma_out, int32_t *status);
+
+/*
  * Local batch aggregates for the multi-GPU cost reduction:
  * out = { sum_b 1/2||r_b||^2 , #successful , #failed , sum_b n_evals } over this
  * handle's problems (after vp_fit) -- always HOST doubles.  The cross-rank sum is one

@@ -72,6 +72,8 @@ def _load():
     lib.vpo_fit.argtypes = [C.c_void_p, C.POINTER(LmOpts), C.POINTER(Report)]
     lib.vpo_fit_trace.argtypes = [C.c_void_p, C.POINTER(LmOpts), C.POINTER(Report), dp, C.c_int]
     lib.vpo_fit_trace.restype = C.c_int
+    lib.vpo_statistics.argtypes = [C.c_void_p, dp, dp, dp]
+    lib.vpo_statistics.restype = C.c_int
     lib.vpo_thin_svd.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp]
     lib.vpo_enorm.argtypes = [C.c_int, dp]
     lib.vpo_enorm.restype = C.c_double
@@ -223,6 +225,16 @@ class Problem:
         tr = np.zeros((max_rows, self.q + 4))
         n = lib().vpo_fit_trace(self._h, C.byref(opts), C.byref(rep), _dp(tr), max_rows)
         return rep, tr[:n]
+
+    def statistics(self):
+        """== FitStatistics::try_calculate: dict(cov (k,k), reduced_chi2, conf_sigma (m,)) or None"""
+        k = self.n + self.q
+        cov = np.zeros((k, k))
+        chi2 = np.zeros(1)
+        sig = np.zeros(self.m)
+        if not lib().vpo_statistics(self._h, _dp(cov), _dp(chi2), _dp(sig)):
+            return None
+        return dict(cov=cov.T.copy(), reduced_chi2=float(chi2[0]), conf_sigma=sig, dof=self.m - k)
 
     def counters(self):
         st = self._struct()

@@ -380,6 +380,84 @@ int vpo_best_fit(const vpo_problem *p, double *fit_out) {
     return 1;
 }
 
+/* == FitStatistics::try_calculate (src/statistics/mod.rs:352-441), single RHS.
+ * cov: (n+q) x (n+q) column-major, ordering [linear coefficients, nonlinear parameters];
+ * conf_sigma[i] = sqrt(j_i^T cov j_i) (the reference's unscaled_confidence_sigma; the Student-t factor of
+ * confidence_band_radius :271-304 is applied by the caller).  Returns 1 ok, 0 = Underdetermined /
+ * MatrixInversion / no cached solution. */
+int vpo_statistics(vpo_problem *p, double *cov, double *reduced_chi2, double *conf_sigma) {
+    if (!p->cached || p->S != 1) return 0;
+    const int m = p->m, n = p->model.n_basis, q = p->model.n_params, k = n + q;
+    if (m <= k) return 0; /* Error::Underdetermined */
+    double *J = (double *)malloc(sizeof(double) * (size_t)m * k); /* model_function_jacobian :481-511 */
+    double *Dk = (double *)malloc(sizeof(double) * (size_t)m * n);
+    vpo_eval_phi(&p->model, m, p->t, p->alpha, J);
+    for (int a = 0; a < q; ++a) {
+        vpo_eval_dphi(&p->model, m, p->t, p->alpha, a, Dk);
+        for (int i = 0; i < m; ++i) {
+            double acc = 0;
+            for (int j = 0; j < n; ++j) acc += Dk[i + (size_t)j * m] * p->C[j];
+            J[i + (size_t)(n + a) * m] = acc;
+        }
+    }
+    const int dof = m - k;
+    double rss = 0;
+    for (int i = 0; i < m; ++i) rss += p->R[i] * p->R[i]; /* weighted residuals == cached R */
+    const double chi2 = rss / (double)dof;
+    /* H = W J ; (H^T H)^{-1} by Gauss-Jordan with partial pivoting in extended precision */
+    long double A[2 * (VP_MAX_BASIS + VP_MAX_PARAMS)][2 * (VP_MAX_BASIS + VP_MAX_PARAMS)];
+    for (int a = 0; a < k; ++a)
+        for (int b = 0; b < k; ++b) {
+            long double acc = 0;
+            for (int i = 0; i < m; ++i) {
+                const long double w = p->w ? p->w[i] : 1.0;
+                acc += (w * J[i + (size_t)a * m]) * (w * J[i + (size_t)b * m]);
+            }
+            A[a][b] = acc;
+            A[a][k + b] = (a == b) ? 1.0L : 0.0L;
+        }
+    int ok = 1;
+    for (int c = 0; c < k && ok; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < k; ++r)
+            if (fabsl(A[r][c]) > fabsl(A[piv][c])) piv = r;
+        if (A[piv][c] == 0.0L || !isfinite((double)A[piv][c])) {
+            ok = 0;
+            break;
+        }
+        if (piv != c)
+            for (int b = 0; b < 2 * k; ++b) {
+                long double t = A[c][b];
+                A[c][b] = A[piv][b];
+                A[piv][b] = t;
+            }
+        const long double d = A[c][c];
+        for (int b = 0; b < 2 * k; ++b) A[c][b] /= d;
+        for (int r = 0; r < k; ++r)
+            if (r != c) {
+                const long double f = A[r][c];
+                for (int b = 0; b < 2 * k; ++b) A[r][b] -= f * A[c][b];
+            }
+    }
+    if (ok) {
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) cov[a + (size_t)b * k] = (double)(A[a][k + b] * chi2);
+        for (int i = 0; i < m; ++i) {
+            double acc = 0;
+            for (int a = 0; a < k; ++a) {
+                double t = 0;
+                for (int b = 0; b < k; ++b) t += cov[a + (size_t)b * k] * J[i + (size_t)b * m];
+                acc += J[i + (size_t)a * m] * t;
+            }
+            conf_sigma[i] = sqrt(acc);
+        }
+        *reduced_chi2 = chi2;
+    }
+    free(J);
+    free(Dk);
+    return ok;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* Levenberg-Marquardt: restatement of levenberg-marquardt 0.14 == MINPACK lmder/lmpar/qrfac/   */
 /* qrsolv (More, Garbow, Hillstrom) with the crate's termination semantics.  */

@@ -79,6 +79,10 @@ int vpo_jacobian(vpo_problem *p, double *J_out);
 /* == FitResult::best_fit (src/fit.rs:55-59,87-91) */
 int vpo_best_fit(const vpo_problem *p, double *fit_out);
 
+/* == FitStatistics::try_calculate (src/statistics/mod.rs:352-441): covariance (n+q)^2 column-major,
+ * reduced chi^2, per-row unscaled confidence sigma.  1 = ok, 0 = underdetermined / singular / not cached */
+int vpo_statistics(vpo_problem *p, double *cov, double *reduced_chi2, double *conf_sigma);
+
 /* == LevMarSolver::fit -> LevenbergMarquardt::minimize (src/solvers/levmar/mod.rs:238-254) */
 void vpo_fit(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep);
 /* vpo_fit + per-evaluation trace rows [x_trial(q), ||r||, ratio, delta, par]; returns rows written */

@@ -15,6 +15,7 @@ from .batch import BatchProblem, LevenbergMarquardt, REPORT_DTYPE  # noqa: F401
 from .model import (ModelBuildError, ModelError, SeparableModel, SeparableModelBuilder, basis,  # noqa: F401
                     multi_exponential_model)
 from .problem import SeparableProblem, SeparableProblemBuilder, SeparableProblemBuilderError  # noqa: F401
-from .solver import (FitError, FitResult, LevMarSolver, MinimizationReport, TerminationReason)  # noqa: F401
+from .solver import (FitError, FitResult, FitStatistics, LevMarSolver, MinimizationReport,  # noqa: F401
+                     TerminationReason)  # noqa: F401
 
 __version__ = "0.1.0"

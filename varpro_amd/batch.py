@@ -310,6 +310,17 @@ class BatchProblem:
         check(self.lib.vp_best_fit(self._h, self._ptr(f)))
         return f.reshape(self.B, self.m) if self.single_rhs else f
 
+    def statistics(self, want_confidence_sigma=True):
+        """== FitStatistics::try_calculate for every problem (vp_statistics): dict(cov (B,k,k),
+        reduced_chi2 (B,), conf_sigma (B,m) or None, status (B,), dof)"""
+        k = self.n + self.q
+        cov = self._empty((self.B, k, k))
+        chi2 = self._empty((self.B,), np.float64)
+        sig = self._empty((self.B, self.m)) if want_confidence_sigma else None
+        st = self._empty((self.B,), np.int32)
+        check(self.lib.vp_statistics(self._h, self._ptr(cov), self._ptr(chi2), self._ptr(sig), self._ptr(st)))
+        return dict(cov=cov, reduced_chi2=chi2, conf_sigma=sig, status=st, dof=self.m - k)
+
     def summary(self):
         """local {sum cost, #successful, #failed, sum n_evals} after fit (vp_summary)"""
         out = (C.c_double * 4)()

@@ -737,6 +737,48 @@ int vp_best_fit(vp_batch *h, void *fit_out) {
     return f.finish(h);
 }
 
+int vp_statistics(vp_batch *h, void *cov_out, double *reduced_chi2_out, void *conf_sigma_out, int32_t *status) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->have_params) return fail(VP_ERR_INVALID, "no parameters set yet");
+    if (h->S != 1) // src/solvers/levmar/mod.rs:271-273: statistics are single-RHS only
+        return fail(VP_ERR_UNSUPPORTED, "fit statistics are only supported for a single right-hand side");
+    if (!h->kern->stats) return fail(VP_ERR_UNSUPPORTED, "no statistics kernel for this model");
+    if (!cov_out || !reduced_chi2_out) return fail(VP_ERR_INVALID, "null output");
+    const size_t ts = tsize(h->dtype);
+    const int k = h->n + h->q;
+    OutBuf cov, chi2, sig, st;
+    if (int rc = cov.init(h, cov_out, (size_t)h->B * k * k * ts)) return rc;
+    if (int rc = chi2.init(h, reduced_chi2_out, (size_t)h->B * sizeof(double))) return rc;
+    if (int rc = sig.init(h, conf_sigma_out, (size_t)h->B * h->m * ts)) return rc;
+    void *st_tmp = nullptr;
+    int32_t *st_dev = status && device_ptrs(h) ? status : nullptr;
+    if (!st_dev) {
+        VP_HIP(hipMalloc(&st_tmp, (size_t)h->B * sizeof(int32_t)));
+        st_dev = (int32_t *)st_tmp;
+    }
+    LaunchParams p;
+    fill_params(h, p);
+    p.C_out = h->d_C;
+    p.cost_out = h->d_cost;
+    p.status = h->d_status;
+    p.Phi_out = cov.dptr;
+    p.dPhi_out = chi2.dptr;
+    p.r_out = sig.dptr;
+    p.J_out = st_dev;
+    int rc = h->kern->stats(p);
+    if (rc == VP_ERR_OK) rc = cov.finish(h);
+    if (rc == VP_ERR_OK) rc = chi2.finish(h);
+    if (rc == VP_ERR_OK) rc = sig.finish(h);
+    if (rc == VP_ERR_OK && status && !device_ptrs(h)) {
+        hipError_t e = hipMemcpyAsync(status, st_dev, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = VP_ERR_HIP;
+    }
+    if (st_tmp) (void)hipFree(st_tmp);
+    if (rc != VP_ERR_OK) return fail(rc, "statistics kernel failed");
+    return VP_ERR_OK;
+}
+
 int vp_summary(vp_batch *h, double out[4]) {
     if (int rc = check_handle(h)) return rc;
     if (!h->have_report) return fail(VP_ERR_INVALID, "vp_summary requires a completed vp_fit");

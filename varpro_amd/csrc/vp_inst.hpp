@@ -2,6 +2,7 @@
 #pragma once
 #include "vp_fit_mp.hpp"
 #include "vp_mrhs.hpp"
+#include "vp_stats.hpp"
 #include "vp_registry.hpp"
 
 #define VP_CAT_(a, b) a##b
@@ -18,7 +19,8 @@
         &::vp::launch_mrhs_stream<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                      \
         &::vp::launch_mrhs_lm<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                          \
         &::vp::launch_mrhs_finish<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                      \
-        ::vp::mrhs_state_bytes<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>>()});
+        ::vp::mrhs_state_bytes<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>>(),                                          \
+        &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>});
 
 #define VP_REGISTER_RT(T, DT, NN, QQ, PP, RR)                                                                          \
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
@@ -28,7 +30,8 @@
         &::vp::launch_best_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                     \
         &::vp::launch_mrhs_factor<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                  \
         &::vp::launch_mrhs_stream<T, ::vp::RtModel<NN, QQ, PP>, RR>, &::vp::launch_mrhs_lm<T, ::vp::RtModel<NN, QQ, PP>, RR>, \
-        &::vp::launch_mrhs_finish<T, ::vp::RtModel<NN, QQ, PP>, RR>, ::vp::mrhs_state_bytes<T, ::vp::RtModel<NN, QQ, PP>>()});
+        &::vp::launch_mrhs_finish<T, ::vp::RtModel<NN, QQ, PP>, RR>, ::vp::mrhs_state_bytes<T, ::vp::RtModel<NN, QQ, PP>>(), \
+        &::vp::launch_stats<T, ::vp::RtModel<NN, QQ, PP>, RR>});
 
 // multi-wave groups (WW waves per problem): problems whose columns do not fit the registers of one wave
 #define VP_REGISTER_MULTIEXP_W(T, DT, NEXP, OFF, RR, WW)                                                               \
@@ -37,4 +40,5 @@
         &::vp::launch_evaluate<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                     \
         &::vp::launch_basis<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr,                               \
         &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                          \
-        &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0});
+        &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0, \
+        &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>});

@@ -24,6 +24,7 @@ struct KernelEntry {
     // multiple-right-hand-side path (vp_mrhs.hpp); all null if not instantiated
     launch_fn mrhs_factor, mrhs_stream, mrhs_lm, mrhs_finish;
     size_t mrhs_state_bytes;
+    launch_fn stats; // batched fit statistics (vp_stats.hpp)
 };
 
 std::vector<KernelEntry> &registry();

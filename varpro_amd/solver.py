@@ -62,6 +62,49 @@ class FitResult:
         return self.minimization_report.termination.was_successful()  # src/fit.rs:120-122
 
 
+class FitStatistics:
+    """== ``FitStatistics`` (src/statistics/mod.rs:27-304) of one single-RHS fit"""
+
+    def __init__(self, covariance_matrix, reduced_chi2, weighted_residuals, conf_sigma, n_linear, n_nonlinear, dof):
+        self._cov = np.asarray(covariance_matrix)
+        self._chi2 = float(reduced_chi2)
+        self._wres = np.asarray(weighted_residuals)
+        self._sigma = np.asarray(conf_sigma)
+        self._n, self._q, self._dof = int(n_linear), int(n_nonlinear), int(dof)
+
+    def covariance_matrix(self):
+        """ordering [linear coefficients, nonlinear parameters] (src/statistics/mod.rs:129)"""
+        return self._cov
+
+    def calculate_correlation_matrix(self):
+        d = np.sqrt(np.diag(self._cov))
+        return self._cov / np.outer(d, d)
+
+    correlation_matrix = calculate_correlation_matrix
+
+    def weighted_residuals(self):
+        return self._wres
+
+    def reduced_chi2(self):
+        return self._chi2
+
+    def regression_standard_error(self):
+        return float(np.sqrt(self._chi2))
+
+    def linear_coefficients_variance(self):
+        return np.diag(self._cov)[:self._n].copy()
+
+    def nonlinear_parameters_variance(self):
+        return np.diag(self._cov)[self._n:].copy()
+
+    def confidence_band_radius(self, probability):
+        """Student-t scaled confidence band (src/statistics/mod.rs:271-304)"""
+        if not (np.isfinite(probability) and 0.0 < probability < 1.0):
+            raise ValueError("probability must be in open interval (0.,1.)")
+        from scipy import stats as _st
+        return _st.t.ppf((probability + 1.0) / 2.0, self._dof) * self._sigma
+
+
 class FitError(RuntimeError):
     """the ``Err(FitResult)`` arm of ``LevMarSolver::fit`` (src/solvers/levmar/mod.rs:248-253)"""
 
@@ -94,3 +137,16 @@ class LevMarSolver:
         if not result.was_successful():
             raise FitError(result)
         return result
+
+    def fit_with_statistics(self, problem):
+        """== ``fit_with_statistics`` (src/solvers/levmar/mod.rs:275-304): single RHS only; raises FitError if
+        the fit or the statistics (underdetermined / singular) fail"""
+        if problem._mrhs:
+            raise ValueError("fit_with_statistics is only supported for problems with a single right hand side")
+        result = self.fit(problem)
+        st = problem._batch.statistics()
+        if int(st["status"][0]) != 0 or problem.linear_coefficients() is None:
+            raise FitError(result)
+        stats = FitStatistics(st["cov"][0], st["reduced_chi2"][0], problem.residuals(), st["conf_sigma"][0],
+                              problem.n, problem.q, st["dof"])
+        return result, stats
