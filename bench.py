@@ -59,13 +59,17 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run even N=1 exercises RCCL
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     B, m = args.batch, args.m
     # ---- synthetic input of BASELINE configs[1] (shard `rank` of the global problem set) ----
-    d = synth.double_exp_batch(B, m=m, first_problem=rank * B, noise=args.noise)
+    first, count = vd.shard_range(world * B, rank, world)  # contiguous block of the global problem set
+    assert count == B
+    d = synth.double_exp_batch(B, m=m, first_problem=first, noise=args.noise)
     mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0])
     Y = torch.from_numpy(d["Y"]).to(dev)
     x = torch.from_numpy(d["x"]).to(dev)
@@ -73,14 +77,19 @@ def main():
     bp = vp.BatchProblem(mdl, Y, x=x)  # device-pointer mode on torch's current stream
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
+    red = torch.zeros(4, dtype=torch.float64, device=dev)
+
     def step():
-        alpha, _c, _rep = bp.fit(guess, want_coefficients=False)
-        s = bp.summary()  # local {sum cost, #ok, #failed, sum evals} (host doubles)
-        # RCCL over xGMI: the scalar LM cost reduction (one 32-byte sum all-reduce per step)
-        return vd.allreduce_summary(s, device=dev)
+        # everything is enqueued asynchronously: the fit kernel, the 4-double batch summary (device side) and
+        # the RCCL-over-xGMI all-reduce of those 32 bytes (the scalar LM cost reduction); no host sync per step
+        bp.fit(guess, want_coefficients=False)
+        bp.summary_device(red)
+        if use_dist:
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        return red
 
     for _ in range(args.warmup):
         step()
@@ -99,6 +108,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    last = last.cpu().numpy()
     total_fits = float(world) * B * args.steps
     value = total_fits / dt
     sum_cost, n_ok, n_bad, n_evals = [float(v) for v in last]
@@ -150,9 +160,10 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             n1 = max(args.steps, 10)
+            red1 = torch.zeros(4, dtype=torch.float64, device=dev)
             for _ in range(n1):
                 bp1.fit(g1, want_coefficients=False)
-                bp1.summary()
+                bp1.summary_device(red1)
             torch.cuda.synchronize()
             dt1 = (time.perf_counter() - t1) / n1
             cfg1 = {"workload": "BASELINE configs[1]: 4096 fits on 1 GPU (tail-latency bound: the slowest fit "
@@ -227,7 +238,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     bp.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

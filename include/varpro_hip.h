@@ -282,6 +282,10 @@ int vp_statistics(vp_batch *h, void *cov_out, double *reduced_chi2_out, void *co
  */
 int vp_summary(vp_batch *h, double out[4]);
 
+/* same aggregates written to 4 DEVICE doubles, enqueued on the handle's stream without any host
+ * synchronisation: the buffer can be handed straight to ncclAllReduce (RCCL) */
+int vp_summary_device(vp_batch *h, double *dev_out4);
+
 /* ---- introspection --------------------------------------------------------------------- */
 
 /* duration in ms of the most recent launch of a kernel family on this handle, measured

@@ -327,6 +327,13 @@ class BatchProblem:
         check(self.lib.vp_summary(self._h, out))
         return np.array(list(out))
 
+    def summary_device(self, out):
+        """the same 4 aggregates into a CUDA float64 tensor of 4 elements, asynchronously on the handle's stream
+        (no host synchronisation): ready to be all-reduced over RCCL"""
+        assert _is_torch(out) and out.is_cuda and out.numel() == 4 and out.dtype == torch.float64
+        check(self.lib.vp_summary_device(self._h, C.c_void_p(out.data_ptr())))
+        return out
+
     def set_timing(self, enable=True):
         check(self.lib.vp_set_timing(self._h, int(enable)))
 

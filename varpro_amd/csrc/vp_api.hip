@@ -791,6 +791,17 @@ int vp_summary(vp_batch *h, double out[4]) {
     return VP_ERR_OK;
 }
 
+int vp_summary_device(vp_batch *h, double *dev_out4) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->have_report) return fail(VP_ERR_INVALID, "vp_summary_device requires a completed vp_fit");
+    if (!dev_out4) return fail(VP_ERR_INVALID, "null output");
+    VP_HIP(hipMemsetAsync(dev_out4, 0, 4 * sizeof(double), h->stream));
+    const unsigned grid = (unsigned)std::min<int64_t>((h->B + 255) / 256, 1024);
+    hipLaunchKernelGGL(summary_kernel, dim3(grid), dim3(256), 0, h->stream, h->d_report, h->B, dev_out4);
+    VP_HIP(hipGetLastError());
+    return VP_ERR_OK;
+}
+
 int vp_set_timing(vp_batch *h, int enable) {
     if (!h) return fail(VP_ERR_INVALID, "null handle");
     h->timing = enable != 0;

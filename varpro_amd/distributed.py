@@ -29,7 +29,7 @@ def allreduce_summary(local4, device=None):
     """sum the per-rank {sum cost, #ok, #failed, sum evals} over all ranks.  Works on whatever backend the
     default process group uses: CUDA tensor for nccl/RCCL, CPU tensor for gloo; identity without a group."""
     v = np.asarray(local4, dtype=np.float64).reshape(4)
-    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_available() or not dist.is_initialized():
         return v.copy()
     backend = dist.get_backend()
     t = torch.from_numpy(v.copy())
