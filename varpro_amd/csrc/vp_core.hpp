@@ -145,8 +145,24 @@ __device__ __forceinline__ void apply_q_cols(T (&C)[NC][R], const T (&g)[N], G &
 // Slow path of the linear solve: truncated SVD of the N x N triangular factor (absolute threshold
 // eps, as nalgebra's SVD::solve at src/solvers/levmar/mod.rs:52-54).  All arithmetic wave-uniform.
 // Returns the minimum-norm c and e = qty - Rm c (the part of the residual that lives in range(Q)).
-template <typename T, int N>
-__device__ __noinline__ void truncated_solve(const T (&Rm)[N][N], const T (&qty)[N], T eps, T (&c)[N], T (&e)[N]) {
+// Arguments and results travel BY VALUE: a by-reference signature would force the caller's R, Q^T y, c, e
+// into scratch memory on every evaluation just for this rarely taken call.
+template <typename T, int N> struct TruncIn {
+    T Rm[N][N];
+    T qty[N];
+    T eps;
+};
+template <typename T, int N> struct TruncOut {
+    T c[N];
+    T e[N];
+};
+template <typename T, int N> __device__ __noinline__ TruncOut<T, N> truncated_solve(const TruncIn<T, N> in) {
+    const T(&Rm)[N][N] = in.Rm;
+    const T(&qty)[N] = in.qty;
+    const T eps = in.eps;
+    TruncOut<T, N> out;
+    T(&c)[N] = out.c;
+    T(&e)[N] = out.e;
     T W[N][N], V[N][N]; // W[col][row]
 #pragma unroll
     for (int j = 0; j < N; ++j)
@@ -210,6 +226,7 @@ __device__ __noinline__ void truncated_solve(const T (&Rm)[N][N], const T (&qty)
         for (int j = i; j < N; ++j) acc = tfma(-Rm[i][j], c[j], acc);
         e[i] = acc;
     }
+    return out;
 }
 
 // c = R^{-1} qty by back substitution, guarded by a rank test equivalent to the reference's
@@ -259,7 +276,22 @@ __device__ __forceinline__ void solve_coeffs(const T (&Rm)[N][N], const T (&qty)
             return;
         }
     }
-    truncated_solve<T, N>(Rm, qty, eps, c, e);
+    {
+        TruncIn<T, N> in;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            in.qty[i] = qty[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) in.Rm[i][j] = (j >= i) ? Rm[i][j] : T(0);
+        }
+        in.eps = eps;
+        const TruncOut<T, N> out = truncated_solve<T, N>(in);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            c[i] = out.c[i];
+            e[i] = out.e[i];
+        }
+    }
     truncated = true;
 }
 

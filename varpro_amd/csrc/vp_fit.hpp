@@ -742,8 +742,15 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
         if (a.cost_out) a.cost_out[b] = (double)objective;
         if (a.status) a.status[b] = st_best;
     }
-    if (lane < Q) a.alpha[b * Q + lane] = dyn_get<Q>(x, lane);
-    if (a.C_out && lane < N) a.C_out[b * N + lane] = dyn_get<N>(cbest, lane);
+    // lane 0 stores the (uniform) results one by one: a lane-indexed gather would turn x[] into a scratch array
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) a.alpha[b * Q + k] = x[k];
+        if (a.C_out) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) a.C_out[b * N + k] = cbest[k];
+        }
+    }
 }
 
 template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchParams &p) {
