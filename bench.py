@@ -170,13 +170,14 @@ def main():
                                 "needs >100 LM evaluations)", "fits_per_s": 4096 / dt1, "ms_per_step": dt1 * 1e3}
             bp1.close()
         # HBM traffic of the Phi kernel from the committed rocprofv3 PMC passes (profiles/), per launch
-        traffic = None
+        traffic = traffic_fit = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if pj.get("batch") == B and pj.get("m") == m:
                 traffic = pj["basis_kernel"]["hbm_bytes_per_launch_corrected"]
+                traffic_fit = pj["fit_kernel"]["hbm_bytes_per_launch_corrected"]
         except Exception:
-            traffic = None
+            traffic = traffic_fit = None
         out = {
             "metric": "independent fits/sec (double-exp, m=%d, fp64)" % m,
             "value": value,
@@ -209,7 +210,7 @@ def main():
                 "kernel": "fit_kernel (vp_fit: device-resident LM, dominant kernel of the timed step)",
                 "bound": "fp64_valu", "achieved": tflops_fit, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops_fit / FP64_VALU_PEAK_TFLOPS,
-                "hbm_achieved_GBps": gbs_fit, "hbm_frac": gbs_fit / HBM_PEAK_GBS,
+                "hbm_achieved_GBps": gbs_fit, "hbm_frac": gbs_fit / HBM_PEAK_GBS, "traffic": traffic_fit,
                 "bytes_per_launch": bytes_fit, "avg_launch_ms": fit_ms, "fits_per_s_kernel_only": B / (fit_ms * 1e-3),
             },
         }
