@@ -1,0 +1,38 @@
+"""A/B timing of library builds on ONE box: python tools/ab_probe.py libA.so libB.so [B]  (each in a subprocess,
+alternating, 3 rounds) -- kernel times from the library's own HIP events."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np, torch
+import varpro_amd as vp
+from varpro_amd import synth, _lib
+B = int(sys.argv[1])
+d = synth.double_exp_batch(B, m=1024, noise=1e-3)
+mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0])
+dev = torch.device("cuda", 0)
+Y = torch.from_numpy(d["Y"]).to(dev); x = torch.from_numpy(d["x"]).to(dev); g = torch.from_numpy(d["tau_guess"]).to(dev)
+bp = vp.BatchProblem(mdl, Y, x=x); bp.set_timing(True)
+out = []
+for wr, wj in ((False, False), (True, False), (True, True)):
+    ts = []
+    for _ in range(6):
+        bp.evaluate(g, want_residuals=wr, want_jacobian=wj); ts.append(bp.last_kernel_ms(_lib.VP_KERNEL_EVALUATE))
+    out.append(min(ts))
+ts = []
+for _ in range(8):
+    a, c, rep = bp.fit(g, want_coefficients=False); ts.append(bp.last_kernel_ms(_lib.VP_KERNEL_FIT))
+r = bp.report_to_numpy(rep)
+ts2 = []
+for _ in range(4):
+    bp.basis(g, device_out=True) if hasattr(bp, "_basis_dev") else None
+print("ev0 %%.3f ev1 %%.3f ev2 %%.3f fit %%.3f ms (median %%.3f)  evals %%d  cost %%.9e" %% (out[0], out[1], out[2], min(ts), sorted(ts)[len(ts)//2], r["n_evals"].sum(), np.nansum(r["objective"])))
+''' % ROOT
+libs = sys.argv[1:3]
+B = sys.argv[3] if len(sys.argv) > 3 else "65536"
+for rnd in range(3):
+    for lib in libs:
+        env = dict(os.environ, VARPRO_HIP_LIBRARY=lib)
+        o = subprocess.run([sys.executable, "-c", CHILD, B], env=env, capture_output=True, text=True)
+        print("%-44s %s" % (os.path.basename(lib), (o.stdout.strip().split("\n") or [""])[-1] or o.stderr[-300:]))

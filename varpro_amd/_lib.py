@@ -28,6 +28,8 @@ VP_ERR_OK, VP_ERR_INVALID, VP_ERR_UNSUPPORTED, VP_ERR_HIP, VP_ERR_NO_DEVICE = 0,
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvarpro_hip.so")
+if os.environ.get("VARPRO_HIP_LIBRARY"):  # developer A/B builds of the same library (tools/); still no fallback
+    LIB_PATH = os.path.abspath(os.environ["VARPRO_HIP_LIBRARY"])
 
 # every symbol include/varpro_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [

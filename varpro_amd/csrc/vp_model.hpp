@@ -144,53 +144,62 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
     constexpr int N = M::N, P = M::P, Q = M::Q;
     constexpr int VW = Layout<R>::VW;
     static_assert(NC >= DOFF + P, "column array too small");
+    // per-column invariants (wave-uniform)
+    int kind[N], s0[N], s1[N];
+    T p0[N], p1[N], rt[N], rt2[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        const int kind = mdl.kind(j);
+        kind[j] = mdl.kind(j);
         const int i0 = mdl.param(j, 0), i1 = mdl.param(j, 1);
-        const T p0 = (i0 >= 0) ? dyn_get<Q>(alpha, i0) : T(0);
-        const T p1 = (i1 >= 0) ? dyn_get<Q>(alpha, i1) : T(0);
+        p0[j] = (i0 >= 0) ? dyn_get<Q>(alpha, i0) : T(0);
+        p1[j] = (i1 >= 0) ? dyn_get<Q>(alpha, i1) : T(0);
         // derivative slots of this basis (pair index or -1)
-        int s0 = -1, s1 = -1;
+        s0[j] = -1;
+        s1[j] = -1;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             if (mdl.pair_basis(p) == j) {
-                if (mdl.pair_arg(p) == 0) s0 = p;
-                else s1 = p;
+                if (mdl.pair_arg(p) == 0) s0[j] = p;
+                else s1[j] = p;
             }
         }
-        const T rt = (kind == VP_BASIS_EXP_DECAY) ? T(1) / p0 : T(0);
-        const T rt2 = (kind == VP_BASIS_EXP_DECAY) ? T(1) / (p0 * p0) : T(0);
+        rt[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? T(1) / p0[j] : T(0);
+        rt2[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? T(1) / (p0[j] * p0[j]) : T(0);
+    }
+    // rows outermost: the grid value and row scale of a row pair are fetched (and masked) ONCE and feed all N
+    // columns, whose independent transcendental pipelines interleave
 #pragma unroll
-        for (int r0 = 0; r0 < R; r0 += VW) {
-            // keep at most VP_BUILD_CHUNK rows of the transcendental pipeline in flight: without the fence the
-            // scheduler interleaves all R rows of a column (R x ~4 fp64 temporaries) and spills
-            if constexpr (R > VP_BUILD_CHUNK)
-                if (r0 % VP_BUILD_CHUNK == 0 && r0 != 0) __builtin_amdgcn_sched_barrier(0);
-            T tt[2], sc[2];
-            src.get(r0, tt, sc);
+    for (int r0 = 0; r0 < R; r0 += VW) {
+        // keep at most VP_BUILD_CHUNK rows in flight: without the fence the scheduler interleaves all R rows
+        // (R x N x ~4 fp64 temporaries) and spills
+        if constexpr (R > VP_BUILD_CHUNK)
+            if (r0 % VP_BUILD_CHUNK == 0 && r0 != 0) __builtin_amdgcn_sched_barrier(0);
+        T tt[2], sc[2];
+        src.get(r0, tt, sc);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
 #pragma unroll
             for (int e = 0; e < VW; ++e) {
                 const int r = r0 + e;
                 const T t = tt[e], scl = sc[e];
                 T f, d0 = T(0), d1 = T(0);
-                if (kind == VP_BASIS_CONST) {
+                if (kind[j] == VP_BASIS_CONST) {
                     f = scl;
-                } else if (kind == VP_BASIS_EXP_DECAY) {
+                } else if (kind[j] == VP_BASIS_EXP_DECAY) {
                     // exp(-t/tau);  d/dtau = exp(-t/tau) * t / tau^2   (shared_test_code/src/lib.rs:101-114)
-                    f = texp(-div_refined(t, p0, rt)) * scl;
-                    d0 = (f * t) * rt2;
-                } else if (kind == VP_BASIS_EXP_RATE) {
-                    f = texp(-p0 * t) * scl;
+                    f = texp(-div_refined(t, p0[j], rt[j])) * scl;
+                    d0 = (f * t) * rt2[j];
+                } else if (kind[j] == VP_BASIS_EXP_RATE) {
+                    f = texp(-p0[j] * t) * scl;
                     d0 = -t * f;
-                } else if (kind == VP_BASIS_EXP_COS) {
+                } else if (kind[j] == VP_BASIS_EXP_COS) {
                     // exp(-a t) cos(b t)   (shared_test_code/src/models.rs:313-314, 349-372)
-                    const T ex = texp(-p0 * t) * scl;
-                    f = ex * tcos(p1 * t);
+                    const T ex = texp(-p0[j] * t) * scl;
+                    f = ex * tcos(p1[j] * t);
                     d0 = f * (-t);
-                    d1 = -t * ex * tsin(p1 * t);
+                    d1 = -t * ex * tsin(p1[j] * t);
                 } else { // VP_BASIS_SIN_PHASE   (src/test_helpers/mod.rs:28-52)
-                    const T ph = p0 * t + p1;
+                    const T ph = p0[j] * t + p1[j];
                     const T cs = tcos(ph) * scl;
                     f = tsin(ph) * scl;
                     d0 = t * cs;
@@ -199,8 +208,8 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                 C[j][r] = f;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    if (p == s0) C[DOFF + p][r] = d0;
-                    if (p == s1) C[DOFF + p][r] = d1;
+                    if (p == s0[j]) C[DOFF + p][r] = d0;
+                    if (p == s1[j]) C[DOFF + p][r] = d1;
                 }
             }
         }
