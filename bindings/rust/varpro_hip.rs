@@ -50,6 +50,7 @@ pub const VP_BASIS_EXP_COS: i32 = 3;
 pub const VP_BASIS_SIN_PHASE: i32 = 4;
 pub const VP_F64: i32 = 0;
 pub const VP_FLAG_OWN_STREAM: i32 = 8;
+pub const VP_FLAG_NO_GRID_RECURRENCE: i32 = 16;
 
 #[link(name = "varpro_hip")]
 extern "C" {

@@ -88,7 +88,12 @@ enum {
     VP_FLAG_DEVICE_PTRS = 1 << 0,   /* every data pointer passed for this handle is a device pointer */
     VP_FLAG_T_PER_PROBLEM = 1 << 1, /* t is [B][m] instead of [m] */
     VP_FLAG_W_PER_PROBLEM = 1 << 2, /* w is [B][m] instead of [m] */
-    VP_FLAG_OWN_STREAM = 1 << 3     /* ignore hip_stream and run on a private non-blocking stream */
+    VP_FLAG_OWN_STREAM = 1 << 3,    /* ignore hip_stream and run on a private non-blocking stream */
+    /* fp64 kernels evaluate exp(-t/tau) on a grid that is uniform to rounding (checked once at creation:
+     * |t_i - (t_0 + i dt)| <= 4 eps |t_i - t_0|) by a per-lane recurrence instead of one exponential per row;
+     * results then agree with the per-row form to ~1e-15 relative instead of 1 ulp.  This flag keeps the per-row
+     * exponential (== the reference's evaluation, shared_test_code/src/lib.rs:101-114) regardless of the grid. */
+    VP_FLAG_NO_GRID_RECURRENCE = 1 << 4
 };
 
 /* per-problem status word (0 == the reference's `cached = Some(..)`) */

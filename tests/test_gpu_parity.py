@@ -37,12 +37,15 @@ def _check_eval(mdl, x, Y, alpha, w=None, tol=TOL):
             assert np.abs(got["J"][b, k] - ref["J"][b, k]).max() <= bound, "J[%d] of problem %d" % (k, b)
         # cost is an absolute quantity of size ||y_w||^2 * eps at a perfect fit
         assert abs(got["cost"][b] - ref["cost"][b]) <= tol * max(ref["cost"][b], (yw[b] ** 2).sum() * 1e-6)
-    # the trait-level calls return the same numbers as the fused call
+    # the trait-level calls return the same numbers as the fused call: the Jacobian call IS the fused kernel
+    # (bit-identical); residuals / coefficients / cost come from the lighter set_params kernel, which on a uniform
+    # grid builds the exponentials by the recurrence -> equal to rounding, not bit for bit
     bp.set_params(alpha)
-    assert np.array_equal(np.asarray(bp.residuals()), got["r"])
+    ymax = np.abs(yw).max()
+    assert np.abs(np.asarray(bp.residuals()) - got["r"]).max() <= 1e-13 * ymax
     assert np.array_equal(np.asarray(bp.jacobian()), got["J"])
-    assert np.array_equal(np.asarray(bp.linear_coefficients()), got["C"])
-    assert np.array_equal(np.asarray(bp.cost()), got["cost"])
+    assert np.abs(np.asarray(bp.linear_coefficients()) - got["C"]).max() <= 1e-11 * np.abs(got["C"]).max()
+    assert np.abs(np.asarray(bp.cost()) - got["cost"]).max() <= 1e-11 * max(got["cost"].max(), ymax ** 2 * 1e-6)
     bp.close()
 
 

@@ -29,8 +29,9 @@ for _ in range(4):
     bp.basis(g, device_out=True) if hasattr(bp, "_basis_dev") else None
 print("ev0 %%.3f ev1 %%.3f ev2 %%.3f fit %%.3f ms (median %%.3f)  evals %%d  cost %%.9e" %% (out[0], out[1], out[2], min(ts), sorted(ts)[len(ts)//2], r["n_evals"].sum(), np.nansum(r["objective"])))
 ''' % ROOT
-libs = sys.argv[1:3]
-B = sys.argv[3] if len(sys.argv) > 3 else "65536"
+libs = [a for a in sys.argv[1:] if a.endswith(".so")]
+rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
+B = rest[0] if rest else "65536"
 for rnd in range(3):
     for lib in libs:
         env = dict(os.environ, VARPRO_HIP_LIBRARY=lib)

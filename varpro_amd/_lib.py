@@ -21,6 +21,7 @@ VP_MAX_PAIRS = 16
 
 VP_F64, VP_F32 = 0, 1
 VP_FLAG_DEVICE_PTRS, VP_FLAG_T_PER_PROBLEM, VP_FLAG_W_PER_PROBLEM, VP_FLAG_OWN_STREAM = 1, 2, 4, 8
+VP_FLAG_NO_GRID_RECURRENCE = 16
 VP_BASIS_SKIP_INVARIANT = 1
 VP_KERNEL_EVALUATE, VP_KERNEL_BASIS, VP_KERNEL_FIT = 0, 1, 2
 

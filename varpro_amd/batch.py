@@ -85,9 +85,10 @@ class LevenbergMarquardt:
 
 
 class BatchProblem:
-    def __init__(self, model, Y, x=None, weights=None, epsilon=None, device=0):
+    def __init__(self, model, Y, x=None, weights=None, epsilon=None, device=0, grid_recurrence=True):
         """model: varpro_amd.SeparableModel; Y: (B, m) or (B, S, m); x: (m,) shared grid or (B, m)
-        per-problem grids (default: model.x); weights: None (unit), (m,) or (B, m)."""
+        per-problem grids (default: model.x); weights: None (unit), (m,) or (B, m).
+        grid_recurrence=False sets VP_FLAG_NO_GRID_RECURRENCE (per-row exponentials even on uniform grids)."""
         self.lib = _lib.load()
         self.model = model
         self.n = model.base_function_count()
@@ -111,7 +112,7 @@ class BatchProblem:
             raise ValueError("Y must be (B, m) or (B, S, m)")
         self.B, self.S, self.m = int(B), int(S), int(m)
         x = self._as_array(x)
-        flags = 0
+        flags = 0 if grid_recurrence else _lib.VP_FLAG_NO_GRID_RECURRENCE
         if self.device_mode:
             flags |= _lib.VP_FLAG_DEVICE_PTRS  # work is enqueued on torch's current stream
         else:

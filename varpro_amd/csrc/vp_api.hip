@@ -105,6 +105,27 @@ __global__ void summary_kernel(const vp_report *__restrict__ rep, int64_t B, dou
         for (int k = 0; k < 4; ++k) atomicAdd(&out4[k], sh[k][0]);
 }
 
+// Uniform-grid check, once per handle: grid g passes if every t_i lies within 4 ulp-of-the-offset of the lattice
+// t_0 + i*dt, dt = (t_{m-1} - t_0)/(m-1):   |t_i - (t_0 + i dt)| <= 4 eps |t_i - t_0|.
+// That is what a linspace-type grid anchored at its first sample satisfies, and it bounds the argument error of
+// the recurrence exp(-(t_0 + i dt)/tau) to 4 eps (t_i - t_0)/|tau| -- the size of the reference's own rounding of
+// the quotient t_i/tau.  Grids with a large offset (|t_0| >> m dt) or irregular sampling fail and keep the
+// per-row exponential.  One block per grid; *flag is AND-ed.
+__global__ void grid_check_kernel(const double *t, int m, int64_t ngrids, int *flag) {
+    const int64_t g = blockIdx.x;
+    if (g >= ngrids) return;
+    const double *tg = t + g * (int64_t)m;
+    const double t0 = tg[0];
+    const double dt = (tg[m - 1] - t0) / (double)(m - 1);
+    bool ok = (dt == dt) && (dt - dt == 0.0) && dt != 0.0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const double lat = __builtin_fma((double)i, dt, t0);
+        const double dev = __builtin_fabs(tg[i] - lat);
+        if (!(dev <= 4.0 * 2.220446049250313e-16 * __builtin_fabs(tg[i] - t0))) ok = false;
+    }
+    if (!ok) atomicAnd(flag, 0);
+}
+
 } // namespace
 
 // ---- the handle ------------------------------------------------------------------------------------
@@ -130,6 +151,7 @@ struct vp_batch {
     int32_t *d_status;  // [B]
     vp_report *d_report; // [B]
     double *d_sum4;
+    bool grid_uniform; // every grid is t_0 + i*dt to rounding (grid_check_kernel): kernels may use the exp recurrence
     bool have_params; // set_params/evaluate/fit has run
     bool r_valid;     // d_R matches d_alpha
     bool have_report;
@@ -225,6 +247,7 @@ void fill_params(vp_batch *h, LaunchParams &p) {
     p.t_stride = (h->flags & VP_FLAG_T_PER_PROBLEM) ? h->m : 0;
     p.w_stride = (h->flags & VP_FLAG_W_PER_PROBLEM) ? h->m : 0;
     p.eps = h->eps;
+    p.grid_uniform = h->grid_uniform ? 1 : 0;
     p.stream = h->stream;
 }
 
@@ -454,6 +477,18 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         VP_TRY(hipMalloc(&h->d_w, w_elems * ts));
         VP_TRY(hipMemcpyAsync(h->d_w, w, w_elems * ts, kin, h->stream));
     }
+    int *d_gflag = nullptr;
+    const bool try_uniform = (dtype == VP_F64) && m >= 3 && !(flags & VP_FLAG_NO_GRID_RECURRENCE) &&
+                             !(std::getenv("VP_GRID_RECURRENCE") && std::atoi(std::getenv("VP_GRID_RECURRENCE")) == 0);
+    if (try_uniform) {
+        const int one = 1;
+        VP_TRY(hipMalloc((void **)&d_gflag, sizeof(int)));
+        VP_TRY(hipMemcpyAsync(d_gflag, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        const int64_t ngrids = (flags & VP_FLAG_T_PER_PROBLEM) ? B : 1;
+        hipLaunchKernelGGL(grid_check_kernel, dim3((unsigned)ngrids), dim3(256), 0, h->stream, (const double *)h->d_t,
+                           (int)m, ngrids, d_gflag);
+        VP_TRY(hipGetLastError());
+    }
     VP_TRY(hipMalloc(&h->d_yw, y_elems * ts));
     {
         // Y_w = W * Y
@@ -474,8 +509,12 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
             hipLaunchKernelGGL(weight_data_kernel<float>, dim3(grid), dim3(256), 0, h->stream, (const float *)ysrc,
                                (const float *)h->d_w, (float *)h->d_yw, (int)m, S, wstride, total);
         VP_TRY(hipGetLastError());
+        int gflag = 0;
+        if (d_gflag) VP_TRY(hipMemcpyAsync(&gflag, d_gflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         VP_TRY(hipStreamSynchronize(h->stream));
         if (ytmp) (void)hipFree(ytmp);
+        if (d_gflag) (void)hipFree(d_gflag);
+        h->grid_uniform = gflag != 0;
     }
     VP_TRY(hipMalloc(&h->d_alpha, (size_t)std::max<int64_t>(1, B * h->q) * ts));
     VP_TRY(hipMalloc(&h->d_C, (size_t)B * S * h->n * ts));

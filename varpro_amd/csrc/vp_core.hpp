@@ -48,7 +48,7 @@ __device__ __forceinline__ void house_qr(T (&C)[NC][R], T (&g)[N], T (&Rm)[N][N]
         const T alpha = group_row<R>(grp, C[k], prow);
         T beta = alpha, gk = T(0), u = T(0);
         if (uni(xn2 != T(0))) {
-            beta = -tcopysign(tsqrt(tfma(alpha, alpha, xn2)), alpha);
+            beta = -tcopysign(usqrt(tfma(alpha, alpha, xn2)), alpha);
             u = alpha - beta;
             gk = T(1) / (beta * u);
         }

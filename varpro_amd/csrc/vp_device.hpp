@@ -16,10 +16,12 @@ template <typename T> struct num;
 template <> struct num<double> {
     static constexpr double eps = 2.220446049250313e-16;
     static constexpr double tiny = 2.2250738585072014e-308; // min positive normal
+    static constexpr double huge = 1.7976931348623157e+308;
 };
 template <> struct num<float> {
     static constexpr float eps = 1.1920929e-07f;
     static constexpr float tiny = 1.17549435e-38f;
+    static constexpr float huge = 3.4028235e+38f;
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
@@ -36,6 +38,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // row ((r/VW)*64*W + gl)*VW + r%VW.
 template <int R, int W = 1> struct Layout {
     static constexpr int VW = (R >= 2) ? 2 : 1;
+    static constexpr int W_ = W;
     static_assert(R == 1 || R % 2 == 0, "R must be 1 or even");
     __device__ __forceinline__ static int row_of(int r, int gl) { return ((r / VW) * (64 * W) + gl) * VW + (r % VW); }
     // rows < 64*W*VW (all pivot rows) live in the first VW registers
@@ -95,26 +98,108 @@ __device__ __forceinline__ float readlane(float x, int lane) {
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
 constexpr int DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
 
+constexpr int DPP_ROR4 = 0x124, DPP_ROR8 = 0x128;
+
+// ---- packed all-reduce ---------------------------------------------------------------------------
+// V values are reduced TOGETHER: at each of the first four levels two values are merged into one register
+// whose two lane halves (with respect to one lane-index bit) carry the partial sums of the two values, so
+// the number of live values halves per level instead of every value paying for every level:
+//   level 0  lane bit 5   v_permlane32_swap (gfx950): a'=[a.lo|b.lo], b'=[a.hi|b.hi], a'+b' -> 3 instr / fp64 pair
+//   level 1  lane bit 4   v_permlane16_swap (gfx950): same with the odd/even 16-lane rows
+//   level 2  lane bit 0   DPP quad_perm xor 1 with keep/send selects                         -> 7 instr / pair
+//   level 3  lane bit 1   DPP quad_perm xor 2
+// and the (at most ceil(V/16)) survivors finish with plain row_ror:4 / row_ror:8 steps.  The total of value
+// v (v < 16) then sits in lane 32*b0(v) + 16*b1(v) + b2(v) + 2*b3(v) and is broadcast with v_readlane.
+// V = 6 costs 45 instructions instead of the 120 of six independent butterflies.
+template <typename T> struct SwapPair {
+    T a, b;
+};
+template <int LEVEL> __device__ __forceinline__ SwapPair<double> lane_swap(double a, double b) {
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if constexpr (LEVEL == 0) {
+        auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        return {__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1])};
+    } else {
+        auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        return {__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1])};
+    }
+}
+template <int LEVEL> __device__ __forceinline__ SwapPair<float> lane_swap(float a, float b) {
+    unsigned ua = (unsigned)__float_as_int(a), ub = (unsigned)__float_as_int(b);
+    if constexpr (LEVEL == 0) {
+        auto r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+        return {__int_as_float((int)r[0]), __int_as_float((int)r[1])};
+    } else {
+        auto r = __builtin_amdgcn_permlane16_swap(ua, ub, false, false);
+        return {__int_as_float((int)r[0]), __int_as_float((int)r[1])};
+    }
+}
+// merge two values at one level: lanes whose level bit is 0 end with a's partial sum, the others with b's
+template <int LEVEL, typename T> __device__ __forceinline__ T merge_level(T a, T b) {
+    if constexpr (LEVEL <= 1) {
+        const SwapPair<T> s = lane_swap<LEVEL>(a, b);
+        return s.a + s.b;
+    } else {
+        const bool hi = (lane_id() & (LEVEL == 2 ? 1 : 2)) != 0;
+        const T keep = hi ? b : a, send = hi ? a : b;
+        if constexpr (LEVEL == 2) return keep + dpp<DPP_XOR1>(send);
+        else return keep + dpp<DPP_XOR2>(send);
+    }
+}
+// a value without a partner at this level: only the bit-0 half of the lanes needs its sum
+template <int LEVEL, typename T> __device__ __forceinline__ T single_level(T a) {
+    if constexpr (LEVEL <= 1) return merge_level<LEVEL>(a, T(0));
+    else if constexpr (LEVEL == 2) return a + dpp<DPP_XOR1>(a);
+    else return a + dpp<DPP_XOR2>(a);
+}
+template <int LEVEL, int V, typename T> __device__ __forceinline__ void pack_level(const T (&x)[V], T (&y)[(V + 1) / 2]) {
+#pragma unroll
+    for (int i = 0; i < V / 2; ++i) y[i] = merge_level<LEVEL>(x[2 * i], x[2 * i + 1]);
+    if constexpr (V % 2 == 1) y[V / 2] = single_level<LEVEL>(x[V - 1]);
+}
+__host__ __device__ constexpr int packed_lane_of(int v) {
+    return 32 * (v & 1) + 16 * ((v >> 1) & 1) + ((v >> 2) & 1) + 2 * ((v >> 3) & 1);
+}
+
 // All-reduce (sum) of V independent values across the 64 lanes; every lane ends with the totals,
 // delivered through v_readlane (SGPRs), i.e. as genuinely scalar values.
-// 4 butterfly steps inside the 16-lane rows (every lane of a row then holds the row sum), 2 row
-// broadcast steps (row 3 then holds the wave sum), one v_readlane pair from lane 63: 20 instructions
-// per fp64 value.  The V chains are interleaved step by step so their latencies overlap.
 template <int V, typename T> __device__ __forceinline__ void wave_allreduce(T (&x)[V]) {
+#ifdef VP_NO_PACKED
+    {
 #pragma unroll
-    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_XOR1>(x[v]);
+        for (int v = 0; v < V; ++v) x[v] += dpp<DPP_XOR1>(x[v]);
 #pragma unroll
-    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_XOR2>(x[v]);
+        for (int v = 0; v < V; ++v) x[v] += dpp<DPP_XOR2>(x[v]);
 #pragma unroll
-    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_HALF_MIRROR>(x[v]);
+        for (int v = 0; v < V; ++v) x[v] += dpp<DPP_HALF_MIRROR>(x[v]);
 #pragma unroll
-    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_MIRROR>(x[v]);
+        for (int v = 0; v < V; ++v) x[v] += dpp<DPP_MIRROR>(x[v]);
 #pragma unroll
-    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_BCAST15, 0xA>(x[v]); // rows 1,3 += rows 0,2
+        for (int v = 0; v < V; ++v) x[v] += dpp<DPP_BCAST15, 0xA>(x[v]); // rows 1,3 += rows 0,2
 #pragma unroll
-    for (int v = 0; v < V; ++v) x[v] += dpp<DPP_BCAST31, 0xC>(x[v]); // rows 2,3 += row 1 (= rows 0+1)
+        for (int v = 0; v < V; ++v) x[v] += dpp<DPP_BCAST31, 0xC>(x[v]); // rows 2,3 += row 1 (= rows 0+1)
 #pragma unroll
-    for (int v = 0; v < V; ++v) x[v] = readlane(x[v], 63);
+        for (int v = 0; v < V; ++v) x[v] = readlane(x[v], 63);
+    }
+#else
+    {
+        constexpr int V1 = (V + 1) / 2, V2 = (V1 + 1) / 2, V3 = (V2 + 1) / 2, V4 = (V3 + 1) / 2;
+        T y1[V1], y2[V2], y3[V3], y4[V4];
+        pack_level<0>(x, y1);
+        pack_level<1>(y1, y2);
+        pack_level<2>(y2, y3);
+        pack_level<3>(y3, y4);
+#pragma unroll
+        for (int i = 0; i < V4; ++i) y4[i] += dpp<DPP_ROR4>(y4[i]);
+#pragma unroll
+        for (int i = 0; i < V4; ++i) y4[i] += dpp<DPP_ROR8>(y4[i]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) x[v] = readlane(y4[v >> 4], packed_lane_of(v & 15));
+    }
+#endif
 }
 template <typename T> __device__ __forceinline__ T wave_sum(T x) {
     T a[1] = {x};
@@ -238,6 +323,21 @@ template <typename T> __device__ __forceinline__ T fsqrt(T h) {
     s = tfma(tfma(-s, s, h), T(0.5) * y, s);
     return s;
 }
+
+// sqrt for the bookkeeping scalars (Householder betas, column norms): the rsq + Newton form, faithfully rounded,
+// BRANCH-FREE (a branch per call chops the surrounding code into tiny scheduling regions): 0 and +inf, for
+// which rsq * h is 0 * inf, are patched by one class test + select; negative / NaN arguments give NaN like
+// the IEEE expansion; fp64 denormals are handled by v_rsq_f64 itself.  12 instructions instead of ~25.
+__device__ __forceinline__ double usqrt(double h) {
+#ifdef VP_NO_USQRT
+    return tsqrt(h);
+#endif
+    const double y = frsqrt(h);
+    const double s0 = h * y;
+    const double s = tfma(tfma(-s0, s0, h), 0.5 * y, s0);
+    return (h == 0.0 || h == __builtin_inf()) ? h : s;
+}
+__device__ __forceinline__ float usqrt(float h) { return tsqrt(h); }
 
 // correctly rounded (to within the last bit in rare ties) quotient a/b given rb ~= 1/b:
 // one Newton correction of the product.  Replaces the 10+ instruction IEEE division sequence

@@ -245,7 +245,7 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
         group_allreduce(grp, s);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            acnorm[j] = tsqrt(s[j]);
+            acnorm[j] = usqrt(s[j]);
             rdiag[j] = acnorm[j];
             wa[j] = acnorm[j];
             ipvt[j] = j;
@@ -294,7 +294,7 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
             const T v = (r >= L::VW || L::row_of(r, lane) >= prow) ? Z[j][r] : T(0);
             s = tfma(v, v, s);
         }
-        T ajnorm = tsqrt(group_sum(grp, s));
+        T ajnorm = usqrt(group_sum(grp, s));
         if (uni(ajnorm == T(0))) {
             rdiag[j] = T(0);
             // remaining columns untouched: their row-prow entries are the R entries
@@ -339,7 +339,7 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
             Rj[j][k] = akj;
             if (uni(rdiag[k] != T(0))) {
                 const T tq = akj / rdiag[k];
-                rdiag[k] = rdiag[k] * tsqrt(tmax(T(0), T(1) - tq * tq));
+                rdiag[k] = rdiag[k] * usqrt(tmax(T(0), T(1) - tq * tq));
                 const T rr = rdiag[k] / wa[k];
                 if (uni(T(0.05) * (rr * rr) <= num<T>::eps)) {
                     T s2 = T(0);
@@ -384,6 +384,7 @@ template <typename T, class M> struct FitArgs {
     int scale_diag;
     double *trace;  // diagnostics (vp_fit_trace): [B][trace_rows][q+4] or null
     int trace_rows;
+    int grid_uniform; // the handle's grids passed grid_check_kernel -> exp recurrence allowed
 };
 
 // Wave-uniform LM state.  It is PARKED in LDS while the fused QR sweep runs (lane 0 writes, every
@@ -436,13 +437,14 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
     }
     __syncthreads(); // orders the LDS writes before the reads below (every lane re-reads only its own rows)
     // the LDS copies are zero-padded to MP rows; valid rows are still i < m (scale 0 beyond)
-    using Src = RowSource<T, R, true, WEIGHTED ? 1 : 0, 1, W>;
+    using Src = RowSource<T, R, true, WEIGHTED ? 1 : 0, 1, W, true>;
     Src src;
     src.t = s_t;
     src.w = s_w;
     src.m = m;
     src.lane = lane;
     src.vec = true;
+    src.set_uniform(a.grid_uniform != 0);
 
     // ---- LM state (wave-uniform) ----
     T x[Q], xt[Q], diag[Q], qtf[Q], step[Q], acnorm[Q], cbest[N];
@@ -550,7 +552,7 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
             nfev = uni(st->nfev);
         }
 
-        const T fnorm1 = tsqrt(u.fn2);
+        const T fnorm1 = usqrt(u.fn2);
         bool need_jac = false;
         if (first) {
             first = false;
@@ -777,6 +779,7 @@ template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchPara
     a.scale_diag = p.opts->scale_diag;
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
+    a.grid_uniform = p.grid_uniform;
     if (a.B <= 0) return VP_ERR_OK;
     const size_t lds = (size_t)(p.w ? 3 : 2) * 64 * R * W * sizeof(T) + ((group_xch_bytes<W>() + 15) / 16) * 16 +
                        (size_t)W * sizeof(LmState<T, M::N, M::Q>);

@@ -52,6 +52,7 @@ struct LaunchParams {
     int64_t t_stride; // 0 (shared) or m
     int64_t w_stride; // 0 (shared) or m
     double eps;
+    int grid_uniform;   // every grid of the handle passed grid_check_kernel: kernels may use the exp recurrence
     hipStream_t stream;
 };
 
@@ -142,6 +143,7 @@ template <typename T, class M> struct EvalArgs {
     int64_t nprob; // B*S
     int64_t t_stride, w_stride;
     T eps;
+    int grid_uniform;
 };
 
 // MODE 0: coefficients/cost/status only; 1: + residuals; 2: + residuals + Jacobian
@@ -165,13 +167,15 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P + ((M
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
 
-    using Src = RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0, W>;
+    // MODE 2 (residual + Jacobian output) is store-bound and register-tight: per-row exponentials there
+    using Src = RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0, W, MODE != 2>;
     Src src;
     src.t = a.t + b * a.t_stride;
     src.w = WEIGHTED ? a.w + b * a.w_stride : nullptr;
     src.m = m;
     src.lane = lane;
     src.vec = ALIGNED;
+    src.set_uniform(a.grid_uniform != 0);
     T C[NC][R];
     const T *yp = a.yw + prob * (int64_t)m;
     constexpr bool yvec = ALIGNED;
@@ -322,6 +326,7 @@ template <typename T, class M, int R, int W = 1> int launch_evaluate(const Launc
     a.t_stride = p.t_stride;
     a.w_stride = p.w_stride;
     a.eps = (T)p.eps;
+    a.grid_uniform = p.grid_uniform;
     if (a.nprob <= 0) return VP_ERR_OK;
     dim3 grid((unsigned)a.nprob), block(64 * W);
     const bool aligned = host_aligned<T>(p.m, {p.t, p.w, p.yw, p.r_out, p.J_out});

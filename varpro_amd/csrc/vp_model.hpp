@@ -84,13 +84,30 @@ __device__ __forceinline__ float tcos(float x) { return __ocml_cos_f32(x); }
 //            kernel): always 2-element accesses, no bounds clamp on the address
 //   WMODE  : 0 = unit weights (compile time), 1 = weights present (compile time), 2 = decide by w != nullptr
 //   VMODE  : 0 = scalar accesses only, 1 = 2-element aligned accesses (compile time), 2 = decide by `vec`
-template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2, int W = 1> struct RowSource {
+//   RECUR  : the kernel may use the uniform-grid exp recurrence of build_columns (it calls set_uniform);
+//            false removes that code path at compile time (kernels that are HBM-bound or off the hot path)
+template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2, int W = 1, bool RECUR = false>
+struct RowSource {
     const T *t;  // grid, indexed by row (LDS or global)
     const T *w;  // weights indexed by row, or nullptr for unit weights
     int m;       // rows >= m are padding
     int lane;    // GROUP lane (wave*64 + lane for multi-wave groups)
     bool vec;    // (!PADDED only) 2-element aligned accesses allowed
+    // uniform-grid recurrence (see build_columns): the grid is t_0 + i*dt to rounding (checked once per handle by
+    // grid_check_kernel) and `delta` = 64*W*VW*dt is the grid distance between a lane's consecutive row pairs
+    bool uniform = false;
+    T delta = T(0);
     using L = Layout<R, W>;
+    static constexpr int kGroupWaves = W;
+    static constexpr bool kRecur = RECUR && sizeof(T) == 8 && (R > L::VW);
+    __device__ __forceinline__ void set_uniform(bool flag) {
+        if constexpr (kRecur) {
+            uniform = flag && m >= 3;
+            if (uniform) delta = (t[m - 1] - t[0]) / T(m - 1) * T(64 * W * L::VW);
+        } else {
+            uniform = false;
+        }
+    }
     __device__ __forceinline__ bool weighted() const {
         if constexpr (WMODE == 0) return false;
         else if constexpr (WMODE == 1) return true;
@@ -166,53 +183,93 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
         rt[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? T(1) / p0[j] : T(0);
         rt2[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? T(1) / (p0[j] * p0[j]) : T(0);
     }
+    // UNIFORM-GRID RECURRENCE (fp64, R > 2): on a grid t_i = t_0 + i*dt a lane's row pairs are delta = 64*W*2*dt
+    // apart, so exp(-t/tau) of pair k is the value of pair k-1 times the wave-uniform ratio exp(-delta/tau):
+    // 2 full exponentials per lane and column instead of R, one multiply (+ a finite clamp that keeps the
+    // zero-scaled padding rows from turning inf*0 into NaN) for the rest.  Error: <= (R/2)*1.5 ulp from the
+    // chain plus the grid's own deviation from the lattice, bounded at handle creation (grid_check_kernel);
+    // the derivative columns still use the actual t_i.
+    constexpr bool kRecur = Src::kRecur;
+    T fu[N][VW], qq[N];
+    bool fast = false;
+    if constexpr (kRecur) {
+        fast = src.uniform;
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                qq[j] = T(1);
+                if (kind[j] == VP_BASIS_EXP_DECAY) qq[j] = texp(-div_refined(src.delta, p0[j], rt[j]));
+                else if (kind[j] == VP_BASIS_EXP_RATE) qq[j] = texp(-p0[j] * src.delta);
+            }
+        }
+    }
     // rows outermost: the grid value and row scale of a row pair are fetched (and masked) ONCE and feed all N
     // columns, whose independent transcendental pipelines interleave
+    auto rows = [&](auto fast_c) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
-    for (int r0 = 0; r0 < R; r0 += VW) {
-        // keep at most VP_BUILD_CHUNK rows in flight: without the fence the scheduler interleaves all R rows
-        // (R x N x ~4 fp64 temporaries) and spills
-        if constexpr (R > VP_BUILD_CHUNK)
-            if (r0 % VP_BUILD_CHUNK == 0 && r0 != 0) __builtin_amdgcn_sched_barrier(0);
-        T tt[2], sc[2];
-        src.get(r0, tt, sc);
+        for (int r0 = 0; r0 < R; r0 += VW) {
+            // keep at most VP_BUILD_CHUNK rows in flight: without the fence the scheduler interleaves all R rows
+            // (R x N x ~4 fp64 temporaries) and spills
+            if constexpr (R > VP_BUILD_CHUNK)
+                if (r0 % VP_BUILD_CHUNK == 0 && r0 != 0) __builtin_amdgcn_sched_barrier(0);
+            T tt[2], sc[2];
+            src.get(r0, tt, sc);
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
+            for (int j = 0; j < N; ++j) {
 #pragma unroll
-            for (int e = 0; e < VW; ++e) {
-                const int r = r0 + e;
-                const T t = tt[e], scl = sc[e];
-                T f, d0 = T(0), d1 = T(0);
-                if (kind[j] == VP_BASIS_CONST) {
-                    f = scl;
-                } else if (kind[j] == VP_BASIS_EXP_DECAY) {
-                    // exp(-t/tau);  d/dtau = exp(-t/tau) * t / tau^2   (shared_test_code/src/lib.rs:101-114)
-                    f = texp(-div_refined(t, p0[j], rt[j])) * scl;
-                    d0 = (f * t) * rt2[j];
-                } else if (kind[j] == VP_BASIS_EXP_RATE) {
-                    f = texp(-p0[j] * t) * scl;
-                    d0 = -t * f;
-                } else if (kind[j] == VP_BASIS_EXP_COS) {
-                    // exp(-a t) cos(b t)   (shared_test_code/src/models.rs:313-314, 349-372)
-                    const T ex = texp(-p0[j] * t) * scl;
-                    f = ex * tcos(p1[j] * t);
-                    d0 = f * (-t);
-                    d1 = -t * ex * tsin(p1[j] * t);
-                } else { // VP_BASIS_SIN_PHASE   (src/test_helpers/mod.rs:28-52)
-                    const T ph = p0[j] * t + p1[j];
-                    const T cs = tcos(ph) * scl;
-                    f = tsin(ph) * scl;
-                    d0 = t * cs;
-                    d1 = cs;
-                }
-                C[j][r] = f;
+                for (int e = 0; e < VW; ++e) {
+                    const int r = r0 + e;
+                    const T t = tt[e], scl = sc[e];
+                    T f, d0 = T(0), d1 = T(0);
+                    if (kind[j] == VP_BASIS_CONST) {
+                        f = scl;
+                    } else if (kind[j] == VP_BASIS_EXP_DECAY) {
+                        // exp(-t/tau);  d/dtau = exp(-t/tau) * t / tau^2   (shared_test_code/src/lib.rs:101-114)
+                        if constexpr (FAST) {
+                            fu[j][e] = (r0 == 0) ? texp(-div_refined(t, p0[j], rt[j]))
+                                                 : tmin(fu[j][e] * qq[j], num<T>::huge);
+                            f = fu[j][e] * scl;
+                        } else {
+                            f = texp(-div_refined(t, p0[j], rt[j])) * scl;
+                        }
+                        d0 = (f * t) * rt2[j];
+                    } else if (kind[j] == VP_BASIS_EXP_RATE) {
+                        if constexpr (FAST) {
+                            fu[j][e] = (r0 == 0) ? texp(-p0[j] * t) : tmin(fu[j][e] * qq[j], num<T>::huge);
+                            f = fu[j][e] * scl;
+                        } else {
+                            f = texp(-p0[j] * t) * scl;
+                        }
+                        d0 = -t * f;
+                    } else if (kind[j] == VP_BASIS_EXP_COS) {
+                        // exp(-a t) cos(b t)   (shared_test_code/src/models.rs:313-314, 349-372)
+                        const T ex = texp(-p0[j] * t) * scl;
+                        f = ex * tcos(p1[j] * t);
+                        d0 = f * (-t);
+                        d1 = -t * ex * tsin(p1[j] * t);
+                    } else { // VP_BASIS_SIN_PHASE   (src/test_helpers/mod.rs:28-52)
+                        const T ph = p0[j] * t + p1[j];
+                        const T cs = tcos(ph) * scl;
+                        f = tsin(ph) * scl;
+                        d0 = t * cs;
+                        d1 = cs;
+                    }
+                    C[j][r] = f;
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if (p == s0[j]) C[DOFF + p][r] = d0;
-                    if (p == s1[j]) C[DOFF + p][r] = d1;
+                    for (int p = 0; p < P; ++p) {
+                        if (p == s0[j]) C[DOFF + p][r] = d0;
+                        if (p == s1[j]) C[DOFF + p][r] = d1;
+                    }
                 }
             }
         }
+    };
+    if constexpr (kRecur) {
+        if (uni(fast)) rows(std::true_type{});
+        else rows(std::false_type{});
+    } else {
+        rows(std::false_type{});
     }
 }
 
