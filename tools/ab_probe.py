@@ -32,8 +32,11 @@ print("ev0 %%.3f ev1 %%.3f ev2 %%.3f fit %%.3f ms (median %%.3f)  evals %%d  cos
 libs = [a for a in sys.argv[1:] if a.endswith(".so")]
 rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
 B = rest[0] if rest else "65536"
+envs = [a for a in rest[1:] if "=" in a] or [""]   # e.g. VP_FIT_CAP=0 VP_FIT_CAP=16 : each lib x each env
 for rnd in range(3):
+  for ev in envs:
     for lib in libs:
         env = dict(os.environ, VARPRO_HIP_LIBRARY=lib)
+        if ev: env[ev.split("=")[0]] = ev.split("=")[1]
         o = subprocess.run([sys.executable, "-c", CHILD, B], env=env, capture_output=True, text=True)
-        print("%-44s %s" % (os.path.basename(lib), (o.stdout.strip().split("\n") or [""])[-1] or o.stderr[-300:]))
+        print("%-30s %-14s %s" % (os.path.basename(lib), ev, (o.stdout.strip().split("\n") or [""])[-1] or o.stderr[-300:]))
