@@ -7,7 +7,7 @@ import pytest
 
 import refdata as rd
 import varpro_amd as vp
-from models import double_exp_builder_model, numpy_reference_eval
+from models import double_exp_builder_model, double_exp_unit_test_model, numpy_reference_eval, oleary_model
 from oracle import oracle as O
 from varpro_amd import basis, synth
 
@@ -384,3 +384,51 @@ def test_uniform_grid_recurrence_agrees_with_per_row_exponentials():
             assert well.mean() > 0.5 and np.median(rel_a) <= 1e-6 and np.quantile(rel_a, 0.9) <= 1e-4, name
         fast.close()
         slow.close()
+
+
+@pytest.mark.parametrize("m", [200, 1000, 1024])
+def test_runtime_descriptor_models_beyond_128_rows(m):
+    # run-time descriptor kernels (RtModel) at 16 rows per lane: the O'Leary exp*cos model with shared parameters
+    # (shared_test_code/src/models.rs:397-425), the unit-test double exponential with swapped columns
+    # (src/test_helpers/mod.rs:56-72) and the sine/exp*cos mix, evaluation and fit vs the oracle.
+    rng = np.random.default_rng(100 + m)
+    B = 8
+    t = np.linspace(0.0, 1.5, m)
+    a_true = np.array([0.5, 2.0, 3.0])
+    mdl = oleary_model(t, a_true)
+    w = rng.uniform(0.5, 1.5, m)
+    Y = (6.0 * np.exp(-2.0 * t) * np.cos(3.0 * t) + 1.0 * np.exp(-0.5 * t) * np.cos(2.0 * t))[None, :] \
+        + 1e-3 * rng.standard_normal((B, m))
+    guess = a_true * rng.uniform(0.9, 1.1, (B, 3))
+    bp = vp.BatchProblem(mdl, Y, x=t, weights=w)
+    ev = bp.evaluate(guess)
+    ref = O.evaluate_batch(mdl, t, Y, guess, w=w, n_threads=2)
+    assert (ev["status"] == 0).all()
+    assert np.abs(ev["C"] - ref["C"]).max() <= TOL * np.abs(ref["C"]).max()
+    assert np.abs(ev["r"] - ref["r"]).max() <= TOL * np.abs(Y * w).max()
+    for k in range(3):
+        assert np.abs(ev["J"][:, k] - ref["J"][:, k]).max() <= TOL * np.abs(ref["J"][:, k]).max() + 1e-12
+    a, c, rep = bp.fit(guess)
+    a_ref, c_ref, rep_ref, _ = O.fit_batch(mdl, t, Y, guess, w=w, n_threads=2)
+    ok = (rep["termination"] > 0) & (rep_ref["termination"] > 0)
+    assert ok.all()
+    assert np.abs(rep["objective"] - rep_ref["objective"]).max() <= 1e-9 * rep_ref["objective"].max()
+    assert np.abs(a - a_ref).max() <= 1e-6 * np.abs(a_ref).max()
+    assert np.abs(a - a_true).max() <= 5e-2  # noise-limited
+    bp.close()
+    # swapped-column double exponential (n=3, q=2, p=2 run-time descriptor)
+    x = np.linspace(0.0, 10.0, m)
+    um = double_exp_unit_test_model(x, [1.0, 3.0])
+    Yd = 4.0 * np.exp(-x / 1.0) + 2.5 * np.exp(-x / 3.0) + 1.0 + 1e-3 * rng.standard_normal((B, m))
+    gd = np.array([1.0, 3.0]) * rng.uniform(0.8, 1.25, (B, 2))
+    bp = vp.BatchProblem(um, Yd, x=x)
+    ev = bp.evaluate(gd)
+    ref = O.evaluate_batch(um, x, Yd, gd, n_threads=2)
+    assert np.abs(ev["C"] - ref["C"]).max() <= TOL * np.abs(ref["C"]).max()
+    assert np.abs(ev["r"] - ref["r"]).max() <= TOL * np.abs(Yd).max()
+    assert np.abs(ev["J"] - ref["J"]).max() <= TOL * np.abs(ref["J"]).max()
+    a, c, rep = bp.fit(gd)
+    assert (rep["termination"] > 0).all() and np.abs(a - [1.0, 3.0]).max() <= 0.05
+    stt = bp.statistics()
+    assert (stt["status"] == 0).all() and np.isfinite(stt["cov"]).all() and np.isfinite(stt["conf_sigma"]).all()
+    bp.close()

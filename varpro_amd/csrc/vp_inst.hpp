@@ -42,3 +42,12 @@
         &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                          \
         &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0, \
         &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>});
+
+// run-time-descriptor models at larger m (WW waves per problem): single-RHS kernel set only
+#define VP_REGISTER_RT_W(T, DT, NN, QQ, PP, RR, WW)                                                                    \
+    static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
+        DT, ::vp::FAMILY_RT, NN, QQ, PP, RR, WW, &::vp::launch_evaluate<T, ::vp::RtModel<NN, QQ, PP>, RR, WW>,        \
+        &::vp::launch_basis<T, ::vp::RtModel<NN, QQ, PP>, RR, WW>, nullptr,                                           \
+        &::vp::launch_fit<T, ::vp::RtModel<NN, QQ, PP>, RR, WW>,                                                      \
+        &::vp::launch_best_fit<T, ::vp::RtModel<NN, QQ, PP>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0,         \
+        &::vp::launch_stats<T, ::vp::RtModel<NN, QQ, PP>, RR, WW>});

@@ -70,10 +70,12 @@ __device__ __forceinline__ double texp(double x) {
     return __builtin_ldexp(p, (int)k);
 }
 __device__ __forceinline__ float texp(float x) { return __ocml_exp_f32(x); }
-__device__ __forceinline__ double tsin(double x) { return __ocml_sin_f64(x); }
-__device__ __forceinline__ float tsin(float x) { return __ocml_sin_f32(x); }
-__device__ __forceinline__ double tcos(double x) { return __ocml_cos_f64(x); }
-__device__ __forceinline__ float tcos(float x) { return __ocml_cos_f32(x); }
+// sin / cos only occur in run-time-descriptor models, whose column build is unrolled over rows x columns x kinds:
+// kept out of line (one copy per kernel instead of R*N inlined Payne-Hanek expansions, which made MBs of code)
+__device__ __noinline__ double tsin(double x) { return __ocml_sin_f64(x); }
+__device__ __noinline__ float tsin(float x) { return __ocml_sin_f32(x); }
+__device__ __noinline__ double tcos(double x) { return __ocml_cos_f64(x); }
+__device__ __noinline__ float tcos(float x) { return __ocml_cos_f32(x); }
 
 // ---- row sources: where the grid value t_i and the row scale of a lane's rows come from -----------
 // scale_i = w_i for rows i < m (1 for unit weights) and 0 for padding rows i >= m, so that padding
