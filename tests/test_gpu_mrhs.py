@@ -110,3 +110,28 @@ def test_mrhs_triple_exponential_config2_shape_small():
     assert np.abs(np.sort(alpha[0]) - d["tau_true"]).max() < 1e-6
     assert np.abs(C[0] - d["C_true"]).max() < 1e-4 * np.abs(d["C_true"]).max()
     bp.close()
+
+
+@pytest.mark.parametrize("S,m", [(3, 20), (40, 256), (64, 1000)])
+def test_mrhs_rank_deficient_basis_takes_the_truncated_svd_branch(S, m):
+    # tau1 == tau2: the reference's svd.solve(eps) (src/solvers/levmar/mod.rs:51-54) returns the minimum-norm
+    # coefficients for every right-hand side; pinned at .epsilon(1e-8) where the truncation decision is well
+    # defined (see the single-RHS twin in test_gpu_more.py).  J is not unique there and is not compared.
+    rng = np.random.default_rng(S + m)
+    x = np.linspace(0.0, 10.0, m)
+    Y = rng.uniform(1, 5, (S, 1)) * np.exp(-x / 2.0) + rng.uniform(0, 1, (S, 1)) + 1e-3 * rng.standard_normal((S, m))
+    mdl = double_exp_builder_model(x, [2.0, 2.0])
+    bp = vp.BatchProblem(mdl, Y[None], x=x, epsilon=1e-8)
+    ev = bp.evaluate(np.array([[2.0, 2.0]]), want_jacobian=False)
+    ref = O.Problem(mdl, x, Y, eps=1e-8)
+    ref.set_params([2.0, 2.0])
+    Cr = ref.linear_coefficients()
+    assert ev["status"][0] == 0
+    assert np.abs(ev["C"][0][:, 0] - ev["C"][0][:, 1]).max() <= 1e-9 * np.abs(Cr).max()  # minimum norm: equal split
+    assert np.abs(ev["C"][0] - Cr).max() <= 1e-9 * np.abs(Cr).max()
+    assert np.abs(ev["r"][0] - ref.residuals()).max() <= TOL * np.abs(Y).max()
+    assert abs(ev["cost"][0] - 0.5 * (ref.residuals() ** 2).sum()) <= 1e-9 * ev["cost"][0]
+    # a fit started at the rank-deficient point leaves it (the device LM sees a regular evaluation, not a failure)
+    a, c, rep = bp.fit(np.array([[2.0, 2.0]]))
+    assert rep["termination"][0] != -1 and np.isfinite(rep["objective"][0])
+    bp.close()

@@ -535,7 +535,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         const int n_ = h->n, p_ = h->p, q_ = h->q;
         VP_TRY(hipMalloc(&h->mrhs.qthin, (size_t)B * n_ * m * ts));
         VP_TRY(hipMalloc(&h->mrhs.g, (size_t)B * std::max(1, p_) * m * ts));
-        VP_TRY(hipMalloc((void **)&h->mrhs.small, (size_t)B * (n_ * n_ + p_ * p_) * sizeof(double)));
+        VP_TRY(hipMalloc((void **)&h->mrhs.small, (size_t)B * mrhs_small_stride_rt(n_, p_) * sizeof(double)));
         VP_TRY(hipMalloc((void **)&h->mrhs.statusA, (size_t)B * sizeof(int32_t)));
         VP_TRY(hipMalloc((void **)&h->mrhs.acc, (size_t)B * 256 * (1 + n_ * n_ + p_) * sizeof(double)));
         VP_TRY(hipMalloc(&h->mrhs.lm_state, (size_t)B * kern->mrhs_state_bytes));

@@ -18,20 +18,25 @@
 // Algorithmic HBM bytes per evaluation (T = 8): trait level  T m S (2 + q) + ... (read Y, write R and J);
 // fit level  T m S  (read Y once).  Deviation from the reference, documented in DESIGN.md: the LM step uses
 // the Gram matrix (normal equations of the q x q trust-region subproblem) instead of a QR of the tall J; the
-// linear sub-problem itself stays Householder-based.  A rank-deficient Phi_w (SVD truncation path) is reported
-// as a failed evaluation on this path.
+// linear sub-problem itself stays Householder-based.  A rank-deficient Phi_w takes the reference's truncated-SVD
+// branch here too: the factor kernel then stores the truncated pseudo-inverse R^+ in place of R^{-1} and the
+// projector P_n = R R^+ onto the retained subspace, and the streaming kernel uses c = R^+ Q^T y,
+// r = y - Q P_n Q^T y (the Jacobian keeps the full Q, like the reference keeps the full U).
 #pragma once
 #include "vp_lm_core.hpp"
 
 namespace vp {
 
-enum { VP_ST_SINGULAR = 3 }; // MRHS fast path: Phi_w numerically rank deficient (no truncated solve here)
+enum { VP_ST_SINGULAR = 3 }; // MRHS path: R has a zero / non-finite diagonal and no truncated solve exists
+// per-problem small workspace: R^{-1} or R^+ (row-major) | G^T G | P_n (row-major) | truncated flag
+template <int N, int P> __host__ __device__ constexpr int mrhs_small_stride() { return 2 * N * N + P * P + 1; }
+inline int mrhs_small_stride_rt(int n, int p) { return 2 * n * n + p * p + 1; }
 
 // device workspace of the MRHS path (owned by the handle)
 struct MrhsWs {
     void *qthin;      // [B][N][m]  T
     void *g;          // [B][P][m]  T
-    double *small;    // [B][N*N + P*P]   R^{-1} (row-major), G^T G
+    double *small;    // [B][mrhs_small_stride]   R^{-1} or R^+ (row-major), G^T G, P_n, truncated flag
     int32_t *statusA; // [B]
     double *acc;      // [B][gx][1 + N*N + P]  per-workgroup partials of sum ||r||^2, sum c c^T, sum c_{j(p)} u_p
     void *lm_state;   // [B] LmVars
@@ -75,7 +80,7 @@ __global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T,
     T g[N], Rm[N][N], qdummy[N];
     house_qr<T, R, N, NC, 0, false, Grp<1>>(C, g, Rm, qdummy, grp);
     // R^{-1} (upper triangular) and the rank test of solve_coeffs
-    double *small = a.ws.small + b * (N * N + P * P);
+    double *small = a.ws.small + b * mrhs_small_stride<N, P>();
     int st = VP_ST_OK;
     bool zero_diag = false;
 #pragma unroll
@@ -101,17 +106,54 @@ __global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T,
         if (!uni(is_finite(inv_f2))) st = VP_ST_NONFINITE;
     } else {
         st = VP_ST_SINGULAR;
+    }
+    // rank deficient to the reference's rule (a singular value <= eps): truncated pseudo-inverse, column by column
+    // (R^+ e_k and (I - R R^+) e_k from the same one-sided Jacobi SVD as the single-RHS kernels; rare path)
+    T Pn[N][N];
+    bool truncated = false;
+    {
+        bool finite_r = true;
 #pragma unroll
         for (int i = 0; i < N; ++i)
 #pragma unroll
-            for (int j = 0; j < N; ++j) Ri[i][j] = T(0);
+            for (int j = i; j < N; ++j) finite_r = finite_r && is_finite(Rm[i][j]);
+        if (uni(st == VP_ST_SINGULAR && finite_r)) {
+            truncated = true;
+            st = VP_ST_OK;
+#pragma unroll 1
+            for (int k = 0; k < N; ++k) {
+                TruncIn<T, N> in;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    in.qty[i] = (i == k) ? T(1) : T(0);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) in.Rm[i][j] = (j >= i) ? Rm[i][j] : T(0);
+                }
+                in.eps = a.eps;
+                const TruncOut<T, N> out = truncated_solve<T, N>(in);
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    dyn_set<N>(Ri[i], k, out.c[i]);
+                    dyn_set<N>(Pn[i], k, ((i == k) ? T(1) : T(0)) - out.e[i]);
+                }
+            }
+        } else if (st != VP_ST_OK) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) Ri[i][j] = T(0);
+        }
     }
     if (lane == 0) {
         a.ws.statusA[b] = st;
 #pragma unroll
         for (int i = 0; i < N; ++i)
 #pragma unroll
-            for (int j = 0; j < N; ++j) small[i * N + j] = (double)Ri[i][j];
+            for (int j = 0; j < N; ++j) {
+                small[i * N + j] = (double)Ri[i][j];
+                small[N * N + P * P + i * N + j] = truncated ? (double)Pn[i][j] : (i == j ? 1.0 : 0.0);
+            }
+        small[2 * N * N + P * P] = truncated ? 1.0 : 0.0;
     }
     // G_p = Q [0; (Q^T W dPhi_p)_{>= N}]  in place on the derivative columns
 #pragma unroll
@@ -186,13 +228,14 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
         if (row < m) v = (col < N) ? qsrc[(int64_t)col * m + row] : gsrc[(int64_t)(col - N) * m + row];
         s_q[idx] = v;
     }
-    const double *small = a.ws.small + b * (N * N + P * P);
+    const double *small = a.ws.small + b * mrhs_small_stride<N, P>();
     T Ri[N][N];
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) Ri[i][j] = (T)small[i * N + j];
     const int stA = a.ws.statusA[b];
+    const bool truncated = uni(small[2 * N * N + P * P] != 0.0); // rank-deficient Phi_w: R^+ and P_n (rare)
     __syncthreads();
 
     using L = Layout<R>;
@@ -232,6 +275,32 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
         }
         __builtin_amdgcn_sched_barrier(0);
         wave_allreduce(tq);
+        // c = R^{-1} T   (truncated: c = R^+ T with the full matrix, and T := P_n T for the residual)
+        T c[N];
+        if (truncated) {
+            T tp[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                T acc = T(0), accp = T(0);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    acc = tfma(Ri[i][j], tq[j], acc);
+                    accp = tfma((T)small[N * N + P * P + i * N + j], tq[j], accp);
+                }
+                c[i] = acc;
+                tp[i] = accp;
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) tq[i] = tp[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                T acc = T(0);
+#pragma unroll
+                for (int j = i; j < N; ++j) acc = tfma(Ri[i][j], tq[j], acc);
+                c[i] = acc;
+            }
+        }
         // r = y - Q T  (in place)
 #pragma unroll
         for (int c0 = 0; c0 < R; c0 += CH) {
@@ -246,15 +315,6 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // c = R^{-1} T
-        T c[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            T acc = T(0);
-#pragma unroll
-            for (int j = i; j < N; ++j) acc = tfma(Ri[i][j], tq[j], acc);
-            c[i] = acc;
-        }
         // ||r||^2 and u = G^T r
         T red[1 + P];
         {
@@ -415,7 +475,7 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
         tr[Q + 3] = (double)s.par;
     }
     if (need_jac) {
-        const double *small = a.ws.small + b * (N * N + P * P);
+        const double *small = a.ws.small + b * mrhs_small_stride<N, P>();
         T A[Q][Q], bv[Q];
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
