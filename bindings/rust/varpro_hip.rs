@@ -73,6 +73,20 @@ extern "C" {
         rep: *mut vp_report) -> i32;
     pub fn vp_best_fit(h: *mut vp_batch, fit_out: *mut c_void) -> i32;
     pub fn vp_summary(h: *mut vp_batch, out: *mut f64) -> i32;
+    pub fn vp_summary_device(h: *mut vp_batch, dev_out4: *mut f64) -> i32;
+    pub fn vp_fit_trace(h: *mut vp_batch, opts: *const vp_lm_opts, alpha_inout: *mut c_void, c_out: *mut c_void,
+        rep: *mut vp_report, trace_out: *mut f64, trace_rows: i32) -> i32;
+    pub fn vp_statistics(h: *mut vp_batch, cov_out: *mut c_void, chi2_out: *mut f64, sigma_out: *mut c_void,
+        status: *mut i32) -> i32;
+    pub fn vp_set_rhs_allreduce(h: *mut vp_batch,
+        f: Option<extern "C" fn(*mut c_void, i64, *mut c_void, *mut c_void) -> i32>, user: *mut c_void,
+        global_rhs_count: i64) -> i32;
+    pub fn vp_set_timing(h: *mut vp_batch, enable: i32) -> i32;
+    pub fn vp_last_kernel_ms(h: *mut vp_batch, which: i32, ms: *mut f32) -> i32;
+    pub fn vp_synchronize(h: *mut vp_batch) -> i32;
+    pub fn vp_last_error_detail() -> i32;
+    pub fn vp_version() -> *const c_char;
+    pub fn vp_device_count() -> i32;
     pub fn vp_last_error() -> *const c_char;
 }
 

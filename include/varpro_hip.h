@@ -291,6 +291,22 @@ int vp_summary(vp_batch *h, double out[4]);
  * synchronisation: the buffer can be handed straight to ncclAllReduce (RCCL) */
 int vp_summary_device(vp_batch *h, double *dev_out4);
 
+/*
+ * One global fit whose right-hand sides are SHARDED over ranks (second row).  The reference fits
+ * all S columns with one shared alpha (src/solvers/levmar/mod.rs:42-73, 154-186); here every rank owns a handle
+ * with its block of the S columns (same model, grid, weights; B problems each) and vp_fit needs ONE exchange per
+ * LM evaluation: the reduced sums {sum ||r||^2, sum c c^T, sum c_j G_p^T r} of the local columns, B*(1+n*n+p)
+ * doubles.  The library leaves the collective to the caller: `fn` must sum `count` DEVICE doubles in place over
+ * all ranks, ordered on `hip_stream` (ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, hip_stream) on
+ * RCCL), and return 0.  Every rank then runs the identical LM step on identical totals.
+ *   global_rhs_count   S of the whole problem (the LM driver's residual count is m * global_rhs_count)
+ *   fn == NULL         back to an unsharded handle
+ * After vp_fit: alpha and the report (objective = global 1/2 sum ||r||^2) are identical on every rank; C, the
+ * residual cache and vp_cost cover the local columns only.
+ */
+typedef int (*vp_allreduce_fn)(void *dev_doubles, int64_t count, void *hip_stream, void *user);
+int vp_set_rhs_allreduce(vp_batch *h, vp_allreduce_fn fn, void *user, int64_t global_rhs_count);
+
 /* ---- introspection --------------------------------------------------------------------- */
 
 /* duration in ms of the most recent launch of a kernel family on this handle, measured

@@ -322,6 +322,44 @@ class BatchProblem:
         check(self.lib.vp_statistics(self._h, self._ptr(cov), self._ptr(chi2), self._ptr(sig), self._ptr(st)))
         return dict(cov=cov, reduced_chi2=chi2, conf_sigma=sig, status=st, dof=self.m - k)
 
+    def set_rhs_allreduce(self, global_rhs_count, group=None):
+        """Shard ONE global fit over ranks by right-hand sides (vp_set_rhs_allreduce): this handle
+        holds the local block of the S columns (torch device tensors); per LM evaluation the B*(1+n*n+p) reduced
+        sums are all-reduced over `group` (torch.distributed: backend "nccl" == RCCL over xGMI; "gloo" is bounced
+        through the host and only meant for tests).  Pass global_rhs_count=None to switch back."""
+        if global_rhs_count is None:
+            self._rhs_cb = None
+            check(self.lib.vp_set_rhs_allreduce(self._h, _lib.ALLREDUCE_FN(0), None, 0))
+            return
+        if not self.device_mode:
+            raise ValueError("right-hand-side sharding needs device tensors (the collective runs on the stream)")
+        import torch
+        import torch.distributed as dist
+
+        dev = self._tdev
+
+        class _Raw:  # zero-copy view of the library's device buffer for torch
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                                 "version": 2}
+
+        def _cb(ptr, count, stream, user):
+            try:
+                t = torch.as_tensor(_Raw(ptr, count), device=dev)
+                if dist.get_backend(group) == "gloo":
+                    h = t.cpu()
+                    dist.all_reduce(h, group=group)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t, group=group)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                self._rhs_cb_error = e
+                return -1
+
+        self._rhs_cb = _lib.ALLREDUCE_FN(_cb)  # keep alive as long as the handle uses it
+        check(self.lib.vp_set_rhs_allreduce(self._h, self._rhs_cb, None, int(global_rhs_count)))
+
     def summary(self):
         """local {sum cost, #successful, #failed, sum n_evals} after fit (vp_summary)"""
         out = (C.c_double * 4)()

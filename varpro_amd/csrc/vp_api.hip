@@ -105,6 +105,19 @@ __global__ void summary_kernel(const vp_report *__restrict__ rep, int64_t B, dou
         for (int k = 0; k < 4; ++k) atomicAdd(&out4[k], sh[k][0]);
 }
 
+// Sum of the streaming kernel's per-workgroup partials in a fixed order: tot[b][i] = sum_g part[b][g][i].  Used
+// when the right-hand sides are sharded over ranks: the totals are all-reduced (vp_set_rhs_allreduce) and the LM
+// step then reads them as a single slot, so that every rank takes bit-identical decisions.
+__global__ void mrhs_reduce_partials_kernel(const double *part, int gx, int nacc, int64_t B, double *tot) {
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= B * nacc) return;
+    const int64_t b = idx / nacc;
+    const int i = (int)(idx - b * nacc);
+    double s = 0.0;
+    for (int g = 0; g < gx; ++g) s += part[((size_t)b * gx + g) * nacc + i];
+    tot[idx] = s;
+}
+
 // Uniform-grid check, once per handle: grid g passes if every t_i lies within 4 ulp-of-the-offset of the lattice
 // t_0 + i*dt, dt = (t_{m-1} - t_0)/(m-1):   |t_i - (t_0 + i dt)| <= 4 eps |t_i - t_0|.
 // That is what a linspace-type grid anchored at its first sample satisfies, and it bounds the argument error of
@@ -162,6 +175,11 @@ struct vp_batch {
     // multiple-right-hand-side path (S > 1): factor/stream/LM-step kernels + their workspace
     bool have_mrhs;
     MrhsWs mrhs;
+    // S-sharded global fits (vp_set_rhs_allreduce)
+    vp_allreduce_fn rhs_allreduce;
+    void *rhs_allreduce_user;
+    int64_t rhs_global; // right-hand sides of the whole problem
+    double *d_mrhs_tot; // [B][1 + n*n + p] totals of the reduced sums (all-reduced across ranks)
 };
 
 namespace {
@@ -343,12 +361,34 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
     if (int rc = h->kern->mrhs_lm(p)) return fail(rc, "mrhs_lm (init) launch failed");
     p.mrhs_init = 0;
     const int max_iter = o.patience * (h->q + 1) + 2;
+    // right-hand sides sharded over ranks: the reduced sums of this rank's columns are totalled in a fixed order,
+    // summed over the ranks by the caller's collective (RCCL all-reduce of B*(1+n*n+p) doubles per evaluation) and
+    // fed to the LM step as a single slot; every rank then takes bit-identical decisions.
+    const int nacc = 1 + h->n * h->n + h->p;
+    MrhsWs ws_tot = h->mrhs;
+    if (h->rhs_allreduce) {
+        if (!h->d_mrhs_tot) VP_HIP(hipMalloc((void **)&h->d_mrhs_tot, (size_t)h->B * nacc * sizeof(double)));
+        ws_tot.acc = h->d_mrhs_tot;
+        p.mrhs_S_global = h->rhs_global;
+    }
     for (int it = 0; it < max_iter; ++it) {
         p.alpha = h->mrhs.alpha_trial;
         p.mrhs_mode = 0;
         if (int rc = h->kern->mrhs_factor(p)) return fail(rc, "mrhs_factor launch failed");
         if (int rc = h->kern->mrhs_stream(p)) return fail(rc, "mrhs_stream launch failed");
+        if (h->rhs_allreduce) {
+            const int64_t total = h->B * nacc;
+            hipLaunchKernelGGL(mrhs_reduce_partials_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                               h->stream, (const double *)h->mrhs.acc, mrhs_gx(h->S), nacc, h->B, h->d_mrhs_tot);
+            VP_HIP(hipGetLastError());
+            if (h->rhs_allreduce(h->d_mrhs_tot, total, (void *)h->stream, h->rhs_allreduce_user) != 0)
+                return fail(VP_ERR_INVALID, "the right-hand-side all-reduce callback reported an error");
+            p.mrhs_ws = &ws_tot;
+            p.mrhs_gx = 1;
+        }
         if (int rc = h->kern->mrhs_lm(p)) return fail(rc, "mrhs_lm launch failed");
+        p.mrhs_ws = &h->mrhs;
+        p.mrhs_gx = 0;
         int32_t nact = 0;
         VP_HIP(hipMemcpyAsync(&nact, h->mrhs.nactive, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         VP_HIP(hipStreamSynchronize(h->stream));
@@ -553,6 +593,7 @@ void vp_batch_destroy(vp_batch *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->d_mrhs_tot);
     (void)hipFree(h->d_t);
     (void)hipFree(h->d_w);
     (void)hipFree(h->d_yw);
@@ -758,6 +799,19 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
     if (int rc2 = copy_out(h, C_out, h->d_C, (size_t)h->B * h->n * ts)) return rc2;
     if (int rc2 = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc2;
     if (int rc2 = tr.finish(h)) return rc2;
+    return VP_ERR_OK;
+}
+
+int vp_set_rhs_allreduce(vp_batch *h, vp_allreduce_fn fn, void *user, int64_t global_rhs_count) {
+    if (int rc = check_handle(h)) return rc;
+    if (fn) {
+        if (h->S <= 1 || !h->have_mrhs)
+            return fail(VP_ERR_UNSUPPORTED, "right-hand-side sharding needs a handle with S > 1 and MRHS kernels");
+        if (global_rhs_count < h->S) return fail(VP_ERR_INVALID, "global_rhs_count smaller than the local S");
+    }
+    h->rhs_allreduce = fn;
+    h->rhs_allreduce_user = user;
+    h->rhs_global = fn ? global_rhs_count : 0;
     return VP_ERR_OK;
 }
 

@@ -45,6 +45,8 @@ struct LaunchParams {
     const void *mrhs_ws; // MRHS path: pointer to the handle's MrhsWs
     int mrhs_mode;      // MRHS stream: 0 = reduced quantities (fit), 1 = trait-level outputs
     int mrhs_init;      // MRHS LM step: 1 = initialise the state
+    int mrhs_gx;        // MRHS LM step: partial-sum slots per problem (0 = the streaming kernel's grid)
+    int64_t mrhs_S_global; // MRHS LM step: right-hand sides of the WHOLE problem when S is sharded (0 = S)
     int basis_flags;
     int m;
     int S;

@@ -414,6 +414,7 @@ template <typename T, int N, int Q, int P> struct MrhsLmArgs {
     const T *alpha0;   // init only
     int pb[P > 0 ? P : 1], pp[P > 0 ? P : 1];
     int m, S;
+    int64_t S_global;  // right-hand sides of the whole problem (== S unless the columns are sharded over ranks)
     int64_t B;
     int init;          // 1: initialise the state from alpha0 and publish the first trial point
     int gx;            // workgroups per problem of the streaming kernel (partial-sum slots)
@@ -465,7 +466,7 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
     const T cost2 = (T)acc[0];
     const bool ok = uni(stA == VP_ST_OK && is_finite(cost2));
     const T fnorm1 = tsqrt(cost2);
-    const bool need_jac = lm_after_eval<T, N, Q, true>(s, a.opts, fnorm1, ok, (long)a.m * a.S);
+    const bool need_jac = lm_after_eval<T, N, Q, true>(s, a.opts, fnorm1, ok, (long)a.m * (long)a.S_global);
     if (a.trace && lane == 0 && s.nfev - 1 < a.trace_rows) {
         double *tr = a.trace + ((size_t)b * a.trace_rows + (s.nfev - 1)) * (Q + 4);
         for (int k = 0; k < Q; ++k) tr[k] = (double)s.xt[k];
@@ -599,8 +600,9 @@ template <typename T, class M, int R> int launch_mrhs_lm(const LaunchParams &p) 
     a.m = p.m;
     a.S = p.S;
     a.B = p.B;
+    a.S_global = p.mrhs_S_global > 0 ? p.mrhs_S_global : p.S;
     a.init = p.mrhs_init;
-    a.gx = mrhs_gx(p.S);
+    a.gx = p.mrhs_gx > 0 ? p.mrhs_gx : mrhs_gx(p.S);
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
     hipLaunchKernelGGL((mrhs_lm_kernel<T, N, Q, P>), dim3((unsigned)p.B), dim3(64), 0, p.stream, a);

@@ -1,4 +1,6 @@
-"""Multi-GPU layer: independent problems shard across ranks, one scalar reduction.
+"""Multi-GPU layer: independent problems shard across ranks with one scalar reduction
+(ShardedFit); one global fit shards its right-hand sides with one small all-reduce per LM evaluation
+(ShardedGlobalFit).
 
 One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU
 tests).  Rank r owns a contiguous block of the batch; every rank runs the full device-resident LM fit on
@@ -50,6 +52,25 @@ class ShardedFit:
         alpha, C, rep = self.batch.fit(alpha0_shard, solver=solver)
         local = self.batch.summary()
         return alpha, C, rep, local, allreduce_summary(local)
+
+    def close(self):
+        self.batch.close()
+
+
+class ShardedGlobalFit:
+    """ONE global fit (shared nonlinear parameters, S right-hand sides) with the COLUMNS sharded over ranks
+    (second row).  Every rank passes its block Y[:, first:first+count, :] as a device tensor; the
+    path has a real exchange step here -- per LM evaluation one sum all-reduce of B*(1+n*n+p) doubles (RCCL
+    over xGMI with backend "nccl") -- after which all ranks take the identical LM step."""
+
+    def __init__(self, model, Y_shard, global_rhs_count, x=None, weights=None, epsilon=None, group=None):
+        from .batch import BatchProblem
+        self.batch = BatchProblem(model, Y_shard, x=x, weights=weights, epsilon=epsilon)
+        self.batch.set_rhs_allreduce(global_rhs_count, group=group)
+
+    def fit(self, alpha0, solver=None):
+        """-> (alpha identical on every rank, C of the LOCAL columns, report with the GLOBAL objective)"""
+        return self.batch.fit(alpha0, solver=solver)
 
     def close(self):
         self.batch.close()
