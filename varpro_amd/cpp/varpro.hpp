@@ -263,6 +263,28 @@ class BatchProblem {
         check(vp_fit(h_, &solver.o, alpha_inout.data(), nullptr, rep.data()));
         return rep;
     }
+    // == FitStatistics::try_calculate for every problem (src/statistics/mod.rs:352-441); single RHS only
+    struct Statistics {
+        std::vector<double> covariance;   // [B][(n+q)^2] column-major, ordering [linear coefficients, parameters]
+        std::vector<double> reduced_chi2; // [B]
+        std::vector<double> conf_sigma;   // [B][m]  multiply by the Student-t quantile for a confidence band
+        std::vector<int32_t> status;      // [B]  0 ok, 4 = Underdetermined / MatrixInversion
+    };
+    Statistics statistics() const {
+        Statistics s;
+        const size_t k = (size_t)(n + q);
+        s.covariance.resize((size_t)B * k * k);
+        s.reduced_chi2.resize((size_t)B);
+        s.conf_sigma.resize((size_t)(B * m));
+        s.status.resize((size_t)B);
+        check(vp_statistics(h_, s.covariance.data(), s.reduced_chi2.data(), s.conf_sigma.data(), s.status.data()));
+        return s;
+    }
+    // one global fit sharded by right-hand sides over ranks: `fn` sums `count` device doubles over all ranks on
+    // the given HIP stream (ncclAllReduce on RCCL); see include/varpro_hip.h
+    void set_rhs_allreduce(vp_allreduce_fn fn, void *user, int64_t global_rhs_count) {
+        check(vp_set_rhs_allreduce(h_, fn, user, global_rhs_count));
+    }
 };
 
 // == SeparableProblem (single problem, S right-hand sides); `None` of the reference == std::nullopt
