@@ -30,69 +30,73 @@ namespace vp {
 // On return: C[k] (k < N) holds v_k (0 above row ROW0+k); g[k]; Rm = upper triangle (Rm[i][j], i <= j);
 // qty[k] = (Q^T C[N])[ROW0+k]; columns >= N hold Q^T (.) in all rows.
 //   HAS_Y: column N is a data column whose top entries are returned in qty
+template <int I, int E, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
 template <typename T, int R, int N, int NC, int ROW0, bool HAS_Y = true, class G>
 __device__ __forceinline__ void house_qr(T (&C)[NC][R], T (&g)[N], T (&Rm)[N][N], T (&qty)[N], G &grp) {
     using L = Layout<R, G::W>;
     const int lane = grp.gl;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int prow = ROW0 + k;
-        // squared norm of the pivot column below the pivot
-        T s = T(0);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const T v = (r >= L::VW || L::row_of(r, lane) > prow) ? C[k][r] : T(0);
-            s = tfma(v, v, s);
-        }
-        const T xn2 = group_sum(grp, s);
-        const T alpha = group_row<R>(grp, C[k], prow);
-        T beta = alpha, gk = T(0), u = T(0);
-        if (uni(xn2 != T(0))) {
-            beta = -tcopysign(usqrt(tfma(alpha, alpha, xn2)), alpha);
-            u = alpha - beta;
-            gk = T(1) / (beta * u);
-        }
-        g[k] = gk;
-        Rm[k][k] = beta;
-        // v_k in place: only the registers holding rows <= prow change (row prow := u, rows above := 0)
+    static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int prow = ROW0 + k;
+        constexpr int NREM = NC - k; // columns k .. NC-1 take part in round k
+        // rows above the pivot of column k hold R entries that were already extracted: clear them, so that the
+        // dot products below run over all registers without masks
 #pragma unroll
         for (int r = 0; r < L::VW && r < R; ++r) {
             const int i = L::row_of(r, lane);
-            C[k][r] = (i > prow) ? C[k][r] : ((i == prow) ? u : T(0));
+            C[k][r] = (i >= prow) ? C[k][r] : T(0);
         }
-        // w_c = v^T c for every remaining column: ONE reduction round for all of them
-        constexpr int NREM = NC - 1;
-        T w[NREM > 0 ? NREM : 1];
+        // ONE reduction round per reflector: the RAW dot products d_j = a_k^T a_j over rows >= prow, j = k..NC-1
+        // (d_k is the squared norm).  With v = a_k - beta e_prow:  v^T a_j = d_j - beta a_j[prow].
+        T d[NREM], top[NREM];
 #pragma unroll
-        for (int c = 0; c < NREM; ++c) w[c] = T(0);
-#pragma unroll
-        for (int j = k + 1; j < NC; ++j) {
+        for (int j = k; j < NC; ++j) {
             T acc = T(0);
 #pragma unroll
             for (int r = 0; r < R; ++r) acc = tfma(C[k][r], C[j][r], acc);
-            w[j - k - 1] = acc;
+            d[j - k] = acc;
+            top[j - k] = C[j][L::reg_of_row(prow)]; // pivot-row entry a_j[prow] (valid in the owning lane)
         }
-        group_allreduce(grp, w);
+        group_allreduce(grp, d);
+        group_bcast<NREM>(grp, top, L::lane_of_row(prow));
+        // beta = -sign(alpha) sigma, sigma = ||a_k||;  u = alpha - beta = sign(alpha)(|alpha| + sigma);
+        // g = 1/(beta u) = -1/(sigma (|alpha| + sigma)) = -rsqrt(d_k) / (|alpha| + sigma): one rsq, one rcp, no
+        // division / sqrt expansion on the critical path.  A zero column (d_k == 0) leaves H = I; a non-finite
+        // norm is passed on into R so that the evaluation is flagged.
+        const T alpha = top[0], nrm2 = d[0];
+        const bool live = nrm2 > T(0) && is_finite(nrm2);
+        const T y = live ? frsqrt(nrm2) : T(0);
+        const T s0 = nrm2 * y;
+        const T sigma = tfma(tfma(-s0, s0, nrm2), T(0.5) * y, s0);
+        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+        const T u = live ? alpha - beta : T(0);
+        const T gk = live ? -y * frcp(tabs(alpha) + sigma) : T(0);
+        g[k] = gk;
+        Rm[k][k] = beta;
+        // v_k in place: row prow := u (rows above are already 0)
+#pragma unroll
+        for (int r = 0; r < L::VW && r < R; ++r) {
+            const int i = L::row_of(r, lane);
+            C[k][r] = (i == prow) ? u : C[k][r];
+        }
 #pragma unroll
         for (int j = k + 1; j < NC; ++j) {
-            const T f = gk * w[j - k - 1];
+            const T f = gk * tfma(-beta, top[j - k], d[j - k]); // g * v^T a_j
 #pragma unroll
             for (int r = 0; r < R; ++r) C[j][r] = tfma(f, C[k][r], C[j][r]);
+            // row prow of the updated column (the same fma the vector update performs on that row):
+            // R entries of the factor columns, Q^T y entry of the data column
+            const T tj = tfma(f, u, top[j - k]);
+            if (j < N) Rm[k][j] = tj;
+            if (HAS_Y && j == N) qty[k] = tj;
         }
-        // row prow of the updated columns: R entries of the factor columns, Q^T y entry of the data column
-        constexpr int NTOP = HAS_Y ? N : N - 1; // last column index whose top entry is needed
-        T top[NTOP > 0 ? NTOP : 1];
-#pragma unroll
-        for (int j = 0; j < (NTOP > 0 ? NTOP : 1); ++j) top[j] = T(0);
-#pragma unroll
-        for (int j = k + 1; j <= NTOP; ++j) top[j - 1] = C[j][L::reg_of_row(prow)];
-        if (k + 1 <= NTOP) group_bcast<(NTOP > 0 ? NTOP : 1)>(grp, top, L::lane_of_row(prow));
-#pragma unroll
-        for (int j = k + 1; j <= NTOP; ++j) {
-            if (j < N) Rm[k][j] = top[j - 1];
-            if (HAS_Y && j == N) qty[k] = top[j - 1];
-        }
-    }
+    });
 }
 
 // z <- Q z for NZ columns (Q = H_0 ... H_{N-1}; V = the first N columns left by house_qr)
@@ -308,13 +312,20 @@ template <typename T, int N> struct EvalUniform {
 // runs the fused sweep, solves for c and forms ||r||^2.
 template <typename T, class M, int R, int NC, class Src, class G>
 __device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::Q], const Src &src, T eps, G &grp,
-                                              T (&C)[NC][R], EvalUniform<T, M::N> &u) {
+                                              T (&C)[NC][R], EvalUniform<T, M::N> &u, SectionClock *clk = nullptr) {
     constexpr int N = M::N;
     using L = Layout<R, G::W>;
     const int lane = grp.gl;
     build_columns<T, M, R, NC, Src>(mdl, alpha, src, C);
+    VP_TICK(clk, 1);
+#ifndef VP_NO_SWEEP_FENCE
+    // keep the scheduler from interleaving the tail of the column build with the first dot products: the
+    // overlapping live ranges (grid values, unscaled exponentials) push a column into scratch otherwise
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     T Rm[N][N], qty[N];
     house_qr<T, R, N, NC, 0, true, G>(C, u.g, Rm, qty, grp);
+    VP_TICK(clk, 2);
     bool truncated;
     solve_coeffs<T, N>(Rm, qty, eps, u.c, u.e, truncated);
     // ||r||^2 = ||e||^2 + sum_{rows >= N} (Q^T y)^2
@@ -322,6 +333,135 @@ __device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const T v = (r >= L::VW || L::row_of(r, lane) >= N) ? C[N][r] : T(0);
+        s = tfma(v, v, s);
+    }
+    T fn2 = group_sum(grp, s);
+#pragma unroll
+    for (int k = 0; k < N; ++k) fn2 = tfma(u.e[k], u.e[k], fn2);
+    u.fn2 = fn2;
+    bool ok = is_finite(fn2);
+#pragma unroll
+    for (int k = 0; k < N; ++k) ok = ok && is_finite(u.c[k]);
+    u.ok = uni(ok);
+}
+
+// ---- constant column first, never materialised -----------------------------------------------------------------
+// For models whose LAST basis is the constant (MultiExpModel<NEXP, true>) the fit kernel factors Phi_w with the
+// column order [scale | exp_1 .. exp_NEXP]: the first column is the row-scale vector s itself (1/0 validity mask or
+// the weights), which does not depend on alpha.  Its reflector v_0 = s - beta_0 e_0 is computed ONCE PER FIT
+// (ConstReflector) and applied implicitly -- d_j = sum_r s_r a_j[r], a_j += tau_j v_0 -- so the column is never
+// held in registers: 2*NEXP+1 register columns instead of 2*NEXP+2, which is what lets the double-exponential
+// sweep (6 x 32 VGPRs before) run without scratch spills.  QR of a column-permuted Phi spans the same range: c, r
+// and J are the same up to rounding; c is returned in MODEL order, e in Q-coordinate ROW order.
+template <typename T> struct ConstReflector {
+    T beta, u, g; // H_0 = I + g v v^T, v = s - beta e_0, u = v[0]
+    bool live;    // false: s == 0 (no valid row)
+};
+
+template <typename T, int R, class Src, class G>
+__device__ __forceinline__ ConstReflector<T> make_const_reflector(const Src &src, G &grp) {
+    using L = Layout<R, G::W>;
+    constexpr int VW = L::VW;
+    T acc = T(0), s0 = T(0);
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += VW) {
+        T tt[2], sc[2];
+        src.get(r0, tt, sc);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            acc = tfma(sc[e], sc[e], acc);
+            if (r0 + e == L::reg_of_row(0)) s0 = sc[e];
+        }
+    }
+    const T nrm2 = group_sum(grp, acc);
+    T top[1] = {s0};
+    group_bcast<1>(grp, top, L::lane_of_row(0));
+    ConstReflector<T> h;
+    h.live = uni(nrm2 > T(0) && is_finite(nrm2));
+    const T sigma = tsqrt(nrm2);
+    h.beta = h.live ? -tcopysign(sigma, top[0]) : top[0];
+    h.u = h.live ? top[0] - h.beta : T(0);
+    h.g = h.live ? T(1) / (h.beta * h.u) : T(0);
+    return h;
+}
+
+// C: [0, NEXP) exponential columns, [NEXP] data column (already loaded with y_w), [NEXP+1, 2 NEXP+1) derivative
+// columns.  On return: columns in Q-coordinates (rows >= N of the data / derivative columns are what the LM uses).
+template <typename T, class M, int R, int NCX, class Src, class G>
+__device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T (&alpha)[M::Q], const Src &src, T eps,
+                                                          G &grp, const ConstReflector<T> &h0, T (&C)[NCX][R],
+                                                          EvalUniform<T, M::N> &u, SectionClock *clk = nullptr) {
+    constexpr int N = M::N, NE = M::N - 1;
+    static_assert(M::kConstLast && NCX == M::N + M::P, "const-first sweep: N-1 exponentials + data + P derivatives");
+    using L = Layout<R, G::W>;
+    constexpr int VW = L::VW;
+    const int lane = grp.gl;
+    build_columns<T, M, R, NCX, Src, NE + 1, true>(mdl, alpha, src, C);
+    VP_TICK(clk, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- reflector 0: the implicit scale column ----
+    T d[NCX], top[NCX];
+#pragma unroll
+    for (int j = 0; j < NCX; ++j) d[j] = T(0);
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += VW) {
+        T tt[2], sc[2];
+        src.get(r0, tt, sc);
+#pragma unroll
+        for (int j = 0; j < NCX; ++j)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) d[j] = tfma(sc[e], C[j][r0 + e], d[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NCX; ++j) top[j] = C[j][L::reg_of_row(0)];
+    group_allreduce(grp, d);
+    group_bcast<NCX>(grp, top, L::lane_of_row(0));
+    T Rm[N][N], qty[N];
+    T tau[NCX];
+    Rm[0][0] = h0.beta;
+#pragma unroll
+    for (int j = 0; j < NCX; ++j) {
+        tau[j] = h0.g * tfma(-h0.beta, top[j], d[j]);
+        const T tj = tfma(tau[j], h0.u, top[j]);
+        if (j < NE) Rm[0][1 + j] = tj;
+        if (j == NE) qty[0] = tj;
+    }
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += VW) {
+        T tt[2], sc[2];
+        src.get(r0, tt, sc);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            const T v = (r0 + e < VW && L::row_of(r0 + e, lane) == 0) ? h0.u : sc[e];
+#pragma unroll
+            for (int j = 0; j < NCX; ++j) C[j][r0 + e] = tfma(tau[j], v, C[j][r0 + e]);
+        }
+    }
+    // ---- reflectors 1..NE on the exponential columns, pivot rows 1..NE ----
+    T g1[NE], R1[NE][NE], q1[NE];
+    house_qr<T, R, NE, NCX, 1, true, G>(C, g1, R1, q1, grp);
+    VP_TICK(clk, 2);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        Rm[1 + i][0] = T(0);
+        qty[1 + i] = q1[i];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) Rm[1 + i][1 + j] = R1[i][j];
+    }
+    T cp[N];
+    bool truncated;
+    solve_coeffs<T, N>(Rm, qty, eps, cp, u.e, truncated);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) u.c[j] = cp[1 + j];
+    u.c[NE] = cp[0];
+    u.g[0] = h0.g;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) u.g[1 + j] = g1[j];
+    // ||r||^2 = ||e||^2 + sum_{rows >= N} (Q^T y)^2
+    T s = T(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const T v = (r >= VW || L::row_of(r, lane) >= N) ? C[NE][r] : T(0);
         s = tfma(v, v, s);
     }
     T fn2 = group_sum(grp, s);
@@ -353,7 +493,7 @@ __device__ __forceinline__ void residual_qcoords(T (&x0)[R], const T (&e)[N], co
 // rows < N zeroed (that is the P_perp).
 //   diagonal models (pair p == (basis p, param p)): done IN PLACE, Z_k is C[N+1+k];
 //   general models: written to the separate array Zs and the caller uses that.
-template <typename T, class M, int R, int NC, class G>
+template <typename T, class M, int R, int NC, class G, int DC = M::N + 1>
 __device__ __forceinline__ void jacobian_qcoords(const M &mdl, T (&C)[NC][R], const T (&c)[M::N],
                                                  T (&Zs)[M::kDiagonalPairs ? 1 : M::Q][R], const G &grp) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
@@ -368,7 +508,7 @@ __device__ __forceinline__ void jacobian_qcoords(const M &mdl, T (&C)[NC][R], co
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const bool top = (r < L::VW) && (L::row_of(r, lane) < N);
-                C[N + 1 + k][r] = top ? T(0) : ck * C[N + 1 + k][r];
+                C[DC + k][r] = top ? T(0) : ck * C[DC + k][r];
             }
         }
     } else {
@@ -381,7 +521,7 @@ __device__ __forceinline__ void jacobian_qcoords(const M &mdl, T (&C)[NC][R], co
                 if (mdl.pair_param(p) == k) {
                     const T cj = -dyn_get<N>(c, mdl.pair_basis(p));
 #pragma unroll
-                    for (int r = 0; r < R; ++r) Zs[k][r] = tfma(cj, C[N + 1 + p][r], Zs[k][r]);
+                    for (int r = 0; r < R; ++r) Zs[k][r] = tfma(cj, C[DC + p][r], Zs[k][r]);
                 }
             }
 #pragma unroll

@@ -31,6 +31,26 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// ---- optional per-section cycle accounting of the fit kernel (tools/fit_clocks.py; -DVP_FIT_CLOCKS) -------------
+struct SectionClock {
+    long long last;
+    long long acc[12];
+    __device__ __forceinline__ void start() {
+        for (int k = 0; k < 12; ++k) acc[k] = 0;
+        last = (long long)__builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void tick(int k) {
+        const long long now = (long long)__builtin_readcyclecounter();
+        acc[k] += now - last;
+        last = now;
+    }
+};
+#ifdef VP_FIT_CLOCKS
+#define VP_TICK(clk, k) do { if (clk) (clk)->tick(k); } while (0)
+#else
+#define VP_TICK(clk, k) do { } while (0)
+#endif
+
 // ---- lane <-> row mapping ---------------------------------------------------------------------
 // A problem is owned by a GROUP of W wavefronts (W = 1: one wavefront; W > 1: one workgroup of W waves for
 // problems whose columns do not fit the registers of one wave).  Rows are dealt to the 64*W group lanes in

@@ -404,7 +404,12 @@ template <typename T, int N, int Q> struct LmState {
 // all-reduce delivers the same totals to all waves), so no LM state is ever exchanged between waves.
 template <typename T, class M, int R, int W, bool WEIGHTED>
 __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
-    constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
+    constexpr int N = M::N, P = M::P, Q = M::Q;
+    // CF: the constant column leads the factorisation and is never materialised (evaluate_core_const_first)
+    constexpr bool CF = M::kConstLast;
+    constexpr int NC = CF ? N + P : N + 1 + P; // register columns
+    constexpr int YC = CF ? N - 1 : N;         // data column
+    constexpr int DC = YC + 1;                 // first derivative column
     constexpr int MP = 64 * R * W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *s_t = reinterpret_cast<T *>(smem_raw);
@@ -445,6 +450,8 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
     src.lane = lane;
     src.vec = true;
     src.set_uniform(a.grid_uniform != 0);
+    ConstReflector<T> h0;
+    if constexpr (CF) h0 = make_const_reflector<T, R, Src, G>(src, grp); // alpha-independent: once per fit
 
     // ---- LM state (wave-uniform) ----
     T x[Q], xt[Q], diag[Q], qtf[Q], step[Q], acnorm[Q], cbest[N];
@@ -486,6 +493,12 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
         ++trow;
     };
 
+#ifdef VP_FIT_CLOCKS
+    SectionClock clk_, *clk = &clk_;
+    clk_.start();
+#else
+    SectionClock *clk = nullptr;
+#endif
     for (;;) {
         // ---- park the LM state in LDS for the duration of the sweep (each wave parks its own copy) ----
         if (grp.lane == 0) {
@@ -518,8 +531,11 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
         // ================= evaluate the VarPro functional at xt =================
         T C[NC][R];
         EvalUniform<T, N> u;
-        load_rows<T, R, W>(s_y, MP, lane, true, C[N]);
-        evaluate_core<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, C, u);
+        load_rows<T, R, W>(s_y, MP, lane, true, C[YC]);
+        VP_TICK(clk, 0);
+        if constexpr (CF) evaluate_core_const_first<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, h0, C, u, clk);
+        else evaluate_core<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, C, u, clk);
+        VP_TICK(clk, 3);
 
         asm volatile("" ::: "memory");
         // ---- un-park ----
@@ -645,16 +661,18 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
             need_jac = good;
         }
 
+        VP_TICK(clk, 4);
         if (need_jac) {
             // ================= Jacobian in Q-coordinates, pivoted QR, Q_J^T r =================
             T Zs[M::kDiagonalPairs ? 1 : Q][R];
-            jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, grp);
-            residual_qcoords<T, R, N>(C[N], u.e, grp);
+            jacobian_qcoords<T, M, R, NC, G, DC>(a.mdl, C, u.c, Zs, grp);
+            residual_qcoords<T, R, N>(C[YC], u.e, grp);
             if constexpr (M::kDiagonalPairs) {
-                jac_qrfac<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[N + 1]), C[N], Rj, acnorm, ipvt, qtf, grp);
+                jac_qrfac<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], Rj, acnorm, ipvt, qtf, grp);
             } else {
-                jac_qrfac<T, R, Q, N>(Zs, C[N], Rj, acnorm, ipvt, qtf, grp);
+                jac_qrfac<T, R, Q, N>(Zs, C[YC], Rj, acnorm, ipvt, qtf, grp);
             }
+            VP_TICK(clk, 5);
             // norm of the scaled gradient
             T gmax = T(0);
             bool degenerate = false;
@@ -701,7 +719,9 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
         }
 
         // ================= trust-region step =================
+        VP_TICK(clk, 6);
         par = lmpar<T, Q>(Rj, ipvt, diag, qtf, delta, par, step, pnorm);
+        VP_TICK(clk, 7);
         if (uni(!is_finite(pnorm))) {
             term = VP_TERM_NUMERICAL;
             break;
@@ -732,7 +752,15 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
         first_tr = false;
 #pragma unroll
         for (int k = 0; k < Q; ++k) xt[k] = x[k] - step[k];
+        VP_TICK(clk, 8);
     }
+#ifdef VP_FIT_CLOCKS
+    // section cycle sums of this fit overwrite the head of its trace record (diagnostic build only)
+    if (a.trace && lane == 0 && a.trace_rows * (Q + 4) >= 12) {
+        double *tr = a.trace + (size_t)b * a.trace_rows * (Q + 4);
+        for (int k = 0; k < 12; ++k) tr[k] = (double)clk_.acc[k];
+    }
+#endif
 
     // ================= results =================
     if (lane == 0) {

@@ -28,6 +28,7 @@ template <int NEXP, bool OFFSET> struct MultiExpModel {
     __host__ __device__ constexpr int pair_arg(int) const { return 0; }
     __host__ __device__ constexpr int pair_param(int p) const { return p; }
     static constexpr bool kDiagonalPairs = true; // pair p <-> (basis p, param p), P == Q
+    static constexpr bool kConstLast = OFFSET;   // the last basis is the constant: see evaluate_core_const_first
 };
 
 // ---- runtime model with compile-time sizes: any mix of kinds / shared parameters ---------------
@@ -35,6 +36,7 @@ template <int N_, int Q_, int P_> struct RtModel {
     static constexpr int N = N_, Q = Q_, P = P_;
     static constexpr bool kStatic = false;
     static constexpr bool kDiagonalPairs = false;
+    static constexpr bool kConstLast = false;
     int32_t kind_[N_];
     int32_t par_[N_][VP_MAX_BASIS_PARAMS];
     int32_t pb_[P_], pa_[P_], pp_[P_];
@@ -158,7 +160,8 @@ struct RowSource {
 // Build the (weighted) basis columns and derivative columns of one problem into the unified column
 // array C:  C[j] = W phi_j  (j < N),  C[N] is left alone (data column),  C[N+1+p] = W dphi_pair_p.
 //   DOFF: index of the first derivative column (N + 1 with a data column at N; N without one)
-template <typename T, class M, int R, int NC, class Src, int DOFF = M::N + 1>
+//   SKIP_CONST: constant basis columns are not written (the caller treats them implicitly)
+template <typename T, class M, int R, int NC, class Src, int DOFF = M::N + 1, bool SKIP_CONST = false>
 __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::Q], const Src &src, T (&C)[NC][R]) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
     constexpr int VW = Layout<R>::VW;
@@ -225,6 +228,7 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                     const T t = tt[e], scl = sc[e];
                     T f, d0 = T(0), d1 = T(0);
                     if (kind[j] == VP_BASIS_CONST) {
+                        if constexpr (SKIP_CONST) continue;
                         f = scl;
                     } else if (kind[j] == VP_BASIS_EXP_DECAY) {
                         // exp(-t/tau);  d/dtau = exp(-t/tau) * t / tau^2   (shared_test_code/src/lib.rs:101-114)
