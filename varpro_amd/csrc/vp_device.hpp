@@ -67,7 +67,7 @@ template <int R, int W = 1> struct Layout {
 };
 
 // exchange area of a multi-wave group in LDS: two phases of all-reduce slots + two phases of broadcast slots
-constexpr int VP_XV = 16; // max values per group all-reduce
+constexpr int VP_XV = 24; // max values per group all-reduce (Gram round of jac_qrfac: Q(Q+1)/2 + Q)
 constexpr int VP_XB = 16; // max values per group broadcast
 template <int W> constexpr int group_xch_bytes() { return W > 1 ? (2 * W * VP_XV + 2 * VP_XB) * 8 : 0; }
 

@@ -224,40 +224,68 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
 }
 
 // MINPACK qrfac (column pivoting, partial-norm downdating) of the Q Jacobian columns Z living in
-// rows >= ROW0, applied simultaneously to the residual column rv (-> qtf), as lmder does.
-// MINPACK's reflector  v = a/ajnorm + e_p,  H = I - v v^T / v_p  is applied in the equivalent
-// unnormalised form  H = I + g v' v'^T,  v' = a + ajnorm e_p,  g = -1/(ajnorm v'_p)  (one reciprocal).
+// rows >= ROW0 (rows < ROW0 of Z are zero), applied simultaneously to the residual column rv (-> qtf), as lmder
+// does.  MINPACK's reflector  v = a/ajnorm + e_p,  H = I - v v^T / v_p  is applied in the equivalent
+// unnormalised form  H = I + g v' v'^T,  v' = a + ajnorm e_p,  g = -1/(ajnorm v'_p).
+// Reduction rounds: ONE for the whole first step -- the Gram matrix of [Z | rv] gives the column norms (pivot
+// choice, acnorm), the pivot column's exact norm and its raw dot products  a^T z_k, a^T rv  (v'^T z = a^T z +
+// ajnorm z[p]) -- and one per further step (raw dots of the new pivot column, its norm among them): Q rounds
+// instead of 1 + 2Q.
 template <typename T, int R, int Q, int ROW0, class G>
 __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q], T (&acnorm)[Q], int (&ipvt)[Q],
                                           T (&qtf)[Q], G &grp) {
     using L = Layout<R, G::W>;
     const int lane = grp.gl;
     T rdiag[Q], wa[Q];
+    T Gm[Q][Q], bz[Q]; // Gram matrix of the columns (symmetric, both triangles kept) and Z^T rv
     {
-        T s[Q];
+        constexpr int NG = Q * (Q + 1) / 2 + Q;
+        T gr[NG];
+        int idx = 0;
 #pragma unroll
-        for (int j = 0; j < Q; ++j) {
+        for (int a = 0; a < Q; ++a)
+#pragma unroll
+            for (int b = a; b < Q; ++b) {
+                T acc = T(0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc = tfma(Z[a][r], Z[b][r], acc);
+                gr[idx++] = acc;
+            }
+#pragma unroll
+        for (int a = 0; a < Q; ++a) {
             T acc = T(0);
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc = tfma(Z[j][r], Z[j][r], acc);
-            s[j] = acc;
+            for (int r = 0; r < R; ++r) acc = tfma(Z[a][r], rv[r], acc);
+            gr[idx++] = acc;
         }
-        group_allreduce(grp, s);
+        group_allreduce(grp, gr);
+        idx = 0;
 #pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            acnorm[j] = usqrt(s[j]);
-            rdiag[j] = acnorm[j];
-            wa[j] = acnorm[j];
-            ipvt[j] = j;
+        for (int a = 0; a < Q; ++a)
+#pragma unroll
+            for (int b = a; b < Q; ++b) {
+                Gm[a][b] = gr[idx];
+                Gm[b][a] = gr[idx];
+                ++idx;
+            }
+#pragma unroll
+        for (int a = 0; a < Q; ++a) bz[a] = gr[idx++];
+#pragma unroll
+        for (int a = 0; a < Q; ++a) {
+            acnorm[a] = usqrt(Gm[a][a]);
+            rdiag[a] = acnorm[a];
+            wa[a] = acnorm[a];
+            ipvt[a] = a;
         }
     }
 #pragma unroll
     for (int i = 0; i < Q; ++i)
 #pragma unroll
-        for (int j = 0; j < Q; ++j) Rj[i][j] = T(0);
-#pragma unroll
-    for (int j = 0; j < Q; ++j) {
-        const int prow = ROW0 + j;
+        for (int k = 0; k < Q; ++k) Rj[i][k] = T(0);
+    static_for<0, Q>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int prow = ROW0 + j;
+        constexpr int NREM = Q - j; // columns j .. Q-1
         // bring the column of largest (downdated) norm into the pivot position
         int kmax = j;
 #pragma unroll
@@ -285,62 +313,92 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
                 const int ti = ipvt[j];
                 ipvt[j] = ipvt[k];
                 ipvt[k] = ti;
+                if constexpr (j == 0) { // the Gram bookkeeping follows the columns (only step 0 uses it)
+#pragma unroll
+                    for (int a = 0; a < Q; ++a) {
+                        const T tmp = Gm[a][0];
+                        Gm[a][0] = Gm[a][k];
+                        Gm[a][k] = tmp;
+                    }
+#pragma unroll
+                    for (int a = 0; a < Q; ++a) {
+                        const T tmp = Gm[0][a];
+                        Gm[0][a] = Gm[k][a];
+                        Gm[k][a] = tmp;
+                    }
+                    const T tb = bz[0];
+                    bz[0] = bz[k];
+                    bz[k] = tb;
+                }
             }
         }
-        // Householder vector for column j (rows >= prow)
-        T s = T(0);
+        // raw dot products of the pivot column a (rows >= prow) with itself, the remaining columns and rv
+        T dz[NREM], dr;
+        if constexpr (j == 0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const T v = (r >= L::VW || L::row_of(r, lane) >= prow) ? Z[j][r] : T(0);
-            s = tfma(v, v, s);
+            for (int k = 0; k < NREM; ++k) dz[k] = Gm[0][k];
+            dr = bz[0];
+        } else {
+            // rows ROW0 .. prow-1 of the pivot column hold R entries that were already extracted: clear them
+#pragma unroll
+            for (int r = 0; r < L::VW && r < R; ++r) {
+                const int i = L::row_of(r, lane);
+                Z[j][r] = (i >= prow) ? Z[j][r] : T(0);
+            }
+            T w[NREM + 1];
+#pragma unroll
+            for (int k = j; k < Q; ++k) {
+                T acc = T(0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc = tfma(Z[j][r], Z[k][r], acc);
+                w[k - j] = acc;
+            }
+            {
+                T acc = T(0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc = tfma(Z[j][r], rv[r], acc);
+                w[NREM] = acc;
+            }
+            group_allreduce(grp, w);
+#pragma unroll
+            for (int k = 0; k < NREM; ++k) dz[k] = w[k];
+            dr = w[NREM];
         }
-        T ajnorm = usqrt(group_sum(grp, s));
+        // pivot-row entries of the same columns and of rv: one broadcast
+        T top[NREM + 1];
+#pragma unroll
+        for (int k = j; k < Q; ++k) top[k - j] = Z[k][L::reg_of_row(prow)];
+        top[NREM] = rv[L::reg_of_row(prow)];
+        group_bcast<NREM + 1>(grp, top, L::lane_of_row(prow));
+        T ajnorm = usqrt(dz[0]);
         if (uni(ajnorm == T(0))) {
             rdiag[j] = T(0);
             // remaining columns untouched: their row-prow entries are the R entries
 #pragma unroll
-            for (int k = j + 1; k < Q; ++k) Rj[j][k] = group_row<R>(grp, Z[k], prow);
-            qtf[j] = group_row<R>(grp, rv, prow);
-            continue;
+            for (int k = j + 1; k < Q; ++k) Rj[j][k] = top[k - j];
+            qtf[j] = top[NREM];
+            return;
         }
-        const T piv = group_row<R>(grp, Z[j], prow);
+        const T piv = top[0];
         if (piv < T(0)) ajnorm = -ajnorm;
-        const T vp = piv + ajnorm;          // v'_p
-        const T gj = -T(1) / (ajnorm * vp); // H = I + gj v' v'^T
+        const T vp = piv + ajnorm;           // v'_p
+        const T gj = -frcp(ajnorm * vp);     // H = I + gj v' v'^T
 #pragma unroll
         for (int r = 0; r < L::VW && r < R; ++r) {
             const int i = L::row_of(r, lane);
-            Z[j][r] = (i > prow) ? Z[j][r] : ((i == prow) ? vp : T(0));
+            Z[j][r] = (i == prow) ? vp : Z[j][r];
         }
-        // dots with the remaining columns and with the residual column: one reduction round
-        T w[Q]; // w[0..Q-j-2]: columns k > j ; w[Q-1]: residual
-#pragma unroll
-        for (int k = 0; k < Q; ++k) w[k] = T(0);
 #pragma unroll
         for (int k = j + 1; k < Q; ++k) {
-            T acc = T(0);
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc = tfma(Z[j][r], Z[k][r], acc);
-            w[k - j - 1] = acc;
-        }
-        {
-            T acc = T(0);
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc = tfma(Z[j][r], rv[r], acc);
-            w[Q - 1] = acc;
-        }
-        group_allreduce(grp, w);
-#pragma unroll
-        for (int k = j + 1; k < Q; ++k) {
-            const T f = gj * w[k - j - 1];
+            const T f = gj * tfma(ajnorm, top[k - j], dz[k - j]); // gj * v'^T z_k
 #pragma unroll
             for (int r = 0; r < R; ++r) Z[k][r] = tfma(f, Z[j][r], Z[k][r]);
-            const T akj = group_row<R>(grp, Z[k], prow);
+            const T akj = tfma(f, vp, top[k - j]); // row prow of the updated column
             Rj[j][k] = akj;
             if (uni(rdiag[k] != T(0))) {
-                const T tq = akj / rdiag[k];
+                const T tq = akj * frcp(rdiag[k]);
                 rdiag[k] = rdiag[k] * usqrt(tmax(T(0), T(1) - tq * tq));
-                const T rr = rdiag[k] / wa[k];
+                const T rr = rdiag[k] * frcp(wa[k]);
                 if (uni(T(0.05) * (rr * rr) <= num<T>::eps)) {
                     T s2 = T(0);
 #pragma unroll
@@ -354,13 +412,13 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
             }
         }
         {
-            const T f = gj * w[Q - 1];
+            const T f = gj * tfma(ajnorm, top[NREM], dr);
 #pragma unroll
             for (int r = 0; r < R; ++r) rv[r] = tfma(f, Z[j][r], rv[r]);
-            qtf[j] = group_row<R>(grp, rv, prow);
+            qtf[j] = tfma(f, vp, top[NREM]);
         }
         rdiag[j] = -ajnorm;
-    }
+    });
 #pragma unroll
     for (int j = 0; j < Q; ++j) Rj[j][j] = rdiag[j];
 }
