@@ -95,3 +95,32 @@ def test_fp32_five_exponentials_config4_shape():
     ok = rep["termination"] > 0
     assert (rep["objective"][ok] <= ev["cost"][ok] * (1 + 1e-3)).all()
     bp.close()
+
+
+def test_fp32_config4_full_size_properties():
+    # BASELINE configs[4] at FULL size: B = 8192 problems, m = 4096, five exponentials + offset, fp32, four waves
+    # per problem.  What fp32 can promise (cond(Phi) >= 1e6): r orthogonal to range(Phi), y = Phi c + r, a fit that
+    # never increases the cost of a problem it reports as successful, consistent summary.
+    taus = [0.5, 1.5, 3.0, 6.0, 12.0]
+    B, m = 8192, 4096
+    d = synth.multi_exp_batch(B, 5, m, taus, noise=1e-3, spread=0.1, guess_spread=0.05, dtype=np.float32)
+    mdl32 = vp.multi_exponential_model(d["x"], d["tau_guess"][0], dtype=np.float32)
+    bp = vp.BatchProblem(mdl32, d["Y"], x=d["x"])
+    ev = bp.evaluate(d["tau_guess"], want_jacobian=False)
+    assert (ev["status"] == 0).mean() > 0.99
+    sub = np.arange(0, B, 64)                      # host-side checks on every 64th problem (fp64 accumulation)
+    phi, _ = bp.basis(d["tau_guess"])
+    P = phi[sub].astype(np.float64)
+    r = ev["r"][sub].astype(np.float64)
+    Y = d["Y"][sub].astype(np.float64)
+    ortho = np.abs(np.einsum("bjm,bm->bj", P, r)) / (np.linalg.norm(P, axis=2) * np.linalg.norm(Y, axis=1)[:, None])
+    assert ortho.max() <= 1e-4
+    recon = np.einsum("bjm,bj->bm", P, ev["C"][sub].astype(np.float64)) + r
+    assert np.abs(recon - Y).max() <= 2e-3 * np.abs(Y).max()   # Phi c in fp32 with |c| up to cond(Phi) * |y|
+    alpha, C, rep = bp.fit(d["tau_guess"])
+    ok = rep["termination"] > 0
+    assert ok.mean() > 0.7                         # fp32 failures of this model are documented
+    assert (rep["objective"][ok] <= ev["cost"][ok] * (1 + 1e-3) + 1e-6).all()
+    s = bp.summary()
+    assert s[1] == ok.sum() and s[1] + s[2] == B and s[3] == rep["n_evals"].sum()
+    bp.close()

@@ -135,3 +135,30 @@ def test_mrhs_rank_deficient_basis_takes_the_truncated_svd_branch(S, m):
     a, c, rep = bp.fit(np.array([[2.0, 2.0]]))
     assert rep["termination"][0] != -1 and np.isfinite(rep["objective"][0])
     bp.close()
+
+
+def test_mrhs_config2_full_size_properties():
+    # BASELINE configs[2] at FULL size (S = 16384 right-hand sides, m = 2048, n = 4, q = 3; 268 MB of data):
+    # size-independent properties instead of the oracle -- the noise-free global fit recovers the decay times
+    # and every column's coefficients, r is orthogonal to range(Phi), y = Phi c + r, cost = 1/2 ||r||^2.
+    d = synth.mrhs_triple_exp()
+    S, m = d["Y"].shape
+    assert (S, m) == (16384, 2048)
+    mdl = _triple(d["x"], d["tau_guess"])
+    bp = vp.BatchProblem(mdl, d["Y"][None], x=d["x"])
+    ev = bp.evaluate(d["tau_guess"][None], want_jacobian=False)
+    assert ev["status"][0] == 0
+    phi, _ = bp.basis(d["tau_guess"][None])
+    Phi = phi[0]                                   # (n, m)
+    r = ev["r"][0].reshape(S, m)
+    C = ev["C"][0]                                 # (S, n)
+    assert np.abs(C @ Phi + r - d["Y"]).max() <= 1e-10 * np.abs(d["Y"]).max()
+    ortho = np.abs(r @ Phi.T) / (np.linalg.norm(r, axis=1)[:, None] * np.linalg.norm(Phi, axis=1)[None, :] + 1e-300)
+    assert ortho.max() <= 1e-9
+    assert abs(ev["cost"][0] - 0.5 * (r ** 2).sum()) <= 1e-10 * ev["cost"][0]
+    alpha, Cf, rep = bp.fit(d["tau_guess"][None])
+    assert rep["termination"][0] > 0 and rep["n_evals"][0] < 40
+    assert np.abs(np.sort(alpha[0]) - d["tau_true"]).max() < 1e-6
+    assert np.abs(Cf[0] - d["C_true"]).max() < 1e-4 * np.abs(d["C_true"]).max()
+    assert rep["objective"][0] <= 1e-12 * 0.5 * (d["Y"] ** 2).sum()
+    bp.close()
