@@ -24,10 +24,11 @@ ts = []
 for _ in range(8):
     a, c, rep = bp.fit(g, want_coefficients=False); ts.append(bp.last_kernel_ms(_lib.VP_KERNEL_FIT))
 r = bp.report_to_numpy(rep)
-ts2 = []
-for _ in range(4):
-    bp.basis(g, device_out=True) if hasattr(bp, "_basis_dev") else None
-print("ev0 %%.3f ev1 %%.3f ev2 %%.3f fit %%.3f ms (median %%.3f)  evals %%d  cost %%.9e" %% (out[0], out[1], out[2], min(ts), sorted(ts)[len(ts)//2], r["n_evals"].sum(), np.nansum(r["objective"])))
+_ph = torch.empty((B, 2, 1024), dtype=torch.float64, device=dev); _dp = torch.empty((B, 2, 1024), dtype=torch.float64, device=dev)
+tb = []
+for _ in range(6):
+    bp.basis(g, skip_invariant=True, out_phi=_ph, out_dphi=_dp); tb.append(bp.last_kernel_ms(_lib.VP_KERNEL_BASIS))
+print("ev0 %%.3f ev1 %%.3f ev2 %%.3f basis %%.3f fit %%.3f ms (median %%.3f)  evals %%d  cost %%.9e" %% (out[0], out[1], out[2], min(tb), min(ts), sorted(ts)[len(ts)//2], r["n_evals"].sum(), np.nansum(r["objective"])))
 ''' % ROOT
 libs = [a for a in sys.argv[1:] if a.endswith(".so")]
 rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
