@@ -361,6 +361,8 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
     if (int rc = h->kern->mrhs_lm(p)) return fail(rc, "mrhs_lm (init) launch failed");
     p.mrhs_init = 0;
     const int max_iter = o.patience * (h->q + 1) + 2;
+    int sync_every = 4;
+    if (const char *e = std::getenv("VP_MRHS_SYNC_EVERY")) sync_every = std::max(1, std::atoi(e));
     // right-hand sides sharded over ranks: the reduced sums of this rank's columns are totalled in a fixed order,
     // summed over the ranks by the caller's collective (RCCL all-reduce of B*(1+n*n+p) doubles per evaluation) and
     // fed to the LM step as a single slot; every rank then takes bit-identical decisions.
@@ -389,6 +391,10 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         if (int rc = h->kern->mrhs_lm(p)) return fail(rc, "mrhs_lm launch failed");
         p.mrhs_ws = &h->mrhs;
         p.mrhs_gx = 0;
+        // the host looks at the number of still-active problems only every few iterations: terminated problems
+        // are skipped on the device (MrhsWs::done), so an iteration enqueued past the end costs three empty
+        // launches, while every avoided read-back saves a full stream drain
+        if ((it + 1) % sync_every != 0 && it + 1 < max_iter) continue;
         int32_t nact = 0;
         VP_HIP(hipMemcpyAsync(&nact, h->mrhs.nactive, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         VP_HIP(hipStreamSynchronize(h->stream));
@@ -580,6 +586,8 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         VP_TRY(hipMalloc((void **)&h->mrhs.acc, (size_t)B * 256 * (1 + n_ * n_ + p_) * sizeof(double)));
         VP_TRY(hipMalloc(&h->mrhs.lm_state, (size_t)B * kern->mrhs_state_bytes));
         VP_TRY(hipMalloc((void **)&h->mrhs.nactive, sizeof(int32_t)));
+        VP_TRY(hipMalloc((void **)&h->mrhs.done, (size_t)B * sizeof(int32_t)));
+        VP_TRY(hipMemsetAsync(h->mrhs.done, 0, (size_t)B * sizeof(int32_t), h->stream));
         VP_TRY(hipMalloc(&h->mrhs.alpha_trial, (size_t)std::max<int64_t>(1, B * q_) * ts));
         h->have_mrhs = true;
     }
@@ -613,6 +621,7 @@ void vp_batch_destroy(vp_batch *h) {
         (void)hipFree(h->mrhs.g);
         (void)hipFree(h->mrhs.small);
         (void)hipFree(h->mrhs.statusA);
+        (void)hipFree(h->mrhs.done);
         (void)hipFree(h->mrhs.acc);
         (void)hipFree(h->mrhs.lm_state);
         (void)hipFree(h->mrhs.nactive);

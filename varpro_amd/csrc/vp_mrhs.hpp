@@ -41,6 +41,7 @@ struct MrhsWs {
     double *acc;      // [B][gx][1 + N*N + P]  per-workgroup partials of sum ||r||^2, sum c c^T, sum c_{j(p)} u_p
     void *lm_state;   // [B] LmVars
     int32_t *nactive; // [1]
+    int32_t *done;    // [B] 1 once the problem's LM loop has terminated: later factor / stream launches skip it
     void *alpha_trial; // [B][q] T
     int32_t *nevals;  // unused
 };
@@ -55,6 +56,7 @@ template <typename T, class M> struct MrhsFactorArgs {
     int64_t B;
     int64_t t_stride, w_stride;
     T eps;
+    int skip_done; // fit loop: problems whose LM loop has terminated are skipped
 };
 
 template <typename T, class M, int R>
@@ -65,6 +67,7 @@ __global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T,
     Grp<1> grp = Grp<1>::make(nullptr);
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
+    if (a.skip_done && uni(a.ws.done[b]) != 0) return;
     const int m = a.m;
     T alpha[Q];
 #pragma unroll
@@ -220,6 +223,9 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
     const int wave = (int)(threadIdx.x >> 6), nwave = (int)(blockDim.x >> 6);
     const int64_t b = blockIdx.y;
     const int m = a.m;
+    if constexpr (MODE == 0) {
+        if (a.ws.done[b] != 0) return; // the LM loop of this problem has terminated (uniform per workgroup)
+    }
     const T *qsrc = (const T *)a.ws.qthin + b * (int64_t)N * m;
     const T *gsrc = (const T *)a.ws.g + b * (int64_t)P * m;
     for (int idx = threadIdx.x; idx < (N + P) * MP; idx += blockDim.x) {
@@ -444,6 +450,7 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
 #pragma unroll
             for (int k = 0; k < Q; ++k) trial[k] = s.xt[k];
             atomicAdd(a.ws.nactive, 1);
+            a.ws.done[b] = 0;
         }
         return;
     }
@@ -506,7 +513,10 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
         *gs = s;
 #pragma unroll
         for (int k = 0; k < Q; ++k) trial[k] = s.xt[k];
-        if (s.term != 0) atomicAdd(a.ws.nactive, -1);
+        if (s.term != 0) {
+            atomicAdd(a.ws.nactive, -1);
+            a.ws.done[b] = 1;
+        }
     }
 }
 
@@ -547,6 +557,7 @@ template <typename T, class M, int R> int launch_mrhs_factor(const LaunchParams 
     a.t_stride = p.t_stride;
     a.w_stride = p.w_stride;
     a.eps = (T)p.eps;
+    a.skip_done = (p.mrhs_mode == 0) ? 1 : 0; // fit loop (reduced sums) vs trait-level evaluation
     hipLaunchKernelGGL((mrhs_factor_kernel<T, M, R>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
