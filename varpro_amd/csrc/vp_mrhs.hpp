@@ -59,12 +59,16 @@ template <typename T, class M> struct MrhsFactorArgs {
     int skip_done; // fit loop: problems whose LM loop has terminated are skipped
 };
 
-template <typename T, class M, int R>
-__global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T, M> a) {
+// W waves per problem: W = 1 for batches that fill the GPU with one wave per problem; W = 4 (R/4 rows per lane) when
+// there are few problems and the factorisation of ONE tall Phi is on the critical path of every LM iteration.
+template <typename T, class M, int R, int W = 1>
+__global__ void __launch_bounds__(64 * W) mrhs_factor_kernel(const MrhsFactorArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + P;
-    using L = Layout<R>;
-    const int lane = lane_id();
-    Grp<1> grp = Grp<1>::make(nullptr);
+    using L = Layout<R, W>;
+    using G = Grp<W>;
+    __shared__ __attribute__((aligned(16))) unsigned char s_xch[group_xch_bytes<W>() > 0 ? group_xch_bytes<W>() : 16];
+    G grp = G::make(s_xch);
+    const int lane = grp.gl; // group lane
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
     if (a.skip_done && uni(a.ws.done[b]) != 0) return;
@@ -72,16 +76,17 @@ __global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T,
     T alpha[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
-    RowSource<T, R> src;
+    using Src = RowSource<T, R, false, 2, 2, W>;
+    Src src;
     src.t = a.t + b * a.t_stride;
     src.w = a.w ? a.w + b * a.w_stride : nullptr;
     src.m = m;
     src.lane = lane;
     src.vec = false;
     T C[NC][R];
-    build_columns<T, M, R, NC, RowSource<T, R>, N>(a.mdl, alpha, src, C);
+    build_columns<T, M, R, NC, Src, N>(a.mdl, alpha, src, C);
     T g[N], Rm[N][N], qdummy[N];
-    house_qr<T, R, N, NC, 0, false, Grp<1>>(C, g, Rm, qdummy, grp);
+    house_qr<T, R, N, NC, 0, false, G>(C, g, Rm, qdummy, grp);
     // R^{-1} (upper triangular) and the rank test of solve_coeffs
     double *small = a.ws.small + b * mrhs_small_stride<N, P>();
     int st = VP_ST_OK;
@@ -176,24 +181,36 @@ __global__ void __launch_bounds__(64) mrhs_factor_kernel(const MrhsFactorArgs<T,
                 for (int r = 0; r < R; ++r) acc = tfma(C[N + p][r], C[N + p2][r], acc);
                 gg[p * P + p2] = acc;
             }
-        wave_allreduce(gg);
+        group_allreduce(grp, gg);
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < P * P; ++i) small[N * N + i] = (double)gg[i];
         }
         T *gout = (T *)a.ws.g + b * (int64_t)P * m;
 #pragma unroll
-        for (int p = 0; p < P; ++p) store_rows<T, R>(gout + (int64_t)p * m, m, lane, false, C[N + p]);
+        for (int p = 0; p < P; ++p) store_rows<T, R, W>(gout + (int64_t)p * m, m, lane, false, C[N + p]);
     }
-    // explicit thin Q: column j = Q e_j
+    // explicit thin Q: column j = Q e_j -- all N unit vectors in one back-sweep (N rounds) when they fit the
+    // registers, else one by one (N*N rounds)
     T *qout = (T *)a.ws.qthin + b * (int64_t)N * m;
+    if constexpr (N * R * (int)(sizeof(T) / 4) <= 96) {
+        T Z[N][R];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        T Z[1][R];
+        for (int j = 0; j < N; ++j)
 #pragma unroll
-        for (int r = 0; r < R; ++r) Z[0][r] = (L::row_of(r, lane) == j) ? T(1) : T(0);
-        apply_q<T, R, N, NC, 1>(C, g, Z, grp);
-        store_rows<T, R>(qout + (int64_t)j * m, m, lane, false, Z[0]);
+            for (int r = 0; r < R; ++r) Z[j][r] = (L::row_of(r, lane) == j) ? T(1) : T(0);
+        apply_q<T, R, N, NC, N>(C, g, Z, grp);
+#pragma unroll
+        for (int j = 0; j < N; ++j) store_rows<T, R, W>(qout + (int64_t)j * m, m, lane, false, Z[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            T Z[1][R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) Z[0][r] = (L::row_of(r, lane) == j) ? T(1) : T(0);
+            apply_q<T, R, N, NC, 1>(C, g, Z, grp);
+            store_rows<T, R, W>(qout + (int64_t)j * m, m, lane, false, Z[0]);
+        }
     }
 }
 
@@ -558,7 +575,14 @@ template <typename T, class M, int R> int launch_mrhs_factor(const LaunchParams 
     a.w_stride = p.w_stride;
     a.eps = (T)p.eps;
     a.skip_done = (p.mrhs_mode == 0) ? 1 : 0; // fit loop (reduced sums) vs trait-level evaluation
-    hipLaunchKernelGGL((mrhs_factor_kernel<T, M, R>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+    // few problems: the factorisation is pure latency -> 4 waves per problem (R/4 rows per lane)
+    if constexpr (R % 4 == 0 && R / 4 >= 2) {
+        if (a.B <= 1024) {
+            hipLaunchKernelGGL((mrhs_factor_kernel<T, M, R / 4, 4>), dim3((unsigned)a.B), dim3(256), 0, p.stream, a);
+            return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL((mrhs_factor_kernel<T, M, R, 1>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
