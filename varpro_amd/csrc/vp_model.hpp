@@ -90,7 +90,9 @@ __device__ __noinline__ float tcos(float x) { return __ocml_cos_f32(x); }
 //   VMODE  : 0 = scalar accesses only, 1 = 2-element aligned accesses (compile time), 2 = decide by `vec`
 //   RECUR  : the kernel may use the uniform-grid exp recurrence of build_columns (it calls set_uniform);
 //            false removes that code path at compile time (kernels that are HBM-bound or off the hot path)
-template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2, int W = 1, bool RECUR = false>
+//   FULL   : (PADDED, unit weights) m == 64*R*W, no padding rows at all: the row scale is the constant 1
+template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2, int W = 1, bool RECUR = false,
+          bool FULL = false>
 struct RowSource {
     const T *t;  // grid, indexed by row (LDS or global)
     const T *w;  // weights indexed by row, or nullptr for unit weights
@@ -124,6 +126,27 @@ struct RowSource {
         const int i = L::row_of(r0, lane);
         if constexpr (L::VW == 2) {
             using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+            if constexpr (PADDED) {
+                // zero-padded LDS copies: the grid value of a padding row is 0 by construction, and so is its
+                // weight; only the unit-weight scale of a partially filled problem needs the validity mask
+                const V2 v = *reinterpret_cast<const V2 *>(t + i);
+                tt[0] = v.x;
+                tt[1] = v.y;
+                if constexpr (WMODE == 1) {
+                    const V2 u = *reinterpret_cast<const V2 *>(w + i);
+                    sc[0] = u.x;
+                    sc[1] = u.y;
+                    return;
+                } else if constexpr (WMODE == 0 && FULL) {
+                    sc[0] = T(1);
+                    sc[1] = T(1);
+                    return;
+                } else if constexpr (WMODE == 0) {
+                    sc[0] = (i < m) ? T(1) : T(0);
+                    sc[1] = (i + 1 < m) ? T(1) : T(0);
+                    return;
+                }
+            }
             if (PADDED || VMODE == 1 || (VMODE == 2 && vec)) {
                 const bool in0 = i < m, in1 = (i + 1) < m; // !PADDED: m even, in1 == in0
                 const int ic = PADDED ? i : (in0 ? i : 0);
