@@ -67,6 +67,12 @@ static void test_errors() {
     EXPECT(variant_of([&] { SeparableProblemBuilder::new_(m).observations({1, 2, 3}).build(); }) == "InvalidLengthOfData");
     EXPECT(variant_of([&] { SeparableProblemBuilder::new_(m).observations({1, 2, 3, 4}).weights({1, 2}).build(); }) ==
            "InvalidLengthOfWeights");
+    // Student-t quantiles (the `distrs` scalar of src/statistics/mod.rs:285-288) against table values
+    EXPECT(std::fabs(student_t_quantile(0.975, 10.0) - 2.2281388519649385) < 1e-10);
+    EXPECT(std::fabs(student_t_quantile(0.95, 3.0) - 2.3533634348018264) < 1e-10);
+    EXPECT(std::fabs(student_t_quantile(0.995, 995.0) - 2.5807794935342003) < 1e-9);
+    EXPECT(std::fabs(student_t_quantile(0.025, 10.0) + 2.2281388519649385) < 1e-10);
+    EXPECT(student_t_quantile(0.5, 7.0) == 0.0);
 }
 
 static void test_gpu() {

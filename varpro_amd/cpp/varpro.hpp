@@ -201,6 +201,68 @@ struct LevenbergMarquardt {
     LevenbergMarquardt &with_scale_diag(bool v) { return o.scale_diag = v ? 1 : 0, *this; }
 };
 
+// ---- Student-t quantile: the scalar the reference takes from the `distrs` crate (src/statistics/mod.rs:285-288) to
+// turn the unscaled confidence sigma into confidence_band_radius(p) = sigma * t_ppf((1+p)/2, dof) ------------------
+namespace detail {
+// regularised incomplete beta function I_x(a, b) (Lentz continued fraction)
+inline double betainc(double a, double b, double x) {
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    const double lbeta = std::lgamma(a) + std::lgamma(b) - std::lgamma(a + b);
+    const double front = std::exp(a * std::log(x) + b * std::log1p(-x) - lbeta);
+    auto cf = [](double a_, double b_, double x_) {
+        const double tiny = 1e-300;
+        double c = 1.0, d = 1.0 - (a_ + b_) * x_ / (a_ + 1.0);
+        if (std::fabs(d) < tiny) d = tiny;
+        d = 1.0 / d;
+        double h = d;
+        for (int m = 1; m <= 500; ++m) {
+            const double m2 = 2.0 * m;
+            double aa = m * (b_ - m) * x_ / ((a_ + m2 - 1.0) * (a_ + m2));
+            d = 1.0 + aa * d;
+            if (std::fabs(d) < tiny) d = tiny;
+            c = 1.0 + aa / c;
+            if (std::fabs(c) < tiny) c = tiny;
+            d = 1.0 / d;
+            h *= d * c;
+            aa = -(a_ + m) * (a_ + b_ + m) * x_ / ((a_ + m2) * (a_ + m2 + 1.0));
+            d = 1.0 + aa * d;
+            if (std::fabs(d) < tiny) d = tiny;
+            c = 1.0 + aa / c;
+            if (std::fabs(c) < tiny) c = tiny;
+            d = 1.0 / d;
+            const double del = d * c;
+            h *= del;
+            if (std::fabs(del - 1.0) < 1e-16) break;
+        }
+        return h;
+    };
+    if (x < (a + 1.0) / (a + b + 2.0)) return front * cf(a, b, x) / a;
+    return 1.0 - front * cf(b, a, 1.0 - x) / b;
+}
+inline double student_t_cdf(double t, double dof) {
+    const double x = dof / (dof + t * t);
+    const double tail = 0.5 * betainc(0.5 * dof, 0.5, x);
+    return t >= 0.0 ? 1.0 - tail : tail;
+}
+} // namespace detail
+
+// t such that P(T <= t) = p for Student's t with `dof` degrees of freedom (bisection on the CDF; |error| < 1e-12 t)
+inline double student_t_quantile(double p, double dof) {
+    if (!(p > 0.0 && p < 1.0) || !(dof > 0.0)) throw std::invalid_argument("student_t_quantile: p in (0,1), dof > 0");
+    if (p == 0.5) return 0.0;
+    const bool upper = p > 0.5;
+    const double pp = upper ? p : 1.0 - p;
+    double lo = 0.0, hi = 1.0;
+    while (detail::student_t_cdf(hi, dof) < pp && hi < 1e300) hi *= 2.0;
+    for (int it = 0; it < 200 && hi - lo > 1e-14 * hi; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        (detail::student_t_cdf(mid, dof) < pp ? lo : hi) = mid;
+    }
+    const double t = 0.5 * (lo + hi);
+    return upper ? t : -t;
+}
+
 // B independent problems x S right-hand sides on one GPU (host-pointer mode; fp64)
 class BatchProblem {
     vp_batch *h_ = nullptr;
@@ -269,6 +331,15 @@ class BatchProblem {
         std::vector<double> reduced_chi2; // [B]
         std::vector<double> conf_sigma;   // [B][m]  multiply by the Student-t quantile for a confidence band
         std::vector<int32_t> status;      // [B]  0 ok, 4 = Underdetermined / MatrixInversion
+        int64_t m = 0, dof = 0;
+        // == FitStatistics::confidence_band_radius (src/statistics/mod.rs:271-304) of problem b
+        std::vector<double> confidence_band_radius(int64_t b, double probability) const {
+            if (!(probability > 0.0 && probability < 1.0)) throw std::invalid_argument("probability must be in (0,1)");
+            const double tq = student_t_quantile(0.5 * (1.0 + probability), (double)dof);
+            std::vector<double> r((size_t)m);
+            for (int64_t i = 0; i < m; ++i) r[(size_t)i] = tq * conf_sigma[(size_t)(b * m + i)];
+            return r;
+        }
     };
     Statistics statistics() const {
         Statistics s;
@@ -277,6 +348,8 @@ class BatchProblem {
         s.reduced_chi2.resize((size_t)B);
         s.conf_sigma.resize((size_t)(B * m));
         s.status.resize((size_t)B);
+        s.m = m;
+        s.dof = m - (int64_t)k;
         check(vp_statistics(h_, s.covariance.data(), s.reduced_chi2.data(), s.conf_sigma.data(), s.status.data()));
         return s;
     }
