@@ -12,12 +12,18 @@ from varpro_amd import synth
 
 NAMES = ["park+load y", "build columns", "house_qr", "solve+norm", "LM accept/terminate", "jacobian + jac_qrfac",
          "gnorm/diag", "lmpar", "prered/next step", "-", "-", "-"]
-for B in [int(a) for a in sys.argv[1:]] or [256, 65536]:
-    d = synth.double_exp_batch(B, m=1024, noise=1e-3)
-    mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0])
+CFG4 = "cfg4" in sys.argv  # fp32 five exponentials + offset, m = 4096, four waves per problem
+for B in [int(a) for a in sys.argv[1:] if a.isdigit()] or [256, 65536]:
+    if CFG4:
+        d = synth.multi_exp_batch(B, 5, 4096, [0.5, 1.5, 3.0, 6.0, 12.0], noise=1e-3, spread=0.1, guess_spread=0.05,
+                                  dtype=np.float32)
+        mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0], dtype=np.float32)
+    else:
+        d = synth.double_exp_batch(B, m=1024, noise=1e-3)
+        mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0])
     bp = vp.BatchProblem(mdl, d["Y"], x=d["x"])
     a, c, rep, tr = bp.fit_trace(d["tau_guess"], max_rows=4)   # 4 rows x (q+4)=6 -> 24 doubles >= 12
-    clk = tr.reshape(B, -1)[:, :12]
+    clk = tr.reshape(B, -1)[:, :12].astype(np.float64)
     ne = rep["n_evals"].astype(np.float64)
     per_iter = clk.sum(0) / ne.sum()
     tot = per_iter.sum()
