@@ -432,3 +432,29 @@ def test_runtime_descriptor_models_beyond_128_rows(m):
     stt = bp.statistics()
     assert (stt["status"] == 0).all() and np.isfinite(stt["cov"]).all() and np.isfinite(stt["conf_sigma"]).all()
     bp.close()
+
+
+def test_overflowing_basis_is_a_failed_evaluation_like_the_reference():
+    # exp(-t/tau) with a small negative tau overflows to inf: the reference's SVD of a matrix with inf entries yields
+    # NaN residuals, i.e. residuals() == None and the fit ends with TerminationReason::User (Err).  The device must
+    # flag the evaluation too -- on the per-row path and on the uniform-grid recurrence path (whose finite clamp
+    # must not hide the overflow) -- and must not let LM continue on a bogus finite cost.
+    x = np.linspace(0.0, 12.5, 1000)
+    rng = np.random.default_rng(8)
+    B = 6
+    Y = 3.0 * np.exp(-x / 1.0) + 2.0 * np.exp(-x / 4.0) + 1.0 + 1e-3 * rng.standard_normal((B, 1000))
+    alpha = np.tile([1.2, 3.5], (B, 1))
+    alpha[1] = [-0.01, 3.5]     # exp(+1250) -> inf
+    alpha[4] = [1.2, -0.005]
+    mdl = double_exp_builder_model(x, alpha[0])
+    ref = O.evaluate_batch(mdl, x, Y, alpha, n_threads=2)
+    for rec in (True, False):
+        bp = vp.BatchProblem(mdl, Y, x=x, grid_recurrence=rec)
+        ev = bp.evaluate(alpha)
+        assert ((ev["status"] != 0) == (ref["status"] != 0)).all(), (rec, ev["status"], ref["status"])
+        assert (ev["status"][[1, 4]] != 0).all() and (ev["status"][[0, 2, 3, 5]] == 0).all()
+        a, c, rep = bp.fit(alpha)
+        a_ref, c_ref, rep_ref, _ = O.fit_batch(mdl, x, Y, alpha, n_threads=2)
+        assert ((rep["termination"] > 0) == (rep_ref["termination"] > 0)).all(), (rep["termination"], rep_ref["termination"])
+        assert (rep["termination"][[1, 4]] <= 0).all() and (rep["termination"][[0, 2, 3, 5]] > 0).all()
+        bp.close()

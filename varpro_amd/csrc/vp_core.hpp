@@ -339,9 +339,11 @@ __device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::
 #pragma unroll
     for (int k = 0; k < N; ++k) fn2 = tfma(u.e[k], u.e[k], fn2);
     u.fn2 = fn2;
+    // a basis column that overflowed (inf / NaN norm) leaves a non-finite diagonal in R: the reference's SVD turns
+    // that into NaN residuals (residuals() == None); c alone would not show it (1/inf = 0)
     bool ok = is_finite(fn2);
 #pragma unroll
-    for (int k = 0; k < N; ++k) ok = ok && is_finite(u.c[k]);
+    for (int k = 0; k < N; ++k) ok = ok && is_finite(u.c[k]) && is_finite(Rm[k][k]);
     u.ok = uni(ok);
 }
 
@@ -468,9 +470,11 @@ __device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T 
 #pragma unroll
     for (int k = 0; k < N; ++k) fn2 = tfma(u.e[k], u.e[k], fn2);
     u.fn2 = fn2;
+    // a basis column that overflowed (inf / NaN norm) leaves a non-finite diagonal in R: the reference's SVD turns
+    // that into NaN residuals (residuals() == None); c alone would not show it (1/inf = 0)
     bool ok = is_finite(fn2);
 #pragma unroll
-    for (int k = 0; k < N; ++k) ok = ok && is_finite(u.c[k]);
+    for (int k = 0; k < N; ++k) ok = ok && is_finite(u.c[k]) && is_finite(Rm[k][k]);
     u.ok = uni(ok);
 }
 
