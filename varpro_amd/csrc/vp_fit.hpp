@@ -39,7 +39,7 @@ template <typename T, int Q, bool U = true> __device__ __forceinline__ T enorm_s
     T s = T(0);
 #pragma unroll
     for (int j = 0; j < Q; ++j) s = tfma(v[j], v[j], s);
-    if (pol<U>(s > T(1e-280) && s < T(1e280))) return fsqrt(s);
+    if (pol<U>(s > T(1e-280) && s < T(1e280))) return usqrt(s);
     T mx = T(0);
 #pragma unroll
     for (int j = 0; j < Q; ++j) mx = tmax(mx, tabs(v[j]));
@@ -191,7 +191,7 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
     if (par == T(0)) par = gnorm * frcp(dxnorm);
     for (int iter = 1;; ++iter) {
         if (par == T(0)) par = tmax(dwarf, p001 * paru);
-        const T sq = fsqrt(par);
+        const T sq = usqrt(par);
 #pragma unroll
         for (int j = 0; j < Q; ++j) wa1[j] = sq * diag[j];
         qrsolv<T, Q, U>(r, ipvt, wa1, qtb, x, sdiag);
@@ -799,7 +799,7 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
             const T ifn = frcp(fnorm);
             const T t1 = enorm_small<T, Q>(wa) * ifn;
             const T temp1 = t1 * t1;
-            const T t2 = (fsqrt(par) * pnorm) * ifn;
+            const T t2 = (usqrt(par) * pnorm) * ifn;
             const T temp2 = t2 * t2;
             if (uni(!is_finite(temp1) || !is_finite(temp2))) {
                 term = VP_TERM_NUMERICAL;
