@@ -14,8 +14,10 @@
 //     C[0..N)      W Phi          (overwritten by the Householder vectors)
 //     C[N]         y_w            (overwritten by Q^T y_w: rows >= N are the projected residual)
 //     C[N+1+p]     W dPhi_pair_p  (overwritten by Q^T W dPhi_p)
-// One fused sweep does everything: reflector k is applied to ALL remaining columns and their dot
-// products share ONE wave reduction round, so an evaluation costs 2N rounds regardless of Q.
+// One fused sweep does everything: reflector k is applied to ALL remaining columns, and its norm and all its dot
+// products come out of ONE wave reduction round (raw dots a_k^T a_j), so an evaluation costs N rounds regardless
+// of Q.  The fit kernel of a model with a constant basis uses evaluate_core_const_first instead: the constant
+// column leads the factorisation, its reflector is computed once per fit and the column is never materialised.
 #pragma once
 #include "vp_device.hpp"
 #include "vp_model.hpp"

@@ -4,8 +4,12 @@
 // The m observations are spread over the lanes, R = ceil(m/64) rows per lane, and every
 // column the algorithm touches (the basis columns of Phi, the data column y, the derivative
 // columns dPhi) lives in VGPRs for the whole evaluation -- Phi never exists in memory.
-// All reductions (column norms, Householder dot products) are wave-level: DPP inside the
-// 16-lane rows, v_readlane across the four rows.  No LDS traffic, no barriers.
+// All reductions (column norms, Householder dot products) are wave-level and PACKED (wave_allreduce: gfx950
+// v_permlane32/16_swap for the two row-level steps, DPP inside the 16-lane rows, v_readlane to broadcast): no
+// LDS traffic, no barriers.  Problems whose columns do not fit one wave use a group of W waves (Grp<W>), whose
+// reductions add one LDS exchange + barrier.
+// Developer A/B switches (off in product builds): VP_NO_PACKED (one DPP butterfly per value), VP_NO_USQRT (IEEE sqrt
+// expansion), VP_NO_SWEEP_FENCE (vp_core.hpp), VP_FIT_CLOCKS (per-section cycle accounting, tools/fit_clocks.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
