@@ -124,3 +124,27 @@ def test_fp32_config4_full_size_properties():
     s = bp.summary()
     assert s[1] == ok.sum() and s[1] + s[2] == B and s[3] == rep["n_evals"].sum()
     bp.close()
+
+
+def test_fp32_multiple_right_hand_sides():
+    # global fit (one alpha, S right-hand sides) in fp32: evaluation vs the fp64 oracle to fp32 accuracy, and the
+    # noise-free fit recovers the decay times to what fp32 resolves
+    rng = np.random.default_rng(4)
+    S, m = 64, 1000
+    x = np.linspace(0.0, 12.5, m)
+    Cm = rng.uniform(1, 100, (S, 3))
+    Y = Cm[:, :1] * np.exp(-x / 1.0) + Cm[:, 1:2] * np.exp(-x / 3.0) + Cm[:, 2:]
+    guess = np.array([1.3, 3.9])
+    mdl32 = vp.multi_exponential_model(x.astype(np.float32), guess.astype(np.float32), dtype=np.float32)
+    mdl64 = vp.multi_exponential_model(x, guess)
+    bp = vp.BatchProblem(mdl32, Y[None].astype(np.float32), x=x.astype(np.float32))
+    ev = bp.evaluate(guess[None].astype(np.float32))
+    ref = O.Problem(mdl64, x, Y)
+    ref.set_params(guess)
+    assert ev["status"][0] == 0
+    assert np.abs(ev["r"][0] - ref.residuals()).max() <= 2e-4 * np.abs(Y).max()
+    assert np.abs(ev["C"][0] - ref.linear_coefficients()).max() <= 5e-3 * np.abs(ref.linear_coefficients()).max()
+    alpha, C, rep = bp.fit(guess[None].astype(np.float32))
+    assert rep["termination"][0] > 0 or rep["objective"][0] <= 1e-8 * 0.5 * (Y ** 2).sum()
+    assert np.abs(np.sort(alpha[0]) - [1.0, 3.0]).max() <= 2e-2
+    bp.close()

@@ -162,3 +162,49 @@ def test_mrhs_config2_full_size_properties():
     assert np.abs(Cf[0] - d["C_true"]).max() < 1e-4 * np.abs(d["C_true"]).max()
     assert rep["objective"][0] <= 1e-12 * 0.5 * (d["Y"] ** 2).sum()
     bp.close()
+
+
+@pytest.mark.parametrize("m", [200, 1000])
+def test_mrhs_runtime_descriptor_models_beyond_128_rows(m):
+    # multiple right-hand sides on the run-time descriptor kernels at 16 rows per lane: the unit-test double
+    # exponential with swapped columns (src/test_helpers/mod.rs:56-72) and the O'Leary exp*cos model with shared
+    # parameters (shared_test_code/src/models.rs:397-425), evaluation vs the oracle and a global fit.
+    from models import double_exp_unit_test_model, oleary_model
+    rng = np.random.default_rng(m)
+    S = 24
+    x = np.linspace(0.0, 10.0, m)
+    Cm = rng.uniform(1, 10, (S, 3))
+    Y = Cm[:, :1] * np.exp(-x / 3.0) + Cm[:, 1:2] * np.exp(-x / 1.0) + Cm[:, 2:] + 1e-4 * rng.standard_normal((S, m))
+    um = double_exp_unit_test_model(x, [1.2, 3.4])
+    bp = vp.BatchProblem(um, Y[None], x=x)
+    ev = bp.evaluate(np.array([[1.2, 3.4]]))
+    ref = O.Problem(um, x, Y)
+    ref.set_params([1.2, 3.4])
+    assert ev["status"][0] == 0
+    assert np.abs(ev["C"][0] - ref.linear_coefficients()).max() <= TOL * np.abs(ref.linear_coefficients()).max()
+    assert np.abs(ev["r"][0] - ref.residuals()).max() <= TOL * np.abs(Y).max()
+    Jr = ref.jacobian()
+    for k in range(2):
+        assert np.abs(ev["J"][0, k] - Jr[k]).max() <= TOL * np.abs(Jr[k]).max()
+    a, C, rep = bp.fit(np.array([[1.2, 3.4]]))
+    assert rep["termination"][0] > 0 and np.abs(a[0] - [1.0, 3.0]).max() <= 1e-2
+    bp.close()
+    t = np.linspace(0.0, 1.5, m)
+    a_true = np.array([0.5, 2.0, 3.0])
+    om = oleary_model(t, a_true)
+    Co = rng.uniform(1, 6, (S, 2))
+    Yo = Co[:, :1] * (np.exp(-2.0 * t) * np.cos(3.0 * t)) + Co[:, 1:] * (np.exp(-0.5 * t) * np.cos(2.0 * t))
+    Yo = Yo + 1e-5 * rng.standard_normal(Yo.shape)
+    g = a_true * np.array([1.05, 0.97, 1.03])
+    bp = vp.BatchProblem(om, Yo[None], x=t)
+    ev = bp.evaluate(g[None])
+    ref = O.Problem(om, t, Yo)
+    ref.set_params(g)
+    assert np.abs(ev["C"][0] - ref.linear_coefficients()).max() <= TOL * np.abs(ref.linear_coefficients()).max()
+    assert np.abs(ev["r"][0] - ref.residuals()).max() <= TOL * np.abs(Yo).max()
+    Jr = ref.jacobian()
+    for k in range(3):
+        assert np.abs(ev["J"][0, k] - Jr[k]).max() <= TOL * np.abs(Jr[k]).max() + 1e-12
+    a, C, rep = bp.fit(g[None])
+    assert rep["termination"][0] > 0 and np.abs(a[0] - a_true).max() <= 1e-3
+    bp.close()
