@@ -188,6 +188,13 @@ class BatchProblem:
         except Exception:
             pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def _shape_rhs(self, *lead_trail):
         return lead_trail
 
