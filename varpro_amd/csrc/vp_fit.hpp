@@ -460,10 +460,12 @@ template <typename T, int N, int Q> struct LmState {
 // W = waves per problem (the workgroup is one group): W > 1 spreads the rows of one problem over W*64 lanes.
 // Every wave of a group runs the identical wave-uniform LM bookkeeping on bit-identical inputs (the group
 // all-reduce delivers the same totals to all waves), so no LM state is ever exchanged between waves.
-// FULL: unit weights and m == 64*R*W (no padding rows): the row-validity masks disappear from every column build
-template <typename T, class M, int R, int W, bool WEIGHTED, bool FULL = false>
+// PADM (unit weights only): 0 = general m; 1 = m == 64*R*W, no padding rows at all; 2 = only the last register pair
+// can hold padding rows -- the row-validity masks (32 SGPRs of hoisted lane masks, two selects per element) disappear
+// from the column build entirely or from all pairs but the last
+template <typename T, class M, int R, int W, bool WEIGHTED, int PADM = 0>
 __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
-    static_assert(!(WEIGHTED && FULL), "FULL is a unit-weight specialisation");
+    static_assert(!(WEIGHTED && PADM != 0), "PADM is a unit-weight specialisation");
     constexpr int N = M::N, P = M::P, Q = M::Q;
     // CF: the constant column leads the factorisation and is never materialised (evaluate_core_const_first)
     constexpr bool CF = M::kConstLast;
@@ -502,7 +504,7 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
     }
     __syncthreads(); // orders the LDS writes before the reads below (every lane re-reads only its own rows)
     // the LDS copies are zero-padded to MP rows; valid rows are still i < m (scale 0 beyond)
-    using Src = RowSource<T, R, true, WEIGHTED ? 1 : 0, 1, W, true, FULL>;
+    using Src = RowSource<T, R, true, WEIGHTED ? 1 : 0, 1, W, true, PADM>;
     Src src;
     src.t = s_t;
     src.w = s_w;
@@ -873,7 +875,9 @@ template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchPara
                        (size_t)W * sizeof(LmState<T, M::N, M::Q>);
     if (p.w) hipLaunchKernelGGL((fit_kernel<T, M, R, W, true>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     else if (p.m == 64 * R * W)
-        hipLaunchKernelGGL((fit_kernel<T, M, R, W, false, true>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
+        hipLaunchKernelGGL((fit_kernel<T, M, R, W, false, 1>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
+    else if (R > 2 && p.m > 64 * (R - 2) * W)
+        hipLaunchKernelGGL((fit_kernel<T, M, R, W, false, 2>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     else hipLaunchKernelGGL((fit_kernel<T, M, R, W, false>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }

@@ -90,9 +90,11 @@ __device__ __noinline__ float tcos(float x) { return __ocml_cos_f32(x); }
 //   VMODE  : 0 = scalar accesses only, 1 = 2-element aligned accesses (compile time), 2 = decide by `vec`
 //   RECUR  : the kernel may use the uniform-grid exp recurrence of build_columns (it calls set_uniform);
 //            false removes that code path at compile time (kernels that are HBM-bound or off the hot path)
-//   FULL   : (PADDED, unit weights) m == 64*R*W, no padding rows at all: the row scale is the constant 1
+//   PADM   : (PADDED, unit weights) which register pairs can hold padding rows, i.e. need the validity select on
+//            the scale:  0 = any pair (general m);  1 = none (m == 64*R*W);  2 = only the LAST pair
+//            (64*(R-2)*W < m < 64*R*W, e.g. m = 1000 in the 1024-row kernel)
 template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2, int W = 1, bool RECUR = false,
-          bool FULL = false>
+          int PADM = 0>
 struct RowSource {
     const T *t;  // grid, indexed by row (LDS or global)
     const T *w;  // weights indexed by row, or nullptr for unit weights
@@ -137,13 +139,11 @@ struct RowSource {
                     sc[0] = u.x;
                     sc[1] = u.y;
                     return;
-                } else if constexpr (WMODE == 0 && FULL) {
-                    sc[0] = T(1);
-                    sc[1] = T(1);
-                    return;
                 } else if constexpr (WMODE == 0) {
-                    sc[0] = (i < m) ? T(1) : T(0);
-                    sc[1] = (i + 1 < m) ? T(1) : T(0);
+                    // r0 is a compile-time constant after unrolling: the select survives only where it can matter
+                    const bool maybe_pad = (PADM == 0) || (PADM == 2 && r0 >= R - L::VW);
+                    sc[0] = (!maybe_pad || i < m) ? T(1) : T(0);
+                    sc[1] = (!maybe_pad || i + 1 < m) ? T(1) : T(0);
                     return;
                 }
             }
