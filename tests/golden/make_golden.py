@@ -91,6 +91,22 @@ def main():
     out["oleary_x"], out["oleary_y"], out["oleary_alpha"], out["oleary_w"] = t, y, alpha, wt
     out["oleary_c"], out["oleary_r"], out["oleary_J"] = c, r, J
     print("oleary done")
+    # case D: ill-conditioned triple exponential + offset (close decay times, cond(Phi) 1e3 .. 1e5), m = 129:
+    # where QR- and SVD-based evaluations drift apart, the 50-digit values say who is right
+    rng = np.random.default_rng(77)
+    m3 = 129
+    x3 = np.linspace(0.0, 12.0, m3)
+    taus = np.array([[1.0, 1.05, 1.1], [2.0, 2.1, 2.2], [1.0, 1.02, 1.04], [3.0, 3.3, 3.6]])
+    for i, tau in enumerate(taus):
+        cc = rng.uniform(1, 50, 4)
+        y3 = sum(cc[j] * np.exp(-x3 / tau[j]) for j in range(3)) + cc[3]
+        y3 = y3 + 1e-4 * np.abs(y3).max() * rng.standard_normal(m3)
+        alpha3 = tau * rng.uniform(0.9, 1.1, 3)
+        c, r, J = evaluate([1, 1, 1, 0], [(0,), (1,), (2,), ()], 3, x3, y3, alpha3)
+        tag = "triple_close%d" % i
+        out[tag + "_x"], out[tag + "_y"], out[tag + "_alpha"] = x3, y3, alpha3
+        out[tag + "_c"], out[tag + "_r"], out[tag + "_J"] = c, r, J
+        print(tag, "done")
     np.savez_compressed(os.path.join(HERE, "golden_eval.npz"), **out)
 
 

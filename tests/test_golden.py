@@ -56,3 +56,47 @@ def test_gpu_matches_high_precision_golden(tag):
     yw = y if w is None else y * w
     _check(ev["C"][0], ev["r"][0], ev["J"][0], cg, rg, Jg, yw, _dkc_scale(mdl, x, alpha, cg, w))
     bp.close()
+
+
+# ---- ill-conditioned triple exponential + offset (close decay times) ------------------------------------------
+# cond(Phi) is 1e3 .. 1e5 here; J = -P_perp D c is a difference of nearly equal vectors, so its error grows like
+# cond(Phi)^2 eps relative to |J|.  The 1e-10 contract is stated for c and r; for J the bound is the conditioning.
+ILL = ["triple_close%d" % i for i in range(4)]
+
+
+def _ill_case(tag):
+    x, y, alpha = G[tag + "_x"], G[tag + "_y"], G[tag + "_alpha"]
+    mdl = vp.multi_exponential_model(x, alpha, offset=True)
+    Phi = np.stack([np.exp(-x / a) for a in alpha] + [np.ones_like(x)], axis=1)
+    return mdl, x, y, alpha, G[tag + "_c"], G[tag + "_r"], G[tag + "_J"], np.linalg.cond(Phi)
+
+
+def _errs(c, r, J, cg, rg, Jg, y):
+    return (np.abs(c - cg).max() / np.abs(cg).max(), np.abs(r - rg).max() / np.abs(y).max(),
+            np.abs(J - Jg).max() / np.abs(Jg).max())
+
+
+@pytest.mark.parametrize("tag", ILL)
+def test_oracle_on_ill_conditioned_golden(tag):
+    mdl, x, y, alpha, cg, rg, Jg, kappa = _ill_case(tag)
+    p = O.Problem(mdl, x, y)
+    p.set_params(alpha)
+    ec, er, eJ = _errs(p.linear_coefficients(), p.residuals(), p.jacobian(), cg, rg, Jg, y)
+    assert ec <= 1e-10 and er <= 1e-10 and eJ <= max(1e-10, 100 * kappa ** 2 * 2.2e-16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ILL)
+def test_gpu_on_ill_conditioned_golden_is_no_worse_than_the_oracle(tag):
+    mdl, x, y, alpha, cg, rg, Jg, kappa = _ill_case(tag)
+    bp = vp.BatchProblem(mdl, y[None, :], x=x)
+    ev = bp.evaluate(alpha[None, :])
+    assert ev["status"][0] == 0
+    ec, er, eJ = _errs(ev["C"][0], ev["r"][0], ev["J"][0], cg, rg, Jg, y)
+    assert ec <= 1e-10 and er <= 1e-10 and eJ <= max(1e-10, 100 * kappa ** 2 * 2.2e-16)
+    p = O.Problem(mdl, x, y)
+    p.set_params(alpha)
+    oc, orr, oJ = _errs(p.linear_coefficients(), p.residuals(), p.jacobian(), cg, rg, Jg, y)
+    # against the 50-digit values the Householder path is about as accurate as the SVD restatement or better
+    assert ec <= 5 * oc + 1e-13 and er <= 5 * orr + 1e-12 and eJ <= 5 * oJ + 1e-12
+    bp.close()
