@@ -158,7 +158,10 @@ class Problem:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().vpo_problem_destroy(self._h)
+            try:
+                lib().vpo_problem_destroy(self._h)
+            except Exception:  # interpreter shutdown: module globals may already be gone
+                pass
             self._h = None
 
     def set_params(self, alpha):
