@@ -458,3 +458,50 @@ def test_overflowing_basis_is_a_failed_evaluation_like_the_reference():
         assert ((rep["termination"] > 0) == (rep_ref["termination"] > 0)).all(), (rep["termination"], rep_ref["termination"])
         assert (rep["termination"][[1, 4]] <= 0).all() and (rep["termination"][[0, 2, 3, 5]] > 0).all()
         bp.close()
+
+
+@pytest.mark.parametrize("m", [90, 600])
+def test_further_runtime_descriptor_shapes(m):
+    # shapes (n, q, p) registered beyond the reference's own test models: rate-form exponentials with and without an
+    # offset, an exp*cos term next to two rate-form exponentials -- evaluation and fit against the oracle
+    rng = np.random.default_rng(m)
+    x = np.linspace(0.0, 6.0, m)
+    B = 6
+
+    def check(mdl, Y, guess, tol_j=1e-8):
+        bp = vp.BatchProblem(mdl, Y, x=x)
+        ev = bp.evaluate(guess)
+        ref = O.evaluate_batch(mdl, x, Y, guess, n_threads=2)
+        assert (ev["status"] == 0).all()
+        assert np.abs(ev["C"] - ref["C"]).max() <= 1e-9 * np.abs(ref["C"]).max()
+        assert np.abs(ev["r"] - ref["r"]).max() <= TOL * np.abs(Y).max()
+        assert np.abs(ev["J"] - ref["J"]).max() <= tol_j * np.abs(ref["J"]).max()
+        a, c, rep = bp.fit(guess)
+        a_ref, c_ref, rep_ref, _ = O.fit_batch(mdl, x, Y, guess, n_threads=2)
+        ok = (rep["termination"] > 0) & (rep_ref["termination"] > 0)
+        assert ok.mean() >= 0.8 and ((rep["termination"] > 0) == (rep_ref["termination"] > 0)).mean() >= 0.8
+        rel = np.abs(rep["objective"] - rep_ref["objective"])[ok] / rep_ref["objective"][ok]
+        assert np.median(rel) <= 1e-8
+        bp.close()
+
+    noise = lambda Y: Y + 1e-3 * np.abs(Y).max() * rng.standard_normal(Y.shape)
+    # (2, 1, 1): exp(-k t) + offset
+    k = rng.uniform(0.5, 2.0, (B, 1))
+    mdl = (vp.SeparableModelBuilder(["k"]).function(["k"], basis.EXP_RATE).partial_deriv("k")
+           .invariant_function(basis.CONST).independent_variable(x).initial_parameters([1.0]).build())
+    check(mdl, noise(3.0 * np.exp(-k * x) + 1.0), k * rng.uniform(0.8, 1.2, (B, 1)))
+    # (4, 3, 3): three rate-form exponentials + offset
+    k3 = np.array([0.3, 1.2, 4.0]) * rng.uniform(0.9, 1.1, (B, 3))
+    mdl = (vp.SeparableModelBuilder(["k1", "k2", "k3"]).function(["k1"], basis.EXP_RATE).partial_deriv("k1")
+           .function(["k2"], basis.EXP_RATE).partial_deriv("k2").function(["k3"], basis.EXP_RATE).partial_deriv("k3")
+           .invariant_function(basis.CONST).independent_variable(x).initial_parameters([0.3, 1.2, 4.0]).build())
+    Y = sum((j + 2.0) * np.exp(-k3[:, j:j + 1] * x) for j in range(3)) + 0.5
+    check(mdl, noise(Y), k3 * rng.uniform(0.95, 1.05, (B, 3)), tol_j=1e-6)
+    # (3, 4, 4): exp(-a t) cos(b t) + two rate-form exponentials
+    p = np.array([0.4, 3.0, 0.2, 1.5]) * rng.uniform(0.95, 1.05, (B, 4))
+    mdl = (vp.SeparableModelBuilder(["a", "b", "k1", "k2"])
+           .function(["a", "b"], basis.EXP_COS).partial_deriv("a").partial_deriv("b")
+           .function(["k1"], basis.EXP_RATE).partial_deriv("k1").function(["k2"], basis.EXP_RATE).partial_deriv("k2")
+           .independent_variable(x).initial_parameters([0.4, 3.0, 0.2, 1.5]).build())
+    Y = 2.0 * np.exp(-p[:, 0:1] * x) * np.cos(p[:, 1:2] * x) + 1.0 * np.exp(-p[:, 2:3] * x) + 3.0 * np.exp(-p[:, 3:4] * x)
+    check(mdl, noise(Y), p * rng.uniform(0.97, 1.03, (B, 4)), tol_j=1e-6)
