@@ -184,12 +184,12 @@ def test_device_exp_accuracy_over_the_argument_range():
 def test_sin_phase_and_exp_rate_kinds():
     rng = np.random.default_rng(2)
     x = np.linspace(0, 4, 90)
-    mdl = (vp.SeparableModelBuilder(["omega", "phi", "k", "unused"])
+    mdl = (vp.SeparableModelBuilder(["omega", "phi", "k", "a", "unused"])
            .function(["omega", "phi"], basis.SIN_PHASE).partial_deriv("omega").partial_deriv("phi")
-           .function(["k"], basis.EXP_RATE).partial_deriv("k")
+           .function(["k", "a"], basis.EXP_COS).partial_deriv("k").partial_deriv("a")
            .function(["unused"], basis.EXP_DECAY).partial_deriv("unused")
-           .independent_variable(x).initial_parameters([2.0, 0.3, 0.7, 2.0]).build())
-    # n=3, q=4, p=4 -> RtModel<3,4,4> is not instantiated: must be reported, not silently mis-run
+           .independent_variable(x).initial_parameters([2.0, 0.3, 0.7, 1.1, 2.0]).build())
+    # n=3, q=5, p=5 -> RtModel<3,5,5> is not instantiated: must be reported, not silently mis-run
     with pytest.raises(vp.VarproHipError) as e:
         vp.BatchProblem(mdl, np.ones((1, 90)), x=x)
     assert e.value.code == -2
