@@ -10,7 +10,9 @@ B problems (problems rank*B .. (rank+1)*B-1 of the global synthetic set); the on
 RCCL all-reduce of 4 doubles per step {sum cost, #ok, #failed, sum evaluations}.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md section 5 for every field):
-  value      whole-job fits/s over all ranks (max-over-ranks time, barrier + synchronize on both sides)
+  value      whole-job fits/s over all ranks (max-over-ranks time, barrier + synchronize on both sides); consecutive
+             steps alternate over two handles / HIP streams so that the straggler tail of one launch overlaps the
+             next step (config.pipelining); config.single_stream holds the same K steps strictly one at a time
   roofline   the stand-alone Phi/dPhi kernel (vp_basis) against the HBM roofline, HIP-event timed live
   roofline_fit  the fused fit kernel: HBM fraction (tiny by design: y is read once per FIT) and the fp64
                 vector-ALU fraction that actually bounds it
@@ -27,6 +29,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The steps alternate over two HIP streams (see --streams) next to RCCL's own stream: with ROCm's default of 4
+# hardware queues per process two of those streams can land on the same queue and serialise.  Must be set before
+# the HIP runtime initialises (torch is imported inside main()).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 
@@ -41,6 +48,9 @@ def main():
                          "north_star 1-GPU headline size; configs[1] (4096) is measured alongside on rank 0")
     ap.add_argument("--m", type=int, default=1024)
     ap.add_argument("--noise", type=float, default=1e-3)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="handles / HIP streams the steps alternate over (software pipelining of consecutive batches: "
+                         "the straggler tail of step k overlaps the bulk of step k+1); 1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -80,34 +90,49 @@ def main():
         if use_dist:
             dist.barrier()
 
-    red = torch.zeros(4, dtype=torch.float64, device=dev)
+    # Software pipelining over consecutive steps: every step is ONE complete batched fit of the B problems (+ the
+    # device-side summary + the RCCL all-reduce), but step k runs on handle / stream k mod NS, so that the tail of a
+    # launch -- a few fits that need >100 LM iterations while the rest of the GPU is already idle -- overlaps the
+    # bulk of the next step's launch.  Each handle owns its own copy of the state; nothing is shared or skipped.
+    ns = max(1, args.streams)
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(ns - 1)]
+    handles = [bp]
+    for st in streams[1:]:
+        with torch.cuda.stream(st):
+            handles.append(vp.BatchProblem(mdl, Y, x=x))
+    reds = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(ns)]
+    torch.cuda.synchronize()
 
-    def step():
+    def step(k, nslots=ns):
         # everything is enqueued asynchronously: the fit kernel, the 4-double batch summary (device side) and
         # the RCCL-over-xGMI all-reduce of those 32 bytes (the scalar LM cost reduction); no host sync per step
-        bp.fit(guess, want_coefficients=False)
-        bp.summary_device(red)
-        if use_dist:
-            dist.all_reduce(red, op=dist.ReduceOp.SUM)
-        return red
+        i = k % nslots
+        with torch.cuda.stream(streams[i]):
+            handles[i].fit(guess, want_coefficients=False)
+            handles[i].summary_device(reds[i])
+            if use_dist:
+                dist.all_reduce(reds[i], op=dist.ReduceOp.SUM)
+        return reds[i]
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        last = step()
-    ev1.record()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def timed(nslots):
+        for k in range(args.warmup):
+            step(k, nslots)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            last_ = step(k, nslots)
+        torch.cuda.synchronize()
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax.item())
+        return dt_, last_
+
+    dt, last = timed(ns)
+    dt_single = timed(1)[0] if ns > 1 else dt  # the same K steps strictly one batch at a time, for reference
     last = last.cpu().numpy()
     total_fits = float(world) * B * args.steps
     value = total_fits / dt
@@ -196,6 +221,9 @@ def main():
                             "double-exponential+offset fits per GPU, m=%d, n=3, q=2, fp64, noise %.0e, full LM fit to "
                             "convergence per step" % (B, m, args.noise),
                 "batch_per_gpu": B, "m": m, "parallelism": "batch-sharded x%d" % world,
+                "pipelining": ("%d handles on %d HIP streams, step k on stream k mod %d: the straggler tail of a launch "
+                               "overlaps the bulk of the next step" % (ns, ns, ns)) if ns > 1 else "none (one batch at a time)",
+                "single_stream": {"fits_per_s": total_fits / dt_single, "ms_per_step": dt_single / args.steps * 1e3},
                 "mean_evaluations_per_fit": evals_per_fit, "fits_successful": n_ok, "fits_failed": n_bad,
                 "sum_cost": sum_cost,
             },
@@ -238,7 +266,8 @@ def main():
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
-    bp.close()
+    for h_ in handles:
+        h_.close()
     if use_dist:
         dist.destroy_process_group()
 
