@@ -64,6 +64,7 @@ extern "C" {
     pub fn vp_jacobian(h: *mut vp_batch, j_out: *mut c_void, status: *mut i32) -> i32;
     pub fn vp_linear_coeffs(h: *mut vp_batch, c_out: *mut c_void, status: *mut i32) -> i32;
     pub fn vp_weighted_data(h: *mut vp_batch, yw_out: *mut c_void) -> i32;
+    pub fn vp_set_observations(h: *mut vp_batch, y: *const c_void) -> i32;
     pub fn vp_cost(h: *mut vp_batch, cost_out: *mut f64) -> i32;
     pub fn vp_evaluate(h: *mut vp_batch, alpha: *const c_void, r: *mut c_void, j: *mut c_void, c: *mut c_void,
         cost: *mut f64, status: *mut i32) -> i32;

@@ -213,6 +213,15 @@ int vp_linear_coeffs(vp_batch *h, void *C_out, int32_t *status);
 /* == SeparableProblem::weighted_data (src/problem.rs:154-156,189-196) */
 int vp_weighted_data(vp_batch *h, void *Yw_out);
 
+/*
+ * Replace the observations of an existing handle (same B, S, m, model, grid and weights): Y_w = W*Y is recomputed on
+ * the handle's stream and every cached result is invalidated.  The batch counterpart of building a new
+ * SeparableProblem with SeparableProblemBuilder::observations (src/problem/builder.rs:219-232) for the next frame
+ * of a stream of same-shaped data, without re-allocating the device state.  Y is [B][S][m] like at creation
+ * (host or device pointer according to the handle's flags).
+ */
+int vp_set_observations(vp_batch *h, const void *Y);
+
 /* 1/2 ||vec R_b||^2 per problem, always f64 [B] (== MinimizationReport::objective_function) */
 int vp_cost(vp_batch *h, double *cost_out);
 

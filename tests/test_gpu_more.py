@@ -505,3 +505,39 @@ def test_further_runtime_descriptor_shapes(m):
            .independent_variable(x).initial_parameters([0.4, 3.0, 0.2, 1.5]).build())
     Y = 2.0 * np.exp(-p[:, 0:1] * x) * np.cos(p[:, 1:2] * x) + 1.0 * np.exp(-p[:, 2:3] * x) + 3.0 * np.exp(-p[:, 3:4] * x)
     check(mdl, noise(Y), p * rng.uniform(0.97, 1.03, (B, 4)), tol_j=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["host", "device"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_set_observations_reuses_the_handle_for_the_next_frame(mode, weighted):
+    # vp_set_observations: same B, m, model, grid, weights, NEW data -- results must be bit-identical with a freshly
+    # created handle, cached results of the old data must be gone
+    rng = np.random.default_rng(31)
+    d1 = synth.double_exp_batch(96, m=1000, noise=1e-3)
+    d2 = synth.double_exp_batch(96, m=1000, first_problem=5000, noise=1e-3)
+    w = rng.uniform(0.5, 1.5, 1000) if weighted else None
+    mdl = double_exp_builder_model(d1["x"], d1["tau_guess"][0])
+    if mode == "device":
+        import torch
+        dev = torch.device("cuda", 0)
+        cv = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        back = lambda a: a.cpu().numpy()
+    else:
+        cv = lambda a: a
+        back = lambda a: np.asarray(a)
+    bp = vp.BatchProblem(mdl, cv(d1["Y"]), x=cv(d1["x"]), weights=cv(w))
+    a1, c1, r1 = bp.fit(cv(d1["tau_guess"]))
+    bp.set_observations(cv(d2["Y"]))
+    with pytest.raises(vp.VarproHipError):
+        bp.cost()  # no parameters set for the new data yet
+    a2, c2, r2 = bp.fit(cv(d2["tau_guess"]))
+    fresh = vp.BatchProblem(mdl, cv(d2["Y"]), x=cv(d2["x"]), weights=cv(w))
+    a3, c3, r3 = fresh.fit(cv(d2["tau_guess"]))
+    assert np.array_equal(back(a2), back(a3)) and np.array_equal(back(c2), back(c3))
+    assert np.array_equal(bp.report_to_numpy(r2)["n_evals"], fresh.report_to_numpy(r3)["n_evals"])
+    assert not np.array_equal(back(a1), back(a2))
+    assert np.array_equal(back(bp.weighted_data()), back(fresh.weighted_data()))
+    with pytest.raises(ValueError):
+        bp.set_observations(cv(d2["Y"][:10]))
+    bp.close()
+    fresh.close()

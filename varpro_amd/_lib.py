@@ -38,7 +38,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_
 # every symbol include/varpro_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "vp_batch_create", "vp_batch_destroy", "vp_set_params", "vp_params", "vp_residuals", "vp_jacobian",
-    "vp_linear_coeffs", "vp_weighted_data", "vp_cost", "vp_evaluate", "vp_basis", "vp_lm_opts_default", "vp_fit", "vp_fit_trace",
+    "vp_linear_coeffs", "vp_weighted_data", "vp_set_observations", "vp_cost", "vp_evaluate", "vp_basis", "vp_lm_opts_default", "vp_fit", "vp_fit_trace",
     "vp_best_fit", "vp_statistics", "vp_summary", "vp_summary_device", "vp_set_rhs_allreduce", "vp_set_timing", "vp_last_kernel_ms", "vp_synchronize", "vp_last_error",
     "vp_last_error_detail", "vp_version", "vp_device_count",
 ]
@@ -101,6 +101,7 @@ def load():
     lib.vp_batch_destroy.argtypes = [vp]
     lib.vp_batch_destroy.restype = None
     lib.vp_set_params.argtypes = [vp, vp]
+    lib.vp_set_observations.argtypes = [vp, vp]
     lib.vp_params.argtypes = [vp, vp]
     lib.vp_residuals.argtypes = [vp, vp, vp]
     lib.vp_jacobian.argtypes = [vp, vp, vp]

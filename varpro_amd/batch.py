@@ -329,6 +329,17 @@ class BatchProblem:
         check(self.lib.vp_statistics(self._h, self._ptr(cov), self._ptr(chi2), self._ptr(sig), self._ptr(st)))
         return dict(cov=cov, reduced_chi2=chi2, conf_sigma=sig, status=st, dof=self.m - k)
 
+    def set_observations(self, Y):
+        """replace the data of this handle by another batch of the same shape (vp_set_observations): the next frame
+        of a stream of same-shaped problems without re-allocating the device state"""
+        Y = self._as_array(Y)
+        want = (self.B, self.m) if self.single_rhs else (self.B, self.S, self.m)
+        if tuple(Y.shape) != want:
+            raise ValueError("observations must have shape %r" % (want,))
+        if self.device_mode and not Y.is_contiguous():
+            Y = Y.contiguous()
+        check(self.lib.vp_set_observations(self._h, self._ptr(Y)))
+
     def set_rhs_allreduce(self, global_rhs_count, group=None):
         """Shard ONE global fit over ranks by right-hand sides (vp_set_rhs_allreduce): this handle
         holds the local block of the S columns (torch device tensors); per LM evaluation the B*(1+n*n+p) reduced

@@ -295,6 +295,11 @@ class BatchProblem {
     }
     vp_batch *handle() const { return h_; }
     void set_params(const std::vector<double> &alpha) { check(vp_set_params(h_, alpha.data())); }
+    // next frame of a stream of same-shaped data: new observations, same model / grid / weights, no re-allocation
+    void set_observations(const std::vector<double> &Y) {
+        if ((int64_t)Y.size() != B * S * m) throw std::invalid_argument("Y must hold B*S*m values");
+        check(vp_set_observations(h_, Y.data()));
+    }
     std::vector<int32_t> status() const {
         std::vector<int32_t> st((size_t)B);
         check(vp_linear_coeffs(h_, nullptr, st.data()));

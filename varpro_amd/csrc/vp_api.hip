@@ -704,6 +704,37 @@ int vp_weighted_data(vp_batch *h, void *Yw_out) {
     return copy_out(h, Yw_out, h->d_yw, (size_t)h->B * h->S * h->m * tsize(h->dtype));
 }
 
+int vp_set_observations(vp_batch *h, const void *Y) {
+    if (int rc = check_handle(h)) return rc;
+    if (!Y) return fail(VP_ERR_INVALID, "Right hand side(s) not provided", VP_BUILD_Y_DATA_MISSING);
+    const size_t ts = tsize(h->dtype);
+    const size_t y_elems = (size_t)h->B * h->S * h->m;
+    // Y_w = W * Y straight into the handle's buffer; host pointers are staged through the buffer itself
+    const void *ysrc = Y;
+    if (!device_ptrs(h)) {
+        VP_HIP(hipMemcpyAsync(h->d_yw, Y, y_elems * ts, hipMemcpyHostToDevice, h->stream));
+        ysrc = h->d_yw; // in place: every element is read once and written once by the same thread
+    }
+    if (h->d_w || ysrc != h->d_yw) {
+        const int64_t total = (int64_t)y_elems;
+        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 65536);
+        const int64_t wstride = (h->flags & VP_FLAG_W_PER_PROBLEM) ? h->m : 0;
+        if (h->dtype == VP_F64)
+            hipLaunchKernelGGL(weight_data_kernel<double>, dim3(grid), dim3(256), 0, h->stream, (const double *)ysrc,
+                               (const double *)h->d_w, (double *)h->d_yw, (int)h->m, h->S, wstride, total);
+        else
+            hipLaunchKernelGGL(weight_data_kernel<float>, dim3(grid), dim3(256), 0, h->stream, (const float *)ysrc,
+                               (const float *)h->d_w, (float *)h->d_yw, (int)h->m, h->S, wstride, total);
+        VP_HIP(hipGetLastError());
+    }
+    if (!device_ptrs(h)) VP_HIP(hipStreamSynchronize(h->stream)); // the caller may reuse its host buffer
+    // the cached evaluation / fit belongs to the old data
+    h->have_params = false;
+    h->r_valid = false;
+    h->have_report = false;
+    return VP_ERR_OK;
+}
+
 int vp_cost(vp_batch *h, double *cost_out) {
     if (int rc = check_handle(h)) return rc;
     if (!h->have_params) return fail(VP_ERR_INVALID, "no parameters set yet");
