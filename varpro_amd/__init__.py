@@ -12,6 +12,7 @@ There is no CPU fallback: every compute call runs on the GPU through ``lib/libva
 """
 from ._lib import VarproHipError, VarproHipUnavailable, device_count, load as load_library  # noqa: F401
 from .batch import BatchProblem, LevenbergMarquardt, REPORT_DTYPE  # noqa: F401
+from .pipeline import FitPipeline  # noqa: F401
 from .model import (ModelBuildError, ModelError, SeparableModel, SeparableModelBuilder, basis,  # noqa: F401
                     multi_exponential_model)
 from .problem import SeparableProblem, SeparableProblemBuilder, SeparableProblemBuilderError  # noqa: F401
