@@ -331,12 +331,16 @@ template <typename T, class M, int R, int W = 1> int launch_evaluate(const Launc
     a.grid_uniform = p.grid_uniform;
     if (a.nprob <= 0) return VP_ERR_OK;
     dim3 grid((unsigned)a.nprob), block(64 * W);
-    const bool aligned = host_aligned<T>(p.m, {p.t, p.w, p.yw, p.r_out, p.J_out});
+    // run-time-descriptor models only get the element-wise (any alignment) variants: half the instantiations of a
+    // path that is not throughput-critical
+    const bool aligned = M::kStatic && host_aligned<T>(p.m, {p.t, p.w, p.yw, p.r_out, p.J_out});
     const int mode = p.J_out ? 2 : (p.r_out ? 1 : 0);
     const int variant = mode * 4 + (aligned ? 2 : 0) + (p.w ? 1 : 0);
 #define VP_EV(MODE_, AL_, W_)                                                                                          \
     case (MODE_) * 4 + (AL_) * 2 + (W_):                                                                               \
-        hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, MODE_, (AL_) != 0, (W_) != 0>), grid, block, 0, p.stream, a); \
+        if constexpr (M::kStatic || (AL_) == 0)                                                                        \
+            hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, MODE_, (AL_) != 0, (W_) != 0>), grid, block, 0, p.stream, \
+                               a);                                                                                     \
         break;
     switch (variant) {
         VP_EV(0, 0, 0) VP_EV(0, 0, 1) VP_EV(0, 1, 0) VP_EV(0, 1, 1)
