@@ -49,7 +49,7 @@ def _check_eval(mdl, x, Y, alpha, w=None, tol=TOL):
     bp.close()
 
 
-@pytest.mark.parametrize("m", [3, 11, 64, 100, 128, 129, 1000, 1023, 1024])
+@pytest.mark.parametrize("m", [3, 11, 64, 100, 128, 129, 200, 256, 257, 500, 512, 513, 1000, 1023, 1024])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_evaluate_double_exp_matches_oracle(m, weighted):
     rng = np.random.default_rng(100 + m)
@@ -209,7 +209,7 @@ def test_fit_config0_recovers_truth():
     bp.close()
 
 
-@pytest.mark.parametrize("m,noise", [(1024, 1e-3), (1024, 0.0), (1000, 1e-3), (100, 1e-3)])
+@pytest.mark.parametrize("m,noise", [(1024, 1e-3), (1024, 0.0), (1000, 1e-3), (100, 1e-3), (256, 1e-3), (400, 1e-3), (512, 1e-3)])
 def test_fit_batch_matches_oracle(m, noise):
     d = synth.double_exp_batch(48, m=m, noise=noise)
     mdl = double_exp_builder_model(d["x"], d["tau_guess"][0])
