@@ -1,7 +1,7 @@
 import sys; sys.path.insert(0, "/root/repo")
 import numpy as np, torch, varpro_amd as vp
 from varpro_amd import synth, _lib
-for m, B in ((512, 131072), (256, 262144), (128, 262144), (32, 262144)):
+for m, B in ((4096, 16384), (2048, 32768), (1024, 65536), (512, 131072), (256, 262144), (128, 262144), (32, 262144)):
     d = synth.double_exp_batch(B, m=m, noise=1e-3)
     mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0])
     dev = torch.device("cuda", 0)
