@@ -37,9 +37,11 @@ int fail(int code, const std::string &msg, int detail = 0) {
 inline size_t tsize(int dtype) { return dtype == VP_F64 ? 8 : 4; }
 
 // ---- small utility kernels (dtype-generic plumbing, not the hot path) ------------------------------
+// (Y and Yw may be the same buffer -- vp_set_observations stages host data through Yw -- hence no __restrict__ on them:
+// every element is read and written by the same thread)
 template <typename T>
-__global__ void weight_data_kernel(const T *__restrict__ Y, const T *__restrict__ w, T *__restrict__ Yw, int m,
-                                   int64_t cols_per_problem, int64_t w_stride, int64_t total) {
+__global__ void weight_data_kernel(const T *Y, const T *__restrict__ w, T *Yw, int m, int64_t cols_per_problem,
+                                   int64_t w_stride, int64_t total) {
     // Y_w = W * Y  (src/problem/builder.rs:307, src/util/mod.rs:86-95)
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
