@@ -61,7 +61,7 @@ def test_mrhs_batch_cost_and_status_reduce_over_rhs():
     bp.close()
 
 
-@pytest.mark.parametrize("n_exp,offset,m", [(1, True, 100), (1, False, 1024), (2, False, 1024), (3, True, 1024),
+@pytest.mark.parametrize("n_exp,offset,m", [(1, True, 100), (1, True, 400), (3, True, 300), (3, True, 512), (1, False, 1024), (2, False, 1024), (3, True, 1024),
                                             (3, True, 57), (3, False, 64), (2, True, 2048)])
 def test_multiexp_family_evaluate_and_fit(n_exp, offset, m):
     taus = [1.0, 3.0, 7.5][:n_exp]
