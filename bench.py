@@ -67,13 +67,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    # (test hooks for a box with ONE GPU: VP_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and VP_BENCH_BACKEND=gloo
+    # replaces RCCL, which refuses two ranks on one device -- the multi-rank control flow can then be exercised there)
+    if os.environ.get("VP_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run even N=1 exercises RCCL
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("VP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     B, m = args.batch, args.m
     # ---- synthetic input of BASELINE configs[1] (shard `rank` of the global problem set) ----
