@@ -32,7 +32,13 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 // make a wave-uniform predicate visible to the compiler as scalar so that branches on it are
 // s_cbranch (no exec-mask juggling around the DPP/readlane code below)
+#ifdef VP_UNI_READFIRSTLANE
 __device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+#else
+// the compare already writes its lane mask to an SGPR pair: testing that mask (ballot) costs no VALU instruction,
+// where materialising the bool in a VGPR and reading lane 0 costs two plus the VALU->SALU round trip
+__device__ __forceinline__ bool uni(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
+#endif
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---- optional per-section cycle accounting of the fit kernel (tools/fit_clocks.py; -DVP_FIT_CLOCKS) -------------
