@@ -107,6 +107,22 @@ def main():
         out[tag + "_x"], out[tag + "_y"], out[tag + "_alpha"] = x3, y3, alpha3
         out[tag + "_c"], out[tag + "_r"], out[tag + "_J"] = c, r, J
         print(tag, "done")
+    # case E: multiple right-hand sides (one alpha, S = 3 columns), weighted, m = 40: per column c_s, r_s and
+    # J_k[:, s] = -P_perp (W dPhi/dalpha_k) c_s   (src/solvers/levmar/mod.rs:147-186); layouts [S][n], [S][m], [q][S][m]
+    rng = np.random.default_rng(5)
+    xm = np.linspace(0.0, 9.0, 40)
+    wm = 0.5 + rng.random(40)
+    alpham = np.array([1.3, 3.8])
+    Cm = rng.uniform(1, 10, (3, 3))
+    Ym = Cm[:, :1] * np.exp(-xm / 1.0) + Cm[:, 1:2] * np.exp(-xm / 3.0) + Cm[:, 2:] + 1e-3 * rng.standard_normal((3, 40))
+    cs, rs, Js = [], [], []
+    for si in range(3):
+        c, r, J = evaluate(kinds, pidx, 2, xm, Ym[si], alpham, wm)
+        cs.append(c); rs.append(r); Js.append(J)
+    out["mrhs3_x"], out["mrhs3_y"], out["mrhs3_alpha"], out["mrhs3_w"] = xm, Ym, alpham, wm
+    out["mrhs3_c"], out["mrhs3_r"] = np.stack(cs), np.stack(rs)
+    out["mrhs3_J"] = np.stack(Js, axis=1)  # [q][S][m]
+    print("mrhs3 done")
     np.savez_compressed(os.path.join(HERE, "golden_eval.npz"), **out)
 
 

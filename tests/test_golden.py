@@ -100,3 +100,36 @@ def test_gpu_on_ill_conditioned_golden_is_no_worse_than_the_oracle(tag):
     # against the 50-digit values the Householder path is about as accurate as the SVD restatement or better
     assert ec <= 5 * oc + 1e-13 and er <= 5 * orr + 1e-12 and eJ <= 5 * oJ + 1e-12
     bp.close()
+
+
+# ---- multiple right-hand sides against the 50-digit values ------------------------------------------------------
+def _mrhs_case():
+    x, Y, alpha, w = G["mrhs3_x"], G["mrhs3_y"], G["mrhs3_alpha"], G["mrhs3_w"]
+    return double_exp_builder_model(x, alpha), x, Y, alpha, w, G["mrhs3_c"], G["mrhs3_r"], G["mrhs3_J"]
+
+
+def _check_mrhs(C, r, J, cg, rg, Jg, Yw):
+    assert np.abs(C - cg).max() <= TOL * np.abs(cg).max()
+    assert np.abs(r - rg).max() <= TOL * np.abs(Yw).max()
+    for k in range(Jg.shape[0]):
+        assert np.abs(J[k] - Jg[k]).max() <= TOL * np.abs(Jg[k]).max() + 1e-13 * np.abs(Yw).max()
+
+
+def test_oracle_mrhs_matches_high_precision_golden():
+    mdl, x, Y, alpha, w, cg, rg, Jg = _mrhs_case()
+    p = O.Problem(mdl, x, Y, w=w)
+    p.set_params(alpha)
+    S, m = Y.shape
+    _check_mrhs(p.linear_coefficients(), p.residuals().reshape(S, m), np.asarray(p.jacobian()).reshape(2, S, m), cg, rg, Jg,
+                Y * w)
+
+
+@pytest.mark.gpu
+def test_gpu_mrhs_matches_high_precision_golden():
+    mdl, x, Y, alpha, w, cg, rg, Jg = _mrhs_case()
+    S, m = Y.shape
+    bp = vp.BatchProblem(mdl, Y[None], x=x, weights=w)
+    ev = bp.evaluate(alpha[None])
+    assert ev["status"][0] == 0
+    _check_mrhs(ev["C"][0], ev["r"][0].reshape(S, m), ev["J"][0].reshape(2, S, m), cg, rg, Jg, Y * w)
+    bp.close()
