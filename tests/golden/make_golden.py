@@ -107,6 +107,39 @@ def main():
         out[tag + "_x"], out[tag + "_y"], out[tag + "_alpha"] = x3, y3, alpha3
         out[tag + "_c"], out[tag + "_r"], out[tag + "_J"] = c, r, J
         print(tag, "done")
+    # case F: fit statistics at the cfg1w point (src/statistics/mod.rs:352-441, 481-511): J = [Phi, (dPhi/dalpha_k c)_k]
+    # unweighted, H = W J, sigma^2 = ||r_w||^2 / (m - n - q), Cov = sigma^2 (H^T H)^-1, conf sigma_i = sqrt(j_i^T Cov j_i)
+    def statistics(kinds_, pidx_, q_, x_, y_, alpha_, w_):
+        mm, nn = len(x_), len(kinds_)
+        X = [mp.mpf(float(v)) for v in x_]
+        A = [mp.mpf(float(v)) for v in alpha_]
+        Wv = [mp.mpf(float(v)) for v in w_]
+        c_, r_, _ = evaluate(kinds_, pidx_, q_, x_, y_, alpha_, w_)
+        cm = [mp.mpf(float(v)) for v in c_]   # float64-rounded coefficients, as the kernel sees them
+        Jm = mp.zeros(mm, nn + q_)
+        for i in range(mm):
+            for j in range(nn):
+                f, df = basis(kinds_[j], X[i], [A[k] for k in pidx_[j]])
+                Jm[i, j] = f
+                for a_, k in enumerate(pidx_[j]):
+                    Jm[i, nn + k] += df[a_] * cm[j]
+        H = mp.zeros(mm, nn + q_)
+        for i in range(mm):
+            for j in range(nn + q_):
+                H[i, j] = Wv[i] * Jm[i, j]
+        rr = sum(mp.mpf(float(v)) ** 2 for v in r_)
+        s2 = rr / (mm - nn - q_)
+        Cov = s2 * mp.inverse(H.T * H)
+        sig = []
+        for i in range(mm):
+            ji = Jm[i, :]
+            sig.append(mp.sqrt((ji * Cov * ji.T)[0, 0]))
+        K = nn + q_
+        return (np.array([[float(Cov[a_, b_]) for b_ in range(K)] for a_ in range(K)]), float(s2),
+                np.array([float(v) for v in sig]))
+    cov, chi2, sig = statistics(kinds, pidx, 2, d["x"], d["Y"][0], d["tau_guess"][0], w)
+    out["cfg1w_cov"], out["cfg1w_chi2"], out["cfg1w_sigma"] = cov, np.array([chi2]), sig
+    print("cfg1w statistics done")
     # case E: multiple right-hand sides (one alpha, S = 3 columns), weighted, m = 40: per column c_s, r_s and
     # J_k[:, s] = -P_perp (W dPhi/dalpha_k) c_s   (src/solvers/levmar/mod.rs:147-186); layouts [S][n], [S][m], [q][S][m]
     rng = np.random.default_rng(5)

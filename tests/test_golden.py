@@ -133,3 +133,31 @@ def test_gpu_mrhs_matches_high_precision_golden():
     assert ev["status"][0] == 0
     _check_mrhs(ev["C"][0], ev["r"][0].reshape(S, m), ev["J"][0].reshape(2, S, m), cg, rg, Jg, Y * w)
     bp.close()
+
+
+# ---- fit statistics against the 50-digit values -----------------------------------------------------------------
+def _stats_check(cov, chi2, sig):
+    cg, sg = G["cfg1w_cov"], G["cfg1w_sigma"]
+    assert abs(chi2 - float(G["cfg1w_chi2"][0])) <= 1e-10 * float(G["cfg1w_chi2"][0])
+    scale = np.sqrt(np.outer(np.diag(cg), np.diag(cg)))  # entries relative to their variances
+    assert (np.abs(cov - cg) / scale).max() <= 1e-8      # cond(H^T H) ~ 1e5 amplifies eps; the crate asserts 1e-5
+    assert np.abs(sig - sg).max() <= 1e-9 * np.abs(sg).max()
+
+
+def test_oracle_statistics_match_high_precision_golden():
+    mdl, x, y, alpha, w, *_ = _case("cfg1w")
+    p = O.Problem(mdl, x, y, w=w)
+    p.set_params(alpha)
+    st = p.statistics()
+    _stats_check(st["cov"], st["reduced_chi2"], st["conf_sigma"])
+
+
+@pytest.mark.gpu
+def test_gpu_statistics_match_high_precision_golden():
+    mdl, x, y, alpha, w, *_ = _case("cfg1w")
+    bp = vp.BatchProblem(mdl, y[None, :], x=x, weights=w)
+    bp.evaluate(alpha[None, :])
+    st = bp.statistics()
+    assert st["status"][0] == 0
+    _stats_check(st["cov"][0], float(st["reduced_chi2"][0]), st["conf_sigma"][0])
+    bp.close()
