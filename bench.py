@@ -304,6 +304,7 @@ def main():
     for h_ in handles:
         h_.close()
     if use_dist:
+        barrier()  # the other ranks wait here while rank 0 takes the per-kernel measurements / CPU baseline
         dist.destroy_process_group()
 
 
