@@ -316,6 +316,18 @@ int vp_summary_device(vp_batch *h, double *dev_out4);
 typedef int (*vp_allreduce_fn)(void *dev_doubles, int64_t count, void *hip_stream, void *user);
 int vp_set_rhs_allreduce(vp_batch *h, vp_allreduce_fn fn, void *user, int64_t global_rhs_count);
 
+/* Single-RHS fit kernel selection of a handle (explicit state; the library reads no environment variables).
+ *   AUTO  : the persistent slot kernel (a wavefront owns several problems whose LM bookkeeping runs lane-parallel,
+ *           problems are handed out from a device-side queue) once the batch exceeds the device's resident
+ *           wavefront slots, otherwise one wavefront per problem; cases the slot kernel does not cover (weights,
+ *           per-problem grids, models without a trailing constant basis) always run one wavefront per problem
+ *   WAVE  : always one wavefront per problem
+ *   SLOTS : the slot kernel whenever it covers the problem, regardless of the batch size
+ * All three implement LevenbergMarquardt::minimize (src/solvers/levmar/mod.rs:247) with identical arithmetic per
+ * problem; results do not depend on which wavefront or slot ran a problem. */
+enum { VP_FIT_KERNEL_AUTO = 0, VP_FIT_KERNEL_WAVE = 1, VP_FIT_KERNEL_SLOTS = 2 };
+int vp_set_fit_kernel(vp_batch *h, int which);
+
 /* ---- introspection --------------------------------------------------------------------- */
 
 /* duration in ms of the most recent launch of a kernel family on this handle, measured

@@ -122,10 +122,54 @@ static void small_jacobi_svd(int n, long double *W, long double *V) {
     }
 }
 
+/* Dot product in twice the working precision without x87 `long double` (which serialises on the x87 stack and does
+ * not exist on other hosts): Ogita-Rump-Oishi Dot2 -- error-free product via fma(), error-free sum via TwoSum --
+ * over four independent accumulator pairs so that the dependent add chains overlap. */
+#if defined(__x86_64__) && defined(__GNUC__)
+__attribute__((target_clones("fma", "default"))) /* fma() inlined to one instruction where the host has it */
+#endif
+static double dot2(int m, const double *a, const double *b) {
+    double s[4] = {0, 0, 0, 0}, c[4] = {0, 0, 0, 0};
+    int i = 0;
+    for (; i + 4 <= m; i += 4)
+        for (int l = 0; l < 4; ++l) {
+            const double x = a[i + l], y = b[i + l];
+            const double pr = x * y, pe = fma(x, y, -pr);
+            const double t = s[l] + pr, z = t - s[l];
+            const double se = (s[l] - (t - z)) + (pr - z);
+            s[l] = t;
+            c[l] += pe + se;
+        }
+    for (; i < m; ++i) {
+        const double x = a[i], y = b[i];
+        const double pr = x * y, pe = fma(x, y, -pr);
+        const double t = s[0] + pr, z = t - s[0];
+        const double se = (s[0] - (t - z)) + (pr - z);
+        s[0] = t;
+        c[0] += pe + se;
+    }
+    /* combine the four partial sums, again error-free */
+    double hi = s[0], lo = c[0];
+    for (int l = 1; l < 4; ++l) {
+        const double t = hi + s[l], z = t - hi;
+        lo += ((hi - (t - z)) + (s[l] - z)) + c[l];
+        hi = t;
+    }
+    return hi + lo;
+}
+
 /* Householder QR (m x n) -> explicit thin Q, then Jacobi SVD of the n x n R: A = (Q U_r) Sigma V^T.
  * Cost ~ 4 m n^2 flops, comparable to nalgebra's bidiagonalisation route (keeps the CPU baseline fair). */
+static void thin_svd_ws(int m, int n, const double *A, double *U, double *sigma, double *V, double *W);
+
 void vpo_thin_svd(int m, int n, const double *A, double *U, double *sigma, double *V) {
     double *W = (double *)malloc(sizeof(double) * (size_t)m * n);
+    thin_svd_ws(m, n, A, U, sigma, V, W);
+    free(W);
+}
+
+/* W: m x n workspace owned by the caller (the problem object: no allocation per evaluation) */
+static void thin_svd_ws(int m, int n, const double *A, double *U, double *sigma, double *V, double *W) {
     double tau[VP_MAX_BASIS];
     long double Rm[VP_MAX_BASIS * VP_MAX_BASIS], Vr[VP_MAX_BASIS * VP_MAX_BASIS];
     memcpy(W, A, sizeof(double) * (size_t)m * n);
@@ -188,7 +232,6 @@ void vpo_thin_svd(int m, int n, const double *A, double *U, double *sigma, doubl
             for (int i = k + 1; i < m; ++i) u[i] -= dot * ak[i];
         }
     }
-    free(W);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -232,8 +275,26 @@ vpo_problem *vpo_problem_create(const vp_model_desc *model, int m, int S, const 
     p->V = (double *)malloc(sizeof(double) * n * n);
     p->C = (double *)malloc(sizeof(double) * (size_t)n * S);
     p->R = (double *)malloc(sizeof(double) * (size_t)m * S);
+    /* workspace of set_params / jacobian / fit, owned by the problem: no allocation per evaluation */
+    p->ws_phi = (double *)malloc(sizeof(double) * (size_t)m * n);
+    p->ws_qr = (double *)malloc(sizeof(double) * (size_t)m * n);
+    p->ws_dk = (double *)malloc(sizeof(double) * (size_t)m * n);
+    p->ws_fvec = (double *)malloc(sizeof(double) * (size_t)m * S);
+    p->ws_fwork = (double *)malloc(sizeof(double) * (size_t)m * S);
+    p->ws_fjac = (double *)malloc(sizeof(double) * (size_t)m * S * (q > 0 ? q : 1));
     p->cached = 0;
     return p;
+}
+
+/* New observations for an existing problem (same model, grid and weights): == building another SeparableProblem
+ * without re-allocating -- the batched helpers keep ONE problem object per thread. */
+void vpo_problem_reset(vpo_problem *p, const double *Y) {
+    const int m = p->m, S = p->S;
+    for (int s = 0; s < S; ++s)
+        for (int i = 0; i < m; ++i) p->Yw[i + (size_t)s * m] = (p->w ? p->w[i] : 1.0) * Y[i + (size_t)s * m];
+    p->cached = 0;
+    p->n_set_params = 0;
+    p->n_jacobians = 0;
 }
 
 void vpo_problem_destroy(vpo_problem *p) {
@@ -247,6 +308,12 @@ void vpo_problem_destroy(vpo_problem *p) {
     free(p->V);
     free(p->C);
     free(p->R);
+    free(p->ws_phi);
+    free(p->ws_qr);
+    free(p->ws_dk);
+    free(p->ws_fvec);
+    free(p->ws_fwork);
+    free(p->ws_fjac);
     free(p);
 }
 
@@ -255,7 +322,7 @@ void vpo_set_params(vpo_problem *p, const double *alpha) {
     const int m = p->m, S = p->S, n = p->model.n_basis, q = p->model.n_params;
     p->n_set_params++;
     memcpy(p->alpha, alpha, sizeof(double) * q); /* :43 model.set_params(params.clone()) */
-    double *Phi_w = (double *)malloc(sizeof(double) * (size_t)m * n);
+    double *Phi_w = p->ws_phi;
     /* :47  Phi_w = &self.weights * Phi */
     vpo_eval_phi(&p->model, m, p->t, p->alpha, Phi_w);
     if (p->w)
@@ -264,19 +331,17 @@ void vpo_set_params(vpo_problem *p, const double *alpha) {
     if (!all_finite(Phi_w, (size_t)m * n)) { /* nalgebra's SVD does not converge on non-finite input:
                                                 treated as the error path, cached = None (:70-72) */
         p->cached = 0;
-        free(Phi_w);
         return;
     }
     /* :51  Phi_w.clone().svd(true, true) */
-    vpo_thin_svd(m, n, Phi_w, p->U, p->sigma, p->V);
+    thin_svd_ws(m, n, Phi_w, p->U, p->sigma, p->V, p->ws_qr);
     /* :52-54  svd.solve(&Y_w, eps): x = V * diag(sigma_i > eps ? 1/sigma_i : 0) * U^T b (absolute threshold) */
     double utb[VP_MAX_BASIS];
     for (int s = 0; s < S; ++s) {
         const double *y = p->Yw + (size_t)s * m;
         for (int j = 0; j < n; ++j) {
-            long double acc = 0;
-            for (int i = 0; i < m; ++i) acc += (long double)p->U[i + (size_t)j * m] * y[i];
-            utb[j] = (p->sigma[j] > p->eps) ? (double)acc / p->sigma[j] : 0.0;
+            const double acc = dot2(m, p->U + (size_t)j * m, y);
+            utb[j] = (p->sigma[j] > p->eps) ? acc / p->sigma[j] : 0.0;
         }
         for (int i = 0; i < n; ++i) {
             double acc = 0;
@@ -291,7 +356,6 @@ void vpo_set_params(vpo_problem *p, const double *alpha) {
             r[i] = y[i] - acc;
         }
     }
-    free(Phi_w);
     p->cached = all_finite(p->C, (size_t)n * S) && all_finite(p->R, (size_t)m * S);
 }
 
@@ -307,7 +371,7 @@ int vpo_jacobian(vpo_problem *p, double *J_out) {
     if (!p->cached) return 0;
     const int m = p->m, S = p->S, n = p->model.n_basis, q = p->model.n_params;
     p->n_jacobians++;
-    double *Dk = (double *)malloc(sizeof(double) * (size_t)m * n);
+    double *Dk = p->ws_dk;
     const double *U = p->U;
     for (int k = 0; k < q; ++k) {
         /* :141  Dk = &self.weights * model.eval_partial_deriv(k) */
@@ -360,7 +424,6 @@ int vpo_jacobian(vpo_problem *p, double *J_out) {
                 }
         }
     }
-    free(Dk);
     return 1;
 }
 
@@ -740,9 +803,9 @@ int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double
     int first_tr = 1, first_update = 1;
     const int max_fev = opts->patience * (n + 1);
     if (n == 0) goto done;
-    fvec = (double *)malloc(sizeof(double) * mr);
-    fwork = (double *)malloc(sizeof(double) * mr);
-    fjac = (double *)malloc(sizeof(double) * (size_t)mr * n);
+    fvec = p->ws_fvec;
+    fwork = p->ws_fwork;
+    fjac = p->ws_fjac;
     memcpy(x, p->alpha, sizeof(double) * n);
     if (!vpo_residuals(p, fvec)) {
         report.termination = VP_TERM_USER;
@@ -914,9 +977,6 @@ int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double
         }
     }
 done:
-    free(fvec);
-    free(fjac);
-    free(fwork);
     if (rep) *rep = report;
     return trow;
 }
@@ -955,10 +1015,11 @@ double vpo_fit_batch(const vp_model_desc *model, int m, int64_t B, const double 
 #endif
         int64_t lo = B * tid / nt, hi = B * (tid + 1) / nt;
         double mine = 0.0;
-        for (int64_t b = lo; b < hi; ++b) {
-            int err;
-            vpo_problem *p = vpo_problem_create(model, m, 1, t, Y + (size_t)b * m, w, svd_epsilon, &err);
-            if (!p) continue;
+        int err;
+        /* one problem object (and workspace arena) per thread, re-used for every fit of its share */
+        vpo_problem *p = (lo < hi) ? vpo_problem_create(model, m, 1, t, Y + (size_t)lo * m, w, svd_epsilon, &err) : NULL;
+        for (int64_t b = lo; b < hi && p; ++b) {
+            vpo_problem_reset(p, Y + (size_t)b * m);
             vpo_set_params(p, alpha_inout + (size_t)b * q); /* build(): initial set_params, untimed (builder.rs:321) */
             vp_report r;
             double t0 = now_s();
@@ -971,8 +1032,8 @@ double vpo_fit_batch(const vp_model_desc *model, int m, int64_t B, const double 
                     for (int j = 0; j < n; ++j) C_out[(size_t)b * n + j] = NAN;
             }
             if (rep) rep[b] = r;
-            vpo_problem_destroy(p);
         }
+        vpo_problem_destroy(p);
         total = mine;
     }
     return total;

@@ -57,6 +57,8 @@ typedef struct vpo_problem {
     double *R;     /* m x S */
     long n_set_params; /* counters for the CPU-baseline report */
     long n_jacobians;
+    /* workspace owned by the problem (no allocation per evaluation): Phi_w, QR scratch, D_k, LM vectors */
+    double *ws_phi, *ws_qr, *ws_dk, *ws_fvec, *ws_fwork, *ws_fjac;
 } vpo_problem;
 
 /* == SeparableProblemBuilder::build (src/problem/builder.rs:278-324) WITHOUT the initial
@@ -64,6 +66,8 @@ typedef struct vpo_problem {
 vpo_problem *vpo_problem_create(const vp_model_desc *model, int m, int S, const double *t, const double *Y,
                                 const double *w, double svd_epsilon, int *build_err);
 void vpo_problem_destroy(vpo_problem *p);
+/* new observations Y (m x S) for an existing problem: same model / grid / weights, no re-allocation */
+void vpo_problem_reset(vpo_problem *p, const double *Y);
 
 /* == SeparableNonlinearModel::eval (src/model/mod.rs:308; closure impl :441-471) : Phi m x n */
 void vpo_eval_phi(const vp_model_desc *model, int m, const double *t, const double *alpha, double *Phi);

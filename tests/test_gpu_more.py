@@ -141,27 +141,6 @@ def test_failures_are_latched_per_problem_and_do_not_abort_the_batch():
     bp2.close()
 
 
-def test_multi_problem_per_wave_lm_kernel_agrees_with_default():
-    d = synth.double_exp_batch(200, m=1024, noise=1e-3)
-    mdl = double_exp_builder_model(d["x"], d["tau_guess"][0])
-    bp = vp.BatchProblem(mdl, d["Y"], x=d["x"])
-    a0, c0, r0 = bp.fit(d["tau_guess"])
-    try:
-        os.environ["VP_FIT_KERNEL"] = "mp"
-        for G in ("1", "7", "32"):
-            os.environ["VP_FIT_GROUP"] = G
-            a1, c1, r1 = bp.fit(d["tau_guess"])
-            assert (r1["termination"] > 0).tolist() == (r0["termination"] > 0).tolist()
-            ok = r0["termination"] > 0
-            rel = np.abs(r1["objective"] - r0["objective"])[ok] / r0["objective"][ok]
-            assert rel.max() <= 1e-6 and np.median(rel) <= 1e-12
-            assert abs(r1["n_evals"].mean() - r0["n_evals"].mean()) <= 0.1 * r0["n_evals"].mean()
-    finally:
-        os.environ.pop("VP_FIT_KERNEL", None)
-        os.environ.pop("VP_FIT_GROUP", None)
-    bp.close()
-
-
 def test_device_exp_accuracy_over_the_argument_range():
     # exp(-t/tau) for arguments 0 .. -700: relative error <= 2 ulp against libm
     m = 1024

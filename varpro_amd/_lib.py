@@ -36,10 +36,12 @@ if os.environ.get("VARPRO_HIP_LIBRARY"):  # developer A/B builds of the same lib
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 
 # every symbol include/varpro_hip.h declares (tests check the library exports all of them)
+VP_FIT_KERNEL_AUTO, VP_FIT_KERNEL_WAVE, VP_FIT_KERNEL_SLOTS = 0, 1, 2
+
 ABI_SYMBOLS = [
     "vp_batch_create", "vp_batch_destroy", "vp_set_params", "vp_params", "vp_residuals", "vp_jacobian",
     "vp_linear_coeffs", "vp_weighted_data", "vp_set_observations", "vp_cost", "vp_evaluate", "vp_basis", "vp_lm_opts_default", "vp_fit", "vp_fit_trace",
-    "vp_best_fit", "vp_statistics", "vp_summary", "vp_summary_device", "vp_set_rhs_allreduce", "vp_set_timing", "vp_last_kernel_ms", "vp_synchronize", "vp_last_error",
+    "vp_best_fit", "vp_statistics", "vp_summary", "vp_summary_device", "vp_set_rhs_allreduce", "vp_set_fit_kernel", "vp_set_timing", "vp_last_kernel_ms", "vp_synchronize", "vp_last_error",
     "vp_last_error_detail", "vp_version", "vp_device_count",
 ]
 
@@ -119,6 +121,7 @@ def load():
     lib.vp_summary.argtypes = [vp, dp]
     lib.vp_summary_device.argtypes = [vp, vp]
     lib.vp_set_rhs_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, C.c_int64]
+    lib.vp_set_fit_kernel.argtypes = [vp, C.c_int]
     lib.vp_set_timing.argtypes = [vp, C.c_int]
     lib.vp_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     lib.vp_synchronize.argtypes = [vp]

@@ -391,6 +391,12 @@ class BatchProblem:
         check(self.lib.vp_summary_device(self._h, C.c_void_p(out.data_ptr())))
         return out
 
+    def set_fit_kernel(self, which):
+        """single-RHS fit kernel selection: "auto" | "wave" (one wavefront per problem) | "slots" (persistent
+        slot kernel wherever it covers the problem) -- see include/varpro_hip.h:vp_set_fit_kernel"""
+        code = {"auto": _lib.VP_FIT_KERNEL_AUTO, "wave": _lib.VP_FIT_KERNEL_WAVE, "slots": _lib.VP_FIT_KERNEL_SLOTS}[which]
+        check(self.lib.vp_set_fit_kernel(self._h, code))
+
     def set_timing(self, enable=True):
         check(self.lib.vp_set_timing(self._h, int(enable)))
 

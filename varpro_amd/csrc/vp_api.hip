@@ -182,6 +182,10 @@ struct vp_batch {
     void *rhs_allreduce_user;
     int64_t rhs_global; // right-hand sides of the whole problem
     double *d_mrhs_tot; // [B][1 + n*n + p] totals of the reduced sums (all-reduced across ranks)
+    // single-RHS fit kernel selection (vp_set_fit_kernel) and the slot kernel's problem queue
+    int fit_kernel;
+    int *d_queue;
+    int num_cus;
 };
 
 namespace {
@@ -269,6 +273,9 @@ void fill_params(vp_batch *h, LaunchParams &p) {
     p.eps = h->eps;
     p.grid_uniform = h->grid_uniform ? 1 : 0;
     p.stream = h->stream;
+    p.queue = h->d_queue;
+    p.num_cus = h->num_cus;
+    p.fit_group = h->fit_kernel;
 }
 
 struct Timer {
@@ -491,6 +498,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     h->p = npairs;
     h->flags = flags;
     h->device = device;
+    h->num_cus = prop.multiProcessorCount;
     const double meps = dtype == VP_F32 ? (double)FLT_EPSILON : DBL_EPSILON;
     h->eps = svd_epsilon < 0 ? meps : std::fabs(svd_epsilon); // src/problem/builder.rs:246-251, 282
     h->kern = kern;
@@ -526,8 +534,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         VP_TRY(hipMemcpyAsync(h->d_w, w, w_elems * ts, kin, h->stream));
     }
     int *d_gflag = nullptr;
-    const bool try_uniform = (dtype == VP_F64) && m >= 3 && !(flags & VP_FLAG_NO_GRID_RECURRENCE) &&
-                             !(std::getenv("VP_GRID_RECURRENCE") && std::atoi(std::getenv("VP_GRID_RECURRENCE")) == 0);
+    const bool try_uniform = (dtype == VP_F64) && m >= 3 && !(flags & VP_FLAG_NO_GRID_RECURRENCE);
     if (try_uniform) {
         const int one = 1;
         VP_TRY(hipMalloc((void **)&d_gflag, sizeof(int)));
@@ -577,6 +584,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     }
     VP_TRY(hipMalloc((void **)&h->d_report, (size_t)B * sizeof(vp_report)));
     VP_TRY(hipMalloc((void **)&h->d_sum4, 4 * sizeof(double)));
+    VP_TRY(hipMalloc((void **)&h->d_queue, sizeof(int)));
     VP_TRY(hipEventCreate(&h->ev0));
     VP_TRY(hipEventCreate(&h->ev1));
     if (S > 1 && kern->mrhs_factor && kern->mrhs_stream && kern->mrhs_lm && kern->mrhs_finish) {
@@ -618,6 +626,7 @@ void vp_batch_destroy(vp_batch *h) {
     }
     (void)hipFree(h->d_report);
     (void)hipFree(h->d_sum4);
+    (void)hipFree(h->d_queue);
     if (h->have_mrhs) {
         (void)hipFree(h->mrhs.qthin);
         (void)hipFree(h->mrhs.g);
@@ -823,13 +832,10 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
         p.trace = (double *)tr.dptr;
         p.trace_rows = trace_rows;
     }
-    // The one-problem-per-wave kernel (vp_fit.hpp) is the default: measured 12.1 vs 8.5-9.8 Mfits/s for the
-    // multi-problem formulation (vp_fit_mp.hpp) on B = 65536 double-exponential fits.  Knobs for A/B runs:
-    // VP_FIT_KERNEL=mp selects the multi-problem kernel, VP_FIT_GROUP=<G> fixes its problems-per-wave.
-    launch_fn fit_fn = h->kern->fit_single ? h->kern->fit_single : h->kern->fit;
-    if (const char *e = std::getenv("VP_FIT_KERNEL"))
-        if (std::strcmp(e, "mp") == 0 && h->kern->fit) fit_fn = h->kern->fit;
-    if (const char *e = std::getenv("VP_FIT_GROUP")) p.fit_group = std::atoi(e);
+    // kern->fit is the persistent slot kernel (vp_fit2.hpp); it falls back to the one-problem-per-wave kernel
+    // (vp_fit.hpp) by itself for the cases it does not cover (weights, per-problem grids, models without a trailing
+    // constant column, batches smaller than the device's resident wave slots).  vp_set_fit_kernel overrides.
+    launch_fn fit_fn = h->kern->fit ? h->kern->fit : h->kern->fit_single;
     Timer tm(h, VP_KERNEL_FIT);
     int rc = fit_fn(p);
     tm.stop();
@@ -934,6 +940,14 @@ int vp_summary_device(vp_batch *h, double *dev_out4) {
     const unsigned grid = (unsigned)std::min<int64_t>((h->B + 255) / 256, 1024);
     hipLaunchKernelGGL(summary_kernel, dim3(grid), dim3(256), 0, h->stream, h->d_report, h->B, dev_out4);
     VP_HIP(hipGetLastError());
+    return VP_ERR_OK;
+}
+
+int vp_set_fit_kernel(vp_batch *h, int which) {
+    if (!h) return fail(VP_ERR_INVALID, "null handle");
+    if (which != VP_FIT_KERNEL_AUTO && which != VP_FIT_KERNEL_WAVE && which != VP_FIT_KERNEL_SLOTS)
+        return fail(VP_ERR_INVALID, "vp_set_fit_kernel: unknown kernel selector");
+    h->fit_kernel = which;
     return VP_ERR_OK;
 }
 

@@ -245,9 +245,11 @@ __device__ __forceinline__ void solve_coeffs(const T (&Rm)[N][N], const T (&qty)
 #pragma unroll
     for (int i = 0; i < N; ++i) zero_diag = zero_diag || (Rm[i][i] == T(0));
     if (!uni(zero_diag)) {
-        T d[N]; // reciprocals of the diagonal
+        // reciprocals of the diagonal (Newton-refined v_rcp, 1-2 ulp: c below is re-rounded by a residual step, and
+        // R^-1 only feeds a bound) -- N IEEE division expansions less per evaluation
+        T d[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) d[i] = T(1) / Rm[i][i];
+        for (int i = 0; i < N; ++i) d[i] = frcp(Rm[i][i]);
         // sigma_min(R) >= 1/||R^{-1}||_F : R^{-1} column by column (upper triangular)
         T inv_f2 = T(0);
         T Ri[N][N];
@@ -391,10 +393,13 @@ __device__ __forceinline__ ConstReflector<T> make_const_reflector(const Src &src
 
 // C: [0, NEXP) exponential columns, [NEXP] data column (already loaded with y_w), [NEXP+1, 2 NEXP+1) derivative
 // columns.  On return: columns in Q-coordinates (rows >= N of the data / derivative columns are what the LM uses).
-template <typename T, class M, int R, int NCX, class Src, class G>
+//   YPRE: the data column arrives as H_0 y_w (the slot kernel applies the alpha-independent reflector once per fit,
+//         vp_fit2.hpp) and skips reflector 0 here; qty0 = (H_0 y_w)[0]
+template <typename T, class M, int R, int NCX, class Src, class G, bool YPRE = false>
 __device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T (&alpha)[M::Q], const Src &src, T eps,
                                                           G &grp, const ConstReflector<T> &h0, T (&C)[NCX][R],
-                                                          EvalUniform<T, M::N> &u, SectionClock *clk = nullptr) {
+                                                          EvalUniform<T, M::N> &u, SectionClock *clk = nullptr,
+                                                          const T qty0 = T(0)) {
     constexpr int N = M::N, NE = M::N - 1;
     static_assert(M::kConstLast && NCX == M::N + M::P, "const-first sweep: N-1 exponentials + data + P derivatives");
     using L = Layout<R, G::W>;
@@ -412,9 +417,11 @@ __device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T 
         T tt[2], sc[2];
         src.get(r0, tt, sc);
 #pragma unroll
-        for (int j = 0; j < NCX; ++j)
+        for (int j = 0; j < NCX; ++j) {
+            if (YPRE && j == NE) continue;
 #pragma unroll
             for (int e = 0; e < VW; ++e) d[j] = tfma(sc[e], C[j][r0 + e], d[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < NCX; ++j) top[j] = C[j][L::reg_of_row(0)];
@@ -425,6 +432,11 @@ __device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T 
     Rm[0][0] = h0.beta;
 #pragma unroll
     for (int j = 0; j < NCX; ++j) {
+        if (YPRE && j == NE) {
+            tau[j] = T(0);
+            qty[0] = qty0;
+            continue;
+        }
         tau[j] = h0.g * tfma(-h0.beta, top[j], d[j]);
         const T tj = tfma(tau[j], h0.u, top[j]);
         if (j < NE) Rm[0][1 + j] = tj;
@@ -438,7 +450,10 @@ __device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T 
         for (int e = 0; e < VW; ++e) {
             const T v = (r0 + e < VW && L::row_of(r0 + e, lane) == 0) ? h0.u : sc[e];
 #pragma unroll
-            for (int j = 0; j < NCX; ++j) C[j][r0 + e] = tfma(tau[j], v, C[j][r0 + e]);
+            for (int j = 0; j < NCX; ++j) {
+                if (YPRE && j == NE) continue;
+                C[j][r0 + e] = tfma(tau[j], v, C[j][r0 + e]);
+            }
         }
     }
     // ---- reflectors 1..NE on the exponential columns, pivot rows 1..NE ----

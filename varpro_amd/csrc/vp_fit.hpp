@@ -423,6 +423,218 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
     for (int j = 0; j < Q; ++j) Rj[j][j] = rdiag[j];
 }
 
+// The same factorisation for a Jacobian given as COLUMN-SCALED columns  z_k = s_k g_k  (Kaufman: z_k = -c_k Q^T D_k for
+// models whose pair p is (basis p, parameter p)):  the reflectors depend only on the directions g_k, so all vector
+// work runs on the unscaled columns G in place -- no scaling pass over the q columns -- and the scales enter as wave-
+// uniform factors:  R_Z = R_G diag(s_perm),  acnorm_k = |s_k| ||g_k||,  pivoting by |s_k| * (downdated norm of g_k),
+// qtf unchanged.  Rows < ROW0 of G (the range(Q) part, not in P_perp) are cleared here.  MINPACK's "zero pivot column"
+// branch is taken on the SCALED norm (s_k == 0 makes z_k a zero column whatever g_k is).
+template <typename T, int R, int Q, int ROW0, class G>
+__device__ __forceinline__ void jac_qrfac_scaled(T (&Z)[Q][R], T (&rv)[R], const T (&s_in)[Q], T (&Rj)[Q][Q],
+                                                 T (&acnorm)[Q], int (&ipvt)[Q], T (&qtf)[Q], G &grp) {
+    using L = Layout<R, G::W>;
+    const int lane = grp.gl;
+    T rdiag[Q], wa[Q], sa[Q], sc[Q]; // rdiag/wa: norms of the UNSCALED columns; sa = |s|; sc = s (follow the columns)
+    T Gm[Q][Q], bz[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k)
+#pragma unroll
+        for (int r = 0; r < L::VW && r < R; ++r) Z[k][r] = (L::row_of(r, lane) < ROW0) ? T(0) : Z[k][r];
+    {
+        constexpr int NG = Q * (Q + 1) / 2 + Q;
+        T gr[NG];
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < Q; ++a)
+#pragma unroll
+            for (int b = a; b < Q; ++b) {
+                T acc = T(0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc = tfma(Z[a][r], Z[b][r], acc);
+                gr[idx++] = acc;
+            }
+#pragma unroll
+        for (int a = 0; a < Q; ++a) {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc = tfma(Z[a][r], rv[r], acc);
+            gr[idx++] = acc;
+        }
+        group_allreduce(grp, gr);
+        idx = 0;
+#pragma unroll
+        for (int a = 0; a < Q; ++a)
+#pragma unroll
+            for (int b = a; b < Q; ++b) {
+                Gm[a][b] = gr[idx];
+                Gm[b][a] = gr[idx];
+                ++idx;
+            }
+#pragma unroll
+        for (int a = 0; a < Q; ++a) bz[a] = gr[idx++];
+#pragma unroll
+        for (int a = 0; a < Q; ++a) {
+            sc[a] = s_in[a];
+            sa[a] = tabs(s_in[a]);
+            rdiag[a] = usqrt(Gm[a][a]);
+            wa[a] = rdiag[a];
+            acnorm[a] = sa[a] * rdiag[a];
+            ipvt[a] = a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i)
+#pragma unroll
+        for (int k = 0; k < Q; ++k) Rj[i][k] = T(0);
+    static_for<0, Q>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int prow = ROW0 + j;
+        constexpr int NREM = Q - j; // columns j .. Q-1
+        // bring the column of largest (downdated, SCALED) norm into the pivot position
+        int kmax = j;
+#pragma unroll
+        for (int k = j + 1; k < Q; ++k)
+            if (dyn_get<Q>(sa, k) * dyn_get<Q>(rdiag, k) > dyn_get<Q>(sa, kmax) * dyn_get<Q>(rdiag, kmax)) kmax = k;
+        kmax = uni(kmax);
+#pragma unroll
+        for (int k = j + 1; k < Q; ++k) {
+            if (kmax == k) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T tmp = Z[j][r];
+                    Z[j][r] = Z[k][r];
+                    Z[k][r] = tmp;
+                }
+#pragma unroll
+                for (int i = 0; i < j; ++i) {
+                    const T tmp = Rj[i][j];
+                    Rj[i][j] = Rj[i][k];
+                    Rj[i][k] = tmp;
+                }
+                T tv = rdiag[j];
+                rdiag[j] = rdiag[k];
+                rdiag[k] = tv;
+                tv = wa[j];
+                wa[j] = wa[k];
+                wa[k] = tv;
+                tv = sa[j];
+                sa[j] = sa[k];
+                sa[k] = tv;
+                tv = sc[j];
+                sc[j] = sc[k];
+                sc[k] = tv;
+                const int ti = ipvt[j];
+                ipvt[j] = ipvt[k];
+                ipvt[k] = ti;
+                if constexpr (j == 0) { // the Gram bookkeeping follows the columns (only step 0 uses it)
+#pragma unroll
+                    for (int a = 0; a < Q; ++a) {
+                        const T tmp = Gm[a][0];
+                        Gm[a][0] = Gm[a][k];
+                        Gm[a][k] = tmp;
+                    }
+#pragma unroll
+                    for (int a = 0; a < Q; ++a) {
+                        const T tmp = Gm[0][a];
+                        Gm[0][a] = Gm[k][a];
+                        Gm[k][a] = tmp;
+                    }
+                    const T tb = bz[0];
+                    bz[0] = bz[k];
+                    bz[k] = tb;
+                }
+            }
+        }
+        // raw dot products of the pivot column g (rows >= prow) with itself, the remaining columns and rv
+        T dz[NREM], dr;
+        if constexpr (j == 0) {
+#pragma unroll
+            for (int k = 0; k < NREM; ++k) dz[k] = Gm[0][k];
+            dr = bz[0];
+        } else {
+#pragma unroll
+            for (int r = 0; r < L::VW && r < R; ++r) {
+                const int i = L::row_of(r, lane);
+                Z[j][r] = (i >= prow) ? Z[j][r] : T(0);
+            }
+            T w[NREM + 1];
+#pragma unroll
+            for (int k = j; k < Q; ++k) {
+                T acc = T(0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc = tfma(Z[j][r], Z[k][r], acc);
+                w[k - j] = acc;
+            }
+            {
+                T acc = T(0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc = tfma(Z[j][r], rv[r], acc);
+                w[NREM] = acc;
+            }
+            group_allreduce(grp, w);
+#pragma unroll
+            for (int k = 0; k < NREM; ++k) dz[k] = w[k];
+            dr = w[NREM];
+        }
+        T top[NREM + 1];
+#pragma unroll
+        for (int k = j; k < Q; ++k) top[k - j] = Z[k][L::reg_of_row(prow)];
+        top[NREM] = rv[L::reg_of_row(prow)];
+        group_bcast<NREM + 1>(grp, top, L::lane_of_row(prow));
+        T an = usqrt(dz[0]); // norm of the unscaled pivot column
+        if (uni(sa[j] * an == T(0))) {
+            // zero (scaled) pivot column: no reflector; the remaining columns' row-prow entries are the R entries
+            rdiag[j] = T(0);
+#pragma unroll
+            for (int k = j + 1; k < Q; ++k) Rj[j][k] = sc[k] * top[k - j];
+            qtf[j] = top[NREM];
+            return;
+        }
+        const T piv = top[0];
+        if (piv < T(0)) an = -an;
+        const T vp = piv + an;         // v'_p of the unscaled column
+        const T gj = -frcp(an * vp);   // H = I + gj v' v'^T
+#pragma unroll
+        for (int r = 0; r < L::VW && r < R; ++r) {
+            const int i = L::row_of(r, lane);
+            Z[j][r] = (i == prow) ? vp : Z[j][r];
+        }
+#pragma unroll
+        for (int k = j + 1; k < Q; ++k) {
+            const T f = gj * tfma(an, top[k - j], dz[k - j]); // gj * v'^T g_k
+#pragma unroll
+            for (int r = 0; r < R; ++r) Z[k][r] = tfma(f, Z[j][r], Z[k][r]);
+            const T akj = tfma(f, vp, top[k - j]); // row prow of the updated (unscaled) column
+            Rj[j][k] = sc[k] * akj;
+            if (uni(rdiag[k] != T(0))) {
+                const T tq = akj * frcp(rdiag[k]);
+                rdiag[k] = rdiag[k] * usqrt(tmax(T(0), T(1) - tq * tq));
+                const T rr = rdiag[k] * frcp(wa[k]);
+                if (uni(T(0.05) * (rr * rr) <= num<T>::eps)) {
+                    T s2 = T(0);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const T v = (r >= L::VW || L::row_of(r, lane) > prow) ? Z[k][r] : T(0);
+                        s2 = tfma(v, v, s2);
+                    }
+                    rdiag[k] = tsqrt(group_sum(grp, s2));
+                    wa[k] = rdiag[k];
+                }
+            }
+        }
+        {
+            const T f = gj * tfma(an, top[NREM], dr);
+#pragma unroll
+            for (int r = 0; r < R; ++r) rv[r] = tfma(f, Z[j][r], rv[r]);
+            qtf[j] = tfma(f, vp, top[NREM]);
+        }
+        // MINPACK: rdiag_z = -ajnorm_z = -(s an); kept unscaled here for the downdating, scaled when R is assembled
+        rdiag[j] = -an;
+    });
+#pragma unroll
+    for (int j = 0; j < Q; ++j) Rj[j][j] = sc[j] * rdiag[j];
+}
+
 template <typename T, class M> struct FitArgs {
     M mdl;
     const T *t;
@@ -593,7 +805,8 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
         // ================= evaluate the VarPro functional at xt =================
         T C[NC][R];
         EvalUniform<T, N> u;
-        load_rows<T, R, W>(s_y, MP, lane, true, C[YC]);
+        if constexpr (R >= 2) load_rows_lds<T, R, W>(s_y, lane, C[YC]);
+        else load_rows<T, R, W>(s_y, MP, lane, true, C[YC]);
         VP_TICK(clk, 0);
         if constexpr (CF) evaluate_core_const_first<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, h0, C, u, clk);
         else evaluate_core<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, C, u, clk);
@@ -726,12 +939,16 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
         VP_TICK(clk, 4);
         if (need_jac) {
             // ================= Jacobian in Q-coordinates, pivoted QR, Q_J^T r =================
-            T Zs[M::kDiagonalPairs ? 1 : Q][R];
-            jacobian_qcoords<T, M, R, NC, G, DC>(a.mdl, C, u.c, Zs, grp);
             residual_qcoords<T, R, N>(C[YC], u.e, grp);
             if constexpr (M::kDiagonalPairs) {
-                jac_qrfac<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], Rj, acnorm, ipvt, qtf, grp);
+                // z_k = -c_k Q^T D_k: factor the unscaled columns in place, the coefficients enter as column scales
+                T zs[Q];
+#pragma unroll
+                for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
+                jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
             } else {
+                T Zs[Q][R];
+                jacobian_qcoords<T, M, R, NC, G, DC>(a.mdl, C, u.c, Zs, grp);
                 jac_qrfac<T, R, Q, N>(Zs, C[YC], Rj, acnorm, ipvt, qtf, grp);
             }
             VP_TICK(clk, 5);

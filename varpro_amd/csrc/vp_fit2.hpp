@@ -1,0 +1,640 @@
+// vp_fit2.hpp -- device-resident Levenberg-Marquardt, PERSISTENT SLOT formulation (the default fit kernel for
+// unit-weight problems on a shared grid whose model ends in a constant column).
+//
+// == LevMarSolver::fit -> levenberg_marquardt::LevenbergMarquardt::minimize (src/solvers/levmar/mod.rs:238-254, call
+// site :247) for a batch.  Same arithmetic per problem as fit_kernel (vp_fit.hpp); what changes is who pays for the
+// wave-uniform LM bookkeeping.  gfx950 has no scalar fp64 unit, so in fit_kernel every scalar operation of the trust
+// region update / lmpar / qrsolv costs a full 64-lane VALU instruction -- a quarter of all instructions of an LM
+// iteration, and the fit kernel is VALU-issue bound (profiles/r01_fit_kernel_valu_pmc.json).  Here a wavefront is
+// PERSISTENT and owns G problem SLOTS whose weighted data columns stay in LDS for the whole fit:
+//
+//   VECTOR phase   for each occupied slot in turn: all 64 lanes run the fused Householder sweep of that problem at
+//                  its trial point and, if the step is accepted, the pivoted QR of its Jacobian -- the code of
+//                  fit_kernel -- and lane 0 posts the handful of wave-uniform results in the slot's LDS record;
+//   SCALAR phase   lane s runs the LM bookkeeping of slot s: G problems' scalar work in ONE pass of instructions;
+//   REFILL         a slot whose fit terminated writes its results and takes the next problem off a global queue
+//                  (one atomic per fit), so waves never idle while problems remain and the slowest fits do not pin
+//                  a workgroup's partners.
+//
+// G is bounded by LDS (one m-row column per slot, 8 waves per CU): 2 at m = 1024 fp64, more for shorter problems.
+// The constant column's reflector H_0 does not depend on alpha, so a slot stores H_0 y_w instead of y_w (applied once
+// per fit when the slot is filled) and the data column skips reflector 0 in every evaluation.
+#pragma once
+#include "vp_fit.hpp"
+
+namespace vp {
+
+// Per-slot LM record in LDS: lane s owns record s in the scalar phase; lane 0 posts evaluation results into it.
+template <typename T, int N, int Q> struct alignas(8) SlotRec {
+    T xt[Q], x[Q], diag[Q], qtf[Q], acnorm[Q], cbest[N], cnew[N];
+    T Rj[Q][Q];
+    T fnorm, delta, par, xnorm, gnorm, pnorm, prered, dirder, objective;
+    T fnorm1, actred, ratio; // outputs of the latest evaluation
+    T qty0;                  // (H_0 y_w)[0]: first entry of Q^T y_w, fixed for the whole fit
+    int ipvt[Q];
+    int flags; // bit0 first, bit1 first_tr, bit2 first_update, bit3 eval ok, bit4 jacobian refreshed, bit5 good
+    int nfev;
+    int term;
+    int status;
+    int prob; // problem index of the slot, -1 = empty
+    int trow; // trace rows written so far
+};
+
+template <typename T, int R> constexpr int fit2_slots() {
+    // LDS budget: 8 resident waves per CU x G columns of 64*R scalars (+ one shared grid per workgroup) <= 160 KiB
+    return (64 * R * (int)sizeof(T) >= 8192) ? 2 : ((64 * R * (int)sizeof(T) >= 4096) ? 4 : 8);
+}
+
+template <typename T, class M> struct Fit2Args {
+    FitArgs<T, M> f;
+    int *queue;        // next problem index to hand out (pre-set to the number of statically assigned problems)
+    int waves_total;   // persistent waves in the grid
+};
+
+#define VP_LDS __attribute__((address_space(3)))
+
+// Launch-wide constants of the slot kernel, staged ONCE per workgroup in LDS: the scalar phase and the refill path
+// (both out of line, see below) read them from there, so they do not occupy SGPRs -- i.e. spill slots -- across the
+// register-critical vector phase.
+template <typename T> struct SlotConsts {
+    T ftol, xtol, gtol, stepbound;
+    T *alpha;          // in: initial guesses, out: final parameters  [B][q]
+    T *C_out;          // [B][n] or null
+    double *cost_out;  // [B] or null
+    int32_t *status;   // [B] or null
+    vp_report *report; // [B]
+    double *trace;     // [B][trace_rows][q+4] or null
+    const T *yw;       // [B][m]
+    int *queue;
+    int64_t B;
+    int trace_rows, scale_diag, max_fev, m;
+};
+
+// Fill a slot: y' = H_0 y_w into the slot's LDS column (row order, zero padded); returns (H_0 y_w)[0].
+template <typename T, int R, class Src, class G>
+__device__ __forceinline__ T fill_slot_column(const T *__restrict__ yp, const int m, T *s_col, const Src &src,
+                                              const ConstReflector<T> &h0, G &grp) {
+    using L = Layout<R, G::W>;
+    constexpr int VW = L::VW;
+    const int lane = grp.gl;
+    T y[R];
+    load_rows<T, R, G::W>(yp, m, lane, vec_aligned<T>(yp, m), y);
+    T acc = T(0);
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += VW) {
+        T tt[2], sc[2];
+        src.get(r0, tt, sc);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) acc = tfma(sc[e], y[r0 + e], acc);
+    }
+    const T d = group_sum(grp, acc);
+    const T top = group_row<R>(grp, y, 0);
+    const T tau = h0.g * tfma(-h0.beta, top, d);
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += VW) {
+        T tt[2], sc[2];
+        src.get(r0, tt, sc);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            const T v = (r0 + e < VW && L::row_of(r0 + e, lane) == 0) ? h0.u : sc[e];
+            y[r0 + e] = tfma(tau, v, y[r0 + e]);
+        }
+    }
+    store_rows<T, R, G::W>(s_col, 64 * R * G::W, lane, true, y);
+    return tfma(tau, h0.u, top);
+}
+
+// (Re)fill slot `s` of a wave with problem `prob` (wave-uniform; < 0 marks the slot empty).  Out of line: executed once
+// per fit, its register needs must not shape the allocation of the LM loop.
+template <typename T, int N, int Q, int R, int PADM>
+__device__ __noinline__ void slot_fill(VP_LDS SlotRec<T, N, Q> *rec, VP_LDS T *s_col, VP_LDS const T *s_t,
+                                       VP_LDS const SlotConsts<T> *k, const int prob, const T h0_beta, const T h0_u,
+                                       const T h0_g) {
+    using G = Grp<1>;
+    G grp = G::make(nullptr);
+    const int lane = grp.lane;
+    if (prob < 0) {
+        if (lane == 0) {
+            rec->prob = -1;
+            rec->term = VP_TERM_NOT_RUN;
+        }
+        return;
+    }
+    using Src = RowSource<T, R, true, 0, 1, 1, true, PADM>;
+    Src src;
+    src.t = (const T *)s_t;
+    src.w = nullptr;
+    src.m = k->m;
+    src.lane = lane;
+    src.vec = true;
+    ConstReflector<T> h0;
+    h0.beta = h0_beta;
+    h0.u = h0_u;
+    h0.g = h0_g;
+    h0.live = true;
+    const T qty0 = fill_slot_column<T, R, Src, G>(k->yw + (int64_t)prob * k->m, k->m, (T *)s_col, src, h0, grp);
+    if (lane == 0) {
+        const T *a0 = k->alpha + (int64_t)prob * Q;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const T v = a0[i];
+            rec->xt[i] = v;
+            rec->x[i] = v;
+            rec->diag[i] = T(1);
+            rec->qtf[i] = T(0);
+            rec->acnorm[i] = T(0);
+            rec->ipvt[i] = i;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) rec->Rj[i][j] = T(0);
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            rec->cbest[i] = T(0);
+            rec->cnew[i] = T(0);
+        }
+        rec->fnorm = rec->delta = rec->par = rec->xnorm = rec->gnorm = rec->pnorm = rec->prered = rec->dirder = T(0);
+        rec->objective = T(0) / T(0);
+        rec->fnorm1 = rec->actred = rec->ratio = T(0);
+        rec->qty0 = qty0;
+        rec->flags = 1 | 2 | 4;
+        rec->nfev = 0;
+        rec->term = VP_TERM_NOT_RUN;
+        rec->status = VP_ST_NOT_EVALUATED;
+        rec->prob = prob;
+        rec->trow = 0;
+    }
+}
+
+// SCALAR phase: lane s runs the LM bookkeeping of slot s on its LDS record (trust-region update, accept / reject,
+// termination tests, gradient test, lmpar, predicted reduction, next trial point) and writes the results of a fit that
+// terminated.  == the body of LevenbergMarquardt::minimize between two evaluations.  Out of line (see slot_fill).
+template <typename T, int N, int Q, int GS>
+__device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP_LDS const SlotConsts<T> *k) {
+    const int lane = lane_id();
+    if (!(lane < GS && recs[lane].prob >= 0)) return;
+    VP_LDS SlotRec<T, N, Q> *s = recs + lane;
+    const T ftol = k->ftol, xtol = k->xtol, gtol = k->gtol, stepbound = k->stepbound;
+    const int scale_diag = k->scale_diag, max_fev = k->max_fev, m = k->m;
+    T x[Q], xt[Q], diag[Q], qtf[Q], acnorm[Q], step[Q];
+    T Rj[Q][Q];
+    int ipvt[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        x[i] = s->x[i];
+        xt[i] = s->xt[i];
+        diag[i] = s->diag[i];
+        qtf[i] = s->qtf[i];
+        acnorm[i] = s->acnorm[i];
+        ipvt[i] = s->ipvt[i];
+        step[i] = T(0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) Rj[i][j] = s->Rj[i][j];
+    }
+    T fnorm = s->fnorm, delta = s->delta, par = s->par, xnorm = s->xnorm, gnorm = s->gnorm;
+    T pnorm = s->pnorm, prered = s->prered, dirder = s->dirder, objective = s->objective;
+    const T fnorm1 = s->fnorm1, actred = s->actred, ratio = s->ratio;
+    const int fl = s->flags;
+    bool first = (fl & 1) != 0, first_tr = (fl & 2) != 0, first_update = (fl & 4) != 0;
+    const bool ok = (fl & 8) != 0, jac_done = (fl & 16) != 0, good_v = (fl & 32) != 0;
+    int nfev = s->nfev, term = 0, status = s->status, trow = s->trow;
+    const int64_t prob = s->prob;
+    bool accept_c = false; // cbest <- cnew
+
+    auto trace_row = [&](T rt) {
+        double *trace = k->trace;
+        const int trace_rows = k->trace_rows;
+        if (trace && trow < trace_rows) {
+            double *tr = trace + ((size_t)prob * trace_rows + trow) * (Q + 4);
+#pragma unroll
+            for (int i = 0; i < Q; ++i) tr[i] = (double)xt[i];
+            tr[Q] = (double)fnorm1;
+            tr[Q + 1] = (double)rt;
+            tr[Q + 2] = (double)delta;
+            tr[Q + 3] = (double)par;
+        }
+        ++trow;
+    };
+
+    bool need_step = false;
+    if (first) {
+        first = false;
+        nfev = 1;
+        status = ok ? VP_ST_OK : VP_ST_NONFINITE;
+        if (!ok) { // residuals() == None
+            term = VP_TERM_USER;
+        } else {
+            fnorm = fnorm1;
+            objective = T(0.5) * fnorm * fnorm;
+            trace_row(T(0) / T(0));
+            accept_c = true;
+            if (Q > m) term = VP_TERM_WRONG_DIMENSIONS;
+            else if (!is_finite(fnorm)) term = VP_TERM_NUMERICAL;
+            else if (fnorm <= num<T>::tiny) term = VP_TERM_RESIDUALS_ZERO;
+            else need_step = true;
+        }
+    } else {
+        nfev += 1;
+        if (!ok) { // residuals() == None at the trial point: the problem keeps the trial parameters
+            term = VP_TERM_USER;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) x[i] = xt[i];
+            accept_c = true;
+            status = VP_ST_NONFINITE;
+        } else {
+            if (ratio <= T(0.25)) {
+                T temp = !(actred < T(0)) ? T(0.5) : T(0.5) * dirder * frcp(dirder + T(0.5) * actred);
+                if (fnorm1 * T(0.1) >= fnorm || temp < T(0.1)) temp = T(0.1);
+                delta = temp * tmin(delta, pnorm * T(10));
+                par = par * frcp(temp);
+            } else if (par == T(0) || ratio >= T(0.75)) {
+                delta = pnorm * T(2);
+                par = par * T(0.5);
+            }
+            trace_row(ratio);
+            if (good_v) {
+#pragma unroll
+                for (int i = 0; i < Q; ++i) x[i] = xt[i];
+                accept_c = true;
+                T tmpv[Q];
+#pragma unroll
+                for (int i = 0; i < Q; ++i) tmpv[i] = scale_diag ? diag[i] * x[i] : x[i];
+                xnorm = enorm_small<T, Q, false>(tmpv);
+                fnorm = fnorm1;
+                objective = T(0.5) * fnorm1 * fnorm1;
+                if (!is_finite(xnorm)) term = VP_TERM_NUMERICAL;
+            }
+            if (!term) {
+                int tcode = 0;
+                if (fnorm <= num<T>::tiny) tcode = VP_TERM_RESIDUALS_ZERO;
+                if (!tcode) {
+                    const bool ftol_check = tabs(actred) <= ftol && prered <= ftol && ratio * T(0.5) <= T(1);
+                    const bool xtol_check = delta <= xtol * xnorm;
+                    if (ftol_check || xtol_check)
+                        tcode = (ftol_check && xtol_check) ? VP_TERM_CONVERGED_BOTH
+                                                           : (ftol_check ? VP_TERM_CONVERGED_FTOL : VP_TERM_CONVERGED_XTOL);
+                }
+                if (!tcode && nfev >= max_fev) tcode = VP_TERM_LOST_PATIENCE;
+                if (!tcode && tabs(actred) <= num<T>::eps && prered <= num<T>::eps && ratio * T(0.5) <= T(1))
+                    tcode = VP_TERM_NO_IMPROVEMENT;
+                if (!tcode && delta <= num<T>::eps * xnorm) tcode = VP_TERM_NO_IMPROVEMENT;
+                if (!tcode && gnorm <= num<T>::eps) tcode = VP_TERM_NO_IMPROVEMENT;
+                term = tcode;
+                // (a rejected step keeps the old Jacobian factor and only re-solves the trust-region problem)
+                need_step = (tcode == 0);
+            }
+        }
+    }
+
+    if (need_step && jac_done) {
+        // the vector phase refreshed (Rj, qtf, acnorm, ipvt) at the accepted point
+        T gmax = T(0);
+        bool degenerate = false;
+        const T ifn = frcp(fnorm);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const T an = dyn_get<Q>(acnorm, ipvt[j]);
+            if (an != T(0)) {
+                T sum = T(0);
+#pragma unroll
+                for (int i = 0; i <= j; ++i) sum = tfma(Rj[i][j], qtf[i], sum);
+                const T temp = tabs(sum * frcp(an) * ifn);
+                if (temp != temp) degenerate = true;
+                gmax = tmax(gmax, temp);
+            }
+        }
+        gnorm = gmax;
+        if (degenerate) {
+            term = VP_TERM_NUMERICAL;
+        } else if (gnorm <= gtol) {
+            term = VP_TERM_ORTHOGONAL;
+        } else if (first_update) {
+            T tmpv[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                if (scale_diag) diag[i] = (acnorm[i] == T(0)) ? T(1) : acnorm[i];
+                tmpv[i] = scale_diag ? diag[i] * x[i] : x[i];
+            }
+            xnorm = enorm_small<T, Q, false>(tmpv);
+            if (!is_finite(xnorm)) term = VP_TERM_NUMERICAL;
+            delta = (xnorm == T(0)) ? stepbound : stepbound * xnorm;
+            first_update = false;
+        } else if (scale_diag) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) diag[i] = tmax(diag[i], acnorm[i]);
+        }
+        if (term) need_step = false;
+    }
+
+    if (need_step) {
+        T Rw[Q][Q]; // lmpar scribbles on the strict lower triangle
+#pragma unroll
+        for (int i = 0; i < Q; ++i)
+#pragma unroll
+            for (int j = 0; j < Q; ++j) Rw[i][j] = Rj[i][j];
+        par = lmpar<T, Q, false>(Rw, ipvt, diag, qtf, delta, par, step, pnorm);
+        if (!is_finite(pnorm)) {
+            term = VP_TERM_NUMERICAL;
+        } else {
+            T wa[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) wa[i] = T(0);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const T pj = dyn_get<Q>(step, ipvt[j]);
+#pragma unroll
+                for (int i = 0; i <= j; ++i) wa[i] = tfma(Rj[i][j], pj, wa[i]);
+            }
+            const T ifn = frcp(fnorm);
+            const T t1 = enorm_small<T, Q, false>(wa) * ifn;
+            const T temp1 = t1 * t1;
+            const T t2 = (usqrt(par) * pnorm) * ifn;
+            const T temp2 = t2 * t2;
+            if (!is_finite(temp1) || !is_finite(temp2)) {
+                term = VP_TERM_NUMERICAL;
+            } else {
+                prered = temp1 + temp2 * T(2);
+                dirder = -(temp1 + temp2);
+                if (first_tr && pnorm < delta) delta = pnorm;
+                first_tr = false;
+#pragma unroll
+                for (int i = 0; i < Q; ++i) xt[i] = x[i] - step[i];
+            }
+        }
+    }
+
+    // write the record back
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        s->x[i] = x[i];
+        s->xt[i] = xt[i];
+        s->diag[i] = diag[i];
+    }
+    if (accept_c) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) s->cbest[i] = s->cnew[i];
+    }
+    s->fnorm = fnorm;
+    s->delta = delta;
+    s->par = par;
+    s->xnorm = xnorm;
+    s->gnorm = gnorm;
+    s->pnorm = pnorm;
+    s->prered = prered;
+    s->dirder = dirder;
+    s->objective = objective;
+    s->flags = (first ? 1 : 0) | (first_tr ? 2 : 0) | (first_update ? 4 : 0);
+    s->nfev = nfev;
+    s->term = term;
+    s->status = status;
+    s->trow = trow;
+
+    if (term != 0) {
+        // results of a finished problem (per-lane scattered stores; a few dozen bytes each)
+        vp_report rep;
+        rep.termination = term;
+        rep.n_evals = nfev;
+        rep.objective = (double)objective;
+        k->report[prob] = rep;
+        double *cost_out = k->cost_out;
+        int32_t *status_out = k->status;
+        T *alpha_out = k->alpha, *C_out = k->C_out;
+        if (cost_out) cost_out[prob] = (double)objective;
+        if (status_out) status_out[prob] = status;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) alpha_out[prob * Q + i] = x[i];
+        if (C_out) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) C_out[prob * N + i] = s->cbest[i];
+        }
+    }
+}
+
+// WPB waves per workgroup share one LDS copy of the grid; the waves are otherwise independent (no barrier after setup)
+template <typename T, class M, int R, int PADM, int GS, int WPB>
+__global__ void __launch_bounds__(64 * WPB, (waves_for<T, R, M::N + M::P>() * WPB) / 4 > 0 ? (waves_for<T, R, M::N + M::P>() * WPB) / 4 : 1)
+    fit2_kernel(const Fit2Args<T, M> args) {
+    static_assert(M::kConstLast && M::kDiagonalPairs, "slot kernel: multi-exponential + offset models");
+    constexpr int N = M::N, P = M::P, Q = M::Q;
+    constexpr int NC = N + P;  // register columns: the constant column is never materialised
+    constexpr int YC = N - 1;  // data column
+    constexpr int DC = YC + 1; // first derivative column
+    constexpr int MP = 64 * R;
+    using Rec = SlotRec<T, N, Q>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *s_t = reinterpret_cast<T *>(smem_raw);
+    const int wave = (int)(threadIdx.x >> 6);
+    T *s_y = s_t + MP + (size_t)wave * GS * MP;
+    Rec *recs = reinterpret_cast<Rec *>(s_t + MP + (size_t)WPB * GS * MP) + (size_t)wave * GS;
+    SlotConsts<T> *kc = reinterpret_cast<SlotConsts<T> *>(reinterpret_cast<Rec *>(s_t + MP + (size_t)WPB * GS * MP) + (size_t)WPB * GS);
+    using G = Grp<1>;
+    G grp = G::make(nullptr);
+    const int lane = grp.lane;
+    const int gw = (int)blockIdx.x * WPB + wave; // persistent wave index
+    T eps_;
+    int m_, uniform_;
+    int64_t B_;
+    {
+        const FitArgs<T, M> &a = args.f;
+        m_ = a.m;
+        eps_ = a.eps;
+        uniform_ = a.grid_uniform;
+        B_ = a.B;
+        // ---- the shared grid (every wave writes the same values: no ownership split needed) + the constants ----
+        T tmp[R];
+        load_rows<T, R>(a.t, m_, lane, vec_aligned<T>(a.t, m_), tmp);
+        store_rows<T, R>(s_t, MP, lane, true, tmp);
+        if (threadIdx.x == 0) {
+            kc->ftol = a.ftol;
+            kc->xtol = a.xtol;
+            kc->gtol = a.gtol;
+            kc->stepbound = a.stepbound;
+            kc->alpha = a.alpha;
+            kc->C_out = a.C_out;
+            kc->cost_out = a.cost_out;
+            kc->status = a.status;
+            kc->report = a.report;
+            kc->trace = a.trace;
+            kc->yw = a.yw;
+            kc->queue = args.queue;
+            kc->B = a.B;
+            kc->trace_rows = a.trace_rows;
+            kc->scale_diag = a.scale_diag;
+            kc->max_fev = a.patience * (Q + 1);
+            kc->m = a.m;
+        }
+    }
+    __syncthreads();
+    const int m = m_;
+    using Src = RowSource<T, R, true, 0, 1, 1, true, PADM>;
+    Src src;
+    src.t = s_t;
+    src.w = nullptr;
+    src.m = m;
+    src.lane = lane;
+    src.vec = true;
+    src.set_uniform(uniform_ != 0);
+    const ConstReflector<T> h0 = make_const_reflector<T, R, Src, G>(src, grp);
+    const M mdl = args.f.mdl;
+
+    auto fill = [&](int s, int prob) __attribute__((always_inline)) {
+        slot_fill<T, N, Q, R, PADM>((VP_LDS Rec *)(recs + s), (VP_LDS T *)(s_y + (size_t)s * MP), (VP_LDS const T *)s_t,
+                                    (VP_LDS const SlotConsts<T> *)kc, prob, h0.beta, h0.u, h0.g);
+    };
+
+    // ---- initial, static assignment: wave gw takes problems gw*GS .. gw*GS+GS-1 ----
+    int nactive = 0;
+#pragma nounroll
+    for (int s = 0; s < GS; ++s) {
+        const int64_t prob = (int64_t)gw * GS + s;
+        const bool have = prob < B_ && h0.live;
+        fill(s, have ? (int)prob : -1);
+        nactive += have ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    while (nactive > 0) {
+        // =============================== VECTOR phase ===============================
+#pragma nounroll
+        for (int s = 0; s < GS; ++s) {
+            Rec *rec = recs + s;
+            if (uni(rec->prob) < 0) continue;
+            T alpha[Q];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) alpha[k] = rec->xt[k];
+            const int fl_in = uni(rec->flags);
+            const bool first = (fl_in & 1) != 0;
+            const T qty0 = rec->qty0;
+            const T fnorm = rec->fnorm, prered = rec->prered;
+
+            T C[NC][R];
+            EvalUniform<T, N> u;
+            load_rows_lds<T, R>(s_y + (size_t)s * MP, lane, C[YC]);
+            evaluate_core_const_first<T, M, R, NC, Src, G, true>(mdl, alpha, src, eps_, grp, h0, C, u, nullptr, qty0);
+
+            const T fnorm1 = usqrt(u.fn2);
+            T actred = T(0), ratio = T(0);
+            bool good = false;
+            if (!first) {
+                const T q1 = fnorm1 * frcp(fnorm);
+                actred = (fnorm1 * T(0.1) < fnorm) ? T(1) - q1 * q1 : T(-1);
+                ratio = (prered == T(0)) ? T(0) : actred * frcp(prered);
+                good = uni(ratio >= T(1.0e-4));
+            }
+            const bool need_jac = u.ok && (first || good);
+            T Rj[Q][Q], acnorm[Q], qtf[Q];
+            int ipvt[Q];
+            if (need_jac) {
+                // z_k = -c_k Q^T D_k: factor the unscaled columns in place, the coefficients enter as column scales
+                residual_qcoords<T, R, N>(C[YC], u.e, grp);
+                T zs[Q];
+#pragma unroll
+                for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
+                jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
+            }
+            if (lane == 0) {
+                rec->fnorm1 = fnorm1;
+                rec->actred = actred;
+                rec->ratio = ratio;
+#pragma unroll
+                for (int k = 0; k < N; ++k) rec->cnew[k] = u.c[k];
+                int fl = fl_in & 7;
+                if (u.ok) fl |= 8;
+                if (need_jac) {
+                    fl |= 16;
+#pragma unroll
+                    for (int k = 0; k < Q; ++k) {
+                        rec->acnorm[k] = acnorm[k];
+                        rec->qtf[k] = qtf[k];
+                        rec->ipvt[k] = ipvt[k];
+#pragma unroll
+                        for (int j = 0; j < Q; ++j) rec->Rj[k][j] = Rj[k][j];
+                    }
+                }
+                if (good) fl |= 32;
+                rec->flags = fl;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        // =============================== SCALAR phase: lane s <-> slot s ===============================
+        slot_scalar_phase<T, N, Q, GS>((VP_LDS Rec *)recs, (VP_LDS const SlotConsts<T> *)kc);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        // =============================== REFILL finished slots from the queue ===============================
+#pragma nounroll
+        for (int s = 0; s < GS; ++s) {
+            if (uni(recs[s].prob) < 0 || uni(recs[s].term) == 0) continue;
+            int next = 0;
+            if (lane == 0) next = __hip_atomic_fetch_add(kc->queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            next = uni(next);
+            const bool have = (int64_t)next < B_;
+            fill(s, have ? next : -1);
+            if (!have) nactive -= 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <typename T, class M, int R, int W = 1> int launch_fit2(const LaunchParams &p) {
+    // the slot kernel covers: one wave per problem, unit weights, one shared grid, model ending in a constant column
+    if constexpr (!(M::kConstLast && M::kDiagonalPairs) || W != 1) {
+        return launch_fit<T, M, R, W>(p);
+    } else {
+        constexpr int GS = fit2_slots<T, R>();
+        constexpr int WPB = 4;
+        constexpr int WPS = waves_for<T, R, M::N + M::P>(); // resident waves per SIMD
+        // fit_group: 0 = automatic (slots once the batch exceeds the resident wave slots of the device: below that one
+        // wave per problem has the lower latency), 1 = one problem per wave (fit_kernel), 2 = slots regardless of B
+        const int64_t cap_waves = (int64_t)p.num_cus * 4 * WPS;
+        if (p.w || p.t_stride != 0 || !p.queue || p.fit_group == 1 || (p.fit_group != 2 && p.B <= cap_waves))
+            return launch_fit<T, M, R, W>(p);
+        Fit2Args<T, M> args;
+        FitArgs<T, M> &a = args.f;
+        if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+        a.t = (const T *)p.t;
+        a.w = nullptr;
+        a.yw = (const T *)p.yw;
+        a.alpha = (T *)p.alpha_out;
+        a.C_out = (T *)p.C_out;
+        a.cost_out = p.cost_out;
+        a.status = p.status;
+        a.report = p.report;
+        a.m = p.m;
+        a.B = p.B;
+        a.t_stride = 0;
+        a.w_stride = 0;
+        a.eps = (T)p.eps;
+        a.ftol = (T)p.opts->ftol;
+        a.xtol = (T)p.opts->xtol;
+        a.gtol = (T)p.opts->gtol;
+        a.stepbound = (T)p.opts->stepbound;
+        a.patience = p.opts->patience;
+        a.scale_diag = p.opts->scale_diag;
+        a.trace = p.trace;
+        a.trace_rows = p.trace_rows;
+        a.grid_uniform = p.grid_uniform;
+        if (a.B <= 0) return VP_ERR_OK;
+        // persistent grid: every resident wave slot of the device, or fewer when the batch is smaller
+        const int64_t cap_blocks = (int64_t)p.num_cus * WPS; // WPB = 4 waves = one per SIMD -> WPS workgroups per CU
+        const int64_t need_blocks = (a.B + (int64_t)GS * WPB - 1) / ((int64_t)GS * WPB);
+        const int64_t blocks = need_blocks < cap_blocks ? need_blocks : cap_blocks;
+        args.queue = p.queue;
+        args.waves_total = (int)(blocks * WPB);
+        if (hipMemsetD32Async((hipDeviceptr_t)p.queue, (int)(blocks * WPB * GS), 1, p.stream) != hipSuccess) return VP_ERR_HIP;
+        const size_t lds = (size_t)64 * R * sizeof(T) * (1 + (size_t)WPB * GS) + (size_t)WPB * GS * sizeof(SlotRec<T, M::N, M::Q>) +
+                           sizeof(SlotConsts<T>);
+#define VP_F2(PADM_)                                                                                                   \
+    hipLaunchKernelGGL((fit2_kernel<T, M, R, PADM_, GS, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), lds, p.stream, args)
+        if (p.m == 64 * R) VP_F2(1);
+        else if (R > 2 && p.m > 64 * (R - 2)) VP_F2(2);
+        else VP_F2(0);
+#undef VP_F2
+        return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+    }
+}
+
+} // namespace vp

@@ -1,6 +1,7 @@
 // vp_inst.hpp -- macros that instantiate one (dtype, model, R) kernel set and register it.
 #pragma once
-#include "vp_fit_mp.hpp"
+#include "vp_fit2.hpp"
+#include "vp_lm_core.hpp"
 #include "vp_mrhs.hpp"
 #include "vp_stats.hpp"
 #include "vp_registry.hpp"
@@ -12,7 +13,7 @@
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
         DT, ::vp::FAMILY_MULTIEXP, NEXP, OFF, 0, RR, 1, &::vp::launch_evaluate<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>, \
         &::vp::launch_basis<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                            \
-        &::vp::launch_fit_mp<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                           \
+        &::vp::launch_fit2<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                           \
         &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                              \
         &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                         \
         &::vp::launch_mrhs_factor<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                      \
@@ -25,7 +26,7 @@
 #define VP_REGISTER_RT(T, DT, NN, QQ, PP, RR)                                                                          \
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
         DT, ::vp::FAMILY_RT, NN, QQ, PP, RR, 1, &::vp::launch_evaluate<T, ::vp::RtModel<NN, QQ, PP>, RR>,             \
-        &::vp::launch_basis<T, ::vp::RtModel<NN, QQ, PP>, RR>, &::vp::launch_fit_mp<T, ::vp::RtModel<NN, QQ, PP>, RR>, \
+        &::vp::launch_basis<T, ::vp::RtModel<NN, QQ, PP>, RR>, &::vp::launch_fit2<T, ::vp::RtModel<NN, QQ, PP>, RR>, \
         &::vp::launch_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                          \
         &::vp::launch_best_fit<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                     \
         &::vp::launch_mrhs_factor<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                  \

@@ -41,7 +41,9 @@ struct LaunchParams {
     const vp_lm_opts *opts;
     double *trace;      // fit diagnostics: [B][trace_rows][q+4] or NULL
     int trace_rows;
-    int fit_group;      // fit: problems per wave (0 = automatic)
+    int fit_group;      // fit: kernel selection (VP_FIT_KERNEL_*): 0 = automatic, 1 = one problem per wave, 2 = slots
+    int *queue;         // fit (slot kernel): device int, the problem queue head
+    int num_cus;        // compute units of the device
     const void *mrhs_ws; // MRHS path: pointer to the handle's MrhsWs
     int mrhs_mode;      // MRHS stream: 0 = reduced quantities (fit), 1 = trait-level outputs
     int mrhs_init;      // MRHS LM step: 1 = initialise the state
@@ -111,6 +113,21 @@ __device__ __forceinline__ void store_rows(T *__restrict__ base, const int m, co
     for (int r = 0; r < R; ++r) {
         const int i = L::row_of(r, lane);
         if (i < m) base[i] = in[r];
+    }
+}
+
+// zero-padded, 16-byte aligned LDS column (64*R*W rows): ONE lane address + immediate offsets, no bounds logic
+template <typename T, int R, int W = 1>
+__device__ __forceinline__ void load_rows_lds(const T *__restrict__ base, const int lane, T (&out)[R]) {
+    using L = Layout<R, W>;
+    static_assert(L::VW == 2, "padded LDS columns are read in row pairs");
+    using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+    const V2 *p = reinterpret_cast<const V2 *>(base) + lane;
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+        const V2 v = p[(r / 2) * 64 * W];
+        out[r] = v.x;
+        out[r + 1] = v.y;
     }
 }
 

@@ -10,7 +10,7 @@
 //                   gradient test, diag scaling, lmpar, predicted reduction, next trial point.
 //
 // Used by the multiple-right-hand-side path (vp_mrhs.hpp); the single-RHS kernels (vp_fit.hpp,
-// vp_fit_mp.hpp) carry the same logic inlined around their register-resident columns.
+// vp_fit2.hpp) carry the same logic inlined around their register-resident columns.
 #pragma once
 #include "vp_fit.hpp"
 

@@ -72,6 +72,42 @@ __device__ __forceinline__ double texp(double x) {
     return __builtin_ldexp(p, (int)k);
 }
 __device__ __forceinline__ float texp(float x) { return __ocml_exp_f32(x); }
+
+// NX exponentials at once: the Horner chains of the NX arguments interleave (ILP), and the 16 fp64 constants of the
+// polynomial are materialised HERE (the empty asm makes each one opaque, i.e. not a loop-invariant the compiler may
+// hoist): 32 SGPRs that would otherwise stay allocated -- and get spilled -- across the whole LM iteration.
+template <int NX> __device__ __forceinline__ void texp_n(const double (&x)[NX], double (&out)[NX]) {
+    double cs[16] = {1.4426950408889634074,  6.93147180559945286227e-01, 2.31904681384629955842e-17,
+                     1.6059043836821613e-10, 2.0876756987868100e-09,     2.5052108385441720e-08,
+                     2.7557319223985893e-07, 2.7557319223985888e-06,     2.4801587301587302e-05,
+                     1.9841269841269841e-04, 1.3888888888888889e-03,     8.3333333333333332e-03,
+                     4.1666666666666664e-02, 1.6666666666666666e-01,     0.5,
+                     1.0};
+#pragma unroll
+    for (int i = 0; i < 14; ++i) asm volatile("" : "+s"(cs[i]));
+    double k[NX], r[NX], p[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        k[i] = __builtin_rint(x[i] * cs[0]);
+        r[i] = __builtin_fma(-k[i], cs[1], x[i]);
+        r[i] = __builtin_fma(-k[i], cs[2], r[i]);
+        p[i] = cs[3];
+    }
+#pragma unroll
+    for (int c = 4; c < 15; ++c)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) p[i] = __builtin_fma(p[i], r[i], cs[c]);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        p[i] = __builtin_fma(p[i], r[i], 1.0);
+        p[i] = __builtin_fma(p[i], r[i], 1.0);
+        out[i] = __builtin_ldexp(p[i], (int)k[i]);
+    }
+}
+template <int NX> __device__ __forceinline__ void texp_n(const float (&x)[NX], float (&out)[NX]) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) out[i] = texp(x[i]);
+}
 // sin / cos only occur in run-time-descriptor models, whose column build is unrolled over rows x columns x kinds:
 // kept out of line (one copy per kernel instead of R*N inlined Payne-Hanek expansions, which made MBs of code)
 __device__ __noinline__ double tsin(double x) { return __ocml_sin_f64(x); }
@@ -108,6 +144,8 @@ struct RowSource {
     using L = Layout<R, W>;
     static constexpr int kGroupWaves = W;
     static constexpr bool kRecur = RECUR && sizeof(T) == 8 && (R > L::VW);
+    // every row is valid and unweighted: the scale is the literal 1 and the recurrence needs no inf * 0 guard
+    static constexpr bool kScaleOne = PADDED && WMODE == 0 && PADM == 1;
     __device__ __forceinline__ void set_uniform(bool flag) {
         if constexpr (kRecur) {
             uniform = flag && m >= 3;
@@ -130,12 +168,14 @@ struct RowSource {
             using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
             if constexpr (PADDED) {
                 // zero-padded LDS copies: the grid value of a padding row is 0 by construction, and so is its
-                // weight; only the unit-weight scale of a partially filled problem needs the validity mask
-                const V2 v = *reinterpret_cast<const V2 *>(t + i);
+                // weight; only the unit-weight scale of a partially filled problem needs the validity mask.
+                // Addressed as (lane pointer)[constant]: ONE address register + immediate offsets (written as t + i the
+                // R/2 addresses become R/2 hoisted loop invariants, i.e. spilled registers)
+                const V2 v = (reinterpret_cast<const V2 *>(t) + lane)[(r0 / 2) * 64 * W];
                 tt[0] = v.x;
                 tt[1] = v.y;
                 if constexpr (WMODE == 1) {
-                    const V2 u = *reinterpret_cast<const V2 *>(w + i);
+                    const V2 u = (reinterpret_cast<const V2 *>(w) + lane)[(r0 / 2) * 64 * W];
                     sc[0] = u.x;
                     sc[1] = u.y;
                     return;
@@ -208,8 +248,11 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                 else s1[j] = p;
             }
         }
-        rt[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? T(1) / p0[j] : T(0);
-        rt2[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? T(1) / (p0[j] * p0[j]) : T(0);
+        // 1/tau by the Newton-refined v_rcp (1-2 ulp): the quotient t/tau is re-rounded by div_refined, and the
+        // derivative scale 1/tau^2 = (1/tau)^2 carries ~2 ulp -- two IEEE division expansions (~13 VALU each, per
+        // column and evaluation) less
+        rt[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? frcp(p0[j]) : T(0);
+        rt2[j] = rt[j] * rt[j];
     }
     // UNIFORM-GRID RECURRENCE (fp64, R > 2): on a grid t_i = t_0 + i*dt a lane's row pairs are delta = 64*W*2*dt
     // apart, so exp(-t/tau) of pair k is the value of pair k-1 times the wave-uniform ratio exp(-delta/tau):
@@ -220,14 +263,38 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
     constexpr bool kRecur = Src::kRecur;
     T fu[N][VW], qq[N];
     bool fast = false;
+    // static models: the first row pair's exponentials and the ratios of ALL columns in one batched evaluation
+    // (texp_n: interleaved Horner chains, polynomial constants live only here)
+    constexpr bool kBatchExp = kRecur && M::kStatic;
     if constexpr (kRecur) {
         fast = src.uniform;
         if (fast) {
+            if constexpr (kBatchExp) {
+                T tt0[2], sc0[2];
+                src.get(0, tt0, sc0);
+                T ax[N * (VW + 1)], ex[N * (VW + 1)];
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                qq[j] = T(1);
-                if (kind[j] == VP_BASIS_EXP_DECAY) qq[j] = texp(-div_refined(src.delta, p0[j], rt[j]));
-                else if (kind[j] == VP_BASIS_EXP_RATE) qq[j] = texp(-p0[j] * src.delta);
+                for (int j = 0; j < N; ++j) {
+                    const bool decay = kind[j] == VP_BASIS_EXP_DECAY, rate = kind[j] == VP_BASIS_EXP_RATE;
+#pragma unroll
+                    for (int e = 0; e < VW; ++e)
+                        ax[j * (VW + 1) + e] = decay ? -div_refined(tt0[e], p0[j], rt[j]) : (rate ? -p0[j] * tt0[e] : T(0));
+                    ax[j * (VW + 1) + VW] = decay ? -div_refined(src.delta, p0[j], rt[j]) : (rate ? -p0[j] * src.delta : T(0));
+                }
+                texp_n(ax, ex);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) fu[j][e] = ex[j * (VW + 1) + e];
+                    qq[j] = ex[j * (VW + 1) + VW];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    qq[j] = T(1);
+                    if (kind[j] == VP_BASIS_EXP_DECAY) qq[j] = texp(-div_refined(src.delta, p0[j], rt[j]));
+                    else if (kind[j] == VP_BASIS_EXP_RATE) qq[j] = texp(-p0[j] * src.delta);
+                }
             }
         }
     }
@@ -256,8 +323,12 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                     } else if (kind[j] == VP_BASIS_EXP_DECAY) {
                         // exp(-t/tau);  d/dtau = exp(-t/tau) * t / tau^2   (shared_test_code/src/lib.rs:101-114)
                         if constexpr (FAST) {
-                            fu[j][e] = (r0 == 0) ? texp(-div_refined(t, p0[j], rt[j]))
-                                                 : tmin(fu[j][e] * qq[j], num<T>::huge);
+                            if constexpr (kBatchExp) {
+                                if (r0 != 0) fu[j][e] = Src::kScaleOne ? fu[j][e] * qq[j] : tmin(fu[j][e] * qq[j], num<T>::huge);
+                            } else {
+                                fu[j][e] = (r0 == 0) ? texp(-div_refined(t, p0[j], rt[j]))
+                                                     : tmin(fu[j][e] * qq[j], num<T>::huge);
+                            }
                             f = fu[j][e] * scl;
                         } else {
                             f = texp(-div_refined(t, p0[j], rt[j])) * scl;
@@ -265,7 +336,11 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                         d0 = (f * t) * rt2[j];
                     } else if (kind[j] == VP_BASIS_EXP_RATE) {
                         if constexpr (FAST) {
-                            fu[j][e] = (r0 == 0) ? texp(-p0[j] * t) : tmin(fu[j][e] * qq[j], num<T>::huge);
+                            if constexpr (kBatchExp) {
+                                if (r0 != 0) fu[j][e] = Src::kScaleOne ? fu[j][e] * qq[j] : tmin(fu[j][e] * qq[j], num<T>::huge);
+                            } else {
+                                fu[j][e] = (r0 == 0) ? texp(-p0[j] * t) : tmin(fu[j][e] * qq[j], num<T>::huge);
+                            }
                             f = fu[j][e] * scl;
                         } else {
                             f = texp(-p0[j] * t) * scl;

@@ -18,8 +18,8 @@ struct KernelEntry {
     int W;      // waves per problem; handles m <= 64*R*W
     launch_fn evaluate;
     launch_fn basis;
-    launch_fn fit;      // multi-problem-per-wave LM (vp_fit_mp.hpp); may be null
-    launch_fn fit_single; // one-problem-per-wave LM (vp_fit.hpp), kept for A/B and diagnostics
+    launch_fn fit;      // persistent slot LM kernel (vp_fit2.hpp; falls back to fit_single by itself); may be null
+    launch_fn fit_single; // one-wavefront(-group)-per-problem LM (vp_fit.hpp)
     launch_fn best_fit; // may be null
     // multiple-right-hand-side path (vp_mrhs.hpp); all null if not instantiated
     launch_fn mrhs_factor, mrhs_stream, mrhs_lm, mrhs_finish;
