@@ -9,14 +9,15 @@ initial guesses to convergence, with the data already resident in HBM.  Weak sca
 B problems (problems rank*B .. (rank+1)*B-1 of the global synthetic set); the only collective is one
 RCCL all-reduce of 4 doubles per step {sum cost, #ok, #failed, sum evaluations}.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md section 5 for every field):
-  value      whole-job fits/s over all ranks (max-over-ranks time, barrier + synchronize on both sides); consecutive
-             steps alternate over two handles / HIP streams so that the straggler tail of one launch overlaps the
-             next step (config.pipelining); config.single_stream holds the same K steps strictly one at a time
-  roofline   the stand-alone Phi/dPhi kernel (vp_basis) against the HBM roofline, HIP-event timed live
-  roofline_fit  the fused fit kernel: HBM fraction (tiny by design: y is read once per FIT) and the fp64
-                vector-ALU fraction that actually bounds it
-  cpu_baseline  the CPU restatement of the reference algorithm (oracle/, kind "port") on the host cores
+Prints ONE JSON line on rank 0 (DESIGN.md section 6 explains every field):
+  value         whole-job fits/s over all ranks, the K steps STRICTLY ONE AT A TIME on one HIP stream (max-over-ranks
+                time, barrier + synchronize on both sides) -- the number that per-kernel durations reproduce
+  config.pipelined_2_streams   the same K steps alternating over two handles / HIP streams (the straggler tail of one
+                launch overlaps the bulk of the next; profiles/r02_pipelined_overlap.json holds the kernel trace)
+  roofline      the stand-alone Phi/dPhi kernel (vp_basis) against the HBM roofline, HIP-event timed live
+  roofline_fit  the fused fit kernel against the fp64 vector-ALU peak that bounds it (+ its HBM fraction)
+  configs0/1/2/4  BASELINE configs[0], [1], [2], [4] measured on rank 0 at N = 1, each with its own roofline
+  cpu_baseline  the CPU restatement of the reference algorithm (oracle/, kind "port") on the host's physical cores
 """
 import argparse
 import json
@@ -29,13 +30,67 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The steps alternate over two HIP streams (see --streams) next to RCCL's own stream: with ROCm's default of 4
-# hardware queues per process two of those streams can land on the same queue and serialise.  Must be set before
-# the HIP runtime initialises (torch is imported inside main()).
+# Two HIP streams (pipelined leg) next to RCCL's own stream: with ROCm's default of 4 hardware queues per process two
+# of them can land on the same queue and serialise.  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# CPU baseline: one OpenMP thread per PHYSICAL core, pinned (read by libgomp when the oracle library is loaded)
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_PROC_BIND", "spread")
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def cpu_topology():
+    """(model name, sockets, physical cores, logical cpus) of the host from /proc/cpuinfo"""
+    model, phys, logical, cores_per_socket = "unknown", set(), 0, 0
+    sockets = set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("processor"):
+                logical += 1
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+                sockets.add(pid)
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+                phys.add((pid, cid))
+            elif line.startswith("cpu cores"):
+                cores_per_socket = max(cores_per_socket, int(line.split(":", 1)[1]))
+    except (OSError, ValueError):
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical or 1
+    nsock = max(1, len(sockets))
+    # (virtualised hosts often report one "core id" per socket: trust the larger of the two counts)
+    ncores = max(len(phys), nsock * cores_per_socket) or logical or 1
+    # cgroup CPU bandwidth limit of this container ("max" or "<quota> <period>" in cgroup v2; cfs_quota_us in v1): more
+    # runnable threads than quota/period are throttled, so that IS the number of host cores this process can use
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return model, nsock, min(ncores, usable), usable, quota
+
+
+# taken NOW: importing torch initialises its OpenMP runtime, which under OMP_PROC_BIND pins the main thread to one
+# place -- the affinity mask read afterwards would show a single core
+CPU_TOPOLOGY = cpu_topology()
 
 
 def main():
@@ -45,13 +100,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536,
                     help="problems per GPU: 65536 = BASELINE configs[3]'s per-GPU shard (524288 over 8 GPUs) and the "
-                         "north_star 1-GPU headline size; configs[1] (4096) is measured alongside on rank 0")
+                         "north_star 1-GPU headline size; configs[0,1,2,4] are measured alongside on rank 0 at N = 1")
     ap.add_argument("--m", type=int, default=1024)
     ap.add_argument("--noise", type=float, default=1e-3)
-    ap.add_argument("--streams", type=int, default=2,
-                    help="handles / HIP streams the steps alternate over (software pipelining of consecutive batches: "
-                         "the straggler tail of step k overlaps the bulk of step k+1); 1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the configs[0,1,2,4] side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -61,6 +114,7 @@ def main():
     import varpro_amd as vp
     from varpro_amd import distributed as vd
     from varpro_amd import synth
+    from varpro_amd import _lib
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -74,6 +128,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run even N=1 exercises RCCL
+    backend = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -82,9 +137,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == world
 
     B, m = args.batch, args.m
-    # ---- synthetic input of BASELINE configs[1] (shard `rank` of the global problem set) ----
+    # ---- synthetic input of BASELINE configs[1]/[3] (shard `rank` of the global problem set) ----
     first, count = vd.shard_range(world * B, rank, world)  # contiguous block of the global problem set
     assert count == B
     d = synth.double_exp_batch(B, m=m, first_problem=first, noise=args.noise)
@@ -92,26 +148,31 @@ def main():
     Y = torch.from_numpy(d["Y"]).to(dev)
     x = torch.from_numpy(d["x"]).to(dev)
     guess = torch.from_numpy(d["tau_guess"]).to(dev)
-    bp = vp.BatchProblem(mdl, Y, x=x)  # device-pointer mode on torch's current stream
 
     def barrier():
         if use_dist:
             dist.barrier()
 
-    # Software pipelining over consecutive steps: every step is ONE complete batched fit of the B problems (+ the
-    # device-side summary + the RCCL all-reduce), but step k runs on handle / stream k mod NS, so that the tail of a
-    # launch -- a few fits that need >100 LM iterations while the rest of the GPU is already idle -- overlaps the
-    # bulk of the next step's launch.  Each handle owns its own copy of the state; nothing is shared or skipped.
-    ns = max(1, args.streams)
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(ns - 1)]
-    handles = [bp]
-    for st in streams[1:]:
-        with torch.cuda.stream(st):
-            handles.append(vp.BatchProblem(mdl, Y, x=x))
-    reds = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(ns)]
-    torch.cuda.synchronize()
+    def allreduce(t):
+        # gloo (single-GPU test hook) reduces on the host; RCCL reduces the 32 bytes on the device over xGMI
+        if backend == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
-    def step(k, nslots=ns):
+    # handle 0 on the current stream; handle 1 on a second stream for the pipelined leg.  Every step is ONE complete
+    # batched fit of the B problems (+ the device-side summary + the all-reduce); each handle owns its full state.
+    streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)]
+    handles = [vp.BatchProblem(mdl, Y, x=x)]
+    with torch.cuda.stream(streams[1]):
+        handles.append(vp.BatchProblem(mdl, Y, x=x))
+    reds = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    bp = handles[0]
+
+    def step(k, nslots):
         # everything is enqueued asynchronously: the fit kernel, the 4-double batch summary (device side) and
         # the RCCL-over-xGMI all-reduce of those 32 bytes (the scalar LM cost reduction); no host sync per step
         i = k % nslots
@@ -119,7 +180,7 @@ def main():
             handles[i].fit(guess, want_coefficients=False)
             handles[i].summary_device(reds[i])
             if use_dist:
-                dist.all_reduce(reds[i], op=dist.ReduceOp.SUM)
+                allreduce(reds[i])
         return reds[i]
 
     def timed(nslots):
@@ -135,109 +196,61 @@ def main():
         dt_ = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            if backend == "gloo":
+                h = tmax.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX)
+                tmax = h
+            else:
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_ = float(tmax.item())
         return dt_, last_
 
-    dt, last = timed(ns)
-    dt_single = timed(1)[0] if ns > 1 else dt  # the same K steps strictly one batch at a time, for reference
+    dt, last = timed(1)            # THE timed region: K steps, one batch at a time
+    dt_pipe = timed(2)[0]          # the same K steps alternating over two handles / streams
     last = last.cpu().numpy()
     total_fits = float(world) * B * args.steps
     value = total_fits / dt
     sum_cost, n_ok, n_bad, n_evals = [float(v) for v in last]
     evals_per_fit = n_evals / (world * B)
 
-    # ---- per-kernel durations with HIP events on the launch stream (rank 0 only) ----
     out = None
     if rank == 0:
-        # fit kernel alone (no summary / collective): K launches bracketed by events
-        for _ in range(2):
-            bp.fit(guess, want_coefficients=False)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.steps):
-            bp.fit(guess, want_coefficients=False)
-        e1.record()
-        torch.cuda.synchronize()
-        fit_ms = e0.elapsed_time(e1) / args.steps
-        # Phi/dPhi kernel: writes n_alpha*m + p*m scalars per problem (constant column not materialised)
+        T = 8
+
+        def event_ms(fn, reps, warm=2):
+            for _ in range(warm):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        def committed_traffic(key, field="hbm_bytes_per_launch_corrected"):
+            """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json)"""
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+                return pj[key][field]
+            except Exception:
+                return None
+
+        # ---- per-kernel durations with HIP events on the launch stream ----
+        fit_ms = event_ms(lambda: bp.fit(guess, want_coefficients=False), args.steps)
         n_alpha, p = 2, 2
         phi = torch.empty((B, n_alpha, m), dtype=torch.float64, device=dev)
         dphi = torch.empty((B, p, m), dtype=torch.float64, device=dev)
-        reps = max(args.steps, 20)
-        for _ in range(3):
-            bp.basis(guess, skip_invariant=True, out_phi=phi, out_dphi=dphi)
-        e0.record()
-        for _ in range(reps):
-            bp.basis(guess, skip_invariant=True, out_phi=phi, out_dphi=dphi)
-        e1.record()
-        torch.cuda.synchronize()
-        basis_ms = e0.elapsed_time(e1) / reps
-        T = 8
+        basis_ms = event_ms(lambda: bp.basis(guess, skip_invariant=True, out_phi=phi, out_dphi=dphi), max(args.steps, 20), 3)
+        del phi, dphi
         bytes_phi = B * (T * (m * n_alpha + m * p) + T * 2) + T * m       # SURVEY 8(d): 32784 B/problem + grid
         bytes_fit = B * T * (m + 2 + 3 + 2)                                # SURVEY 8(d) B_fit = 8248 B/fit
         gbs_phi = bytes_phi / (basis_ms * 1e-3) / 1e9
         gbs_fit = bytes_fit / (fit_ms * 1e-3) / 1e9
-        # algorithmic fp64 flops of the fused fit: per evaluation
-        #   exp: 2m x 28 ; QR sweep of [Phi|y|D] (n=3, 3 extra cols): 2m*(5+4+3)*2 ; per fit additionally
-        #   jacobian QR ~ 2m*2*3 per accepted step (~ evaluations)
+        # algorithmic fp64 flops of one evaluation of the fused fit (DESIGN.md section 5): two exp columns 2m x 28,
+        # fused sweep over [Phi | y | D] 4m(5+4+3), Jacobian QR 12m
         flops_eval = 2 * m * 28 + 4 * m * (5 + 4 + 3) + 12 * m
         tflops_fit = B * evals_per_fit * flops_eval / (fit_ms * 1e-3) / 1e12
-        # BASELINE configs[1] (B = 4096 on one GPU) alongside: same generator, first 4096 problems
-        cfg1 = None
-        if B >= 4096 and world == 1:
-            bp1 = vp.BatchProblem(mdl, Y[:4096].contiguous(), x=x)
-            g1 = guess[:4096].contiguous()
-            for _ in range(3):
-                bp1.fit(g1, want_coefficients=False)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n1 = max(args.steps, 10)
-            red1 = torch.zeros(4, dtype=torch.float64, device=dev)
-            for _ in range(n1):
-                bp1.fit(g1, want_coefficients=False)
-                bp1.summary_device(red1)
-            torch.cuda.synchronize()
-            dt1 = (time.perf_counter() - t1) / n1
-            # the same batch pipelined over 4 handles / streams: one 4096-problem launch leaves most of the GPU idle
-            # (it is bound by the latency of its slowest fit), consecutive batches fill it
-            st4 = [torch.cuda.Stream(device=dev) for _ in range(4)]
-            h4, r4 = [], []
-            for st in st4:
-                with torch.cuda.stream(st):
-                    h4.append(vp.BatchProblem(mdl, Y[:4096].contiguous(), x=x))
-                    r4.append(torch.zeros(4, dtype=torch.float64, device=dev))
-            torch.cuda.synchronize()
-
-            def step4(k):
-                with torch.cuda.stream(st4[k % 4]):
-                    h4[k % 4].fit(g1, want_coefficients=False)
-                    h4[k % 4].summary_device(r4[k % 4])
-
-            for k in range(8):
-                step4(k)
-            torch.cuda.synchronize()
-            t4 = time.perf_counter()
-            n4 = 4 * n1
-            for k in range(n4):
-                step4(k)
-            torch.cuda.synchronize()
-            dt4 = (time.perf_counter() - t4) / n4
-            for h_ in h4:
-                h_.close()
-            cfg1 = {"workload": "BASELINE configs[1]: 4096 fits on 1 GPU (one launch is bound by the latency of its "
-                                "slowest fit, >100 LM evaluations)", "fits_per_s": 4096 / dt1, "ms_per_step": dt1 * 1e3,
-                    "pipelined_4_streams": {"fits_per_s": 4096 / dt4, "ms_per_step": dt4 * 1e3}}
-            bp1.close()
-        # HBM traffic of the Phi kernel from the committed rocprofv3 PMC passes (profiles/), per launch
-        traffic = traffic_fit = None
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pj.get("batch") == B and pj.get("m") == m:
-                traffic = pj["basis_kernel"]["hbm_bytes_per_launch_corrected"]
-                traffic_fit = pj["fit_kernel"]["hbm_bytes_per_launch_corrected"]
-        except Exception:
-            traffic = traffic_fit = None
         out = {
             "metric": "independent fits/sec (double-exp, m=%d, fp64)" % m,
             "value": value,
@@ -254,51 +267,190 @@ def main():
             "config": {
                 "workload": "BASELINE configs[3] per-GPU shard (= north_star 1-GPU headline): %d independent "
                             "double-exponential+offset fits per GPU, m=%d, n=3, q=2, fp64, noise %.0e, full LM fit to "
-                            "convergence per step" % (B, m, args.noise),
+                            "convergence per step, one batch at a time on one HIP stream" % (B, m, args.noise),
                 "batch_per_gpu": B, "m": m, "parallelism": "batch-sharded x%d" % world,
-                "pipelining": ("%d handles on %d HIP streams, step k on stream k mod %d: the straggler tail of a launch "
-                               "overlaps the bulk of the next step" % (ns, ns, ns)) if ns > 1 else "none (one batch at a time)",
-                "single_stream": {"fits_per_s": total_fits / dt_single, "ms_per_step": dt_single / args.steps * 1e3},
+                "world_size": dist.get_world_size() if use_dist else 1,
+                "collective_backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if use_dist else None,
+                "pipelined_2_streams": {
+                    "fits_per_s": total_fits / dt_pipe, "ms_per_step": dt_pipe / args.steps * 1e3,
+                    "note": "same K steps, step k on handle/stream k mod 2: the straggler tail of a launch overlaps the "
+                            "bulk of the next step (kernel trace: profiles/r02_pipelined_overlap.json)"},
                 "mean_evaluations_per_fit": evals_per_fit, "fits_successful": n_ok, "fits_failed": n_bad,
                 "sum_cost": sum_cost,
             },
             "roofline": {
                 "kernel": "basis_kernel (vp_basis: stand-alone Phi/dPhi evaluation)",
                 "bound": "hbm", "achieved": gbs_phi, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs_phi / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": gbs_phi / HBM_PEAK_GBS, "traffic": committed_traffic("basis_kernel"),
                 "bytes_per_launch": bytes_phi, "avg_launch_ms": basis_ms,
             },
-            "configs1": cfg1,
             "roofline_fit": {
-                "kernel": "fit_kernel (vp_fit: device-resident LM, dominant kernel of the timed step)",
+                "kernel": "fit2_kernel (vp_fit: persistent slot kernel, dominant kernel of the timed step)",
                 "bound": "fp64_valu", "achieved": tflops_fit, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops_fit / FP64_VALU_PEAK_TFLOPS,
-                "hbm_achieved_GBps": gbs_fit, "hbm_frac": gbs_fit / HBM_PEAK_GBS, "traffic": traffic_fit,
+                "frac": tflops_fit / FP64_VALU_PEAK_TFLOPS, "flops_per_evaluation": flops_eval,
+                "hbm_achieved_GBps": gbs_fit, "hbm_frac": gbs_fit / HBM_PEAK_GBS, "traffic": committed_traffic("fit2_kernel"),
                 "bytes_per_launch": bytes_fit, "avg_launch_ms": fit_ms, "fits_per_s_kernel_only": B / (fit_ms * 1e-3),
             },
         }
 
+        # ================= side measurements: BASELINE configs[0], [1], [2], [4] (rank 0, N = 1 only) =================
+        if world == 1 and not args.no_side_configs:
+            # ---- configs[0]: the reference's own bench problem, ONE fit (latency, not throughput) ----
+            c0 = synth.config0()
+            mdl0 = vp.multi_exponential_model(c0["x"], c0["tau_guess"])
+            bp0 = vp.BatchProblem(mdl0, torch.from_numpy(c0["y"][None, :]).to(dev), x=torch.from_numpy(c0["x"]).to(dev))
+            g0 = torch.from_numpy(c0["tau_guess"][None, :]).to(dev)
+            a0, _c0, rep0 = bp0.fit(g0)
+            r0 = bp0.report_to_numpy(rep0)
+            us0 = event_ms(lambda: bp0.fit(g0, want_coefficients=False), 50, 5) * 1e3
+            out["configs0"] = {
+                "workload": "BASELINE configs[0]: benches/double_exponential_without_noise.rs, 1 fit, m=1024 (quirk grid), "
+                            "fit only (setup excluded)",
+                "us_per_fit": us0, "evaluations": int(r0["n_evals"][0]), "termination": int(r0["termination"][0]),
+                "us_per_evaluation": us0 / max(1, int(r0["n_evals"][0])),
+                "max_abs_tau_error": float(np.abs(a0.cpu().numpy()[0] - c0["tau_true"]).max()),
+                "roofline": {"kernel": "fit_kernel (one wavefront)", "bound": "latency",
+                             "note": "one wavefront on one SIMD of 1024: a dependent chain of ~1800 VALU instructions "
+                                     "per LM evaluation; no throughput roofline applies to a single fit"},
+            }
+            bp0.close()
+
+            # ---- configs[1]: B = 4096 on one GPU, one launch at a time ----
+            if B >= 4096:
+                bp1 = vp.BatchProblem(mdl, Y[:4096].contiguous(), x=x)
+                g1 = guess[:4096].contiguous()
+                ms1 = event_ms(lambda: bp1.fit(g1, want_coefficients=False), max(args.steps, 20), 3)
+                red1 = torch.zeros(4, dtype=torch.float64, device=dev)
+                bp1.summary_device(red1)
+                ev1 = float(red1.cpu()[3])
+                out["configs1"] = {
+                    "workload": "BASELINE configs[1]: 4096 fits on 1 GPU, one launch at a time (bound by the latency of "
+                                "its slowest fit, >100 LM evaluations; kernel selection automatic = one wavefront per problem)",
+                    "fits_per_s": 4096 / (ms1 * 1e-3), "ms_per_step": ms1,
+                    "roofline": {"kernel": "fit_kernel", "bound": "fp64_valu",
+                                 "achieved": ev1 * flops_eval / (ms1 * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": ev1 * flops_eval / (ms1 * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS},
+                }
+                bp1.close()
+
+            # ---- configs[2]: one alpha shared by S = 16384 right-hand sides, m = 2048, triple-exp + offset ----
+            S2, m2 = 16384, 2048
+            d2 = synth.mrhs_triple_exp(S=S2, m=m2)
+            mdl2 = vp.multi_exponential_model(d2["x"], d2["tau_guess"], offset=True)
+            Y2 = torch.from_numpy(d2["Y"][None]).to(dev)
+            bp2 = vp.BatchProblem(mdl2, Y2, x=torch.from_numpy(d2["x"]).to(dev))
+            g2 = torch.from_numpy(d2["tau_guess"][None]).to(dev)
+            bp2.set_timing(True)
+            ts = []
+            for _ in range(6):
+                bp2.evaluate(g2, want_residuals=True, want_jacobian=True)
+                ts.append(bp2.last_kernel_ms(_lib.VP_KERNEL_EVALUATE))
+            ev2_ms = min(ts[1:])
+            bytes_ev2 = T * m2 * S2 * (2 + 3)                      # T*m*S*(2+q) = 1.34 GB
+            tf = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                a2, _C2, rep2 = bp2.fit(g2, want_coefficients=False)
+                torch.cuda.synchronize()
+                tf.append((time.perf_counter() - t0) * 1e3)
+            r2 = bp2.report_to_numpy(rep2)
+            fit2_ms = min(tf[1:])
+            out["configs2"] = {
+                "workload": "BASELINE configs[2]: global fit, 1 alpha shared by %d right-hand sides, m=%d, triple-exp+offset" % (S2, m2),
+                "trait_evaluation_ms": ev2_ms, "global_fit_ms": fit2_ms, "evaluations": int(r2["n_evals"][0]),
+                "termination": int(r2["termination"][0]),
+                "max_abs_tau_error": float(np.abs(a2.cpu().numpy()[0] - d2["tau_true"]).max()),
+                "roofline": {"kernel": "mrhs_stream_kernel<MODE 1> (+ mrhs_factor_kernel): y in, r and J out", "bound": "hbm",
+                             "achieved": bytes_ev2 / (ev2_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": bytes_ev2 / (ev2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bytes_ev2,
+                             "traffic": committed_traffic("mrhs_stream_kernel_mode1")},
+                "roofline_fit": {"kernel": "mrhs_stream_kernel<MODE 0>: y re-read once per LM evaluation", "bound": "hbm",
+                                 "achieved": T * m2 * S2 * int(r2["n_evals"][0]) / (fit2_ms * 1e-3) / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": T * m2 * S2 * int(r2["n_evals"][0]) / (fit2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            }
+            bp2.close()
+            del Y2
+
+            # ---- configs[4]: fp32 five exponentials + offset, m = 4096, batch 8192 ----
+            B4, m4 = 8192, 4096
+            d4 = synth.multi_exp_batch(B4, 5, m4, [0.5, 1.5, 3.0, 6.0, 12.0], noise=1e-3, spread=0.1, guess_spread=0.05,
+                                       dtype=np.float32)
+            mdl4 = vp.multi_exponential_model(d4["x"], d4["tau_guess"][0], dtype=np.float32)
+            Y4 = torch.from_numpy(d4["Y"]).to(dev)
+            g4 = torch.from_numpy(d4["tau_guess"]).to(dev)
+            bp4 = vp.BatchProblem(mdl4, Y4, x=torch.from_numpy(d4["x"]).to(dev))
+            ms4 = event_ms(lambda: bp4.fit(g4, want_coefficients=False), 5, 2)
+            _a4, _c4, rep4 = bp4.fit(g4, want_coefficients=False)
+            r4 = bp4.report_to_numpy(rep4)
+            # fp32 flops of one evaluation: 5 exp columns (m x 5 x ~20), sweep over 11 register columns
+            # 4m(11+10+9+8+7+6) with the constant column implicit, Jacobian QR of 5 columns ~100m
+            flops4 = m4 * (5 * 20 + 4 * 51 + 100)
+            tf4 = float(r4["n_evals"].sum()) * flops4 / (ms4 * 1e-3) / 1e12
+            out["configs4"] = {
+                "workload": "BASELINE configs[4]: %d fp32 fits, five exponentials + offset (n=6, q=5), m=%d" % (B4, m4),
+                "fits_per_s": B4 / (ms4 * 1e-3), "ms_per_step": ms4, "mean_evaluations_per_fit": float(r4["n_evals"].mean()),
+                "fraction_failed": float((r4["termination"] <= 0).mean()),
+                "roofline": {"kernel": "fit_kernel<float, 5 exp + offset, 4 wavefronts per problem>", "bound": "fp32_valu",
+                             "achieved": tf4, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf4 / FP32_VALU_PEAK_TFLOPS, "flops_per_evaluation": flops4},
+            }
+            bp4.close()
+            del Y4
+
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, rank 0, N=1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        cores = O.max_threads()
-        pilot_n = min(B, 16 * cores)
+        cpu_model, sockets, phys_cores, usable, quota = CPU_TOPOLOGY
+        # one pinned thread per physical core, capped by the container's CPU bandwidth quota (a cgroup limit of N CPUs
+        # throttles anything beyond N runnable threads: measured on the GPU box, tools/cpu_scaling_probe.py)
+        threads = max(1, phys_cores if quota is None else min(phys_cores, int(quota)))
+        # (i) SURVEY 8(d)(i): single thread on configs[0] -- the reference is single-threaded by design
+        c0 = synth.config0()
+        mdl0 = vp.multi_exponential_model(c0["x"], c0["tau_guess"])
+        reps0 = 200
+        Y0 = np.tile(c0["y"][None, :], (reps0, 1))
+        G0 = np.tile(c0["tau_guess"][None, :], (reps0, 1))
+        _a, _c, rep0, secs0 = O.fit_batch(mdl0, c0["x"], Y0, G0, n_threads=1)
+        # (ii) single thread on the batch workload (the yardstick for the parallel efficiency)
+        n1 = 256
         t1 = time.perf_counter()
-        O.fit_batch(mdl, d["x"], d["Y"][:pilot_n], d["tau_guess"][:pilot_n], n_threads=cores)
+        _a, _c, rep1, secs1 = O.fit_batch(mdl, d["x"], d["Y"][:n1], d["tau_guess"][:n1], n_threads=1)
+        rate1 = n1 / secs1
+        # (iii) all physical cores, pinned, static split; sample sized for ~cpu_seconds of wall time
+        pilot_n = min(B, 32 * threads)
+        t1 = time.perf_counter()
+        O.fit_batch(mdl, d["x"], d["Y"][:pilot_n], d["tau_guess"][:pilot_n], n_threads=threads)
         pilot = time.perf_counter() - t1
         n_cpu = int(min(max(pilot_n, args.cpu_seconds * pilot_n / max(pilot, 1e-6)), 262144))
         dd = d if n_cpu <= B else synth.double_exp_batch(n_cpu, m=m, noise=args.noise)
         t1 = time.perf_counter()
-        _a, _c, rep_cpu, _s = O.fit_batch(mdl, dd["x"], dd["Y"][:n_cpu], dd["tau_guess"][:n_cpu], n_threads=cores)
+        _a, _c, rep_cpu, secs_fit = O.fit_batch(mdl, dd["x"], dd["Y"][:n_cpu], dd["tau_guess"][:n_cpu], n_threads=threads)
         wall = time.perf_counter() - t1
         out["cpu_baseline"] = {
-            "value": n_cpu / wall, "unit": "fits/s", "cores": cores, "kind": "port",
-            "sample": "first %d problems of the same synthetic workload, %d OpenMP threads, %.1f s wall "
-                      "(problem construction + initial evaluation included)" % (n_cpu, cores, wall),
+            "value": n_cpu / wall, "unit": "fits/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model, "sockets": sockets, "physical_cores": phys_cores, "logical_cpus_usable": usable,
+            "cgroup_cpu_quota": quota,
+            "threads": threads, "pinning": "OMP_PLACES=%s OMP_PROC_BIND=%s" % (os.environ.get("OMP_PLACES"), os.environ.get("OMP_PROC_BIND")),
+            "sample": "first %d problems of the same synthetic workload, %d pinned OpenMP threads (one per physical core%s), "
+                      "%.1f s wall (problem construction + initial evaluation included)"
+                      % (n_cpu, threads, "" if quota is None or quota >= phys_cores else
+                         ", capped by the container's cgroup CPU quota of %g CPUs" % quota, wall),
+            "fits_per_s_inside_fits": n_cpu / max(secs_fit, 1e-9),
             "mean_evaluations_per_fit": float(rep_cpu["n_evals"].mean()),
+            "single_thread_fits_per_s": rate1,
+            "parallel_efficiency": (n_cpu / max(secs_fit, 1e-9)) / (threads * rate1),
+            "configs0_single_thread": {"us_per_fit": secs0 / reps0 * 1e6, "evaluations_per_fit": float(rep0["n_evals"].mean()),
+                                       "us_per_evaluation": secs0 / reps0 * 1e6 / float(rep0["n_evals"].mean())},
             "note": "CPU restatement of the reference algorithm (oracle/varpro_oracle.c), not the Rust reference",
         }
+        # what the whole host would deliver at the measured per-core rate and parallel efficiency, had the container all
+        # of its physical cores (an extrapolation, labelled as such; `value` above is what was measured)
+        eff = out["cpu_baseline"]["parallel_efficiency"]
+        out["cpu_baseline"]["extrapolated_all_physical_cores_fits_per_s"] = rate1 * phys_cores * min(1.0, eff)
+        out["cpu_baseline"]["extrapolated_single_socket_fits_per_s"] = rate1 * (phys_cores / sockets) * min(1.0, eff)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        out["gpu_over_cpu_single_socket_extrapolated"] = value / out["cpu_baseline"]["extrapolated_single_socket_fits_per_s"]
     if rank == 0:
         print(json.dumps(out))
     for h_ in handles:

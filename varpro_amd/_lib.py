@@ -24,6 +24,7 @@ VP_FLAG_DEVICE_PTRS, VP_FLAG_T_PER_PROBLEM, VP_FLAG_W_PER_PROBLEM, VP_FLAG_OWN_S
 VP_FLAG_NO_GRID_RECURRENCE = 16
 VP_BASIS_SKIP_INVARIANT = 1
 VP_KERNEL_EVALUATE, VP_KERNEL_BASIS, VP_KERNEL_FIT = 0, 1, 2
+VP_ST_OK, VP_ST_NONFINITE, VP_ST_NOT_EVALUATED = 0, 1, 2
 
 VP_ERR_OK, VP_ERR_INVALID, VP_ERR_UNSUPPORTED, VP_ERR_HIP, VP_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 

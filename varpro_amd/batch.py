@@ -84,6 +84,49 @@ class LevenbergMarquardt:
         return o
 
 
+def _tensors_in(obj):
+    if _is_torch(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_in(v)
+    elif isinstance(obj, (tuple, list)):
+        for v in obj:
+            yield from _tensors_in(v)
+
+
+def _device_entry(fn):
+    """Stream discipline of device-pointer mode.  A handle enqueues all its work on ONE HIP stream: the stream that
+    was current when the handle was created (one handle <-> one stream, include/varpro_hip.h).  If the caller's current
+    stream is a different one, the call is bracketed: the handle's stream waits for the caller's stream (inputs
+    ready), the body runs with the handle's stream current (so torch allocates the outputs there), the caller's stream
+    waits for the handle's stream (outputs ready), and every tensor that crosses is recorded on the other stream so
+    that the caching allocator does not recycle its memory while that stream still uses it."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        if not self.device_mode:
+            return fn(self, *args, **kwargs)
+        cur = torch.cuda.current_stream(self._tdev)
+        hs = self._tstream
+        if cur.cuda_stream == hs.cuda_stream:
+            return fn(self, *args, **kwargs)
+        hs.wait_stream(cur)
+        for t in _tensors_in((args, kwargs)):
+            if t.is_cuda:
+                t.record_stream(hs)
+        with torch.cuda.stream(hs):
+            out = fn(self, *args, **kwargs)
+        cur.wait_stream(hs)
+        for t in _tensors_in(out):
+            if t.is_cuda:
+                t.record_stream(cur)
+        return out
+
+    return wrapper
+
+
 class BatchProblem:
     def __init__(self, model, Y, x=None, weights=None, epsilon=None, device=0, grid_recurrence=True):
         """model: varpro_amd.SeparableModel; Y: (B, m) or (B, S, m); x: (m,) shared grid or (B, m)
@@ -137,7 +180,8 @@ class BatchProblem:
         stream = None
         if self.device_mode:
             device = Y.device.index if Y.device.index is not None else torch.cuda.current_device()
-            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            self._tstream = torch.cuda.current_stream(device)  # the handle's stream for its whole life
+            stream = C.c_void_p(self._tstream.cuda_stream)
         self.device = int(device)
         h = C.c_void_p()
         desc = model.desc()
@@ -199,34 +243,48 @@ class BatchProblem:
         return lead_trail
 
     # ---- LeastSquaresProblem surface, batch-wise ----
+    @_device_entry
     def set_params(self, alpha):
         """== SeparableProblem::set_params (src/solvers/levmar/mod.rs:42-73)"""
         a = self._as_array(alpha).reshape(self.B, self.q)
         check(self.lib.vp_set_params(self._h, self._ptr(a)))
 
+    @_device_entry
     def params(self):
         out = self._empty((self.B, self.q))
         check(self.lib.vp_params(self._h, self._ptr(out)))
         return out
 
+    @_device_entry
     def status(self):
         st = self._empty((self.B,), np.int32)
         check(self.lib.vp_linear_coeffs(self._h, None, self._ptr(st)))
         return st
 
+    @_device_entry
     def residuals(self, with_status=False):
         """== residuals() (src/solvers/levmar/mod.rs:91-95): (B, S*m) column-stacked per problem"""
         r = self._empty((self.B, self.S * self.m))
         st = self._empty((self.B,), np.int32)
         check(self.lib.vp_residuals(self._h, self._ptr(r), self._ptr(st)))
+        if self._never_evaluated(st):
+            r = None  # residuals() before any set_params(): the reference returns None (cached is None)
         return (r, st) if with_status else r
 
+    @_device_entry
     def jacobian(self, with_status=False):
         """== jacobian() (src/solvers/levmar/mod.rs:101-201): (B, q, S*m); J[b, k] is column k"""
         J = self._empty((self.B, self.q, self.S * self.m))
         st = self._empty((self.B,), np.int32)
         check(self.lib.vp_jacobian(self._h, self._ptr(J), self._ptr(st)))
+        if self._never_evaluated(st):
+            J = None  # jacobian() before any set_params(): None, not an uninitialised buffer
         return (J, st) if with_status else J
+
+    @_device_entry
+    def _never_evaluated(self, st):
+        first = int(st[0].item()) if _is_torch(st) else int(st[0])
+        return first == _lib.VP_ST_NOT_EVALUATED
 
     def linear_coefficients(self):
         """(B, n) for single RHS, (B, S, n) for MRHS (each [b] is the reference's n x S matrix, column-major)"""
@@ -234,16 +292,19 @@ class BatchProblem:
         check(self.lib.vp_linear_coeffs(self._h, self._ptr(Cm), None))
         return Cm.reshape(self.B, self.n) if self.single_rhs else Cm
 
+    @_device_entry
     def weighted_data(self):
         Yw = self._empty((self.B, self.S, self.m))
         check(self.lib.vp_weighted_data(self._h, self._ptr(Yw)))
         return Yw.reshape(self.B, self.m) if self.single_rhs else Yw
 
+    @_device_entry
     def cost(self):
         c = self._empty((self.B,), np.float64)
         check(self.lib.vp_cost(self._h, self._ptr(c)))
         return c
 
+    @_device_entry
     def evaluate(self, alpha, want_residuals=True, want_jacobian=True):
         """fused set_params + residuals + jacobian + coefficients + cost in one launch (vp_evaluate)"""
         a = self._as_array(alpha).reshape(self.B, self.q)
@@ -257,6 +318,7 @@ class BatchProblem:
         return dict(r=r, J=J, C=Cm.reshape(self.B, self.n) if self.single_rhs else Cm, cost=cost, status=st)
 
     # ---- model surface ----
+    @_device_entry
     def basis(self, alpha, skip_invariant=False, want_phi=True, want_dphi=True, out_phi=None, out_dphi=None):
         """== eval / eval_partial_deriv for the batch, UNWEIGHTED (vp_basis): Phi (B, n, m), dPhi (B, p, m)"""
         a = self._as_array(alpha).reshape(self.B, self.q)
@@ -268,6 +330,7 @@ class BatchProblem:
         return phi, dphi
 
     # ---- solver surface ----
+    @_device_entry
     def fit(self, alpha0, solver=None, want_coefficients=True):
         """== LevMarSolver::fit for every problem (vp_fit).  Returns (alpha, C, report) where report
         is a structured numpy array (termination, n_evals, objective); termination > 0 <=> Ok."""
@@ -312,12 +375,14 @@ class BatchProblem:
             return rep.cpu().numpy().view(REPORT_DTYPE).reshape(-1)
         return rep
 
+    @_device_entry
     def best_fit(self):
         """== FitResult::best_fit (src/fit.rs:55-59, 87-91)"""
         f = self._empty((self.B, self.S, self.m))
         check(self.lib.vp_best_fit(self._h, self._ptr(f)))
         return f.reshape(self.B, self.m) if self.single_rhs else f
 
+    @_device_entry
     def statistics(self, want_confidence_sigma=True):
         """== FitStatistics::try_calculate for every problem (vp_statistics): dict(cov (B,k,k),
         reduced_chi2 (B,), conf_sigma (B,m) or None, status (B,), dof)"""
@@ -329,6 +394,7 @@ class BatchProblem:
         check(self.lib.vp_statistics(self._h, self._ptr(cov), self._ptr(chi2), self._ptr(sig), self._ptr(st)))
         return dict(cov=cov, reduced_chi2=chi2, conf_sigma=sig, status=st, dof=self.m - k)
 
+    @_device_entry
     def set_observations(self, Y):
         """replace the data of this handle by another batch of the same shape (vp_set_observations): the next frame
         of a stream of same-shaped problems without re-allocating the device state"""
@@ -363,13 +429,18 @@ class BatchProblem:
 
         def _cb(ptr, count, stream, user):
             try:
-                t = torch.as_tensor(_Raw(ptr, count), device=dev)
-                if dist.get_backend(group) == "gloo":
-                    h = t.cpu()
-                    dist.all_reduce(h, group=group)
-                    t.copy_(h)
-                else:
-                    dist.all_reduce(t, group=group)
+                # the library hands over the stream its kernels run on: the collective must be ordered on THAT
+                # stream (after the partial-sum kernel, before the LM step), whatever torch's current stream is
+                sptr = int(stream) if stream else 0
+                lib_stream = torch.cuda.ExternalStream(sptr, device=dev) if sptr else torch.cuda.default_stream(dev)
+                with torch.cuda.stream(lib_stream):
+                    t = torch.as_tensor(_Raw(ptr, count), device=dev)
+                    if dist.get_backend(group) == "gloo":
+                        h = t.cpu()
+                        dist.all_reduce(h, group=group)
+                        t.copy_(h)
+                    else:
+                        dist.all_reduce(t, group=group)
                 return 0
             except Exception as e:  # never let an exception cross the C boundary
                 self._rhs_cb_error = e
@@ -378,12 +449,14 @@ class BatchProblem:
         self._rhs_cb = _lib.ALLREDUCE_FN(_cb)  # keep alive as long as the handle uses it
         check(self.lib.vp_set_rhs_allreduce(self._h, self._rhs_cb, None, int(global_rhs_count)))
 
+    @_device_entry
     def summary(self):
         """local {sum cost, #successful, #failed, sum n_evals} after fit (vp_summary)"""
         out = (C.c_double * 4)()
         check(self.lib.vp_summary(self._h, out))
         return np.array(list(out))
 
+    @_device_entry
     def summary_device(self, out):
         """the same 4 aggregates into a CUDA float64 tensor of 4 elements, asynchronously on the handle's stream
         (no host synchronisation): ready to be all-reduced over RCCL"""

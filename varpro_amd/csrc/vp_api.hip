@@ -186,6 +186,7 @@ struct vp_batch {
     int fit_kernel;
     int *d_queue;
     int num_cus;
+    void *tmp_a, *tmp_b; // scratch allocations of vp_batch_create (freed by destroy if create fails half way)
 };
 
 namespace {
@@ -333,11 +334,28 @@ int run_evaluate(vp_batch *h, void *r_dev, void *J_dev, void *C_dev) {
     return reduce_rhs(h);
 }
 
-int check_handle(vp_batch *h) {
-    if (!h) return fail(VP_ERR_INVALID, "null handle");
-    VP_HIP(hipSetDevice(h->device));
-    return 0;
-}
+// Every entry point runs with the handle's device current and leaves the calling thread's current device as it found
+// it (a process that drives several GPUs -- torch with another current device, say -- must not see it change).
+struct DeviceGuard {
+    int prev = -1;
+    bool armed = false;
+    int enter(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) {
+            VP_HIP(hipSetDevice(device));
+            armed = prev >= 0;
+        }
+        return 0;
+    }
+    ~DeviceGuard() {
+        if (armed) (void)hipSetDevice(prev);
+    }
+};
+
+#define VP_ENTER(h)                                                                                                   \
+    if (!(h)) return fail(VP_ERR_INVALID, "null handle");                                                             \
+    DeviceGuard dev_guard__;                                                                                          \
+    if (int rc__ = dev_guard__.enter((h)->device)) return rc__
 
 // == LevMarSolver::fit for problems with multiple right-hand sides (global fit): host-stepped loop of
 // {factor, streaming reduction over Y, LM step} launches; all LM state stays on the device, the host only
@@ -476,7 +494,8 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     int ndev = vp_device_count();
     if (ndev <= 0) return fail(VP_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= ndev) return fail(VP_ERR_INVALID, "bad device index");
-    VP_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard__;
+    if (int rc__ = dev_guard__.enter(device)) return rc__;
     hipDeviceProp_t prop;
     VP_HIP(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -533,7 +552,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         VP_TRY(hipMalloc(&h->d_w, w_elems * ts));
         VP_TRY(hipMemcpyAsync(h->d_w, w, w_elems * ts, kin, h->stream));
     }
-    int *d_gflag = nullptr;
+    int *&d_gflag = reinterpret_cast<int *&>(h->tmp_a);
     const bool try_uniform = (dtype == VP_F64) && m >= 3 && !(flags & VP_FLAG_NO_GRID_RECURRENCE);
     if (try_uniform) {
         const int one = 1;
@@ -547,7 +566,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     VP_TRY(hipMalloc(&h->d_yw, y_elems * ts));
     {
         // Y_w = W * Y
-        void *ytmp = nullptr;
+        void *&ytmp = h->tmp_b;
         const void *ysrc = Y;
         if (!device_ptrs(h)) {
             VP_TRY(hipMalloc(&ytmp, y_elems * ts));
@@ -567,8 +586,10 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         int gflag = 0;
         if (d_gflag) VP_TRY(hipMemcpyAsync(&gflag, d_gflag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         VP_TRY(hipStreamSynchronize(h->stream));
-        if (ytmp) (void)hipFree(ytmp);
-        if (d_gflag) (void)hipFree(d_gflag);
+        (void)hipFree(ytmp);
+        ytmp = nullptr;
+        (void)hipFree(d_gflag);
+        d_gflag = nullptr;
         h->grid_uniform = gflag != 0;
     }
     VP_TRY(hipMalloc(&h->d_alpha, (size_t)std::max<int64_t>(1, B * h->q) * ts));
@@ -588,6 +609,10 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     VP_TRY(hipEventCreate(&h->ev0));
     VP_TRY(hipEventCreate(&h->ev1));
     if (S > 1 && kern->mrhs_factor && kern->mrhs_stream && kern->mrhs_lm && kern->mrhs_finish) {
+        if (B > 65535) { // the streaming kernel's grid is (workgroups per problem, problems): gridDim.y <= 65535
+            vp_batch_destroy(h);
+            return fail(VP_ERR_UNSUPPORTED, "at most 65535 problems per handle with multiple right-hand sides");
+        }
         const int n_ = h->n, p_ = h->p, q_ = h->q;
         VP_TRY(hipMalloc(&h->mrhs.qthin, (size_t)B * n_ * m * ts));
         VP_TRY(hipMalloc(&h->mrhs.g, (size_t)B * std::max(1, p_) * m * ts));
@@ -609,7 +634,8 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
 
 void vp_batch_destroy(vp_batch *h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dev_guard__;
+    (void)dev_guard__.enter(h->device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_mrhs_tot);
     (void)hipFree(h->d_t);
@@ -627,17 +653,18 @@ void vp_batch_destroy(vp_batch *h) {
     (void)hipFree(h->d_report);
     (void)hipFree(h->d_sum4);
     (void)hipFree(h->d_queue);
-    if (h->have_mrhs) {
-        (void)hipFree(h->mrhs.qthin);
-        (void)hipFree(h->mrhs.g);
-        (void)hipFree(h->mrhs.small);
-        (void)hipFree(h->mrhs.statusA);
-        (void)hipFree(h->mrhs.done);
-        (void)hipFree(h->mrhs.acc);
-        (void)hipFree(h->mrhs.lm_state);
-        (void)hipFree(h->mrhs.nactive);
-        (void)hipFree(h->mrhs.alpha_trial);
-    }
+    (void)hipFree(h->tmp_a);
+    (void)hipFree(h->tmp_b);
+    // (the struct is zero-initialised: freeing unconditionally also covers a create that failed half way)
+    (void)hipFree(h->mrhs.qthin);
+    (void)hipFree(h->mrhs.g);
+    (void)hipFree(h->mrhs.small);
+    (void)hipFree(h->mrhs.statusA);
+    (void)hipFree(h->mrhs.done);
+    (void)hipFree(h->mrhs.acc);
+    (void)hipFree(h->mrhs.lm_state);
+    (void)hipFree(h->mrhs.nactive);
+    (void)hipFree(h->mrhs.alpha_trial);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -645,7 +672,7 @@ void vp_batch_destroy(vp_batch *h) {
 }
 
 int vp_set_params(vp_batch *h, const void *alpha) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!alpha) return fail(VP_ERR_INVALID, "null alpha");
     const size_t bytes = (size_t)h->B * h->q * tsize(h->dtype);
     VP_HIP(hipMemcpyAsync(h->d_alpha, alpha, bytes, device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -659,7 +686,7 @@ int vp_set_params(vp_batch *h, const void *alpha) {
 }
 
 int vp_params(vp_batch *h, void *alpha_out) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!h->have_params) return fail(VP_ERR_INVALID, "no parameters set yet");
     return copy_out(h, alpha_out, h->d_alpha, (size_t)h->B * h->q * tsize(h->dtype));
 }
@@ -681,7 +708,7 @@ static int copy_status(vp_batch *h, int32_t *status) {
 }
 
 int vp_residuals(vp_batch *h, void *r_out, int32_t *status) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!h->have_params) return copy_status(h, status) ? VP_ERR_HIP : VP_ERR_OK;
     if (!h->r_valid) {
         if (int rc = ensure_R(h)) return rc;
@@ -693,7 +720,7 @@ int vp_residuals(vp_batch *h, void *r_out, int32_t *status) {
 }
 
 int vp_jacobian(vp_batch *h, void *J_out, int32_t *status) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!h->have_params) return copy_status(h, status) ? VP_ERR_HIP : VP_ERR_OK;
     if (!J_out) return fail(VP_ERR_INVALID, "null J_out");
     OutBuf J;
@@ -704,19 +731,19 @@ int vp_jacobian(vp_batch *h, void *J_out, int32_t *status) {
 }
 
 int vp_linear_coeffs(vp_batch *h, void *C_out, int32_t *status) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!h->have_params) return copy_status(h, status) ? VP_ERR_HIP : VP_ERR_OK;
     if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * tsize(h->dtype))) return rc;
     return copy_status(h, status);
 }
 
 int vp_weighted_data(vp_batch *h, void *Yw_out) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     return copy_out(h, Yw_out, h->d_yw, (size_t)h->B * h->S * h->m * tsize(h->dtype));
 }
 
 int vp_set_observations(vp_batch *h, const void *Y) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!Y) return fail(VP_ERR_INVALID, "Right hand side(s) not provided", VP_BUILD_Y_DATA_MISSING);
     const size_t ts = tsize(h->dtype);
     const size_t y_elems = (size_t)h->B * h->S * h->m;
@@ -747,14 +774,14 @@ int vp_set_observations(vp_batch *h, const void *Y) {
 }
 
 int vp_cost(vp_batch *h, double *cost_out) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!h->have_params) return fail(VP_ERR_INVALID, "no parameters set yet");
     return copy_out(h, cost_out, h->d_cost, (size_t)h->B * sizeof(double));
 }
 
 int vp_evaluate(vp_batch *h, const void *alpha, void *r_out, void *J_out, void *C_out, double *cost_out,
                 int32_t *status) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!alpha) return fail(VP_ERR_INVALID, "null alpha");
     const size_t ts = tsize(h->dtype);
     VP_HIP(hipMemcpyAsync(h->d_alpha, alpha, (size_t)h->B * h->q * ts,
@@ -773,7 +800,7 @@ int vp_evaluate(vp_batch *h, const void *alpha, void *r_out, void *J_out, void *
 }
 
 int vp_basis(vp_batch *h, const void *alpha, void *Phi_out, void *dPhi_out, int flags) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!alpha) return fail(VP_ERR_INVALID, "null alpha");
     const size_t ts = tsize(h->dtype);
     int ncols = 0;
@@ -806,7 +833,7 @@ int vp_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, 
 
 int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep,
                  double *trace_out, int trace_rows) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!alpha_inout) return fail(VP_ERR_INVALID, "null alpha");
     if (h->S != 1) return mrhs_fit(h, opts, alpha_inout, C_out, rep, trace_out, trace_rows);
     if (!h->kern->fit && !h->kern->fit_single) return fail(VP_ERR_UNSUPPORTED, "no fit kernel for this model");
@@ -851,7 +878,7 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
 }
 
 int vp_set_rhs_allreduce(vp_batch *h, vp_allreduce_fn fn, void *user, int64_t global_rhs_count) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (fn) {
         if (h->S <= 1 || !h->have_mrhs)
             return fail(VP_ERR_UNSUPPORTED, "right-hand-side sharding needs a handle with S > 1 and MRHS kernels");
@@ -864,7 +891,7 @@ int vp_set_rhs_allreduce(vp_batch *h, vp_allreduce_fn fn, void *user, int64_t gl
 }
 
 int vp_best_fit(vp_batch *h, void *fit_out) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!h->have_params) return fail(VP_ERR_INVALID, "no parameters set yet");
     if (!h->kern->best_fit) return fail(VP_ERR_UNSUPPORTED, "no best_fit kernel for this model");
     OutBuf f;
@@ -879,7 +906,7 @@ int vp_best_fit(vp_batch *h, void *fit_out) {
 }
 
 int vp_statistics(vp_batch *h, void *cov_out, double *reduced_chi2_out, void *conf_sigma_out, int32_t *status) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!h->have_params) return fail(VP_ERR_INVALID, "no parameters set yet");
     if (h->S != 1) // src/solvers/levmar/mod.rs:271-273: statistics are single-RHS only
         return fail(VP_ERR_UNSUPPORTED, "fit statistics are only supported for a single right-hand side");
@@ -921,7 +948,7 @@ int vp_statistics(vp_batch *h, void *cov_out, double *reduced_chi2_out, void *co
 }
 
 int vp_summary(vp_batch *h, double out[4]) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!h->have_report) return fail(VP_ERR_INVALID, "vp_summary requires a completed vp_fit");
     VP_HIP(hipMemsetAsync(h->d_sum4, 0, 4 * sizeof(double), h->stream));
     const unsigned grid = (unsigned)std::min<int64_t>((h->B + 255) / 256, 1024);
@@ -933,7 +960,7 @@ int vp_summary(vp_batch *h, double out[4]) {
 }
 
 int vp_summary_device(vp_batch *h, double *dev_out4) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     if (!h->have_report) return fail(VP_ERR_INVALID, "vp_summary_device requires a completed vp_fit");
     if (!dev_out4) return fail(VP_ERR_INVALID, "null output");
     VP_HIP(hipMemsetAsync(dev_out4, 0, 4 * sizeof(double), h->stream));
@@ -964,7 +991,7 @@ int vp_last_kernel_ms(vp_batch *h, int which, float *ms) {
 }
 
 int vp_synchronize(vp_batch *h) {
-    if (int rc = check_handle(h)) return rc;
+    VP_ENTER(h);
     VP_HIP(hipStreamSynchronize(h->stream));
     return VP_ERR_OK;
 }

@@ -587,10 +587,14 @@ template <typename T, class M, int R, int W = 1> int launch_fit2(const LaunchPar
         constexpr int GS = fit2_slots<T, R>();
         constexpr int WPB = 4;
         constexpr int WPS = waves_for<T, R, M::N + M::P>(); // resident waves per SIMD
-        // fit_group: 0 = automatic (slots once the batch exceeds the resident wave slots of the device: below that one
-        // wave per problem has the lower latency), 1 = one problem per wave (fit_kernel), 2 = slots regardless of B
+        // fit_group: 0 = automatic, 1 = one problem per wave (fit_kernel), 2 = slots regardless of B.
+        // Automatic: a launch costs (work / throughput) + the latency of its slowest fit (~0.5 ms at m = 1024: >100 LM
+        // evaluations of one problem, nothing to overlap them with).  The slot kernel has the higher throughput (fewer
+        // instructions per evaluation) but a slot shares its wave with G-1 others, i.e. the slowest fit advances more
+        // slowly while its partners are busy: measured cross-over at ~16x the device's resident waves (32768 problems
+        // on MI355X, tools/slot_probe.py).
         const int64_t cap_waves = (int64_t)p.num_cus * 4 * WPS;
-        if (p.w || p.t_stride != 0 || !p.queue || p.fit_group == 1 || (p.fit_group != 2 && p.B <= cap_waves))
+        if (p.w || p.t_stride != 0 || !p.queue || p.fit_group == 1 || (p.fit_group != 2 && p.B <= 16 * cap_waves))
             return launch_fit<T, M, R, W>(p);
         Fit2Args<T, M> args;
         FitArgs<T, M> &a = args.f;

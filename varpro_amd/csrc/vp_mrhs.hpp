@@ -501,21 +501,23 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
     }
     if (need_jac) {
         const double *small = a.ws.small + b * mrhs_small_stride<N, P>();
-        T A[Q][Q], bv[Q];
+        // J^T J and J^T r are assembled and factored in DOUBLE for both dtypes (the accumulators are double): an fp32
+        // handle would otherwise square the conditioning of J in fp32 and drop columns from cond(J) ~ 3e3 on
+        double A[Q][Q], bv[Q];
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
-            bv[k] = T(0);
+            bv[k] = 0.0;
 #pragma unroll
-            for (int l = 0; l < Q; ++l) A[k][l] = T(0);
+            for (int l = 0; l < Q; ++l) A[k][l] = 0.0;
         }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int kp = a.pp[p], jp = a.pb[p];
-            dyn_set<Q>(bv, kp, dyn_get<Q>(bv, kp) - (T)acc[1 + N * N + p]);
+            dyn_set<Q>(bv, kp, dyn_get<Q>(bv, kp) - acc[1 + N * N + p]);
 #pragma unroll
             for (int p2 = 0; p2 < P; ++p2) {
                 const int kp2 = a.pp[p2], jp2 = a.pb[p2];
-                const T contrib = (T)acc[1 + jp * N + jp2] * (T)small[N * N + p * P + p2];
+                const double contrib = acc[1 + jp * N + jp2] * small[N * N + p * P + p2];
 #pragma unroll
                 for (int k = 0; k < Q; ++k)
 #pragma unroll
@@ -523,7 +525,15 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
                         if (k == kp && l == kp2) A[k][l] += contrib;
             }
         }
-        gram_to_qr<T, Q>(A, bv, s.Rj, s.acnorm, s.ipvt, s.qtf);
+        double Rd[Q][Q], acd[Q], qd[Q];
+        gram_to_qr<double, Q>(A, bv, Rd, acd, s.ipvt, qd);
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            s.acnorm[k] = (T)acd[k];
+            s.qtf[k] = (T)qd[k];
+#pragma unroll
+            for (int l = 0; l < Q; ++l) s.Rj[k][l] = (T)Rd[k][l];
+        }
     }
     lm_next_step<T, N, Q, true>(s, a.opts, need_jac);
     if (lane == 0) {

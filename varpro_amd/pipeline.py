@@ -33,15 +33,27 @@ class FitPipeline:
 
     def submit(self, Y, alpha0, solver=None, want_coefficients=True):
         """enqueue the fit of one batch (asynchronous); returns (alpha, C, report, slot_index).  Y and alpha0 must be
-        ready on the CURRENT stream (the slot's stream waits for it)."""
+        ready on the CURRENT stream (the slot's stream waits for it); they may be dropped right after the call.
+        The results are valid on the current stream after wait(slot)."""
         i = self._k % len(self.slots)
         self._k += 1
         st = self.streams[i]
-        st.wait_stream(torch.cuda.current_stream(self.device))
+        cur = torch.cuda.current_stream(self.device)
+        st.wait_stream(cur)
+        # Y / alpha0 were allocated on the caller's stream and are read on the slot's stream: tell the caching
+        # allocator, or a caller that drops them right after submit() (`pipe.submit(Y.cuda(), g)` in a loop) has
+        # their memory handed to the next H2D copy while the slot is still reading it
+        for t in (Y, alpha0):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(st)
         with torch.cuda.stream(st):
             h = self.slots[i]
             h.set_observations(Y)
             alpha, C, rep = h.fit(alpha0, solver=solver, want_coefficients=want_coefficients)
+        # the results are allocated on the slot's stream and consumed on the caller's stream after wait()
+        for t in (alpha, C, rep):
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)
         return alpha, C, rep, i
 
     def wait(self, slot=None):
