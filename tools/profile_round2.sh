@@ -28,7 +28,7 @@ def short(name):
 trace = []
 for fn in glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        trace.append((short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Grid_Size", 0) or 0),
+        trace.append((short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0),
                       r.get("Queue_Id", ""), int(r.get("VGPR_Count", 0) or 0), int(r.get("Scratch_Size", 0) or 0)))
 agg = collections.defaultdict(list)
 for k, s, e, g, q, v, sc in trace: agg[(k, g)].append(e - s)

@@ -17,6 +17,8 @@
 //                  a workgroup's partners.
 //
 // G is bounded by LDS (one m-row column per slot, 8 waves per CU): 2 at m = 1024 fp64, more for shorter problems.
+// Problems too long for one wave run on a GROUP of W waves (one workgroup); there the scalar phase additionally runs
+// on ONE wave instead of being repeated by all W (fp32 five-exponential fits at m = 4096: BASELINE configs[4]).
 // The constant column's reflector H_0 does not depend on alpha, so a slot stores H_0 y_w instead of y_w (applied once
 // per fit when the slot is filled) and the data column skips reflector 0 in every evaluation.
 #pragma once
@@ -40,9 +42,14 @@ template <typename T, int N, int Q> struct alignas(8) SlotRec {
     int trow; // trace rows written so far
 };
 
-template <typename T, int R> constexpr int fit2_slots() {
-    // LDS budget: 8 resident waves per CU x G columns of 64*R scalars (+ one shared grid per workgroup) <= 160 KiB
-    return (64 * R * (int)sizeof(T) >= 8192) ? 2 : ((64 * R * (int)sizeof(T) >= 4096) ? 4 : 8);
+// Slots per group from the LDS budget: a workgroup holds ONE copy of the grid and NG groups x GS columns of 64*R*W
+// scalars; `blocks_per_cu` workgroups are resident per CU (160 KiB of LDS).  Capped at 8 (lanes 0..GS-1 of ONE wave
+// run the scalar phase; beyond 8 the divergent branches of lmpar eat the gain).
+template <typename T, int R, int W, int NG, int BLOCKS_PER_CU> constexpr int fit2_slots() {
+    constexpr int col = 64 * R * W * (int)sizeof(T);
+    constexpr int budget = (160 * 1024) / BLOCKS_PER_CU - col - 3 * 1024; // grid + records/constants/exchange area
+    constexpr int gs = budget / (NG * col);
+    return gs < 1 ? 1 : (gs > 8 ? 8 : gs);
 }
 
 template <typename T, class M> struct Fit2Args {
@@ -106,21 +113,27 @@ __device__ __forceinline__ T fill_slot_column(const T *__restrict__ yp, const in
 
 // (Re)fill slot `s` of a wave with problem `prob` (wave-uniform; < 0 marks the slot empty).  Out of line: executed once
 // per fit, its register needs must not shape the allocation of the LM loop.
-template <typename T, int N, int Q, int R, int PADM>
+template <typename T, int N, int Q, int R, int W, int PADM>
 __device__ __noinline__ void slot_fill(VP_LDS SlotRec<T, N, Q> *rec, VP_LDS T *s_col, VP_LDS const T *s_t,
-                                       VP_LDS const SlotConsts<T> *k, const int prob, const T h0_beta, const T h0_u,
-                                       const T h0_g) {
-    using G = Grp<1>;
-    G grp = G::make(nullptr);
-    const int lane = grp.lane;
+                                       VP_LDS const SlotConsts<T> *k, VP_LDS unsigned char *xch, const int prob,
+                                       const T h0_beta, const T h0_u, const T h0_g) {
+    using G = Grp<W>;
+    G grp = G::make((unsigned char *)xch);
+    const int lane = grp.gl; // group lane
+    // W > 1, barrier on entry: (i) every wave decides from the slot's record whether to call this function -- the
+    // record must not change before ALL waves have read it (a wave that saw prob = -1 early would skip the call and
+    // its barriers: deadlock); (ii) the group's exchange phase restarts at 0 here, so every wave must be done with
+    // the caller's last exchange before the buffers are reused
+    if constexpr (W > 1) __syncthreads();
     if (prob < 0) {
         if (lane == 0) {
             rec->prob = -1;
             rec->term = VP_TERM_NOT_RUN;
         }
+        if constexpr (W > 1) __syncthreads();
         return;
     }
-    using Src = RowSource<T, R, true, 0, 1, 1, true, PADM>;
+    using Src = RowSource<T, R, true, 0, 1, W, true, PADM>;
     Src src;
     src.t = (const T *)s_t;
     src.w = nullptr;
@@ -163,6 +176,7 @@ __device__ __noinline__ void slot_fill(VP_LDS SlotRec<T, N, Q> *rec, VP_LDS T *s
         rec->prob = prob;
         rec->trow = 0;
     }
+    if constexpr (W > 1) __syncthreads(); // column + record visible to all waves; exchange buffers quiescent again
 }
 
 // SCALAR phase: lane s runs the LM bookkeeping of slot s on its LDS record (trust-region update, accept / reject,
@@ -409,27 +423,40 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
     }
 }
 
-// WPB waves per workgroup share one LDS copy of the grid; the waves are otherwise independent (no barrier after setup)
-template <typename T, class M, int R, int PADM, int GS, int WPB>
-__global__ void __launch_bounds__(64 * WPB, (waves_for<T, R, M::N + M::P>() * WPB) / 4 > 0 ? (waves_for<T, R, M::N + M::P>() * WPB) / 4 : 1)
-    fit2_kernel(const Fit2Args<T, M> args) {
+// A workgroup = NG groups of W waves (W = 1: NG = 4 independent waves; W > 1: ONE group, whose reductions use
+// workgroup barriers).  The groups share one LDS copy of the grid; each owns GS slots.  With W > 1 the scalar phase
+// runs on wave 0 of the group only -- the one-problem-per-group kernel has all W waves repeat the bookkeeping.
+template <typename T, class M, int R, int W, int PADM, int GS, int NG, int WPS>
+__global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W * NG) / 4 : 1) fit2_kernel(const Fit2Args<T, M> args) {
     static_assert(M::kConstLast && M::kDiagonalPairs, "slot kernel: multi-exponential + offset models");
+    static_assert(W == 1 || NG == 1, "multi-wave groups synchronise with workgroup barriers: one group per workgroup");
     constexpr int N = M::N, P = M::P, Q = M::Q;
     constexpr int NC = N + P;  // register columns: the constant column is never materialised
     constexpr int YC = N - 1;  // data column
     constexpr int DC = YC + 1; // first derivative column
-    constexpr int MP = 64 * R;
+    constexpr int MP = 64 * R * W;
     using Rec = SlotRec<T, N, Q>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *s_t = reinterpret_cast<T *>(smem_raw);
-    const int wave = (int)(threadIdx.x >> 6);
-    T *s_y = s_t + MP + (size_t)wave * GS * MP;
-    Rec *recs = reinterpret_cast<Rec *>(s_t + MP + (size_t)WPB * GS * MP) + (size_t)wave * GS;
-    SlotConsts<T> *kc = reinterpret_cast<SlotConsts<T> *>(reinterpret_cast<Rec *>(s_t + MP + (size_t)WPB * GS * MP) + (size_t)WPB * GS);
-    using G = Grp<1>;
-    G grp = G::make(nullptr);
-    const int lane = grp.lane;
-    const int gw = (int)blockIdx.x * WPB + wave; // persistent wave index
+    const int gi = (W == 1) ? (int)(threadIdx.x >> 6) : 0; // group within the workgroup
+    T *s_y = s_t + MP + (size_t)gi * GS * MP;
+    Rec *recs_all = reinterpret_cast<Rec *>(s_t + MP + (size_t)NG * GS * MP);
+    Rec *recs = recs_all + (size_t)gi * GS;
+    SlotConsts<T> *kc = reinterpret_cast<SlotConsts<T> *>(recs_all + (size_t)NG * GS);
+    int *s_pop = reinterpret_cast<int *>(kc + 1);                                   // [GS] queue pops (W > 1)
+    unsigned char *s_xch = reinterpret_cast<unsigned char *>(s_pop + ((GS + 3) / 4) * 4); // group exchange area (W > 1)
+    using G = Grp<W>;
+    G grp = G::make(s_xch);
+    const int lane = grp.gl; // group lane: row ownership
+    const int gw = (int)blockIdx.x * NG + gi; // persistent group index
+    auto group_sync = [&]() __attribute__((always_inline)) {
+        if constexpr (W > 1) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
     T eps_;
     int m_, uniform_;
     int64_t B_;
@@ -439,10 +466,10 @@ __global__ void __launch_bounds__(64 * WPB, (waves_for<T, R, M::N + M::P>() * WP
         eps_ = a.eps;
         uniform_ = a.grid_uniform;
         B_ = a.B;
-        // ---- the shared grid (every wave writes the same values: no ownership split needed) + the constants ----
+        // ---- the shared grid (every group writes the same values: no ownership split needed) + the constants ----
         T tmp[R];
-        load_rows<T, R>(a.t, m_, lane, vec_aligned<T>(a.t, m_), tmp);
-        store_rows<T, R>(s_t, MP, lane, true, tmp);
+        load_rows<T, R, W>(a.t, m_, lane, vec_aligned<T>(a.t, m_), tmp);
+        store_rows<T, R, W>(s_t, MP, lane, true, tmp);
         if (threadIdx.x == 0) {
             kc->ftol = a.ftol;
             kc->xtol = a.xtol;
@@ -465,7 +492,7 @@ __global__ void __launch_bounds__(64 * WPB, (waves_for<T, R, M::N + M::P>() * WP
     }
     __syncthreads();
     const int m = m_;
-    using Src = RowSource<T, R, true, 0, 1, 1, true, PADM>;
+    using Src = RowSource<T, R, true, 0, 1, W, true, PADM>;
     Src src;
     src.t = s_t;
     src.w = nullptr;
@@ -477,11 +504,13 @@ __global__ void __launch_bounds__(64 * WPB, (waves_for<T, R, M::N + M::P>() * WP
     const M mdl = args.f.mdl;
 
     auto fill = [&](int s, int prob) __attribute__((always_inline)) {
-        slot_fill<T, N, Q, R, PADM>((VP_LDS Rec *)(recs + s), (VP_LDS T *)(s_y + (size_t)s * MP), (VP_LDS const T *)s_t,
-                                    (VP_LDS const SlotConsts<T> *)kc, prob, h0.beta, h0.u, h0.g);
+        slot_fill<T, N, Q, R, W, PADM>((VP_LDS Rec *)(recs + s), (VP_LDS T *)(s_y + (size_t)s * MP), (VP_LDS const T *)s_t,
+                                       (VP_LDS const SlotConsts<T> *)kc, (VP_LDS unsigned char *)s_xch, prob, h0.beta, h0.u,
+                                       h0.g);
+        if constexpr (W > 1) grp.phase = 0; // slot_fill leaves the exchange buffers quiescent (barrier at its end)
     };
 
-    // ---- initial, static assignment: wave gw takes problems gw*GS .. gw*GS+GS-1 ----
+    // ---- initial, static assignment: group gw takes problems gw*GS .. gw*GS+GS-1 ----
     int nactive = 0;
 #pragma nounroll
     for (int s = 0; s < GS; ++s) {
@@ -490,8 +519,7 @@ __global__ void __launch_bounds__(64 * WPB, (waves_for<T, R, M::N + M::P>() * WP
         fill(s, have ? (int)prob : -1);
         nactive += have ? 1 : 0;
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    group_sync();
 
     while (nactive > 0) {
         // =============================== VECTOR phase ===============================
@@ -509,7 +537,7 @@ __global__ void __launch_bounds__(64 * WPB, (waves_for<T, R, M::N + M::P>() * WP
 
             T C[NC][R];
             EvalUniform<T, N> u;
-            load_rows_lds<T, R>(s_y + (size_t)s * MP, lane, C[YC]);
+            load_rows_lds<T, R, W>(s_y + (size_t)s * MP, lane, C[YC]);
             evaluate_core_const_first<T, M, R, NC, Src, G, true>(mdl, alpha, src, eps_, grp, h0, C, u, nullptr, qty0);
 
             const T fnorm1 = usqrt(u.fn2);
@@ -532,7 +560,7 @@ __global__ void __launch_bounds__(64 * WPB, (waves_for<T, R, M::N + M::P>() * WP
                 for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
                 jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
             }
-            if (lane == 0) {
+            if (lane == 0) { // group lane 0
                 rec->fnorm1 = fnorm1;
                 rec->actred = actred;
                 rec->ratio = ratio;
@@ -555,46 +583,60 @@ __global__ void __launch_bounds__(64 * WPB, (waves_for<T, R, M::N + M::P>() * WP
                 rec->flags = fl;
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        group_sync();
 
-        // =============================== SCALAR phase: lane s <-> slot s ===============================
-        slot_scalar_phase<T, N, Q, GS>((VP_LDS Rec *)recs, (VP_LDS const SlotConsts<T> *)kc);
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // =============================== SCALAR phase: lane s of wave 0 <-> slot s ===============================
+        if (grp.wave == 0) slot_scalar_phase<T, N, Q, GS>((VP_LDS Rec *)recs, (VP_LDS const SlotConsts<T> *)kc);
+        group_sync();
 
         // =============================== REFILL finished slots from the queue ===============================
+        if constexpr (W > 1) {
+            // one pop per finished slot by group lane 0, published through LDS (all waves must agree on the index)
+            if (lane == 0) {
+                for (int s = 0; s < GS; ++s)
+                    s_pop[s] = (recs[s].prob >= 0 && recs[s].term != 0)
+                                   ? __hip_atomic_fetch_add(kc->queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : -1;
+            }
+            __syncthreads();
+        }
 #pragma nounroll
         for (int s = 0; s < GS; ++s) {
             if (uni(recs[s].prob) < 0 || uni(recs[s].term) == 0) continue;
             int next = 0;
-            if (lane == 0) next = __hip_atomic_fetch_add(kc->queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            next = uni(next);
+            if constexpr (W > 1) {
+                next = uni(s_pop[s]);
+            } else {
+                if (lane == 0) next = __hip_atomic_fetch_add(kc->queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                next = uni(next);
+            }
             const bool have = (int64_t)next < B_;
             fill(s, have ? next : -1);
             if (!have) nactive -= 1;
         }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        group_sync();
     }
 }
 
 template <typename T, class M, int R, int W = 1> int launch_fit2(const LaunchParams &p) {
-    // the slot kernel covers: one wave per problem, unit weights, one shared grid, model ending in a constant column
-    if constexpr (!(M::kConstLast && M::kDiagonalPairs) || W != 1) {
+    // the slot kernel covers: unit weights, one shared grid, model ending in a constant column
+    if constexpr (!(M::kConstLast && M::kDiagonalPairs)) {
         return launch_fit<T, M, R, W>(p);
     } else {
-        constexpr int GS = fit2_slots<T, R>();
-        constexpr int WPB = 4;
-        constexpr int WPS = waves_for<T, R, M::N + M::P>(); // resident waves per SIMD
-        // fit_group: 0 = automatic, 1 = one problem per wave (fit_kernel), 2 = slots regardless of B.
-        // Automatic: a launch costs (work / throughput) + the latency of its slowest fit (~0.5 ms at m = 1024: >100 LM
-        // evaluations of one problem, nothing to overlap them with).  The slot kernel has the higher throughput (fewer
-        // instructions per evaluation) but a slot shares its wave with G-1 others, i.e. the slowest fit advances more
-        // slowly while its partners are busy: measured cross-over at ~16x the device's resident waves (32768 problems
-        // on MI355X, tools/slot_probe.py).
-        const int64_t cap_waves = (int64_t)p.num_cus * 4 * WPS;
-        if (p.w || p.t_stride != 0 || !p.queue || p.fit_group == 1 || (p.fit_group != 2 && p.B <= 16 * cap_waves))
+        constexpr int NG = (W == 1) ? 4 : 1;                 // groups per workgroup
+        constexpr int WPS = waves_for<T, R, M::N + M::P>();  // resident waves per SIMD
+        constexpr int BPC = (4 * WPS) / (W * NG) > 0 ? (4 * WPS) / (W * NG) : 1; // workgroups per CU
+        constexpr int GS = fit2_slots<T, R, W, NG, BPC>();
+        // fit_group: 0 = automatic, 1 = one problem per wave(-group) (fit_kernel), 2 = slots regardless of B.
+        // Automatic, W = 1: a launch costs (work / throughput) + the latency of its slowest fit (~0.5 ms at m = 1024:
+        // >100 LM evaluations of one problem, nothing to overlap them with).  The slot kernel has the higher
+        // throughput (fewer instructions per evaluation) but a slot shares its wave with G-1 others, i.e. the slowest
+        // fit advances more slowly while its partners are busy: measured cross-over at ~16x the device's resident
+        // waves (32768 problems on MI355X, tools/slot_probe.py).  W > 1: the slot kernel runs the LM bookkeeping on
+        // one wave instead of all W and is never slower.
+        const int64_t cap_groups = (int64_t)p.num_cus * BPC * NG;
+        const bool small = (W == 1) ? (p.B <= 16 * cap_groups) : false;
+        if (p.w || p.t_stride != 0 || !p.queue || p.fit_group == 1 || (p.fit_group != 2 && small))
             return launch_fit<T, M, R, W>(p);
         Fit2Args<T, M> args;
         FitArgs<T, M> &a = args.f;
@@ -622,19 +664,20 @@ template <typename T, class M, int R, int W = 1> int launch_fit2(const LaunchPar
         a.trace_rows = p.trace_rows;
         a.grid_uniform = p.grid_uniform;
         if (a.B <= 0) return VP_ERR_OK;
-        // persistent grid: every resident wave slot of the device, or fewer when the batch is smaller
-        const int64_t cap_blocks = (int64_t)p.num_cus * WPS; // WPB = 4 waves = one per SIMD -> WPS workgroups per CU
-        const int64_t need_blocks = (a.B + (int64_t)GS * WPB - 1) / ((int64_t)GS * WPB);
+        // persistent grid: every resident workgroup slot of the device, or fewer when the batch is smaller
+        const int64_t cap_blocks = (int64_t)p.num_cus * BPC;
+        const int64_t need_blocks = (a.B + (int64_t)GS * NG - 1) / ((int64_t)GS * NG);
         const int64_t blocks = need_blocks < cap_blocks ? need_blocks : cap_blocks;
         args.queue = p.queue;
-        args.waves_total = (int)(blocks * WPB);
-        if (hipMemsetD32Async((hipDeviceptr_t)p.queue, (int)(blocks * WPB * GS), 1, p.stream) != hipSuccess) return VP_ERR_HIP;
-        const size_t lds = (size_t)64 * R * sizeof(T) * (1 + (size_t)WPB * GS) + (size_t)WPB * GS * sizeof(SlotRec<T, M::N, M::Q>) +
-                           sizeof(SlotConsts<T>);
+        args.waves_total = (int)(blocks * NG * W);
+        if (hipMemsetD32Async((hipDeviceptr_t)p.queue, (int)(blocks * NG * GS), 1, p.stream) != hipSuccess) return VP_ERR_HIP;
+        const size_t lds = (size_t)64 * R * W * sizeof(T) * (1 + (size_t)NG * GS) + (size_t)NG * GS * sizeof(SlotRec<T, M::N, M::Q>) +
+                           sizeof(SlotConsts<T>) + (size_t)((GS + 3) / 4) * 4 * sizeof(int) + (size_t)group_xch_bytes<W>() + 16;
 #define VP_F2(PADM_)                                                                                                   \
-    hipLaunchKernelGGL((fit2_kernel<T, M, R, PADM_, GS, WPB>), dim3((unsigned)blocks), dim3(64 * WPB), lds, p.stream, args)
-        if (p.m == 64 * R) VP_F2(1);
-        else if (R > 2 && p.m > 64 * (R - 2)) VP_F2(2);
+    hipLaunchKernelGGL((fit2_kernel<T, M, R, W, PADM_, GS, NG, WPS>), dim3((unsigned)blocks), dim3(64 * W * NG), lds,   \
+                       p.stream, args)
+        if (p.m == 64 * R * W) VP_F2(1);
+        else if (R > 2 && p.m > 64 * (R - 2) * W) VP_F2(2);
         else VP_F2(0);
 #undef VP_F2
         return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;

@@ -39,7 +39,8 @@
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
         DT, ::vp::FAMILY_MULTIEXP, NEXP, OFF, 0, RR, WW,                                                               \
         &::vp::launch_evaluate<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                     \
-        &::vp::launch_basis<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr,                               \
+        &::vp::launch_basis<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                        \
+        &::vp::launch_fit2<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                         \
         &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                          \
         &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0, \
         &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>});

@@ -14,8 +14,11 @@ namespace vp {
 
 // Minimum waves per SIMD the register allocator must leave room for (2 <=> 256 VGPRs per lane, 1 <=> 512),
 // chosen from the register footprint of the NC resident columns (R rows x sizeof(T)/4 VGPRs each).
+#ifndef VP_TWO_WAVE_VGPRS
+#define VP_TWO_WAVE_VGPRS 200
+#endif
 template <typename T, int R, int NC> constexpr int waves_for() {
-    return (NC * R * (int)(sizeof(T) / 4) <= 200) ? 2 : 1;
+    return (NC * R * (int)(sizeof(T) / 4) <= VP_TWO_WAVE_VGPRS) ? 2 : 1;
 }
 // launch bound (2nd argument = waves per SIMD) for a kernel whose workgroup is one group of W waves
 template <typename T, int R, int NC, int W> constexpr int group_waves_per_eu() {
