@@ -298,3 +298,56 @@ def evaluate_batch(model, t, Y, alpha, w=None, eps=-1.0, n_threads=1, want_jac=T
 
 def max_threads():
     return lib().vpo_max_threads()
+
+
+# ---- the fp32-storage build of the same restatement (oracle/Makefile: libvarpro_oracle_f32.so) -------------------------
+# Yardstick for the fp32 device path (BASELINE configs[4]): "what does the reference ALGORITHM do in single precision on
+# this problem" -- same entry points, float buffers.  Slightly optimistic (mixed expressions are evaluated in double
+# before rounding to float), see the Makefile.
+_lib32 = None
+
+
+def lib_f32():
+    global _lib32
+    if _lib32 is None:
+        path = os.path.join(_HERE, "libvarpro_oracle_f32.so")
+        if not os.path.exists(path):
+            build()
+        l32 = C.CDLL(path)
+        fp = C.POINTER(C.c_float)
+        l32.vpo_fit_batch.restype = C.c_float
+        l32.vpo_fit_batch.argtypes = [C.POINTER(ModelDesc), C.c_int, C.c_int64, fp, fp, fp, C.c_float, C.POINTER(LmOpts), fp,
+                                      fp, C.c_void_p, C.c_int]
+        l32.vpo_evaluate_batch.argtypes = [C.POINTER(ModelDesc), C.c_int, C.c_int64, fp, fp, fp, C.c_float, fp, fp, fp, fp,
+                                           fp, C.POINTER(C.c_int32), C.c_int]
+        l32.vpo_lm_opts_default.argtypes = [C.POINTER(LmOpts)]
+        _lib32 = l32
+    return _lib32
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def default_opts_f32(**kw):
+    o = LmOpts()
+    lib_f32().vpo_lm_opts_default(C.byref(o))  # 30 * FLT_EPSILON tolerances
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def fit_batch_f32(model, t, Y, alpha0, w=None, eps=-1.0, opts=None, n_threads=1):
+    """fp32-storage oracle: returns (alpha[B,q] float32, C[B,n] float32, report[B], seconds inside the fits)"""
+    d = desc_of(model)
+    t = np.ascontiguousarray(t, dtype=np.float32)
+    Y = np.ascontiguousarray(Y, dtype=np.float32)
+    B, m = Y.shape
+    alpha = np.array(alpha0, dtype=np.float32, order="C", copy=True).reshape(B, d.n_params)
+    Cout = np.empty((B, d.n_basis), dtype=np.float32)
+    rep = np.zeros(B, dtype=REPORT_DTYPE)
+    opts = opts or default_opts_f32()
+    w_ = None if w is None else np.ascontiguousarray(w, dtype=np.float32)
+    secs = lib_f32().vpo_fit_batch(C.byref(d), m, B, _fp(t), _fp(Y), _fp(w_), float(eps), C.byref(opts), _fp(alpha),
+                                   _fp(Cout), rep.ctypes.data_as(C.c_void_p), int(n_threads))
+    return alpha, Cout, rep, float(secs)

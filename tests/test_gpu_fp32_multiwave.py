@@ -119,11 +119,51 @@ def test_fp32_config4_full_size_properties():
     assert np.abs(recon - Y).max() <= 2e-3 * np.abs(Y).max()   # Phi c in fp32 with |c| up to cond(Phi) * |y|
     alpha, C, rep = bp.fit(d["tau_guess"])
     ok = rep["termination"] > 0
-    assert ok.mean() > 0.7                         # fp32 failures of this model are documented
+    # (the fp32 restatement of the reference algorithm fails on ~12-15 % of this problem set as well:
+    # test_fp32_config4_fit_against_the_fp32_and_fp64_oracles)
+    assert ok.mean() >= 0.8
     assert (rep["objective"][ok] <= ev["cost"][ok] * (1 + 1e-3) + 1e-6).all()
     s = bp.summary()
     assert s[1] == ok.sum() and s[1] + s[2] == B and s[3] == rep["n_evals"].sum()
     bp.close()
+
+
+@pytest.mark.parametrize("kernel", ["wave", "slots"])
+def test_fp32_config4_fit_against_the_fp32_and_fp64_oracles(kernel):
+    # BASELINE configs[4] (five exponentials + offset, fp32, m = 4096) on a 384-problem sample, against
+    #   (a) the fp32-storage build of the oracle (oracle/Makefile: the reference ALGORITHM in single precision) and
+    #   (b) the fp64 oracle on the same (float -> double converted) inputs.
+    # cond(Phi) of five exponentials is >= 1e6, beyond what fp32 resolves: a share of the fits ends with
+    # TerminationReason::User (non-finite evaluation) -- in the fp32 restatement of the reference just as on the device.
+    # Asserted: the device fails no more often than the fp32 oracle (+ 5 points), agrees with it on success / failure
+    # for the bulk of the problems, and where both succeed reaches an objective that is as good (fp32 tolerance) -- and
+    # its successful fits are as good as the fp64 oracle's to the accuracy fp32 data allow.
+    taus = [0.5, 1.5, 3.0, 6.0, 12.0]
+    B, m = 384, 4096
+    d = synth.multi_exp_batch(B, 5, m, taus, noise=1e-3, spread=0.1, guess_spread=0.05, dtype=np.float32)
+    mdl32 = vp.multi_exponential_model(d["x"], d["tau_guess"][0], dtype=np.float32)
+    bp = vp.BatchProblem(mdl32, d["Y"], x=d["x"])
+    bp.set_fit_kernel(kernel)
+    alpha, C, rep = bp.fit(d["tau_guess"])
+    bp.close()
+    a32, c32, r32, _ = O.fit_batch_f32(mdl32, d["x"], d["Y"], d["tau_guess"], n_threads=8)
+    x64, Y64, g64 = d["x"].astype(np.float64), d["Y"].astype(np.float64), d["tau_guess"].astype(np.float64)
+    a64, c64, r64, _ = O.fit_batch(mdl32, x64, Y64, g64, n_threads=8)
+    ok, ok32, ok64 = rep["termination"] > 0, r32["termination"] > 0, r64["termination"] > 0
+    assert ok32.mean() < 0.97                                   # the fp32 reference algorithm does fail on this model
+    assert (~ok).mean() <= (~ok32).mean() + 0.05                # the device is not worse than it
+    assert (ok == ok32).mean() >= 0.8                           # and mostly fails / succeeds on the same problems
+    assert ok.mean() >= 0.75
+    scale = 0.5 * (Y64 ** 2).sum(1)
+    both = ok & ok32
+    # same minimum in fp32 terms: the objectives differ by no more than fp32 rounding of a residual of this size
+    rel = np.abs(rep["objective"] - r32["objective"])[both] / np.maximum(r32["objective"][both], 1e-7 * scale[both])
+    assert np.median(rel) <= 1e-2 and (rel <= 0.5).mean() >= 0.9
+    # against fp64: a successful device fit is never (noticeably) worse than the fp64 oracle's minimum
+    b64 = ok & ok64
+    assert b64.mean() >= 0.5
+    excess = (rep["objective"] - r64["objective"])[b64] / np.maximum(r64["objective"][b64], 1e-7 * scale[b64])
+    assert np.median(excess) <= 1e-2 and (excess <= 0.5).mean() >= 0.9
 
 
 def test_fp32_multiple_right_hand_sides():

@@ -187,6 +187,12 @@ struct vp_batch {
     int *d_queue;
     int num_cus;
     void *tmp_a, *tmp_b; // scratch allocations of vp_batch_create (freed by destroy if create fails half way)
+    // MRHS fit: a captured HIP graph of VP_MRHS_GRAPH_ITERS {factor, stream, LM step} iterations (replayed per batch
+    // of iterations: one graph launch instead of 3 x ITERS kernel launches), the options it was captured with
+    hipGraphExec_t mrhs_graph;
+    vp_lm_opts mrhs_graph_opts;
+    hipStream_t cap_stream;
+    bool mrhs_graph_failed;
 };
 
 namespace {
@@ -388,8 +394,6 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
     if (int rc = h->kern->mrhs_lm(p)) return fail(rc, "mrhs_lm (init) launch failed");
     p.mrhs_init = 0;
     const int max_iter = o.patience * (h->q + 1) + 2;
-    int sync_every = 4;
-    if (const char *e = std::getenv("VP_MRHS_SYNC_EVERY")) sync_every = std::max(1, std::atoi(e));
     // right-hand sides sharded over ranks: the reduced sums of this rank's columns are totalled in a fixed order,
     // summed over the ranks by the caller's collective (RCCL all-reduce of B*(1+n*n+p) doubles per evaluation) and
     // fed to the LM step as a single slot; every rank then takes bit-identical decisions.
@@ -400,28 +404,74 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         ws_tot.acc = h->d_mrhs_tot;
         p.mrhs_S_global = h->rhs_global;
     }
-    for (int it = 0; it < max_iter; ++it) {
-        p.alpha = h->mrhs.alpha_trial;
-        p.mrhs_mode = 0;
-        if (int rc = h->kern->mrhs_factor(p)) return fail(rc, "mrhs_factor launch failed");
-        if (int rc = h->kern->mrhs_stream(p)) return fail(rc, "mrhs_stream launch failed");
+    // The loop is device-driven: iterations are ENQUEUED in batches with no host synchronisation in between -- a
+    // problem whose LM loop has terminated is skipped on the device (MrhsWs::done), so an iteration enqueued past the
+    // end costs three empty launches (~microseconds), while every read-back of the active count costs a full stream
+    // drain.  The host looks at the count after 12 iterations (a typical global fit needs fewer than that many
+    // evaluations), then after every further 24.
+    constexpr int GRAPH_ITERS = 12;
+    auto enqueue_iteration = [&](LaunchParams &lp) -> int {
+        lp.alpha = h->mrhs.alpha_trial;
+        lp.mrhs_mode = 0;
+        if (int rc = h->kern->mrhs_factor(lp)) return fail(rc, "mrhs_factor launch failed");
+        if (int rc = h->kern->mrhs_stream(lp)) return fail(rc, "mrhs_stream launch failed");
         if (h->rhs_allreduce) {
             const int64_t total = h->B * nacc;
             hipLaunchKernelGGL(mrhs_reduce_partials_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                               h->stream, (const double *)h->mrhs.acc, mrhs_gx(h->S), nacc, h->B, h->d_mrhs_tot);
+                               lp.stream, (const double *)h->mrhs.acc, mrhs_gx(h->S), nacc, h->B, h->d_mrhs_tot);
             VP_HIP(hipGetLastError());
-            if (h->rhs_allreduce(h->d_mrhs_tot, total, (void *)h->stream, h->rhs_allreduce_user) != 0)
+            if (h->rhs_allreduce(h->d_mrhs_tot, total, (void *)lp.stream, h->rhs_allreduce_user) != 0)
                 return fail(VP_ERR_INVALID, "the right-hand-side all-reduce callback reported an error");
-            p.mrhs_ws = &ws_tot;
-            p.mrhs_gx = 1;
+            lp.mrhs_ws = &ws_tot;
+            lp.mrhs_gx = 1;
         }
-        if (int rc = h->kern->mrhs_lm(p)) return fail(rc, "mrhs_lm launch failed");
-        p.mrhs_ws = &h->mrhs;
-        p.mrhs_gx = 0;
-        // the host looks at the number of still-active problems only every few iterations: terminated problems
-        // are skipped on the device (MrhsWs::done), so an iteration enqueued past the end costs three empty
-        // launches, while every avoided read-back saves a full stream drain
-        if ((it + 1) % sync_every != 0 && it + 1 < max_iter) continue;
+        if (int rc = h->kern->mrhs_lm(lp)) return fail(rc, "mrhs_lm launch failed");
+        lp.mrhs_ws = &h->mrhs;
+        lp.mrhs_gx = 0;
+        return 0;
+    };
+    // A batch of GRAPH_ITERS iterations as ONE captured HIP graph (no trace, no all-reduce callback: both put host
+    // state into the launch sequence).  Captured on a private stream -- the handle's stream may be the null stream,
+    // which cannot be captured -- and replayed on the handle's stream.  The graph holds the LM options by value: it
+    // is re-captured when they change.
+    const bool want_graph = !p.trace && !h->rhs_allreduce && !h->mrhs_graph_failed;
+    if (want_graph && (!h->mrhs_graph || std::memcmp(&h->mrhs_graph_opts, &o, sizeof(o)) != 0)) {
+        if (h->mrhs_graph) {
+            (void)hipGraphExecDestroy(h->mrhs_graph);
+            h->mrhs_graph = nullptr;
+        }
+        bool ok = true;
+        if (!h->cap_stream) ok = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
+        hipGraph_t g = nullptr;
+        if (ok) ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            LaunchParams gp = p;
+            gp.stream = h->cap_stream;
+            for (int it = 0; it < GRAPH_ITERS && ok; ++it) ok = enqueue_iteration(gp) == 0;
+            const bool ended = hipStreamEndCapture(h->cap_stream, &g) == hipSuccess;
+            ok = ok && ended && g != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&h->mrhs_graph, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+        if (!ok) {
+            (void)hipGetLastError();
+            h->mrhs_graph = nullptr;
+            h->mrhs_graph_failed = true; // fall back to plain launches for the rest of this handle's life
+        } else {
+            h->mrhs_graph_opts = o;
+        }
+    }
+    int next_check = GRAPH_ITERS;
+    for (int it = 0; it < max_iter;) {
+        if (want_graph && h->mrhs_graph) {
+            VP_HIP(hipGraphLaunch(h->mrhs_graph, h->stream));
+            it += GRAPH_ITERS;
+        } else {
+            if (int rc = enqueue_iteration(p)) return rc;
+            ++it;
+            if (it < next_check && it < max_iter) continue;
+            next_check += 2 * GRAPH_ITERS;
+        }
         int32_t nact = 0;
         VP_HIP(hipMemcpyAsync(&nact, h->mrhs.nactive, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         VP_HIP(hipStreamSynchronize(h->stream));
@@ -432,10 +482,11 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
     p.report = h->d_report;
     if (int rc = h->kern->mrhs_finish(p)) return fail(rc, "mrhs_finish launch failed");
     tm.stop();
-    if (int rc = ensure_R(h)) return rc;
-    if (int rc = run_evaluate(h, h->d_R, nullptr, h->d_C)) return rc;
+    // coefficients, cost and status at the final point: one more pass over Y WITHOUT writing the residual cache (the
+    // m x S residual matrix is produced on demand by vp_residuals, as after a single-RHS fit)
+    if (int rc = run_evaluate(h, nullptr, nullptr, h->d_C)) return rc;
     h->have_params = true;
-    h->r_valid = true;
+    h->r_valid = false;
     h->have_report = true;
     if (int rc = copy_out(h, alpha_inout, h->d_alpha, (size_t)h->B * h->q * ts)) return rc;
     if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
@@ -665,6 +716,8 @@ void vp_batch_destroy(vp_batch *h) {
     (void)hipFree(h->mrhs.lm_state);
     (void)hipFree(h->mrhs.nactive);
     (void)hipFree(h->mrhs.alpha_trial);
+    if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
