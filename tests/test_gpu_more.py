@@ -168,10 +168,16 @@ def test_sin_phase_and_exp_rate_kinds():
            .function(["k", "a"], basis.EXP_COS).partial_deriv("k").partial_deriv("a")
            .function(["unused"], basis.EXP_DECAY).partial_deriv("unused")
            .independent_variable(x).initial_parameters([2.0, 0.3, 0.7, 1.1, 2.0]).build())
-    # n=3, q=5, p=5 -> RtModel<3,5,5> is not instantiated: must be reported, not silently mis-run
-    with pytest.raises(vp.VarproHipError) as e:
-        vp.BatchProblem(mdl, np.ones((1, 90)), x=x)
-    assert e.value.code == -2
+    # n=3, q=5, p=5 -> no specialised RtModel<3,5,5> instantiation: accepted by the generic fallback kernels
+    # (vp_generic.hpp; round 1 reported VP_ERR_UNSUPPORTED here) and evaluated like any other model
+    y5 = 1.5 * np.sin(2.1 * x + 0.25) + 0.8 * np.exp(-0.6 * x) * np.cos(1.0 * x) + 0.5 * np.exp(-x / 1.7)
+    bp5 = vp.BatchProblem(mdl, y5[None, :], x=x)
+    a5 = np.array([[2.0, 0.3, 0.7, 1.1, 2.0]])
+    ev5 = bp5.evaluate(a5)
+    c5, r5, J5 = numpy_reference_eval(mdl, x, y5, a5[0])
+    assert np.abs(ev5["C"][0] - c5).max() <= 1e-9 * np.abs(c5).max()
+    assert np.abs(ev5["r"][0] - r5).max() <= 1e-9 * np.abs(y5).max()
+    bp5.close()
     mdl2 = (vp.SeparableModelBuilder(["omega", "phi", "k", "a"])
             .function(["omega", "phi"], basis.SIN_PHASE).partial_deriv("omega").partial_deriv("phi")
             .function(["k", "a"], basis.EXP_COS).partial_deriv("k").partial_deriv("a")

@@ -187,6 +187,8 @@ struct vp_batch {
     int *d_queue;
     int num_cus;
     void *tmp_a, *tmp_b; // scratch allocations of vp_batch_create (freed by destroy if create fails half way)
+    void *d_gen_ws;      // generic fallback kernels: gen_blocks workspace slots of (n + 1 + p + q) columns x m
+    int gen_blocks;
     // MRHS fit: a captured HIP graph of VP_MRHS_GRAPH_ITERS {factor, stream, LM step} iterations (replayed per batch
     // of iterations: one graph launch instead of 3 x ITERS kernel launches), the options it was captured with
     hipGraphExec_t mrhs_graph;
@@ -282,6 +284,8 @@ void fill_params(vp_batch *h, LaunchParams &p) {
     p.stream = h->stream;
     p.queue = h->d_queue;
     p.num_cus = h->num_cus;
+    p.gen_ws = h->d_gen_ws;
+    p.gen_blocks = h->gen_blocks;
     p.fit_group = h->fit_kernel;
 }
 
@@ -552,9 +556,10 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(VP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
 
+    // a specialised (register-resident) kernel set if one is instantiated for this (dtype, model, m), else the generic
+    // fallback kernels (vp_generic.hpp): any descriptor, any m -- slower, but never a CPU path and never "unsupported"
     const KernelEntry *kern = find_kernels(dtype, *model, m);
-    if (!kern)
-        return fail(VP_ERR_UNSUPPORTED, "no kernel instantiation for this (dtype, model, m); see DESIGN.md coverage table");
+    if (!kern) kern = generic_kernels(dtype);
 
     vp_batch *h = new vp_batch();
     std::memset(h, 0, sizeof(*h));
@@ -657,6 +662,14 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     VP_TRY(hipMalloc((void **)&h->d_report, (size_t)B * sizeof(vp_report)));
     VP_TRY(hipMalloc((void **)&h->d_sum4, 4 * sizeof(double)));
     VP_TRY(hipMalloc((void **)&h->d_queue, sizeof(int)));
+    if (kern->family == FAMILY_GENERIC) {
+        // one workspace slot per persistent workgroup; at most 1024 workgroups and 4 GiB
+        const size_t slot = (size_t)(h->n + 1 + h->p + h->q) * (size_t)m * ts;
+        int64_t blocks = std::min<int64_t>(B * S, 1024);
+        while (blocks > 1 && (size_t)blocks * slot > ((size_t)4 << 30)) blocks /= 2;
+        h->gen_blocks = (int)blocks;
+        VP_TRY(hipMalloc(&h->d_gen_ws, (size_t)blocks * slot));
+    }
     VP_TRY(hipEventCreate(&h->ev0));
     VP_TRY(hipEventCreate(&h->ev1));
     if (S > 1 && kern->mrhs_factor && kern->mrhs_stream && kern->mrhs_lm && kern->mrhs_finish) {
@@ -704,6 +717,7 @@ void vp_batch_destroy(vp_batch *h) {
     (void)hipFree(h->d_report);
     (void)hipFree(h->d_sum4);
     (void)hipFree(h->d_queue);
+    (void)hipFree(h->d_gen_ws);
     (void)hipFree(h->tmp_a);
     (void)hipFree(h->tmp_b);
     // (the struct is zero-initialised: freeing unconditionally also covers a create that failed half way)

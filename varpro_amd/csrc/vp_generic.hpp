@@ -1,0 +1,725 @@
+// vp_generic.hpp -- generic fallback kernels: ANY model descriptor include/varpro_hip.h admits (n <= VP_MAX_BASIS,
+// q <= VP_MAX_PARAMS, p <= VP_MAX_PAIRS, any mix of basis kinds and shared parameters) at ANY m, single right-hand
+// side.  The reference accepts any SeparableNonlinearModel (src/model/mod.rs:239-363); the specialised kernels
+// (vp_kernels.hpp, vp_fit.hpp, vp_fit2.hpp) keep all columns of a problem in registers and therefore exist only for
+// compile-time shapes and sizes (vp_registry.hpp).  Everything else lands here: slower, but HIP -- never a CPU path.
+//
+// One 256-thread workgroup per problem, persistent over the batch; the problem's columns
+//     [ W Phi (n) | y_w (1) | W dPhi_pair (p) | J (q) ]
+// live in a global-memory workspace slot owned by the workgroup (L2-resident for the sizes this path sees), rows
+// strided over the threads.  Same algorithm as the register kernels -- Householder QR of Phi_w applied to y and the
+// derivative columns, truncated-SVD solve of the n x n factor (absolute epsilon, src/solvers/levmar/mod.rs:52-54),
+// Kaufman Jacobian J_k = -P_perp (sum_p c_j(p) W dPhi_p) (:101-201), MINPACK qrfac with column pivoting on the
+// explicit J and the crate's LM driver (:238-254) -- with run-time loop bounds.  Dot products of a reflector with all
+// remaining columns are taken in ONE pass and reduced through LDS ("multi-dot").  The wave-uniform LM bookkeeping
+// (lmpar / qrsolv / termination rules) is the SAME code as everywhere else (vp_lm_core.hpp), instantiated for
+// q = 1..8 and dispatched on the run-time q by thread 0.
+#pragma once
+#include <cstring>
+
+#include "vp_lm_core.hpp"
+
+namespace vp {
+namespace gen {
+
+constexpr int TB = 256;                                                  // threads per workgroup
+constexpr int MAXC = VP_MAX_BASIS + 1 + VP_MAX_PAIRS + VP_MAX_PARAMS;    // workspace columns
+constexpr int MAXV = VP_MAX_BASIS + 1 + VP_MAX_PAIRS;                    // values per multi-dot
+
+template <typename T> struct GenArgs {
+    vp_model_desc mdl;
+    int P;                                   // dependency pairs
+    int pb[VP_MAX_PAIRS], pa[VP_MAX_PAIRS], pp[VP_MAX_PAIRS]; // pair -> basis, argument slot, parameter
+    const T *t, *w, *yw;
+    int S;              // right-hand sides per problem (evaluate only; fits are single-RHS here)
+    const T *alpha;     // evaluate / basis / best_fit: [B][q]
+    T *alpha_io;        // fit: in guess, out result
+    T *r_out, *J_out, *C_out;
+    const T *C_in;      // best_fit
+    double *cost_out;
+    int32_t *status;
+    vp_report *report;
+    T *Phi_out, *dPhi_out;
+    int skip_invariant, n_phi_cols;
+    T *ws;              // [gridDim.x][MAXC-ish][m] workspace
+    int64_t ws_cols;    // columns per slot = n + 1 + P + q
+    int m;
+    int64_t B;
+    int64_t t_stride, w_stride;
+    T eps;
+    LmOpts<T> lm;
+    double *trace;
+    int trace_rows;
+};
+
+template <typename T> __device__ __forceinline__ T g_exp(T x);
+template <> __device__ __forceinline__ double g_exp(double x) { return texp(x); }
+template <> __device__ __forceinline__ float g_exp(float x) { return texp(x); }
+
+// value and the (up to two) argument derivatives of one basis function at t -- the formulas of vp_model.hpp
+template <typename T>
+__device__ __forceinline__ void basis_eval(int kind, T t, T p0, T p1, T &f, T &d0, T &d1) {
+    d0 = T(0);
+    d1 = T(0);
+    switch (kind) {
+    case VP_BASIS_CONST: f = T(1); break;
+    case VP_BASIS_EXP_DECAY: {
+        const T rt = frcp(p0);
+        f = g_exp(-div_refined(t, p0, rt));
+        d0 = (f * t) * (rt * rt);
+    } break;
+    case VP_BASIS_EXP_RATE:
+        f = g_exp(-p0 * t);
+        d0 = -t * f;
+        break;
+    case VP_BASIS_EXP_COS: {
+        const T ex = g_exp(-p0 * t);
+        f = ex * tcos(p1 * t);
+        d0 = f * (-t);
+        d1 = -t * ex * tsin(p1 * t);
+    } break;
+    default: { // VP_BASIS_SIN_PHASE
+        const T ph = p0 * t + p1;
+        const T cs = tcos(ph);
+        f = tsin(ph);
+        d0 = t * cs;
+        d1 = cs;
+    } break;
+    }
+}
+
+template <typename T> struct GenShared {
+    T part[MAXV][TB];   // multi-dot partials
+    T red[MAXV];        // reduced values
+    T f[MAXV];          // per-column update factors of the current reflector
+    T Rm[VP_MAX_BASIS][VP_MAX_BASIS];
+    T g[VP_MAX_BASIS], qty[VP_MAX_BASIS], c[VP_MAX_BASIS], e[VP_MAX_BASIS];
+    T alpha[VP_MAX_PARAMS];
+    T fn2;
+    int ok;
+    // Jacobian QR
+    T rdiag[VP_MAX_PARAMS], wa[VP_MAX_PARAMS], acnorm[VP_MAX_PARAMS], qtf[VP_MAX_PARAMS];
+    T Rj[VP_MAX_PARAMS][VP_MAX_PARAMS];
+    int ipvt[VP_MAX_PARAMS], col[VP_MAX_PARAMS]; // col: workspace column of the logical (pivoted) Jacobian column
+    int flag;
+};
+
+// nv dot-type sums at once: every thread holds vals[0..nv), afterwards sh.red[0..nv) holds the totals (all threads)
+template <typename T> __device__ __forceinline__ void multi_reduce(GenShared<T> &sh, const T *vals, int nv) {
+    const int tid = (int)threadIdx.x;
+    for (int v = 0; v < nv; ++v) sh.part[v][tid] = vals[v];
+    __syncthreads();
+    // 8 threads per value, then a short serial tail: fixed order, deterministic
+    for (int v = tid >> 3; v < nv; v += TB / 8) {
+        const int sub = tid & 7;
+        T s = T(0);
+        for (int i = sub; i < TB; i += 8) s += sh.part[v][i];
+        sh.part[v][sub] = s; // (the sub-th partial slot is only read by this group after its own loop)
+    }
+    __syncthreads();
+    if (tid < nv) {
+        T s = T(0);
+        for (int i = 0; i < 8; ++i) s += sh.part[tid][i];
+        sh.red[tid] = s;
+    }
+    __syncthreads();
+}
+
+// one-sided Jacobi SVD solve of the n x n upper-triangular Rm: minimum-norm c with the reference's absolute
+// singular-value threshold, e = qty - Rm c (thread 0 only; run-time n)
+template <typename T> __device__ void svd_solve(GenShared<T> &sh, int n, T eps) {
+    T W[VP_MAX_BASIS][VP_MAX_BASIS], V[VP_MAX_BASIS][VP_MAX_BASIS]; // [col][row]
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            W[j][i] = (i <= j) ? sh.Rm[i][j] : T(0);
+            V[j][i] = (i == j) ? T(1) : T(0);
+        }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                T a = 0, b = 0, gg = 0;
+                for (int i = 0; i < n; ++i) {
+                    a = tfma(W[p][i], W[p][i], a);
+                    b = tfma(W[q][i], W[q][i], b);
+                    gg = tfma(W[p][i], W[q][i], gg);
+                }
+                if (gg != T(0) && tabs(gg) > num<T>::eps * T(0.25) * tsqrt(a * b)) {
+                    rotated = true;
+                    const T zeta = (b - a) / (T(2) * gg);
+                    const T tt = tcopysign(T(1), zeta) / (tabs(zeta) + tsqrt(T(1) + zeta * zeta));
+                    const T cs = T(1) / tsqrt(T(1) + tt * tt), sn = cs * tt;
+                    for (int i = 0; i < n; ++i) {
+                        T x = W[p][i], y = W[q][i];
+                        W[p][i] = cs * x - sn * y;
+                        W[q][i] = sn * x + cs * y;
+                        x = V[p][i];
+                        y = V[q][i];
+                        V[p][i] = cs * x - sn * y;
+                        V[q][i] = sn * x + cs * y;
+                    }
+                }
+            }
+        if (!rotated) break;
+    }
+    for (int i = 0; i < n; ++i) sh.c[i] = T(0);
+    for (int j = 0; j < n; ++j) {
+        T s2 = 0, d = 0;
+        for (int i = 0; i < n; ++i) {
+            s2 = tfma(W[j][i], W[j][i], s2);
+            d = tfma(W[j][i], sh.qty[i], d);
+        }
+        const T sg = tsqrt(s2);
+        const T coef = (sg > eps) ? d / s2 : T(0);
+        for (int i = 0; i < n; ++i) sh.c[i] = tfma(coef, V[j][i], sh.c[i]);
+    }
+    for (int i = 0; i < n; ++i) {
+        T acc = sh.qty[i];
+        for (int j = i; j < n; ++j) acc = tfma(-sh.Rm[i][j], sh.c[j], acc);
+        sh.e[i] = acc;
+    }
+}
+
+// One evaluation at sh.alpha for problem b.  Workspace columns: [0,n) Phi -> Householder vectors, n: y -> Q^T y,
+// [n+1, n+1+P): derivative columns -> Q^T(.).  With want_rj: column n <- r (original coordinates), columns
+// [n+1+P, n+1+P+q) <- J_k.  Sets sh.c, sh.fn2, sh.ok.
+template <typename T>
+__device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b, bool want_rj, int64_t prob = -1) {
+    const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params, P = a.P;
+    const int NCQ = n + 1 + P; // columns that take part in the sweep
+    const T *tp = a.t + b * a.t_stride;
+    const T *wp = a.w ? a.w + b * a.w_stride : nullptr;
+    const T *yp = a.yw + (prob >= 0 ? prob : b) * (int64_t)m; // prob = b*S + s for multiple right-hand sides
+    auto col = [&](int c) { return ws + (int64_t)c * m; };
+    // ---- columns ----
+    for (int i = tid; i < m; i += TB) {
+        const T t = tp[i], sc = wp ? wp[i] : T(1);
+        for (int j = 0; j < n; ++j) {
+            const int i0 = a.mdl.param[j][0], i1 = a.mdl.param[j][1];
+            T f, d0, d1;
+            basis_eval<T>(a.mdl.kind[j], t, i0 >= 0 ? sh.alpha[i0] : T(0), i1 >= 0 ? sh.alpha[i1] : T(0), f, d0, d1);
+            col(j)[i] = f * sc;
+            for (int p = 0; p < P; ++p)
+                if (a.pb[p] == j) col(n + 1 + p)[i] = (a.pa[p] == 0 ? d0 : d1) * sc;
+        }
+        col(n)[i] = yp[i];
+    }
+    __syncthreads();
+    // ---- Householder sweep: H_k = I + g_k v_k v_k^T, v_k = a_k[k:] with v_k[k] = alpha - beta ----
+    for (int k = 0; k < n; ++k) {
+        T vals[MAXV];
+        const int nv = NCQ - k;
+        for (int v = 0; v < nv; ++v) vals[v] = T(0);
+        const T *ak = col(k);
+        for (int i = k + tid; i < m; i += TB) {
+            const T x = ak[i];
+            for (int v = 0; v < nv; ++v) vals[v] = tfma(x, col(k + v)[i], vals[v]);
+        }
+        multi_reduce(sh, vals, nv);
+        if (tid == 0) {
+            const T alpha = ak[k], nrm2 = sh.red[0];
+            const bool live = nrm2 > T(0) && is_finite(nrm2);
+            const T sigma = live ? tsqrt(nrm2) : T(0);
+            const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+            const T u = live ? alpha - beta : T(0);
+            const T gk = live ? T(1) / (beta * u) : T(0);
+            sh.g[k] = gk;
+            sh.Rm[k][k] = beta;
+            sh.f[0] = u; // slot 0: the new pivot entry of v_k
+            for (int v = 1; v < nv; ++v) {
+                const T top = col(k + v)[k];
+                const T f = gk * tfma(-beta, top, sh.red[v]);
+                sh.f[v] = f;
+                const T tj = tfma(f, u, top);
+                if (k + v < n) sh.Rm[k][k + v] = tj;
+                else if (k + v == n) sh.qty[k] = tj;
+            }
+        }
+        __syncthreads();
+        {
+            const T u = sh.f[0];
+            T *akw = col(k);
+            if (tid == 0) akw[k] = u;
+            __syncthreads();
+            for (int i = k + tid; i < m; i += TB) {
+                const T x = akw[i];
+                for (int v = 1; v < nv; ++v) {
+                    T *cj = col(k + v);
+                    cj[i] = tfma(sh.f[v], x, cj[i]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- c, e, ||r||^2 ----
+    if (tid == 0) {
+        svd_solve(sh, n, a.eps);
+        bool ok = true;
+        for (int k = 0; k < n; ++k) ok = ok && is_finite(sh.c[k]) && is_finite(sh.Rm[k][k]);
+        sh.ok = ok ? 1 : 0;
+    }
+    {
+        T vals[1] = {T(0)};
+        const T *y = col(n);
+        for (int i = n + tid; i < m; i += TB) vals[0] = tfma(y[i], y[i], vals[0]);
+        multi_reduce(sh, vals, 1);
+        if (tid == 0) {
+            T fn2 = sh.red[0];
+            for (int k = 0; k < n; ++k) fn2 = tfma(sh.e[k], sh.e[k], fn2);
+            sh.fn2 = fn2;
+            if (!is_finite(fn2)) sh.ok = 0;
+        }
+    }
+    __syncthreads();
+    if (!want_rj) return;
+    // ---- r~ and J~ in Q-coordinates, then back with Q = H_0 ... H_{n-1} ----
+    {
+        T *y = col(n);
+        if (tid < n) y[tid] = sh.e[tid];
+        for (int k = 0; k < q; ++k) {
+            T *zk = col(NCQ + k);
+            for (int i = tid; i < m; i += TB) {
+                T acc = T(0);
+                if (i >= n)
+                    for (int p = 0; p < P; ++p)
+                        if (a.pp[p] == k) acc = tfma(-sh.c[a.pb[p]], col(n + 1 + p)[i], acc);
+                zk[i] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = n - 1; k >= 0; --k) {
+        T vals[MAXV];
+        const int nv = 1 + q;
+        for (int v = 0; v < nv; ++v) vals[v] = T(0);
+        const T *vk = col(k);
+        for (int i = k + tid; i < m; i += TB) {
+            const T x = vk[i];
+            vals[0] = tfma(x, col(n)[i], vals[0]);
+            for (int v = 1; v < nv; ++v) vals[v] = tfma(x, col(NCQ + v - 1)[i], vals[v]);
+        }
+        multi_reduce(sh, vals, nv);
+        const T gk = sh.g[k];
+        for (int i = k + tid; i < m; i += TB) {
+            const T x = vk[i];
+            col(n)[i] = tfma(gk * sh.red[0], x, col(n)[i]);
+            for (int v = 1; v < nv; ++v) {
+                T *z = col(NCQ + v - 1);
+                z[i] = tfma(gk * sh.red[v], x, z[i]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T> __global__ void __launch_bounds__(TB) gen_evaluate_kernel(const GenArgs<T> a) {
+    __shared__ GenShared<T> sh;
+    const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params, S = a.S;
+    T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
+    const bool want_rj = a.r_out || a.J_out;
+    for (int64_t prob = blockIdx.x; prob < a.B * S; prob += gridDim.x) { // prob = b*S + s: every RHS on its own
+        const int64_t b = prob / S;
+        const int64_t s = prob - b * S;
+        if (tid < q) sh.alpha[tid] = a.alpha[b * q + tid];
+        __syncthreads();
+        evaluate<T>(a, sh, ws, b, want_rj, prob);
+        if (tid == 0) {
+            if (a.status) a.status[prob] = sh.ok ? VP_ST_OK : VP_ST_NONFINITE;
+            if (a.cost_out) a.cost_out[prob] = 0.5 * (double)sh.fn2;
+        }
+        if (a.C_out && tid < n) a.C_out[prob * n + tid] = sh.c[tid];
+        if (a.r_out)
+            for (int i = tid; i < m; i += TB) a.r_out[prob * (int64_t)m + i] = ws[(int64_t)n * m + i];
+        if (a.J_out)
+            for (int k = 0; k < q; ++k) // J[b][k][s][m]
+                for (int i = tid; i < m; i += TB)
+                    a.J_out[((b * q + k) * S + s) * (int64_t)m + i] = ws[(int64_t)(n + 1 + a.P + k) * m + i];
+        __syncthreads();
+    }
+}
+
+// MINPACK qrfac with column pivoting (== the oracle's qrfac) on the explicit Jacobian columns, cooperative; the
+// residual column is carried along for qtf (lmder).  Columns are pivoted logically through sh.col[].
+template <typename T> __device__ void jac_qrfac(const GenArgs<T> &a, GenShared<T> &sh, T *ws) {
+    const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params;
+    const int J0 = n + 1 + a.P;
+    auto colp = [&](int c) { return ws + (int64_t)c * m; };
+    T *rv = colp(n);
+    {
+        T vals[MAXV];
+        for (int k = 0; k < q; ++k) vals[k] = T(0);
+        for (int i = tid; i < m; i += TB)
+            for (int k = 0; k < q; ++k) {
+                const T x = colp(J0 + k)[i];
+                vals[k] = tfma(x, x, vals[k]);
+            }
+        multi_reduce(sh, vals, q);
+        if (tid == 0)
+            for (int k = 0; k < q; ++k) {
+                sh.acnorm[k] = tsqrt(sh.red[k]);
+                sh.rdiag[k] = sh.acnorm[k];
+                sh.wa[k] = sh.acnorm[k];
+                sh.ipvt[k] = k;
+                sh.col[k] = J0 + k;
+                for (int l = 0; l < q; ++l) sh.Rj[k][l] = T(0);
+            }
+        __syncthreads();
+    }
+    const int minmn = m < q ? m : q;
+    for (int j = 0; j < minmn; ++j) {
+        if (tid == 0) {
+            int kmax = j;
+            for (int k = j; k < q; ++k)
+                if (sh.rdiag[k] > sh.rdiag[kmax]) kmax = k;
+            if (kmax != j) {
+                int ti = sh.col[j];
+                sh.col[j] = sh.col[kmax];
+                sh.col[kmax] = ti;
+                for (int i = 0; i < j; ++i) { // finished rows of R follow their columns
+                    const T tmp = sh.Rj[i][j];
+                    sh.Rj[i][j] = sh.Rj[i][kmax];
+                    sh.Rj[i][kmax] = tmp;
+                }
+                sh.rdiag[kmax] = sh.rdiag[j];
+                sh.wa[kmax] = sh.wa[j];
+                ti = sh.ipvt[j];
+                sh.ipvt[j] = sh.ipvt[kmax];
+                sh.ipvt[kmax] = ti;
+            }
+        }
+        __syncthreads();
+        T *aj = colp(sh.col[j]);
+        // raw dots of the pivot column (rows >= j) with itself, the remaining columns and the residual
+        T vals[MAXV];
+        const int nv = (q - j) + 1;
+        for (int v = 0; v < nv; ++v) vals[v] = T(0);
+        for (int i = j + tid; i < m; i += TB) {
+            const T x = aj[i];
+            for (int k = j; k < q; ++k) vals[k - j] = tfma(x, colp(sh.col[k])[i], vals[k - j]);
+            vals[nv - 1] = tfma(x, rv[i], vals[nv - 1]);
+        }
+        multi_reduce(sh, vals, nv);
+        if (tid == 0) {
+            T ajnorm = tsqrt(sh.red[0]);
+            if (ajnorm == T(0)) {
+                sh.rdiag[j] = T(0);
+                for (int k = j + 1; k < q; ++k) sh.Rj[j][k] = colp(sh.col[k])[j];
+                sh.qtf[j] = rv[j];
+                sh.flag = 0;
+            } else {
+                const T piv = aj[j];
+                if (piv < T(0)) ajnorm = -ajnorm;
+                const T vp = piv + ajnorm;         // unnormalised reflector: v' = a + ajnorm e_j, H = I + gj v' v'^T
+                const T gj = T(-1) / (ajnorm * vp);
+                sh.f[0] = vp;
+                for (int k = j + 1; k < q; ++k) {
+                    const T top = colp(sh.col[k])[j];
+                    const T f = gj * tfma(ajnorm, top, sh.red[k - j]);
+                    sh.f[k - j] = f;
+                    const T akj = tfma(f, vp, top);
+                    sh.Rj[j][k] = akj;
+                    if (sh.rdiag[k] != T(0)) {
+                        const T tq = akj / sh.rdiag[k];
+                        const T d = T(1) - tq * tq;
+                        sh.rdiag[k] *= tsqrt(d > T(0) ? d : T(0));
+                    }
+                }
+                {
+                    const T top = rv[j];
+                    const T f = gj * tfma(ajnorm, top, sh.red[nv - 1]);
+                    sh.f[nv - 1] = f;
+                    sh.qtf[j] = tfma(f, vp, top);
+                }
+                sh.rdiag[j] = -ajnorm;
+                sh.flag = 1;
+            }
+        }
+        __syncthreads();
+        if (sh.flag) {
+            if (tid == 0) aj[j] = sh.f[0];
+            __syncthreads();
+            for (int i = j + tid; i < m; i += TB) {
+                const T x = aj[i];
+                for (int k = j + 1; k < q; ++k) {
+                    T *ak = colp(sh.col[k]);
+                    ak[i] = tfma(sh.f[k - j], x, ak[i]);
+                }
+                rv[i] = tfma(sh.f[nv - 1], x, rv[i]);
+            }
+            __syncthreads();
+            // MINPACK's recompute rule for badly downdated norms
+            for (int k = j + 1; k < q; ++k) {
+                bool redo = false;
+                if (sh.rdiag[k] != T(0)) {
+                    const T r = sh.rdiag[k] / sh.wa[k];
+                    redo = T(0.05) * (r * r) <= num<T>::eps;
+                }
+                if (redo) { // uniform: decided from shared values
+                    T v1[1] = {T(0)};
+                    const T *ak = colp(sh.col[k]);
+                    for (int i = j + 1 + tid; i < m; i += TB) v1[0] = tfma(ak[i], ak[i], v1[0]);
+                    multi_reduce(sh, v1, 1);
+                    if (tid == 0) {
+                        sh.rdiag[k] = tsqrt(sh.red[0]);
+                        sh.wa[k] = sh.rdiag[k];
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0)
+        for (int j = 0; j < q; ++j) sh.Rj[j][j] = sh.rdiag[j];
+    __syncthreads();
+}
+
+// the scalar LM bookkeeping for a run-time q: the templated code of vp_lm_core.hpp, dispatched by thread 0
+template <typename T, int Q> struct LmBox {
+    LmVars<T, VP_MAX_BASIS, Q> s;
+};
+template <typename T> union LmAny {
+    LmBox<T, 1> b1;
+    LmBox<T, 2> b2;
+    LmBox<T, 3> b3;
+    LmBox<T, 4> b4;
+    LmBox<T, 5> b5;
+    LmBox<T, 6> b6;
+    LmBox<T, 7> b7;
+    LmBox<T, 8> b8;
+};
+#define VP_GEN_DISPATCH(q, ...)                                                                                        \
+    switch (q) {                                                                                                       \
+    case 1: { auto &S = lm.b1.s; constexpr int QQ = 1; (void)QQ; __VA_ARGS__; } break;                                        \
+    case 2: { auto &S = lm.b2.s; constexpr int QQ = 2; (void)QQ; __VA_ARGS__; } break;                                        \
+    case 3: { auto &S = lm.b3.s; constexpr int QQ = 3; (void)QQ; __VA_ARGS__; } break;                                        \
+    case 4: { auto &S = lm.b4.s; constexpr int QQ = 4; (void)QQ; __VA_ARGS__; } break;                                        \
+    case 5: { auto &S = lm.b5.s; constexpr int QQ = 5; (void)QQ; __VA_ARGS__; } break;                                        \
+    case 6: { auto &S = lm.b6.s; constexpr int QQ = 6; (void)QQ; __VA_ARGS__; } break;                                        \
+    case 7: { auto &S = lm.b7.s; constexpr int QQ = 7; (void)QQ; __VA_ARGS__; } break;                                        \
+    default: { auto &S = lm.b8.s; constexpr int QQ = 8; (void)QQ; __VA_ARGS__; } break;                                       \
+    }
+
+template <typename T> __global__ void __launch_bounds__(TB) gen_fit_kernel(const GenArgs<T> a) {
+    __shared__ GenShared<T> sh;
+    __shared__ LmAny<T> lm;
+    __shared__ int s_need_jac, s_term, s_trow;
+    const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params;
+    T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        if (tid == 0) {
+            T a0[VP_MAX_PARAMS];
+            for (int k = 0; k < q; ++k) a0[k] = a.alpha_io[b * q + k];
+            VP_GEN_DISPATCH(q, (lm_init<T, VP_MAX_BASIS, QQ>(S, a0)));
+            for (int k = 0; k < q; ++k) sh.alpha[k] = a0[k];
+            for (int k = 0; k < n; ++k) sh.c[k] = T(0);
+            s_term = 0;
+            s_trow = 0;
+        }
+        __syncthreads();
+        T cbest[VP_MAX_BASIS]; // thread 0 only
+        for (int k = 0; k < VP_MAX_BASIS; ++k) cbest[k] = T(0);
+        if (q == 0) { // LevenbergMarquardt::minimize with no parameters: NoParameters (a failure)
+            if (tid == 0) s_term = VP_TERM_NO_PARAMETERS;
+            __syncthreads();
+        }
+        while (s_term == 0) {
+            evaluate<T>(a, sh, ws, b, true);
+            if (tid == 0) {
+                const T fnorm1 = tsqrt(sh.fn2);
+                bool need = false;
+                VP_GEN_DISPATCH(q, {
+                    // trace row: [x_trial, ||r||, ratio (not recorded here), delta, par] after the update
+                    need = lm_after_eval<T, VP_MAX_BASIS, QQ, false>(S, a.lm, fnorm1, sh.ok != 0, (long)m);
+                    if (S.accepted)
+                        for (int k = 0; k < n; ++k) cbest[k] = sh.c[k];
+                    if (a.trace && s_trow < a.trace_rows) {
+                        double *tr = a.trace + ((size_t)b * a.trace_rows + s_trow) * (q + 4);
+                        for (int k = 0; k < QQ; ++k) tr[k] = (double)S.xt[k];
+                        tr[q] = (double)fnorm1;
+                        tr[q + 1] = 0.0 / 0.0;
+                        tr[q + 2] = (double)S.delta;
+                        tr[q + 3] = (double)S.par;
+                    }
+                    ++s_trow;
+                    s_term = S.term;
+                });
+                s_need_jac = need ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_term != 0) break;
+            if (s_need_jac) jac_qrfac<T>(a, sh, ws);
+            if (tid == 0) {
+                VP_GEN_DISPATCH(q, {
+                    if (s_need_jac) {
+                        for (int k = 0; k < QQ; ++k) {
+                            S.acnorm[k] = sh.acnorm[k];
+                            S.qtf[k] = sh.qtf[k];
+                            S.ipvt[k] = sh.ipvt[k];
+                            for (int l = 0; l < QQ; ++l) S.Rj[k][l] = sh.Rj[k][l];
+                        }
+                    }
+                    lm_next_step<T, VP_MAX_BASIS, QQ, false>(S, a.lm, s_need_jac != 0);
+                    s_term = S.term;
+                    for (int k = 0; k < QQ; ++k) sh.alpha[k] = S.xt[k];
+                });
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            vp_report rep;
+            VP_GEN_DISPATCH(q, {
+                rep.termination = S.term;
+                rep.n_evals = S.nfev;
+                rep.objective = (double)S.objective;
+                for (int k = 0; k < QQ; ++k) a.alpha_io[b * q + k] = S.x[k];
+                if (a.status) a.status[b] = S.status;
+            });
+            if (q == 0) {
+                rep.termination = VP_TERM_NO_PARAMETERS;
+                rep.n_evals = 0;
+                rep.objective = 0.0 / 0.0;
+                if (a.status) a.status[b] = VP_ST_NOT_EVALUATED;
+            }
+            a.report[b] = rep;
+            if (a.cost_out) a.cost_out[b] = rep.objective;
+            if (a.C_out)
+                for (int k = 0; k < n; ++k) a.C_out[b * n + k] = cbest[k];
+        }
+        __syncthreads();
+    }
+}
+
+// stand-alone Phi / dPhi (UNWEIGHTED) and best fit: element-wise, no workspace
+template <typename T> __global__ void __launch_bounds__(TB) gen_basis_kernel(const GenArgs<T> a) {
+    const int m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params, P = a.P;
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const T *tp = a.t + b * a.t_stride;
+        for (int i = (int)threadIdx.x; i < m; i += TB) {
+            const T t = tp[i];
+            int colo = 0;
+            for (int j = 0; j < n; ++j) {
+                const int i0 = a.mdl.param[j][0], i1 = a.mdl.param[j][1];
+                T f, d0, d1;
+                basis_eval<T>(a.mdl.kind[j], t, i0 >= 0 ? a.alpha[b * q + i0] : T(0), i1 >= 0 ? a.alpha[b * q + i1] : T(0), f,
+                              d0, d1);
+                if (a.Phi_out && !(a.skip_invariant && a.mdl.kind[j] == VP_BASIS_CONST)) {
+                    a.Phi_out[(b * a.n_phi_cols + colo) * (int64_t)m + i] = f;
+                    ++colo;
+                }
+                if (a.dPhi_out)
+                    for (int p = 0; p < P; ++p)
+                        if (a.pb[p] == j) a.dPhi_out[(b * P + p) * (int64_t)m + i] = (a.pa[p] == 0 ? d0 : d1);
+            }
+        }
+    }
+}
+
+template <typename T> __global__ void __launch_bounds__(TB) gen_best_fit_kernel(const GenArgs<T> a) {
+    const int m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params;
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const T *tp = a.t + b * a.t_stride;
+        for (int i = (int)threadIdx.x; i < m; i += TB) {
+            const T t = tp[i];
+            T acc = T(0);
+            for (int j = 0; j < n; ++j) {
+                const int i0 = a.mdl.param[j][0], i1 = a.mdl.param[j][1];
+                T f, d0, d1;
+                basis_eval<T>(a.mdl.kind[j], t, i0 >= 0 ? a.alpha[b * q + i0] : T(0), i1 >= 0 ? a.alpha[b * q + i1] : T(0), f,
+                              d0, d1);
+                acc = tfma(f, a.C_in[b * n + j], acc);
+            }
+            a.r_out[b * (int64_t)m + i] = acc;
+        }
+    }
+}
+
+// ---- host-side launchers (type-erased LaunchParams, vp_kernels.hpp) -------------------------------------------------
+template <typename T> inline bool fill_args(const LaunchParams &p, GenArgs<T> &a) {
+    std::memset(&a, 0, sizeof(a));
+    a.mdl = *p.model;
+    int np = 0;
+    for (int j = 0; j < p.model->n_basis; ++j)
+        for (int k = 0; k < VP_MAX_BASIS_PARAMS; ++k)
+            if (p.model->param[j][k] >= 0) {
+                if (np >= VP_MAX_PAIRS) return false;
+                a.pb[np] = j;
+                a.pa[np] = k;
+                a.pp[np] = p.model->param[j][k];
+                ++np;
+            }
+    a.P = np;
+    a.t = (const T *)p.t;
+    a.w = (const T *)p.w;
+    a.yw = (const T *)p.yw;
+    a.S = p.S > 0 ? p.S : 1;
+    a.alpha = (const T *)p.alpha;
+    a.alpha_io = (T *)p.alpha_out;
+    a.r_out = (T *)p.r_out;
+    a.J_out = (T *)p.J_out;
+    a.C_out = (T *)p.C_out;
+    a.cost_out = p.cost_out;
+    a.status = p.status;
+    a.report = p.report;
+    a.Phi_out = (T *)p.Phi_out;
+    a.dPhi_out = (T *)p.dPhi_out;
+    a.ws = (T *)p.gen_ws;
+    a.ws_cols = p.model->n_basis + 1 + np + p.model->n_params;
+    a.m = p.m;
+    a.B = p.B;
+    a.t_stride = p.t_stride;
+    a.w_stride = p.w_stride;
+    a.eps = (T)p.eps;
+    if (p.opts) {
+        a.lm.ftol = (T)p.opts->ftol;
+        a.lm.xtol = (T)p.opts->xtol;
+        a.lm.gtol = (T)p.opts->gtol;
+        a.lm.stepbound = (T)p.opts->stepbound;
+        a.lm.patience = p.opts->patience;
+        a.lm.scale_diag = p.opts->scale_diag;
+    }
+    a.trace = p.trace;
+    a.trace_rows = p.trace_rows;
+    return true;
+}
+
+template <typename T> int launch_evaluate(const LaunchParams &p) {
+    GenArgs<T> a;
+    if (!fill_args(p, a) || !p.gen_ws) return VP_ERR_UNSUPPORTED;
+    if (a.B <= 0) return VP_ERR_OK;
+    hipLaunchKernelGGL((gen_evaluate_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+template <typename T> int launch_fit(const LaunchParams &p) {
+    GenArgs<T> a;
+    if (!fill_args(p, a) || !p.gen_ws) return VP_ERR_UNSUPPORTED;
+    if (a.B <= 0) return VP_ERR_OK;
+    hipLaunchKernelGGL((gen_fit_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+template <typename T> int launch_basis(const LaunchParams &p) {
+    GenArgs<T> a;
+    if (!fill_args(p, a)) return VP_ERR_UNSUPPORTED;
+    a.skip_invariant = (p.basis_flags & VP_BASIS_SKIP_INVARIANT) ? 1 : 0;
+    int ncols = 0;
+    for (int j = 0; j < p.model->n_basis; ++j)
+        if (!(a.skip_invariant && p.model->kind[j] == VP_BASIS_CONST)) ++ncols;
+    a.n_phi_cols = ncols;
+    if (a.B <= 0) return VP_ERR_OK;
+    const unsigned grid = (unsigned)(a.B < 4096 ? a.B : 4096);
+    hipLaunchKernelGGL((gen_basis_kernel<T>), dim3(grid), dim3(TB), 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+template <typename T> int launch_best_fit(const LaunchParams &p) {
+    GenArgs<T> a;
+    if (!fill_args(p, a)) return VP_ERR_UNSUPPORTED;
+    if (p.S != 1) return VP_ERR_UNSUPPORTED;
+    a.C_in = (const T *)p.C_out;
+    if (a.B <= 0) return VP_ERR_OK;
+    const unsigned grid = (unsigned)(a.B < 4096 ? a.B : 4096);
+    hipLaunchKernelGGL((gen_best_fit_kernel<T>), dim3(grid), dim3(TB), 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+} // namespace gen
+} // namespace vp

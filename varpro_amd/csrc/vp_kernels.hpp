@@ -47,6 +47,8 @@ struct LaunchParams {
     int fit_group;      // fit: kernel selection (VP_FIT_KERNEL_*): 0 = automatic, 1 = one problem per wave, 2 = slots
     int *queue;         // fit (slot kernel): device int, the problem queue head
     int num_cus;        // compute units of the device
+    void *gen_ws;       // generic fallback kernels (vp_generic.hpp): workspace, gen_blocks slots
+    int gen_blocks;
     const void *mrhs_ws; // MRHS path: pointer to the handle's MrhsWs
     int mrhs_mode;      // MRHS stream: 0 = reduced quantities (fit), 1 = trait-level outputs
     int mrhs_init;      // MRHS LM step: 1 = initialise the state

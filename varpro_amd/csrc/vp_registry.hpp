@@ -8,7 +8,7 @@ namespace vp {
 
 typedef int (*launch_fn)(const LaunchParams &);
 
-enum { FAMILY_MULTIEXP = 1, FAMILY_RT = 2 };
+enum { FAMILY_MULTIEXP = 1, FAMILY_RT = 2, FAMILY_GENERIC = 3 };
 
 struct KernelEntry {
     int dtype;  // VP_F64 / VP_F32
@@ -37,5 +37,7 @@ struct Registrar {
 int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out);
 
 const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m);
+// the generic fallback set (vp_generic.hpp): any descriptor, any m, single right-hand side fits
+const KernelEntry *generic_kernels(int dtype);
 
 } // namespace vp
