@@ -391,7 +391,7 @@ def main():
                 "workload": "BASELINE configs[4]: %d fp32 fits, five exponentials + offset (n=6, q=5), m=%d" % (B4, m4),
                 "fits_per_s": B4 / (ms4 * 1e-3), "ms_per_step": ms4, "mean_evaluations_per_fit": float(r4["n_evals"].mean()),
                 "fraction_failed": float((r4["termination"] <= 0).mean()),
-                "roofline": {"kernel": "fit_kernel<float, 5 exp + offset, 4 wavefronts per problem>", "bound": "fp32_valu",
+                "roofline": {"kernel": "fit2_kernel<float, 5 exp + offset, 4 wavefronts per problem, 3 slots per group>", "bound": "fp32_valu",
                              "achieved": tf4, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf4 / FP32_VALU_PEAK_TFLOPS, "flops_per_evaluation": flops4},
             }

@@ -82,6 +82,8 @@ extern "C" {
     pub fn vp_set_rhs_allreduce(h: *mut vp_batch,
         f: Option<extern "C" fn(*mut c_void, i64, *mut c_void, *mut c_void) -> i32>, user: *mut c_void,
         global_rhs_count: i64) -> i32;
+    /// single-RHS fit kernel selection: 0 = automatic, 1 = one wavefront per problem, 2 = persistent slot kernel
+    pub fn vp_set_fit_kernel(h: *mut vp_batch, which: i32) -> i32;
     pub fn vp_set_timing(h: *mut vp_batch, enable: i32) -> i32;
     pub fn vp_last_kernel_ms(h: *mut vp_batch, which: i32, ms: *mut f32) -> i32;
     pub fn vp_synchronize(h: *mut vp_batch) -> i32;

@@ -606,6 +606,9 @@ __device__ __forceinline__ void jac_qrfac_scaled(T (&Z)[Q][R], T (&rv)[R], const
             for (int r = 0; r < R; ++r) Z[k][r] = tfma(f, Z[j][r], Z[k][r]);
             const T akj = tfma(f, vp, top[k - j]); // row prow of the updated (unscaled) column
             Rj[j][k] = sc[k] * akj;
+            // MINPACK downdates the partial column norms only to choose LATER pivots: when a single column remains after
+            // this step there is no choice left (its rdiag is overwritten by its exact norm in the next step)
+            if constexpr (j < Q - 2)
             if (uni(rdiag[k] != T(0))) {
                 const T tq = akj * frcp(rdiag[k]);
                 rdiag[k] = rdiag[k] * usqrt(tmax(T(0), T(1) - tq * tq));
