@@ -151,6 +151,17 @@ def test_generic_fit_matches_the_oracle(m, weighted):
     assert (np.abs(cost - rep["objective"])[ok] <= 1e-8 * rep["objective"][ok]).all()
     bf = bp.best_fit()
     assert np.abs(bf[ok] - (C[ok, None, :] * np.stack([O.eval_phi(mdl, x, a).T for a in alpha[ok]])).sum(2)).max() <= 1e-9 * np.abs(Y).max()
+    # fit statistics (FitStatistics::try_calculate) through the generic kernel vs the oracle at the device's parameters
+    st = bp.statistics()
+    for b in np.flatnonzero(sane)[:3]:
+        pr = O.Problem(mdl, x, Y[b], w=w)
+        pr.set_params(alpha[b])
+        ref = pr.statistics()
+        assert st["status"][b] == 0 and ref is not None
+        assert abs(st["reduced_chi2"][b] - ref["reduced_chi2"]) <= 1e-8 * ref["reduced_chi2"]
+        scale = np.sqrt(np.outer(np.diag(ref["cov"]), np.diag(ref["cov"])))
+        assert np.abs(st["cov"][b] - ref["cov"]).max() <= 1e-6 * scale.max() and (np.abs(st["cov"][b] - ref["cov"]) <= 1e-5 * scale).all()
+        assert np.abs(st["conf_sigma"][b] - ref["conf_sigma"]).max() <= 1e-6 * np.abs(ref["conf_sigma"]).max()
     bp.close()
 
 

@@ -634,6 +634,140 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_best_fit_kernel(
     }
 }
 
+// == FitStatistics::try_calculate (src/statistics/mod.rs:352-441) with run-time shapes: H = W [Phi, (dPhi/dalpha_k c)_k]
+// = Q R by the same multi-dot Householder sweep (K = n + q <= 16 columns in the workspace), Cov = chi^2 R^-1 R^-T,
+// sigma_i = sqrt(chi^2) ||R^-T j_i|| with the UNweighted rows j_i (the math of vp_stats.hpp).
+constexpr int MAXK = VP_MAX_BASIS + VP_MAX_PARAMS;
+template <typename T> struct GenStatsArgs {
+    GenArgs<T> g;       // model, t, w, alpha, ws, m, B, strides
+    const T *C;         // [B][n]
+    const double *cost; // [B]
+    const int32_t *status_in;
+    T *cov_out;         // [B][K*K]
+    double *chi2_out;   // [B]
+    T *sigma_out;       // [B][m] or null
+    int32_t *status_out;
+};
+
+template <typename T> __global__ void __launch_bounds__(TB) gen_stats_kernel(const GenStatsArgs<T> sa) {
+    const GenArgs<T> &a = sa.g;
+    __shared__ GenShared<T> sh;
+    __shared__ T Rk[MAXK][MAXK], Ri[MAXK][MAXK], cc[VP_MAX_BASIS], al[VP_MAX_PARAMS];
+    __shared__ int s_ok;
+    const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params, K = n + q;
+    T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
+    auto col = [&](int c) { return ws + (int64_t)c * m; };
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        if (tid < n) cc[tid] = sa.C[b * n + tid];
+        if (tid < q) al[tid] = a.alpha[b * q + tid];
+        __syncthreads();
+        const T *tp = a.t + b * a.t_stride;
+        const T *wp = a.w ? a.w + b * a.w_stride : nullptr;
+        // J rows (optionally weighted) into columns 0..K-1
+        auto build = [&](bool weighted) {
+            for (int i = tid; i < m; i += TB) {
+                const T t = tp[i], sc = (weighted && wp) ? wp[i] : T(1);
+                T jr[MAXK];
+                for (int k = 0; k < q; ++k) jr[n + k] = T(0);
+                for (int j = 0; j < n; ++j) {
+                    const int i0 = a.mdl.param[j][0], i1 = a.mdl.param[j][1];
+                    T f, d0, d1;
+                    basis_eval<T>(a.mdl.kind[j], t, i0 >= 0 ? al[i0] : T(0), i1 >= 0 ? al[i1] : T(0), f, d0, d1);
+                    jr[j] = f;
+                    if (i0 >= 0) jr[n + i0] = tfma(cc[j], d0, jr[n + i0]);
+                    if (i1 >= 0) jr[n + i1] = tfma(cc[j], d1, jr[n + i1]);
+                }
+                for (int c = 0; c < K; ++c) col(c)[i] = jr[c] * sc;
+            }
+            __syncthreads();
+        };
+        build(true);
+        // Householder QR of the K columns (R only)
+        for (int k = 0; k < K; ++k) {
+            T vals[MAXV];
+            const int nv = K - k;
+            for (int v = 0; v < nv; ++v) vals[v] = T(0);
+            const T *ak = col(k);
+            for (int i = k + tid; i < m; i += TB) {
+                const T x = ak[i];
+                for (int v = 0; v < nv; ++v) vals[v] = tfma(x, col(k + v)[i], vals[v]);
+            }
+            multi_reduce(sh, vals, nv);
+            if (tid == 0) {
+                const T alpha = ak[k], nrm2 = sh.red[0];
+                const bool live = nrm2 > T(0) && is_finite(nrm2);
+                const T sigma = live ? tsqrt(nrm2) : T(0);
+                const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+                const T u = live ? alpha - beta : T(0);
+                const T gk = live ? T(1) / (beta * u) : T(0);
+                Rk[k][k] = beta;
+                sh.f[0] = u;
+                for (int v = 1; v < nv; ++v) {
+                    const T top = col(k + v)[k];
+                    const T f = gk * tfma(-beta, top, sh.red[v]);
+                    sh.f[v] = f;
+                    Rk[k][k + v] = tfma(f, u, top);
+                }
+            }
+            __syncthreads();
+            {
+                T *akw = col(k);
+                if (tid == 0) akw[k] = sh.f[0];
+                __syncthreads();
+                for (int i = k + tid; i < m; i += TB) {
+                    const T x = akw[i];
+                    for (int v = 1; v < nv; ++v) {
+                        T *cj = col(k + v);
+                        cj[i] = tfma(sh.f[v], x, cj[i]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const int dof = m - K;
+        if (tid == 0) {
+            bool ok = dof > 0 && sa.status_in[b] == VP_ST_OK;
+            for (int i = 0; i < K; ++i) ok = ok && Rk[i][i] != T(0) && is_finite(Rk[i][i]);
+            const T chi2 = ok ? (T)(2.0 * sa.cost[b] / (double)dof) : T(0) / T(0);
+            for (int i = 0; i < K; ++i)
+                for (int j = 0; j < K; ++j) Ri[i][j] = T(0);
+            if (ok)
+                for (int j = 0; j < K; ++j)
+                    for (int i = j; i >= 0; --i) {
+                        T acc = (i == j) ? T(1) : T(0);
+                        for (int l = i + 1; l <= j; ++l) acc = tfma(-Rk[i][l], Ri[l][j], acc);
+                        Ri[i][j] = acc / Rk[i][i];
+                    }
+            const T nanv = T(0) / T(0);
+            for (int bi = 0; bi < K; ++bi)
+                for (int ai = 0; ai < K; ++ai) {
+                    T val = T(0);
+                    for (int l = (ai > bi ? ai : bi); l < K; ++l) val = tfma(Ri[ai][l], Ri[bi][l], val);
+                    sa.cov_out[b * (K * K) + bi * K + ai] = ok ? val * chi2 : nanv;
+                }
+            sa.chi2_out[b] = (double)chi2;
+            sa.status_out[b] = ok ? VP_ST_OK : 4 /* VP_ST_STATS_FAILED */;
+            s_ok = ok ? 1 : 0;
+            sh.fn2 = chi2;
+        }
+        __syncthreads();
+        if (sa.sigma_out) {
+            build(false);
+            const T s0 = s_ok ? tsqrt(sh.fn2) : T(0) / T(0);
+            for (int i = tid; i < m; i += TB) {
+                T acc = T(0);
+                for (int c = 0; c < K; ++c) {
+                    T v = T(0);
+                    for (int r = 0; r <= c; ++r) v = tfma(Ri[r][c], col(r)[i], v);
+                    acc = tfma(v, v, acc);
+                }
+                sa.sigma_out[b * (int64_t)m + i] = s0 * tsqrt(acc);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- host-side launchers (type-erased LaunchParams, vp_kernels.hpp) -------------------------------------------------
 template <typename T> inline bool fill_args(const LaunchParams &p, GenArgs<T> &a) {
     std::memset(&a, 0, sizeof(a));
@@ -718,6 +852,21 @@ template <typename T> int launch_best_fit(const LaunchParams &p) {
     if (a.B <= 0) return VP_ERR_OK;
     const unsigned grid = (unsigned)(a.B < 4096 ? a.B : 4096);
     hipLaunchKernelGGL((gen_best_fit_kernel<T>), dim3(grid), dim3(TB), 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+template <typename T> int launch_stats(const LaunchParams &p) {
+    GenStatsArgs<T> sa;
+    if (!fill_args(p, sa.g) || !p.gen_ws) return VP_ERR_UNSUPPORTED;
+    sa.C = (const T *)p.C_out;
+    sa.cost = p.cost_out;
+    sa.status_in = p.status;
+    sa.cov_out = (T *)p.Phi_out;
+    sa.chi2_out = (double *)p.dPhi_out;
+    sa.sigma_out = (T *)p.r_out;
+    sa.status_out = (int32_t *)p.J_out;
+    if (sa.g.B <= 0) return VP_ERR_OK;
+    hipLaunchKernelGGL((gen_stats_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, sa);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 

@@ -274,11 +274,17 @@ template <typename T, class M> struct BasisArgs {
 
 // Stand-alone Phi/dPhi: reads q scalars (+ the shared grid from L2), writes (n + p) * m scalars per
 // problem with 16-byte-per-lane fully coalesced stores: HBM-write-bound by construction.
+// W == 1: four problems per workgroup, one per wave (a quarter of the workgroup dispatches for the same stores: 1-2 % on
+// the median launch; non-temporal stores, also tried, cost 5-15 %: tools/basis_probe.py)
+#ifndef VP_BASIS_WPB
+#define VP_BASIS_WPB 4
+#endif
 template <typename T, class M, int R, int W, bool ALIGNED>
-__global__ void __launch_bounds__(64 * W) basis_kernel(const BasisArgs<T, M> a) {
+__global__ void __launch_bounds__(64 * W * (W == 1 ? VP_BASIS_WPB : 1)) basis_kernel(const BasisArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
-    const int lane = (int)threadIdx.x; // group lane
-    const int64_t b = blockIdx.x;
+    constexpr int PPB = (W == 1) ? VP_BASIS_WPB : 1;
+    const int lane = (W == 1) ? (int)(threadIdx.x & 63u) : (int)threadIdx.x; // group lane
+    const int64_t b = (int64_t)blockIdx.x * PPB + ((W == 1) ? (int)(threadIdx.x >> 6) : 0);
     if (b >= a.B) return;
     const int m = a.m;
     T alpha[Q];
@@ -389,9 +395,11 @@ template <typename T, class M, int R, int W = 1> int launch_basis(const LaunchPa
     a.B = p.B;
     a.t_stride = p.t_stride;
     if (a.B <= 0) return VP_ERR_OK;
+    constexpr int PPB = (W == 1) ? VP_BASIS_WPB : 1;
+    const dim3 grid((unsigned)((a.B + PPB - 1) / PPB)), block(64 * W * PPB);
     if (host_aligned<T>(p.m, {p.t, p.Phi_out, p.dPhi_out}))
-        hipLaunchKernelGGL((basis_kernel<T, M, R, W, true>), dim3((unsigned)a.B), dim3(64 * W), 0, p.stream, a);
-    else hipLaunchKernelGGL((basis_kernel<T, M, R, W, false>), dim3((unsigned)a.B), dim3(64 * W), 0, p.stream, a);
+        hipLaunchKernelGGL((basis_kernel<T, M, R, W, true>), grid, block, 0, p.stream, a);
+    else hipLaunchKernelGGL((basis_kernel<T, M, R, W, false>), grid, block, 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
