@@ -27,8 +27,10 @@ def _fit_with(kernel, mdl, Y, x, guess, trace_rows=0):
 
 
 # m -> rows per lane R -> slots per wavefront: 1024 -> 2, 1000 -> 2 (padding in the last register pair),
-# 512 -> 4, 300 -> 4 (general padding), 100 -> 8
-@pytest.mark.parametrize("m,B", [(1024, 301), (1000, 77), (512, 203), (300, 64), (100, 517)])
+# 512 -> 4, 300 -> 4 (general padding), 100 -> 8; 2048 / 2000 -> R = 32 at one wave per SIMD, 2 slots; 4096 / 4000 ->
+# a group of four waves per problem (scalar phase on wave 0 only)
+@pytest.mark.parametrize("m,B", [(1024, 301), (1000, 77), (512, 203), (300, 64), (100, 517), (2048, 45), (2000, 33),
+                                 (4096, 37), (4000, 21)])
 def test_slot_kernel_equals_wave_kernel(m, B):
     d = synth.double_exp_batch(B, m=m, noise=1e-3)
     mdl = double_exp_builder_model(d["x"], d["tau_guess"][0])

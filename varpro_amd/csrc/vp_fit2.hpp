@@ -45,11 +45,14 @@ template <typename T, int N, int Q> struct alignas(8) SlotRec {
 // Slots per group from the LDS budget: a workgroup holds ONE copy of the grid and NG groups x GS columns of 64*R*W
 // scalars; `blocks_per_cu` workgroups are resident per CU (160 KiB of LDS).  Capped at 8 (lanes 0..GS-1 of ONE wave
 // run the scalar phase; beyond 8 the divergent branches of lmpar eat the gain).
+#ifndef VP_SLOT_CAP
+#define VP_SLOT_CAP 8
+#endif
 template <typename T, int R, int W, int NG, int BLOCKS_PER_CU> constexpr int fit2_slots() {
     constexpr int col = 64 * R * W * (int)sizeof(T);
     constexpr int budget = (160 * 1024) / BLOCKS_PER_CU - col - 3 * 1024; // grid + records/constants/exchange area
     constexpr int gs = budget / (NG * col);
-    return gs < 1 ? 1 : (gs > 8 ? 8 : gs);
+    return gs < 1 ? 1 : (gs > VP_SLOT_CAP ? VP_SLOT_CAP : gs);
 }
 
 template <typename T, class M> struct Fit2Args {

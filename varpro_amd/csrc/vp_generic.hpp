@@ -338,7 +338,7 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_evaluate_kernel(
     }
 }
 
-// MINPACK qrfac with column pivoting (== the oracle's qrfac) on the explicit Jacobian columns, cooperative; the
+// MINPACK qrfac with column pivoting (lmder's factorisation, src/solvers/levmar/mod.rs:247) on the explicit Jacobian columns, cooperative; the
 // residual column is carried along for qtf (lmder).  Columns are pivoted logically through sh.col[].
 template <typename T> __device__ void jac_qrfac(const GenArgs<T> &a, GenShared<T> &sh, T *ws) {
     const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params;
