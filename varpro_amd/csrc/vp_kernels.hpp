@@ -290,6 +290,8 @@ __global__ void __launch_bounds__(64 * W * (W == 1 ? VP_BASIS_WPB : 1)) basis_ke
     T alpha[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
+    // (per-row exponentials: the stand-alone Phi kernel is the model-evaluation API and keeps its 2-ulp accuracy; the
+    // uniform-grid recurrence would cut its VALU work 3x but only buys ~5 % here -- the kernel is store-bound)
     using Src = RowSource<T, R, false, 0, ALIGNED ? 1 : 0, W>;
     Src src;
     src.t = a.t + b * a.t_stride;
