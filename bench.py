@@ -96,8 +96,8 @@ CPU_TOPOLOGY = cpu_topology()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)  # 100 x ~2.6 ms: a timed region a GPU-busy sampler can see
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=65536,
                     help="problems per GPU: 65536 = BASELINE configs[3]'s per-GPU shard (524288 over 8 GPUs) and the "
                          "north_star 1-GPU headline size; configs[0,1,2,4] are measured alongside on rank 0 at N = 1")
