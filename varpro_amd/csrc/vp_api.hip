@@ -126,17 +126,19 @@ __global__ void mrhs_reduce_partials_kernel(const double *part, int gx, int nacc
 // the recurrence exp(-(t_0 + i dt)/tau) to 4 eps (t_i - t_0)/|tau| -- the size of the reference's own rounding of
 // the quotient t_i/tau.  Grids with a large offset (|t_0| >> m dt) or irregular sampling fail and keep the
 // per-row exponential.  One block per grid; *flag is AND-ed.
-__global__ void grid_check_kernel(const double *t, int m, int64_t ngrids, int *flag) {
+template <typename T> __global__ void grid_check_kernel(const T *t, int m, int64_t ngrids, int *flag) {
     const int64_t g = blockIdx.x;
     if (g >= ngrids) return;
-    const double *tg = t + g * (int64_t)m;
-    const double t0 = tg[0];
-    const double dt = (tg[m - 1] - t0) / (double)(m - 1);
+    const T *tg = t + g * (int64_t)m;
+    const double t0 = (double)tg[0];
+    const double dt = ((double)tg[m - 1] - t0) / (double)(m - 1);
+    // to the rounding of the grid's own type: 4 ulp of the distance from t_0
+    const double tol = 4.0 * (sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07);
     bool ok = (dt == dt) && (dt - dt == 0.0) && dt != 0.0;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         const double lat = __builtin_fma((double)i, dt, t0);
-        const double dev = __builtin_fabs(tg[i] - lat);
-        if (!(dev <= 4.0 * 2.220446049250313e-16 * __builtin_fabs(tg[i] - t0))) ok = false;
+        const double dev = __builtin_fabs((double)tg[i] - lat);
+        if (!(dev <= tol * __builtin_fabs((double)tg[i] - t0))) ok = false;
     }
     if (!ok) atomicAnd(flag, 0);
 }
@@ -609,14 +611,19 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         VP_TRY(hipMemcpyAsync(h->d_w, w, w_elems * ts, kin, h->stream));
     }
     int *&d_gflag = reinterpret_cast<int *&>(h->tmp_a);
-    const bool try_uniform = (dtype == VP_F64) && m >= 3 && !(flags & VP_FLAG_NO_GRID_RECURRENCE);
+    // (fp32 handles: only the Gram fit kernel, vp_fitg.hpp, uses the flag -- the other fp32 kernels have no recurrence)
+    const bool try_uniform = m >= 3 && !(flags & VP_FLAG_NO_GRID_RECURRENCE);
     if (try_uniform) {
         const int one = 1;
         VP_TRY(hipMalloc((void **)&d_gflag, sizeof(int)));
         VP_TRY(hipMemcpyAsync(d_gflag, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
         const int64_t ngrids = (flags & VP_FLAG_T_PER_PROBLEM) ? B : 1;
-        hipLaunchKernelGGL(grid_check_kernel, dim3((unsigned)ngrids), dim3(256), 0, h->stream, (const double *)h->d_t,
-                           (int)m, ngrids, d_gflag);
+        if (dtype == VP_F64)
+            hipLaunchKernelGGL(grid_check_kernel<double>, dim3((unsigned)ngrids), dim3(256), 0, h->stream,
+                               (const double *)h->d_t, (int)m, ngrids, d_gflag);
+        else
+            hipLaunchKernelGGL(grid_check_kernel<float>, dim3((unsigned)ngrids), dim3(256), 0, h->stream,
+                               (const float *)h->d_t, (int)m, ngrids, d_gflag);
         VP_TRY(hipGetLastError());
     }
     VP_TRY(hipMalloc(&h->d_yw, y_elems * ts));

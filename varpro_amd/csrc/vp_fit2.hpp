@@ -66,18 +66,21 @@ template <typename T, class M> struct Fit2Args {
 // Launch-wide constants of the slot kernel, staged ONCE per workgroup in LDS: the scalar phase and the refill path
 // (both out of line, see below) read them from there, so they do not occupy SGPRs -- i.e. spill slots -- across the
 // register-critical vector phase.
-template <typename T> struct SlotConsts {
+//   T = arithmetic type of the LM bookkeeping, TO = storage type of the handle's arrays (they differ in the Gram kernel,
+//   vp_fitg.hpp: fp32 data, fp64 bookkeeping)
+template <typename T, typename TO = T> struct SlotConsts {
     T ftol, xtol, gtol, stepbound;
-    T *alpha;          // in: initial guesses, out: final parameters  [B][q]
-    T *C_out;          // [B][n] or null
+    TO *alpha;         // in: initial guesses, out: final parameters  [B][q]
+    TO *C_out;         // [B][n] or null
     double *cost_out;  // [B] or null
     int32_t *status;   // [B] or null
     vp_report *report; // [B]
     double *trace;     // [B][trace_rows][q+4] or null
-    const T *yw;       // [B][m]
+    const TO *yw;      // [B][m]
     int *queue;
     int64_t B;
     int trace_rows, scale_diag, max_fev, m;
+    T eps;             // (Gram kernel) rank threshold of the linear solve
 };
 
 // Fill a slot: y' = H_0 y_w into the slot's LDS column (row order, zero padded); returns (H_0 y_w)[0].
@@ -185,8 +188,8 @@ __device__ __noinline__ void slot_fill(VP_LDS SlotRec<T, N, Q> *rec, VP_LDS T *s
 // SCALAR phase: lane s runs the LM bookkeeping of slot s on its LDS record (trust-region update, accept / reject,
 // termination tests, gradient test, lmpar, predicted reduction, next trial point) and writes the results of a fit that
 // terminated.  == the body of LevenbergMarquardt::minimize between two evaluations.  Out of line (see slot_fill).
-template <typename T, int N, int Q, int GS>
-__device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP_LDS const SlotConsts<T> *k) {
+template <typename T, int N, int Q, int GS, typename TO = T>
+__device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP_LDS const SlotConsts<T, TO> *k) {
     const int lane = lane_id();
     if (!(lane < GS && recs[lane].prob >= 0)) return;
     VP_LDS SlotRec<T, N, Q> *s = recs + lane;
@@ -414,14 +417,14 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
         k->report[prob] = rep;
         double *cost_out = k->cost_out;
         int32_t *status_out = k->status;
-        T *alpha_out = k->alpha, *C_out = k->C_out;
+        TO *alpha_out = k->alpha, *C_out = k->C_out;
         if (cost_out) cost_out[prob] = (double)objective;
         if (status_out) status_out[prob] = status;
 #pragma unroll
-        for (int i = 0; i < Q; ++i) alpha_out[prob * Q + i] = x[i];
+        for (int i = 0; i < Q; ++i) alpha_out[prob * Q + i] = (TO)x[i];
         if (C_out) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) C_out[prob * N + i] = s->cbest[i];
+            for (int i = 0; i < N; ++i) C_out[prob * N + i] = (TO)s->cbest[i];
         }
     }
 }

@@ -1,6 +1,7 @@
 // vp_inst.hpp -- macros that instantiate one (dtype, model, R) kernel set and register it.
 #pragma once
 #include "vp_fit2.hpp"
+#include "vp_fitg.hpp"
 #include "vp_lm_core.hpp"
 #include "vp_mrhs.hpp"
 #include "vp_stats.hpp"
@@ -44,6 +45,23 @@
         &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                          \
         &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0, \
         &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>});
+
+// fp32, many columns x many rows: the fit runs on the fp64 Gram matrix (vp_fitg.hpp; falls back to the slot kernel for
+// weighted problems / per-problem grids); evaluate / basis / statistics stay on the WW-wave Householder kernels
+namespace vp {
+template <class M, int R, int W> int launch_fitg_or_slots(const LaunchParams &p) {
+    return launch_fitg<M>(p, &launch_fit2<float, M, R, W>);
+}
+} // namespace vp
+#define VP_REGISTER_MULTIEXP_W_GRAM(NEXP, OFF, RR, WW)                                                                 \
+    static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
+        VP_F32, ::vp::FAMILY_MULTIEXP, NEXP, OFF, 0, RR, WW,                                                           \
+        &::vp::launch_evaluate<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                 \
+        &::vp::launch_basis<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                    \
+        &::vp::launch_fitg_or_slots<::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                   \
+        &::vp::launch_fit<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                      \
+        &::vp::launch_best_fit<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0, \
+        &::vp::launch_stats<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>});
 
 // run-time-descriptor models at larger m (WW waves per problem): single-RHS kernel set only
 #define VP_REGISTER_RT_W(T, DT, NN, QQ, PP, RR, WW)                                                                    \
