@@ -383,17 +383,19 @@ def main():
             ms4 = event_ms(lambda: bp4.fit(g4, want_coefficients=False), 5, 2)
             _a4, _c4, rep4 = bp4.fit(g4, want_coefficients=False)
             r4 = bp4.report_to_numpy(rep4)
-            # fp32 flops of one evaluation: 5 exp columns (m x 5 x ~20), sweep over 11 register columns
-            # 4m(11+10+9+8+7+6) with the constant column implicit, Jacobian QR of 5 columns ~100m
-            flops4 = m4 * (5 * 20 + 4 * 51 + 100)
+            # the fit runs on the fp64 Gram matrix of [Phi | y | dPhi] (vp_fitg.hpp): per row 66 fp64 FMAs + 11 adds
+            # (77 accumulators), 5 recurrence + 10 derivative multiplies = 158 fp64 flops
+            flops4 = m4 * 158
             tf4 = float(r4["n_evals"].sum()) * flops4 / (ms4 * 1e-3) / 1e12
             out["configs4"] = {
                 "workload": "BASELINE configs[4]: %d fp32 fits, five exponentials + offset (n=6, q=5), m=%d" % (B4, m4),
                 "fits_per_s": B4 / (ms4 * 1e-3), "ms_per_step": ms4, "mean_evaluations_per_fit": float(r4["n_evals"].mean()),
                 "fraction_failed": float((r4["termination"] <= 0).mean()),
-                "roofline": {"kernel": "fit2_kernel<float, 5 exp + offset, 4 wavefronts per problem, 3 slots per group>", "bound": "fp32_valu",
-                             "achieved": tf4, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf4 / FP32_VALU_PEAK_TFLOPS, "flops_per_evaluation": flops4},
+                "roofline": {"kernel": "fitg_kernel<5 exp + offset> (fp32 data, fp64 Gram pass + Cholesky-based LM; 4 wavefronts per "
+                                       "problem, 8 slots per group)", "bound": "fp64_valu",
+                             "achieved": tf4, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf4 / FP64_VALU_PEAK_TFLOPS, "flops_per_evaluation": flops4,
+                             "hbm_bytes_per_evaluation": 4 * m4},
             }
             bp4.close()
             del Y4
