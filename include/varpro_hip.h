@@ -326,7 +326,11 @@ int vp_set_rhs_allreduce(vp_batch *h, vp_allreduce_fn fn, void *user, int64_t gl
  *   WAVE  : always one wavefront per problem
  *   SLOTS : the slot kernel whenever it covers the problem, regardless of the batch size
  * All three implement LevenbergMarquardt::minimize (src/solvers/levmar/mod.rs:247) with identical arithmetic per
- * problem; results do not depend on which wavefront or slot ran a problem. */
+ * problem; results do not depend on which wavefront or slot ran a problem.
+ * One exception to "identical arithmetic": VP_F32 handles whose model needs more than one wavefront's registers (five
+ * exponentials + offset beyond 128 rows, BASELINE.json configs[4]) are fitted under AUTO / SLOTS on the fp64 Gram matrix
+ * of [Phi | y | dPhi] (normal equations in double; unit weights, shared grid) -- more accurate than an fp32 Householder
+ * sweep and deterministic, but not bit-identical to WAVE, which keeps the fp32 Householder kernels. */
 enum { VP_FIT_KERNEL_AUTO = 0, VP_FIT_KERNEL_WAVE = 1, VP_FIT_KERNEL_SLOTS = 2 };
 int vp_set_fit_kernel(vp_batch *h, int which);
 
