@@ -108,8 +108,8 @@ enum {
     VP_ERR_OK = 0,
     VP_ERR_INVALID = -1,     /* bad handle / argument / shape (builder errors, src/problem/builder.rs:15-46) */
     VP_ERR_UNSUPPORTED = -2, /* operation not available for this handle (every MODEL the descriptor can express is
-                              * accepted -- shapes without a specialised kernel run on generic kernels; what remains
-                              * unsupported: global fits (S > 1) for such shapes, m < n) */
+                              * accepted -- shapes without a specialised kernel run on generic kernels, global fits
+                              * included; what remains unsupported: right-hand-side sharding for such shapes, m < n) */
     VP_ERR_HIP = -3,         /* HIP runtime failure */
     VP_ERR_NO_DEVICE = -4    /* no gfx950 device / library built without device code */
 };

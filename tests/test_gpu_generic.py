@@ -166,7 +166,7 @@ def test_generic_fit_matches_the_oracle(m, weighted):
 
 
 def test_generic_multiple_right_hand_sides_evaluate_and_fp32():
-    # S > 1 trait-level evaluation on a shape without MRHS kernels (every RHS as its own column); fp32 handle
+    # S > 1 on a shape without MRHS kernels: trait-level evaluation (every RHS as its own column), global fit; fp32 handle
     m, S = 700, 5
     x = 10.0 * np.arange(m) / (m - 1) + 0.01
     kinds = [basis.EXP_COS, basis.EXP_RATE, basis.SIN_PHASE, basis.CONST, basis.EXP_DECAY]
@@ -184,9 +184,28 @@ def test_generic_multiple_right_hand_sides_evaluate_and_fp32():
     Jr = ref.jacobian()
     for k in range(6):
         assert np.abs(ev["J"][0, k] - Jr[k]).max() <= 1e-9 * np.abs(Jr[k]).max()
-    with pytest.raises(vp.VarproHipError):
-        bp.fit(alpha[None])                       # global fits need the MRHS kernels: a clear error, not a wrong answer
+    # the global fit of a shape without MRHS kernels: one workgroup per problem walks the S columns (gen_mrhs_fit_kernel)
+    a_fit, C_fit, rep, tr = bp.fit_trace(alpha[None] * 1.02, max_rows=10)
+    rr, tr_ref = ref.fit_trace(max_rows=10)
+    assert rep["termination"][0] > 0 and rr.termination > 0
+    for i in range(min(4, len(tr_ref), int(rep["n_evals"][0]))):   # same trajectory for the leading evaluations
+        if tr_ref[i, 6] < 1e-6 * tr_ref[0, 6]:
+            break
+        assert np.abs(tr[0, i, :6] - tr_ref[i, :6]).max() <= 1e-6 * np.abs(tr_ref[i, :6]).max(), i
+        assert abs(tr[0, i, 6] - tr_ref[i, 6]) <= 1e-6 * tr_ref[i, 6], i
+    assert abs(rep["objective"][0] - rr.objective) <= 1e-6 * rr.objective
+    assert np.abs(a_fit[0] - ref.params()).max() <= 1e-4 * np.abs(ref.params()).max()
+    assert C_fit.shape == (1, S, 5)
+    assert np.abs(C_fit[0] - ref.linear_coefficients()).max() <= 1e-4 * np.abs(C_fit).max()
+    r = bp.residuals()
+    assert abs(0.5 * (np.asarray(r) ** 2).sum() - rep["objective"][0]) <= 1e-8 * rep["objective"][0]
     bp.close()
+    # a batch of two independent global fits, no trace
+    bp2 = vp.BatchProblem(mdl, np.stack([Y, Y[::-1]]), x=x)
+    a2, C2, rep2 = bp2.fit(np.stack([alpha, alpha]) * 1.02)
+    assert (rep2["termination"] > 0).all()
+    assert np.abs(a2[0] - a_fit[0]).max() <= 1e-9 and np.abs(a2[1] - a_fit[0]).max() <= 1e-6 * np.abs(a_fit).max()
+    bp2.close()
     mdl32 = SeparableModel(["a", "b", "c", "d", "e", "f"], kinds, params, x.astype(np.float32), alpha.astype(np.float32),
                            dtype=np.float32)
     bp32 = vp.BatchProblem(mdl32, Y[:1].astype(np.float32), x=x.astype(np.float32))

@@ -374,7 +374,7 @@ struct DeviceGuard {
 // reads back one int (number of still-active problems) per iteration.
 int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep, double *trace_out,
              int trace_rows) {
-    if (!h->have_mrhs) return fail(VP_ERR_UNSUPPORTED, "no MRHS kernels for this (model, m)");
+    if (!h->have_mrhs && !h->kern->mrhs_fit_whole) return fail(VP_ERR_UNSUPPORTED, "no MRHS kernels for this (model, m)");
     vp_lm_opts o;
     if (opts) o = *opts;
     else vp_lm_opts_default(&o, h->dtype);
@@ -392,6 +392,30 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         VP_HIP(hipMemsetAsync(tr.dptr, 0xFF, tr_bytes, h->stream));
         p.trace = (double *)tr.dptr;
         p.trace_rows = trace_rows;
+    }
+    if (!h->have_mrhs) {
+        // generic fallback kernels: the whole global fit is one launch (vp_generic.hpp, gen_mrhs_fit_kernel), which also
+        // leaves the coefficients / cost / status of every column at the final point
+        if (h->rhs_allreduce) return fail(VP_ERR_UNSUPPORTED, "right-hand-side sharding needs the MRHS kernel set");
+        p.alpha_out = h->d_alpha;
+        p.C_out = h->d_C;
+        p.cost_out = h->d_cost_bs;
+        p.status = h->d_status_bs;
+        p.report = h->d_report;
+        {
+            Timer tm(h, VP_KERNEL_FIT);
+            if (int rc = h->kern->mrhs_fit_whole(p)) return fail(rc, "generic global-fit launch failed");
+            tm.stop();
+        }
+        if (int rc = reduce_rhs(h)) return rc;
+        h->have_params = true;
+        h->r_valid = false;
+        h->have_report = true;
+        if (int rc = copy_out(h, alpha_inout, h->d_alpha, (size_t)h->B * h->q * ts)) return rc;
+        if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
+        if (int rc = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc;
+        if (int rc = tr.finish(h)) return rc;
+        return VP_ERR_OK;
     }
     VP_HIP(hipMemsetAsync(h->mrhs.nactive, 0, sizeof(int32_t), h->stream));
     Timer tm(h, VP_KERNEL_FIT);

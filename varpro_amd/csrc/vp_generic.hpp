@@ -590,6 +590,142 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_fit_kernel(const
     }
 }
 
+// Global fit (one alpha, S right-hand sides; == LevMarSolver::fit on a SeparableProblem<MRHS>, src/solvers/levmar/
+// mod.rs:172-186 for the Jacobian of the stacked residual) for ANY descriptor: one workgroup per problem walks the S
+// columns per evaluation -- each gets its own projection (evaluate), its Kaufman columns stay in Q-coordinates (an
+// orthogonal change of basis: J^T J and J^T r are the same) and only sum ||r||^2, J^T J, J^T r are carried, in double;
+// the LM step factors J^T J by pivoted Cholesky (gram_to_qr, as the specialised MRHS path).  The fallback for models
+// without MRHS kernel instantiations: one workgroup per problem, correctness over speed.
+template <typename T> __global__ void __launch_bounds__(TB) gen_mrhs_fit_kernel(const GenArgs<T> a) {
+    __shared__ GenShared<T> sh;
+    __shared__ LmAny<T> lm;
+    __shared__ int s_term, s_trow, s_okall;
+    __shared__ double s_acc[1 + VP_MAX_PARAMS * VP_MAX_PARAMS + VP_MAX_PARAMS]; // sum ||r||^2 | J^T J (q x q) | J^T r
+    const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params, P = a.P, NS = a.S; // (S names the LM state inside VP_GEN_DISPATCH)
+    const int NCQ = n + 1 + P;
+    T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
+    auto col = [&](int c) { return ws + (int64_t)c * m; };
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        if (tid == 0) {
+            T a0[VP_MAX_PARAMS];
+            for (int k = 0; k < q; ++k) a0[k] = a.alpha_io[b * q + k];
+            VP_GEN_DISPATCH(q, (lm_init<T, VP_MAX_BASIS, QQ>(S, a0)));
+            for (int k = 0; k < q; ++k) sh.alpha[k] = a0[k];
+            s_term = (q == 0) ? VP_TERM_NO_PARAMETERS : 0;
+            s_trow = 0;
+        }
+        __syncthreads();
+        while (s_term == 0) {
+            if (tid == 0) {
+                for (int i = 0; i < 1 + q * q + q; ++i) s_acc[i] = 0.0;
+                s_okall = 1;
+            }
+            __syncthreads();
+            for (int s = 0; s < NS; ++s) {
+                evaluate<T>(a, sh, ws, b, false, b * NS + s);
+                // Kaufman columns in Q-coordinates: z_k = -sum_{pairs p of parameter k} c_{basis(p)} (Q^T D_p), rows >= n
+                for (int k = 0; k < q; ++k) {
+                    T *zk = col(NCQ + k);
+                    for (int i = n + tid; i < m; i += TB) {
+                        T acc = T(0);
+                        for (int p = 0; p < P; ++p)
+                            if (a.pp[p] == k) acc = tfma(-sh.c[a.pb[p]], col(n + 1 + p)[i], acc);
+                        zk[i] = acc;
+                    }
+                }
+                __syncthreads();
+                for (int k = 0; k < q; ++k) {
+                    T vals[MAXV];
+                    const int nv = q - k + 1; // z_k . z_l (l >= k), z_k . r
+                    for (int v = 0; v < nv; ++v) vals[v] = T(0);
+                    const T *zk = col(NCQ + k), *y = col(n);
+                    for (int i = n + tid; i < m; i += TB) {
+                        const T x = zk[i];
+                        for (int l = k; l < q; ++l) vals[l - k] = tfma(x, col(NCQ + l)[i], vals[l - k]);
+                        vals[nv - 1] = tfma(x, y[i], vals[nv - 1]);
+                    }
+                    multi_reduce(sh, vals, nv);
+                    if (tid == 0) {
+                        for (int l = k; l < q; ++l) s_acc[1 + k * q + l] += (double)sh.red[l - k];
+                        s_acc[1 + q * q + k] += (double)sh.red[nv - 1];
+                    }
+                    __syncthreads();
+                }
+                if (tid == 0) {
+                    s_acc[0] += (double)sh.fn2;
+                    if (!sh.ok) s_okall = 0;
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                const T fnorm1 = tsqrt((T)s_acc[0]);
+                VP_GEN_DISPATCH(q, {
+                    const bool need = lm_after_eval<T, VP_MAX_BASIS, QQ, false>(S, a.lm, fnorm1, s_okall != 0 && is_finite(fnorm1),
+                                                                                 (long)m * (long)NS);
+                    if (a.trace && s_trow < a.trace_rows) {
+                        double *tr = a.trace + ((size_t)b * a.trace_rows + s_trow) * (q + 4);
+                        for (int k = 0; k < QQ; ++k) tr[k] = (double)S.xt[k];
+                        tr[q] = (double)fnorm1;
+                        tr[q + 1] = 0.0 / 0.0;
+                        tr[q + 2] = (double)S.delta;
+                        tr[q + 3] = (double)S.par;
+                    }
+                    ++s_trow;
+                    if (S.term == 0) {
+                        if (need) {
+                            double A[QQ][QQ], bv[QQ], Rd[QQ][QQ], acd[QQ], qd[QQ];
+                            for (int k = 0; k < QQ; ++k) {
+                                bv[k] = s_acc[1 + q * q + k];
+                                for (int l = 0; l < QQ; ++l) A[k][l] = (l >= k) ? s_acc[1 + k * q + l] : s_acc[1 + l * q + k];
+                            }
+                            gram_to_qr<double, QQ>(A, bv, Rd, acd, S.ipvt, qd);
+                            for (int k = 0; k < QQ; ++k) {
+                                S.acnorm[k] = (T)acd[k];
+                                S.qtf[k] = (T)qd[k];
+                                for (int l = 0; l < QQ; ++l) S.Rj[k][l] = (T)Rd[k][l];
+                            }
+                        }
+                        lm_next_step<T, VP_MAX_BASIS, QQ, false>(S, a.lm, need);
+                    }
+                    s_term = S.term;
+                    for (int k = 0; k < QQ; ++k) sh.alpha[k] = S.xt[k];
+                });
+            }
+            __syncthreads();
+        }
+        // ---- results: parameters + report, then coefficients / cost / status of every column at the final point ----
+        if (tid == 0) {
+            vp_report rep;
+            rep.termination = VP_TERM_NO_PARAMETERS;
+            rep.n_evals = 0;
+            rep.objective = 0.0 / 0.0;
+            VP_GEN_DISPATCH(q, {
+                if (q > 0) {
+                    rep.termination = S.term;
+                    rep.n_evals = S.nfev;
+                    rep.objective = (double)S.objective;
+                    for (int k = 0; k < QQ; ++k) {
+                        a.alpha_io[b * q + k] = S.x[k];
+                        sh.alpha[k] = S.x[k];
+                    }
+                }
+            });
+            a.report[b] = rep;
+        }
+        __syncthreads();
+        for (int s = 0; s < NS; ++s) {
+            const int64_t prob = b * NS + s;
+            evaluate<T>(a, sh, ws, b, false, prob);
+            if (tid == 0) {
+                if (a.status) a.status[prob] = sh.ok ? VP_ST_OK : VP_ST_NONFINITE;
+                if (a.cost_out) a.cost_out[prob] = 0.5 * (double)sh.fn2;
+            }
+            if (a.C_out && tid < n) a.C_out[prob * n + tid] = sh.c[tid];
+            __syncthreads();
+        }
+    }
+}
+
 // stand-alone Phi / dPhi (UNWEIGHTED) and best fit: element-wise, no workspace
 template <typename T> __global__ void __launch_bounds__(TB) gen_basis_kernel(const GenArgs<T> a) {
     const int m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params, P = a.P;
@@ -829,6 +965,13 @@ template <typename T> int launch_fit(const LaunchParams &p) {
     if (!fill_args(p, a) || !p.gen_ws) return VP_ERR_UNSUPPORTED;
     if (a.B <= 0) return VP_ERR_OK;
     hipLaunchKernelGGL((gen_fit_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+template <typename T> int launch_mrhs_fit(const LaunchParams &p) {
+    GenArgs<T> a;
+    if (!fill_args(p, a) || !p.gen_ws) return VP_ERR_UNSUPPORTED;
+    if (a.B <= 0) return VP_ERR_OK;
+    hipLaunchKernelGGL((gen_mrhs_fit_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 template <typename T> int launch_basis(const LaunchParams &p) {

@@ -25,6 +25,7 @@ struct KernelEntry {
     launch_fn mrhs_factor, mrhs_stream, mrhs_lm, mrhs_finish;
     size_t mrhs_state_bytes;
     launch_fn stats; // batched fit statistics (vp_stats.hpp)
+    launch_fn mrhs_fit_whole; // S > 1 fit as ONE launch (generic fallback kernels only; null elsewhere)
 };
 
 std::vector<KernelEntry> &registry();
