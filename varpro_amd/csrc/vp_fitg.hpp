@@ -121,7 +121,7 @@ __device__ __noinline__ void slotg_fill(VP_LDS SlotRec<double, N, Q> *rec, VP_LD
 }
 
 // Lane s: Gram of slot s -> results of the evaluation in the slot's record (what the vector phase of fit2_kernel posts).
-//   gram: [W][GS][NV] per-wave partial Grams (each wave of the group streamed a quarter of the rows)
+//   gram: [GS][NV] Grams of the slots (partial 0 of the [W][GS][NV] area, already totalled over the waves)
 template <int NE, int GS, int W>
 __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs, VP_LDS double *gram,
                                         VP_LDS const SlotConsts<double, float> *k) {
@@ -131,14 +131,7 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
     if (!(lane < GS && recs[lane].prob >= 0)) return;
     VP_LDS SlotRec<double, N, Q> *rec = recs + lane;
     VP_LDS double *g = gram + (size_t)lane * GI::NV;
-    if constexpr (W > 1) { // total the partials in place (fixed order)
-        for (int i = 0; i < GI::NV; ++i) {
-            double t = g[i];
-#pragma unroll
-            for (int w = 1; w < W; ++w) t += g[(size_t)w * GS * GI::NV + i];
-            g[i] = t;
-        }
-    }
+    // (the W per-wave partial Grams were totalled into partial 0 by the whole group before this call)
     const double eps = k->eps;
     // ---- A = Phi^T Phi (basis order e_0..e_{NE-1}, const) = L L^T ----
     // A column whose pivot d_i (its squared distance from the span of the columns before it) is <= max(eps^2,
@@ -418,6 +411,17 @@ __global__ void __launch_bounds__(64 * W, (2 * W) / 4 > 0 ? (2 * W) / 4 : 1) fit
             wave_reduce_store<GI::NV>(acc, (VP_LDS double *)(gram + ((size_t)wv * GS + s) * GI::NV));
         }
         __syncthreads();
+        // total the W per-wave partial Grams in place (fixed order; all threads: one LDS round trip instead of 77 serial
+        // ones on the lanes of wave 0)
+        if constexpr (W > 1) {
+            for (int i = threadIdx.x; i < GS * GI::NV; i += 64 * W) {
+                double t = gram[i];
+#pragma unroll
+                for (int w = 1; w < W; ++w) t += gram[(size_t)w * GS * GI::NV + i];
+                gram[i] = t;
+            }
+            __syncthreads();
+        }
         VP_CK(0);
         // ===== wave 0, lane s: Gram -> evaluation results, then the LM bookkeeping of slot s; queue pops for finished slots =====
         if (wv == 0) {
