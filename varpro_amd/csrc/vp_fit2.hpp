@@ -527,6 +527,18 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
     }
     group_sync();
 
+#ifdef VP_FIT2_CLOCKS
+    long long ck[4] = {0, 0, 0, 0};
+    long long c0 = __builtin_amdgcn_s_memtime();
+#define VP_CK2(i)                                                                                                      \
+    do {                                                                                                               \
+        const long long c1 = __builtin_amdgcn_s_memtime();                                                             \
+        ck[i] += c1 - c0;                                                                                              \
+        c0 = c1;                                                                                                       \
+    } while (0)
+#else
+#define VP_CK2(i)
+#endif
     while (nactive > 0) {
         // =============================== VECTOR phase ===============================
 #pragma nounroll
@@ -590,10 +602,12 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
             }
         }
         group_sync();
+        VP_CK2(0);
 
         // =============================== SCALAR phase: lane s of wave 0 <-> slot s ===============================
         if (grp.wave == 0) slot_scalar_phase<T, N, Q, GS>((VP_LDS Rec *)recs, (VP_LDS const SlotConsts<T> *)kc);
         group_sync();
+        VP_CK2(1);
 
         // =============================== REFILL finished slots from the queue ===============================
         if constexpr (W > 1) {
@@ -621,7 +635,14 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
             if (!have) nactive -= 1;
         }
         group_sync();
+        VP_CK2(2);
     }
+#ifdef VP_FIT2_CLOCKS
+    if (args.f.trace && blockIdx.x == 0 && threadIdx.x == 0) {
+        double *tr = args.f.trace + (size_t)(args.f.trace_rows - 1) * (Q + 4);
+        for (int i = 0; i < 3; ++i) tr[i] = (double)ck[i];
+    }
+#endif
 }
 
 template <typename T, class M, int R, int W = 1> int launch_fit2(const LaunchParams &p) {
