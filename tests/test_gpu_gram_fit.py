@@ -27,9 +27,9 @@ def _oracle64(mdl, d):
     return O.fit_batch(mdl, d["x"].astype(np.float64), d["Y"].astype(np.float64), d["tau_guess"].astype(np.float64), n_threads=8)
 
 
-@pytest.mark.parametrize("m", [4096, 2000, 300])
+@pytest.mark.parametrize("m", [4096, 2000, 300, 200])
 def test_gram_fit_reaches_the_fp64_minimum(m):
-    # m = 2000 / 300: rows not a multiple of the 256-row chunks (masked tail), fewer chunks than waves in the group
+    # m = 2000 / 300 / 200: rows not a multiple of the 256-row chunks (masked tail), fewer chunks than waves in the group
     B = 96
     d = synth.multi_exp_batch(B, 5, m, TAUS, noise=1e-3, spread=0.1, guess_spread=0.05, dtype=np.float32)
     mdl, alpha, C, rep = _fit(d)
@@ -144,3 +144,19 @@ def test_gram_fit_options_and_weighted_fallback():
     a2, c2, r2 = bp.fit(d["tau_guess"])
     bp.close()
     assert (r2["termination"] != 0).all()
+
+
+def test_gram_fit_single_problem_and_device_pointers():
+    # B = 1 (one group, one slot) and torch device tensors in / out
+    import torch
+    d = synth.multi_exp_batch(1, 5, 4096, TAUS, noise=1e-3, spread=0.1, guess_spread=0.05, dtype=np.float32)
+    mdl, a_h, c_h, rep_h = _fit(d)
+    dev = torch.device("cuda", 0)
+    bp = vp.BatchProblem(mdl, torch.from_numpy(d["Y"]).to(dev), x=torch.from_numpy(d["x"]).to(dev))
+    a_d, c_d, rep_d = bp.fit(torch.from_numpy(d["tau_guess"]).to(dev))
+    rep_d = bp.report_to_numpy(rep_d)
+    assert np.array_equal(a_d.cpu().numpy(), a_h) and np.array_equal(c_d.cpu().numpy(), c_h)
+    assert rep_d["n_evals"][0] == rep_h["n_evals"][0] and rep_d["termination"][0] == rep_h["termination"][0]
+    r = np.asarray(bp.residuals().cpu())            # the residual cache comes from the Householder evaluate kernel
+    assert abs(0.5 * float((r.astype(np.float64) ** 2).sum()) - rep_h["objective"][0]) <= 5e-2 * rep_h["objective"][0]
+    bp.close()
