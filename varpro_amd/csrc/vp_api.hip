@@ -508,13 +508,17 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         if (nact <= 0) break;
     }
     // final parameters + reports, then one trait-level evaluation at the final point (C, cost, status, R cache)
+    // final parameters + reports; coefficients, cost and status of every column at the final point come from the best
+    // point's pass (double-buffered per-column results, MrhsWs::cbuf) -- no further pass over Y.  The m x S residual
+    // matrix is produced on demand by vp_residuals, as after a single-RHS fit.
     p.alpha_out = h->d_alpha;
     p.report = h->d_report;
+    p.C_out = h->d_C;
+    p.cost_out = h->d_cost_bs;
+    p.status = h->d_status_bs;
     if (int rc = h->kern->mrhs_finish(p)) return fail(rc, "mrhs_finish launch failed");
     tm.stop();
-    // coefficients, cost and status at the final point: one more pass over Y WITHOUT writing the residual cache (the
-    // m x S residual matrix is produced on demand by vp_residuals, as after a single-RHS fit)
-    if (int rc = run_evaluate(h, nullptr, nullptr, h->d_C)) return rc;
+    if (int rc = reduce_rhs(h)) return rc;
     h->have_params = true;
     h->r_valid = false;
     h->have_report = true;
@@ -719,6 +723,13 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         VP_TRY(hipMalloc((void **)&h->mrhs.done, (size_t)B * sizeof(int32_t)));
         VP_TRY(hipMemsetAsync(h->mrhs.done, 0, (size_t)B * sizeof(int32_t), h->stream));
         VP_TRY(hipMalloc(&h->mrhs.alpha_trial, (size_t)std::max<int64_t>(1, B * q_) * ts));
+        for (int i = 0; i < 2; ++i) {
+            VP_TRY(hipMalloc(&h->mrhs.cbuf[i], (size_t)B * S * n_ * ts));
+            VP_TRY(hipMalloc((void **)&h->mrhs.costbuf[i], (size_t)B * S * sizeof(double)));
+            VP_TRY(hipMalloc((void **)&h->mrhs.stbuf[i], (size_t)B * S * sizeof(int32_t)));
+        }
+        VP_TRY(hipMalloc((void **)&h->mrhs.widx, (size_t)B * sizeof(int32_t)));
+        VP_TRY(hipMalloc((void **)&h->mrhs.bidx, (size_t)B * sizeof(int32_t)));
         h->have_mrhs = true;
     }
 #undef VP_TRY
@@ -761,6 +772,13 @@ void vp_batch_destroy(vp_batch *h) {
     (void)hipFree(h->mrhs.lm_state);
     (void)hipFree(h->mrhs.nactive);
     (void)hipFree(h->mrhs.alpha_trial);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(h->mrhs.cbuf[i]);
+        (void)hipFree(h->mrhs.costbuf[i]);
+        (void)hipFree(h->mrhs.stbuf[i]);
+    }
+    (void)hipFree(h->mrhs.widx);
+    (void)hipFree(h->mrhs.bidx);
     if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -43,7 +43,13 @@ struct MrhsWs {
     int32_t *nactive; // [1]
     int32_t *done;    // [B] 1 once the problem's LM loop has terminated: later factor / stream launches skip it
     void *alpha_trial; // [B][q] T
-    int32_t *nevals;  // unused
+    // per-column results of the fit's passes, double-buffered: the pass at a trial point writes buffer widx[b]; when the LM
+    // accepts the point that buffer becomes bidx[b] (the best point's) and the next pass writes the other one.  After the
+    // loop the best buffer IS (C, cost, status) at the final parameters -- no extra evaluation.
+    void *cbuf[2];        // [B][S][n] T
+    double *costbuf[2];   // [B][S]
+    int32_t *stbuf[2];    // [B][S]
+    int32_t *widx, *bidx; // [B]
 };
 
 template <typename T, class M> struct MrhsFactorArgs {
@@ -258,6 +264,7 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
 #pragma unroll
         for (int j = 0; j < N; ++j) Ri[i][j] = (T)small[i * N + j];
     const int stA = a.ws.statusA[b];
+    const int wsel = (MODE == 0) ? (uni(a.ws.widx[b]) & 1) : 0;
     const bool truncated = uni(small[2 * N * N + P * P] != 0.0); // rank-deficient Phi_w: R^+ and P_n (rare)
     __syncthreads();
 
@@ -365,6 +372,16 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
             __builtin_amdgcn_sched_barrier(0);
             wave_allreduce(red);
             acc_cost += red[0];
+            { // the column's coefficients / cost / status at this trial point (kept if the LM accepts it)
+                bool ok = is_finite(red[0]) && stA == VP_ST_OK;
+#pragma unroll
+                for (int i = 0; i < N; ++i) ok = ok && is_finite(c[i]);
+                if (lane == 0) {
+                    a.ws.costbuf[wsel][prob] = 0.5 * (double)red[0];
+                    a.ws.stbuf[wsel][prob] = ok ? VP_ST_OK : (stA != VP_ST_OK ? stA : VP_ST_NONFINITE);
+                }
+                if (lane < N) ((T *)a.ws.cbuf[wsel])[prob * N + lane] = dyn_get<N>(c, lane);
+            }
 #pragma unroll
             for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -468,6 +485,8 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
             for (int k = 0; k < Q; ++k) trial[k] = s.xt[k];
             atomicAdd(a.ws.nactive, 1);
             a.ws.done[b] = 0;
+            a.ws.widx[b] = 0;
+            a.ws.bidx[b] = 0;
         }
         return;
     }
@@ -490,7 +509,13 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
     const T cost2 = (T)acc[0];
     const bool ok = uni(stA == VP_ST_OK && is_finite(cost2));
     const T fnorm1 = tsqrt(cost2);
+    const bool first_eval = s.first != 0;
     const bool need_jac = lm_after_eval<T, N, Q, true>(s, a.opts, fnorm1, ok, (long)a.m * (long)a.S_global);
+    if (lane == 0 && (s.accepted || first_eval)) { // the pass that just ran evaluated the new best point: keep its buffer
+        const int w = a.ws.widx[b] & 1;
+        a.ws.bidx[b] = w;
+        a.ws.widx[b] = w ^ 1;
+    }
     if (a.trace && lane == 0 && s.nfev - 1 < a.trace_rows) {
         double *tr = a.trace + ((size_t)b * a.trace_rows + (s.nfev - 1)) * (Q + 4);
         for (int k = 0; k < Q; ++k) tr[k] = (double)s.xt[k];
@@ -670,11 +695,33 @@ __global__ void mrhs_finish_kernel(const LmVars<T, N, Q> *st, int64_t B, T *alph
     rep[b] = r;
 }
 
+// (C, cost, status) of every column at the final parameters = the best point's buffer
+template <typename T>
+__global__ void mrhs_gather_kernel(const MrhsWs ws, int64_t B, int S, int n, T *C_out, double *cost_bs, int32_t *status_bs) {
+    const int64_t b = blockIdx.y;
+    if (b >= B) return;
+    const int sel = ws.bidx[b] & 1;
+    const T *cs = (const T *)ws.cbuf[sel] + b * (int64_t)S * n;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)S * n; i += (int64_t)gridDim.x * blockDim.x)
+        C_out[b * (int64_t)S * n + i] = cs[i];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+        cost_bs[b * S + i] = ws.costbuf[sel][b * S + i];
+        status_bs[b * S + i] = ws.stbuf[sel][b * S + i];
+    }
+}
+
 template <typename T, class M, int R> int launch_mrhs_finish(const LaunchParams &p) {
     const MrhsWs &ws = *reinterpret_cast<const MrhsWs *>(p.mrhs_ws);
     const unsigned grid = (unsigned)((p.B + 63) / 64);
     hipLaunchKernelGGL((mrhs_finish_kernel<T, M::N, M::Q>), dim3(grid), dim3(64), 0, p.stream,
                        (const LmVars<T, M::N, M::Q> *)ws.lm_state, p.B, (T *)p.alpha_out, p.report);
+    if (p.C_out && p.cost_out && p.status) {
+        const int64_t per = (int64_t)p.S * M::N;
+        unsigned gx = (unsigned)((per + 255) / 256);
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL((mrhs_gather_kernel<T>), dim3(gx, (unsigned)p.B), dim3(256), 0, p.stream, ws, p.B, p.S, (int)M::N,
+                           (T *)p.C_out, p.cost_out, p.status);
+    }
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
