@@ -235,9 +235,15 @@ template <typename T, int N, int P> struct MrhsStreamArgs {
     int64_t B;
 };
 
+#ifndef VP_MRHS_WAVES
+#define VP_MRHS_WAVES 8
+#endif
+#ifndef VP_MRHS_CH
+#define VP_MRHS_CH 8
+#endif
 // MODE 0: reduced quantities for the LM loop; MODE 1: trait-level outputs
 template <typename T, int N, int P, int R, int MODE>
-__global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArgs<T, N, P> a) {
+__global__ void __launch_bounds__(64 * VP_MRHS_WAVES) mrhs_stream_kernel(const MrhsStreamArgs<T, N, P> a) {
     constexpr int MP = 64 * R;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *s_q = reinterpret_cast<T *>(smem_raw); // [N][MP]
@@ -258,24 +264,23 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
         s_q[idx] = v;
     }
     const double *small = a.ws.small + b * mrhs_small_stride<N, P>();
-    T Ri[N][N];
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j < N; ++j) Ri[i][j] = (T)small[i * N + j];
+    // R^{-1} (or R^+) sits in LDS behind the columns, not in 2 N^2 VGPRs: read (broadcast) once per right-hand side
+    T *s_ri = s_q + (size_t)(N + P) * MP;
+    if (threadIdx.x < N * N) s_ri[threadIdx.x] = (T)small[threadIdx.x];
     const int stA = a.ws.statusA[b];
     const int wsel = (MODE == 0) ? (uni(a.ws.widx[b]) & 1) : 0;
     const bool truncated = uni(small[2 * N * N + P * P] != 0.0); // rank-deficient Phi_w: R^+ and P_n (rare)
     __syncthreads();
 
     using L = Layout<R>;
-    T acc_cost = T(0), acc_cc[N][N], acc_v[P > 0 ? P : 1];
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j < N; ++j) acc_cc[i][j] = T(0);
-#pragma unroll
-    for (int p = 0; p < P; ++p) acc_v[p] = T(0);
+    // the 1 + N^2 + P wave-uniform sums (cost | c c^T | c_{j(p)} u_p) live ONE PER LANE in a single register: lane k
+    // accumulates sum k (same fma per sum as a register per sum would do; 2 VGPRs instead of 2 (1 + N^2 + P))
+    constexpr int NACC = 1 + N * N + P;
+    static_assert(NACC <= 64, "one lane per accumulator");
+    T accv = T(0);
+    const int ak = lane < NACC ? lane : 0;
+    const int ai = (ak >= 1 && ak <= N * N) ? (ak - 1) / N : 0, aj = (ak >= 1 && ak <= N * N) ? (ak - 1) % N : 0;
+    const int ap = ak > N * N ? ak - 1 - N * N : 0;
 
     const int64_t gw = (int64_t)blockIdx.x * nwave + wave, nw = (int64_t)gridDim.x * nwave;
     for (int64_t s = gw; s < a.S; s += nw) {
@@ -286,7 +291,7 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
         load_rows<T, R>(yp, m, lane, yvec, y);
         // All row loops are processed in chunks of CH rows separated by scheduling fences: without them the
         // scheduler hoists the LDS reads of every (column, row) ahead (7 columns x R rows) and spills.
-        constexpr int CH = (R > 8) ? 8 : R;
+        constexpr int CH = (R > VP_MRHS_CH) ? VP_MRHS_CH : R;
         // T = Q^T y
         T tq[N];
 #pragma unroll
@@ -314,7 +319,7 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
                 T acc = T(0), accp = T(0);
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    acc = tfma(Ri[i][j], tq[j], acc);
+                    acc = tfma(s_ri[i * N + j], tq[j], acc);
                     accp = tfma((T)small[N * N + P * P + i * N + j], tq[j], accp);
                 }
                 c[i] = acc;
@@ -327,7 +332,7 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
             for (int i = 0; i < N; ++i) {
                 T acc = T(0);
 #pragma unroll
-                for (int j = i; j < N; ++j) acc = tfma(Ri[i][j], tq[j], acc);
+                for (int j = i; j < N; ++j) acc = tfma(s_ri[i * N + j], tq[j], acc);
                 c[i] = acc;
             }
         }
@@ -371,7 +376,6 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
             }
             __builtin_amdgcn_sched_barrier(0);
             wave_allreduce(red);
-            acc_cost += red[0];
             { // the column's coefficients / cost / status at this trial point (kept if the LM accepts it)
                 bool ok = is_finite(red[0]) && stA == VP_ST_OK;
 #pragma unroll
@@ -382,12 +386,17 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
                 }
                 if (lane < N) ((T *)a.ws.cbuf[wsel])[prob * N + lane] = dyn_get<N>(c, lane);
             }
+            {
+                T cpb = T(0), up = T(0); // c_{j(p)}, u_p of this lane's pair
 #pragma unroll
-            for (int i = 0; i < N; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) acc_cc[i][j] = tfma(c[i], c[j], acc_cc[i][j]);
-#pragma unroll
-            for (int p = 0; p < P; ++p) acc_v[p] = tfma(dyn_get<N>(c, a.pb[p]), red[1 + p], acc_v[p]);
+                for (int p = 0; p < P; ++p) {
+                    cpb = (ap == p) ? dyn_get<N>(c, a.pb[p]) : cpb;
+                    up = (ap == p) ? red[1 + p] : up;
+                }
+                const T fa_ = (ak == 0) ? red[0] : (ak <= N * N ? dyn_get<N>(c, ai) : cpb);
+                const T fb_ = (ak == 0) ? T(1) : (ak <= N * N ? dyn_get<N>(c, aj) : up);
+                accv = tfma(fa_, fb_, accv);
+            }
         } else {
             T r1[1] = {red[0]};
             wave_allreduce(r1);
@@ -426,19 +435,9 @@ __global__ void __launch_bounds__(512, 2) mrhs_stream_kernel(const MrhsStreamArg
     if constexpr (MODE == 0) {
         // workgroup-level reduction of the per-wave partial sums, then ONE plain store per workgroup into its
         // own slot acc[b][blockIdx.x][:] (no atomics: 2048 waves x 20 same-address atomics cost ~0.5 ms)
-        constexpr int NACC = 1 + N * N + P;
         __syncthreads(); // everyone is done reading s_q / s_g: reuse the front of the LDS as scratch
         double *s_part = reinterpret_cast<double *>(smem_raw);
-        if (lane == 0) {
-            double *mine = s_part + wave * NACC;
-            mine[0] = (double)acc_cost;
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) mine[1 + i * N + j] = (double)acc_cc[i][j];
-#pragma unroll
-            for (int p = 0; p < P; ++p) mine[1 + N * N + p] = (double)acc_v[p];
-        }
+        if (lane < NACC) s_part[wave * NACC + lane] = (double)accv;
         __syncthreads();
         if (threadIdx.x < NACC) {
             double tot = 0.0;
@@ -636,8 +635,8 @@ template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams 
     a.m = p.m;
     a.S = p.S;
     a.B = p.B;
-    const size_t lds = (size_t)(N + P) * 64 * R * sizeof(T);
-    const int waves_per_wg = 8;
+    const size_t lds = (size_t)(N + P) * 64 * R * sizeof(T) + (size_t)N * N * sizeof(T);
+    const int waves_per_wg = VP_MRHS_WAVES;
     const int gx = mrhs_gx(p.S);
     dim3 grid((unsigned)gx, (unsigned)p.B), block(64 * waves_per_wg);
     hipError_t e;
