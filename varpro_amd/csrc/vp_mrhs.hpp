@@ -257,11 +257,41 @@ __global__ void __launch_bounds__(64 * VP_MRHS_WAVES) mrhs_stream_kernel(const M
     }
     const T *qsrc = (const T *)a.ws.qthin + b * (int64_t)N * m;
     const T *gsrc = (const T *)a.ws.g + b * (int64_t)P * m;
-    for (int idx = threadIdx.x; idx < (N + P) * MP; idx += blockDim.x) {
-        const int col = idx / MP, row = idx - col * MP;
-        T v = T(0);
-        if (row < m) v = (col < N) ? qsrc[(int64_t)col * m + row] : gsrc[(int64_t)(col - N) * m + row];
-        s_q[idx] = v;
+    // stage Q and G in LDS.  Fast path (row pairs divide evenly over the workgroup, m even): every thread requests ALL of
+    // its 16-byte pieces before it stores the first one -- the element-by-element loop below is (N+P)*MP/threads dependent
+    // global loads deep, ~6 us in front of a pass that streams for ~60
+    auto stage_slow = [&]() __attribute__((always_inline)) {
+        for (int idx = threadIdx.x; idx < (N + P) * MP; idx += blockDim.x) {
+            const int col = idx / MP, row = idx - col * MP;
+            T v = T(0);
+            if (row < m) v = (col < N) ? qsrc[(int64_t)col * m + row] : gsrc[(int64_t)(col - N) * m + row];
+            s_q[idx] = v;
+        }
+    };
+    constexpr int NT = 64 * VP_MRHS_WAVES, PAIRS = MP / 2;
+    if constexpr (PAIRS % NT == 0 && sizeof(T) == 8) {
+        if ((m & 1) == 0 && blockDim.x == NT) {
+            constexpr int KP = PAIRS / NT;
+            double2 tmp[(N + P) * KP];
+#pragma unroll
+            for (int c = 0; c < N + P; ++c) {
+                const T *src = (c < N) ? qsrc + (int64_t)c * m : gsrc + (int64_t)(c - N) * m;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    const int row = 2 * ((int)threadIdx.x + k * NT);
+                    tmp[c * KP + k] = (row < m) ? *reinterpret_cast<const double2 *>(src + row) : make_double2(0.0, 0.0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < N + P; ++c)
+#pragma unroll
+                for (int k = 0; k < KP; ++k)
+                    *reinterpret_cast<double2 *>(s_q + (size_t)c * MP + 2 * ((int)threadIdx.x + k * NT)) = tmp[c * KP + k];
+        } else {
+            stage_slow();
+        }
+    } else {
+        stage_slow();
     }
     const double *small = a.ws.small + b * mrhs_small_stride<N, P>();
     // R^{-1} (or R^+) sits in LDS behind the columns, not in 2 N^2 VGPRs: read (broadcast) once per right-hand side
