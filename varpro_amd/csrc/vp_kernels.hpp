@@ -274,10 +274,14 @@ template <typename T, class M> struct BasisArgs {
 
 // Stand-alone Phi/dPhi: reads q scalars (+ the shared grid from L2), writes (n + p) * m scalars per
 // problem with 16-byte-per-lane fully coalesced stores: HBM-write-bound by construction.
-// W == 1: four problems per workgroup, one per wave (a quarter of the workgroup dispatches for the same stores: 1-2 % on
-// the median launch; non-temporal stores, also tried, cost 5-15 %: tools/basis_probe.py)
+// W == 1: EIGHT problems per workgroup, one per wave: 0.377 vs 0.403 ms (4 per workgroup) vs 0.429 (16) on the same box
+// (tools/basis_var_probe.py).  What was measured around it (tools/store_pattern.hip, pure stores of the same 2.1 GB):
+// one 16-byte store per thread in a linear sweep 0.313 ms (6.85 TB/s), hipMemset 0.33, one wave per problem 0.36-0.38,
+// persistent waves 0.41-0.46; an element-wise form of this kernel (thread = one row pair of one column) follows the
+// linear sweep but its extra index / reciprocal arithmetic per 32 bytes makes the clocks sag (0.36-0.50 ms); stores
+// issued row pair by row pair at 41 VGPRs: no change; non-temporal stores: 5-15 % slower.
 #ifndef VP_BASIS_WPB
-#define VP_BASIS_WPB 4
+#define VP_BASIS_WPB 8
 #endif
 template <typename T, class M, int R, int W, bool ALIGNED>
 __global__ void __launch_bounds__(64 * W * (W == 1 ? VP_BASIS_WPB : 1)) basis_kernel(const BasisArgs<T, M> a) {
