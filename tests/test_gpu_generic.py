@@ -216,3 +216,37 @@ def test_generic_multiple_right_hand_sides_evaluate_and_fp32():
     a32, c32, rep32 = bp32.fit(alpha[None].astype(np.float32) * 1.02)
     assert rep32["termination"][0] > 0 or rep32["objective"][0] <= 1e-4 * 0.5 * (Y[0] ** 2).sum()
     bp32.close()
+
+
+def test_generic_global_fit_weighted_and_fp32():
+    # the generic one-launch global fit with weights (fp64, against the oracle) and on an fp32 handle (recovers the truth
+    # to what fp32 resolves)
+    m, S = 600, 7
+    x = 8.0 * np.arange(m) / (m - 1) + 0.05
+    kinds = [basis.EXP_DECAY, basis.EXP_RATE, basis.EXP_COS, basis.CONST]
+    params = [(0,), (1,), (2, 3), ()]
+    alpha = np.array([1.7, 0.9, 0.25, 1.3])
+    mdl = SeparableModel(["a", "b", "c", "d"], kinds, params, x, alpha)
+    rng = np.random.default_rng(21)
+    Phi = O.eval_phi(mdl, x, alpha).T
+    Ctrue = rng.uniform(1, 5, (S, 4))
+    Y = Ctrue @ Phi.T + 1e-3 * rng.standard_normal((S, m))
+    w = np.linspace(0.5, 2.0, m)
+    guess = alpha * np.array([1.04, 0.97, 1.03, 0.98])
+    bp = vp.BatchProblem(mdl, Y[None], x=x, weights=w)
+    a_fit, C_fit, rep = bp.fit(guess[None])
+    ref = O.Problem(mdl, x, Y, w=w)
+    ref.set_params(guess)
+    rr = ref.fit()
+    assert rep["termination"][0] > 0 and rr.termination > 0
+    assert abs(rep["objective"][0] - rr.objective) <= 1e-6 * rr.objective
+    assert np.abs(a_fit[0] - ref.params()).max() <= 1e-5 * np.abs(ref.params()).max()
+    assert np.abs(C_fit[0] - ref.linear_coefficients()).max() <= 1e-4 * np.abs(C_fit).max()
+    bp.close()
+    mdl32 = SeparableModel(["a", "b", "c", "d"], kinds, params, x.astype(np.float32), alpha.astype(np.float32), dtype=np.float32)
+    Yc = Ctrue @ Phi.T                                            # noise-free: the truth is the minimum
+    bp32 = vp.BatchProblem(mdl32, Yc[None].astype(np.float32), x=x.astype(np.float32))
+    a32, C32, rep32 = bp32.fit(guess[None].astype(np.float32))
+    assert rep32["termination"][0] > 0 or rep32["objective"][0] <= 1e-8 * 0.5 * (Yc ** 2).sum()
+    assert np.abs(a32[0] - alpha).max() <= 2e-2 * np.abs(alpha).max()
+    bp32.close()
