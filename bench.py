@@ -228,6 +228,20 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
 
+        def event_ms_each(fn, reps, warm=3):
+            """mean duration of INDIVIDUAL launches (an event pair around each one): what a kernel trace reports per
+            dispatch.  Back-to-back launches of a kernel made of very short-lived waves start filling the CUs the
+            draining launch frees, so elapsed / reps understates the per-dispatch duration (0.295 vs 0.352 ms here)."""
+            for _ in range(warm):
+                fn()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a_, b_ in ev:
+                a_.record()
+                fn()
+                b_.record()
+            torch.cuda.synchronize()
+            return sum(a_.elapsed_time(b_) for a_, b_ in ev) / reps
+
         def committed_traffic(key, field="hbm_bytes_per_launch_corrected"):
             """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json)"""
             try:
@@ -241,7 +255,8 @@ def main():
         n_alpha, p = 2, 2
         phi = torch.empty((B, n_alpha, m), dtype=torch.float64, device=dev)
         dphi = torch.empty((B, p, m), dtype=torch.float64, device=dev)
-        basis_ms = event_ms(lambda: bp.basis(guess, skip_invariant=True, out_phi=phi, out_dphi=dphi), max(args.steps, 20), 3)
+        basis_ms = event_ms_each(lambda: bp.basis(guess, skip_invariant=True, out_phi=phi, out_dphi=dphi), max(args.steps, 20), 3)
+        basis_ms_back_to_back = event_ms(lambda: bp.basis(guess, skip_invariant=True, out_phi=phi, out_dphi=dphi), max(args.steps, 20), 3)
         del phi, dphi
         bytes_phi = B * (T * (m * n_alpha + m * p) + T * 2) + T * m       # 32784 B/problem + grid
         bytes_fit = B * T * (m + 2 + 3 + 2)                                # SURVEY 8(d) B_fit = 8248 B/fit
@@ -279,10 +294,10 @@ def main():
                 "sum_cost": sum_cost,
             },
             "roofline": {
-                "kernel": "basis_kernel (vp_basis: stand-alone Phi/dPhi evaluation)",
+                "kernel": "basis_rowpair_kernel (vp_basis: stand-alone Phi/dPhi evaluation; one thread per row pair of a problem)",
                 "bound": "hbm", "achieved": gbs_phi, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs_phi / HBM_PEAK_GBS, "traffic": committed_traffic("basis_kernel"),
-                "bytes_per_launch": bytes_phi, "avg_launch_ms": basis_ms,
+                "frac": gbs_phi / HBM_PEAK_GBS, "traffic": committed_traffic("basis_rowpair_kernel") or committed_traffic("basis_kernel"),
+                "bytes_per_launch": bytes_phi, "avg_launch_ms": basis_ms, "back_to_back_ms_per_launch": basis_ms_back_to_back,
             },
             "roofline_fit": {
                 "kernel": "fit2_kernel (vp_fit: persistent slot kernel, dominant kernel of the timed step)",

@@ -283,6 +283,9 @@ template <typename T, class M> struct BasisArgs {
 #ifndef VP_BASIS_WPB
 #define VP_BASIS_WPB 8
 #endif
+#ifndef VP_BASIS_ROWPAIR
+#define VP_BASIS_ROWPAIR 1 /* multi-exponential fp64: the thread-per-row-pair kernel below */
+#endif
 template <typename T, class M, int R, int W, bool ALIGNED>
 __global__ void __launch_bounds__(64 * W * (W == 1 ? VP_BASIS_WPB : 1)) basis_kernel(const BasisArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
@@ -322,6 +325,37 @@ __global__ void __launch_bounds__(64 * W * (W == 1 ? VP_BASIS_WPB : 1)) basis_ke
             store_rows<T, R, W>(p, m, lane, ALIGNED, C[N + 1 + pidx]);
         }
     }
+}
+
+// Multi-exponential models in fp64 with aligned arrays (the case the HBM target is priced on): a THREAD owns one row pair
+// of one problem -- it evaluates the NE exponentials and their derivatives there, stores 2 NE x 16 bytes and retires; a
+// 256-thread workgroup covers 512 rows.  Workgroups are dispatched in address order, so every output column is written by
+// short-lived waves sweeping forward -- the closest this output layout gets to a memset's store pattern
+// (tools/store_pattern.hip: linear sweep 6.85 TB/s, one wave per problem 5.7-6.1): 0.352 vs 0.376 ms for 2.15 GB.  Same
+// arithmetic per element as build_columns; tau's reciprocal is recomputed per thread (8 of ~125 instructions).
+template <class M> __global__ void __launch_bounds__(256) basis_rowpair_kernel(const BasisArgs<double, M> a, const int blocks_per_problem) {
+    constexpr int NE = M::kConstLast ? M::N - 1 : M::N, Q = M::Q, P = M::P;
+    const int64_t b = blockIdx.x / (unsigned)blocks_per_problem;
+    const int piece = (int)(blockIdx.x - (unsigned)b * (unsigned)blocks_per_problem);
+    const int i = 2 * (piece * 256 + (int)threadIdx.x);
+    const int m = a.m;
+    if (i >= m) return;
+    const double2 tv = *reinterpret_cast<const double2 *>(a.t + b * a.t_stride + i);
+    double *phi = a.Phi_out ? a.Phi_out + b * (int64_t)a.n_phi_cols * m + i : nullptr;
+    double *dphi = a.dPhi_out ? a.dPhi_out + b * (int64_t)P * m + i : nullptr;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const double tau = a.alpha[b * Q + k];
+        const double rt = frcp(tau), rt2 = rt * rt;
+        double2 f, d;
+        f.x = texp(-div_refined(tv.x, tau, rt));
+        f.y = texp(-div_refined(tv.y, tau, rt));
+        d.x = (f.x * tv.x) * rt2;
+        d.y = (f.y * tv.y) * rt2;
+        if (phi) *reinterpret_cast<double2 *>(phi + (int64_t)k * m) = f;
+        if (dphi) *reinterpret_cast<double2 *>(dphi + (int64_t)k * m) = d;
+    }
+    if (M::kConstLast && !a.skip_invariant && phi) *reinterpret_cast<double2 *>(phi + (int64_t)NE * m) = make_double2(1.0, 1.0);
 }
 
 // ---- host-side launch templates ------------------------------------------------------------------
@@ -401,6 +435,15 @@ template <typename T, class M, int R, int W = 1> int launch_basis(const LaunchPa
     a.B = p.B;
     a.t_stride = p.t_stride;
     if (a.B <= 0) return VP_ERR_OK;
+#if VP_BASIS_ROWPAIR
+    if constexpr (M::kStatic && M::kDiagonalPairs && sizeof(T) == 8) {
+        const int bpp = (p.m / 2 + 255) / 256;
+        if (host_aligned<T>(p.m, {p.t, p.Phi_out, p.dPhi_out}) && a.B * bpp < ((int64_t)1 << 31)) {
+            hipLaunchKernelGGL((basis_rowpair_kernel<M>), dim3((unsigned)(a.B * bpp)), dim3(256), 0, p.stream, a, bpp);
+            return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+        }
+    }
+#endif
     constexpr int PPB = (W == 1) ? VP_BASIS_WPB : 1;
     const dim3 grid((unsigned)((a.B + PPB - 1) / PPB)), block(64 * W * PPB);
     if (host_aligned<T>(p.m, {p.t, p.Phi_out, p.dPhi_out}))
