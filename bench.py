@@ -106,6 +106,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-configs", action="store_true", help="skip the configs[0,1,2,4] side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--emulate-shards", type=int, default=8,
+                    help="N = 1 only: run the G per-GPU shards of BASELINE configs[3] (G x batch problems) one after another "
+                         "on this device and report per-shard time / evaluations and the predicted weak-scaling efficiency "
+                         "mean/max (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -242,13 +246,39 @@ def main():
             torch.cuda.synchronize()
             return sum(a_.elapsed_time(b_) for a_, b_ in ev) / reps
 
+        TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")
+
         def committed_traffic(key, field="hbm_bytes_per_launch_corrected"):
-            """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json)"""
-            try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-                return pj[key][field]
-            except Exception:
-                return None
+            """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r0x_pmc_traffic.json; separate
+            FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950) -- NOT measured in this run: see traffic_source"""
+            for fn in TRAFFIC_FILES:
+                try:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    return pj[key][field]
+                except Exception:
+                    continue
+            return None
+
+        def traffic_source(key):
+            for fn in TRAFFIC_FILES:
+                try:
+                    if key in json.load(open(os.path.join(ROOT, "profiles", fn))):
+                        return "committed PMC: profiles/" + fn
+                except Exception:
+                    continue
+            return None
+
+        def committed_valu_issue(key):
+            """VALU issue fraction over the launch from the committed SQ PMC pass (profiles/r0x_fit_kernels_valu_pmc.json)"""
+            for fn in ("r03_fit_kernels_valu_pmc.json", "r02_fit_kernels_valu_pmc.json"):
+                try:
+                    e = json.load(open(os.path.join(ROOT, "profiles", fn)))[key]
+                    # wave-level VALU instructions x 4 issue cycles / (1024 SIMDs x launch duration x 2.4 GHz)
+                    frac = e["SQ_INSTS_VALU"] * 4.0 / (1024.0 * e["avg_duration_ns_under_pmc"] * 1e-9 * 2.4e9)
+                    return frac, "committed PMC: profiles/" + fn
+                except Exception:
+                    continue
+            return None, None
 
         # ---- per-kernel durations with HIP events on the launch stream ----
         fit_ms = event_ms(lambda: bp.fit(guess, want_coefficients=False), args.steps)
@@ -262,9 +292,9 @@ def main():
         bytes_fit = B * T * (m + 2 + 3 + 2)                                # SURVEY 8(d) B_fit = 8248 B/fit
         gbs_phi = bytes_phi / (basis_ms * 1e-3) / 1e9
         gbs_fit = bytes_fit / (fit_ms * 1e-3) / 1e9
-        # algorithmic fp64 flops of one evaluation of the fused fit: two exp columns 2m x 28,
-        # fused sweep over [Phi | y | D] 4m(5+4+3), Jacobian QR 12m
-        flops_eval = 2 * m * 28 + 4 * m * (5 + 4 + 3) + 12 * m
+        # algorithmic fp64 flops of one evaluation, SURVEY 8(d): m n_alpha E_exp + 2 m n^2 + 4 m n S + (4n+2) m S q with
+        # n = 3, n_alpha = 2, q = 2, S = 1, E_exp = 28 -> 116736 at m = 1024
+        flops_eval = m * 2 * 28 + 2 * m * 9 + 4 * m * 3 + (4 * 3 + 2) * m * 2
         tflops_fit = B * evals_per_fit * flops_eval / (fit_ms * 1e-3) / 1e12
         out = {
             "metric": "independent fits/sec (double-exp, m=%d, fp64)" % m,
@@ -280,9 +310,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[3] per-GPU shard (= north_star 1-GPU headline): %d independent "
-                            "double-exponential+offset fits per GPU, m=%d, n=3, q=2, fp64, noise %.0e, full LM fit to "
-                            "convergence per step, one batch at a time on one HIP stream" % (B, m, args.noise),
+                "workload": "B=%d fits/GPU, m=%d, fp64, n=3, q=2 (double-exp+offset), full LM fit per step = BASELINE "
+                            "configs[3] per-GPU shard = north_star 1-GPU headline; noise %.0e, one batch at a time on one "
+                            "HIP stream" % (B, m, args.noise),
                 "batch_per_gpu": B, "m": m, "parallelism": "batch-sharded x%d" % world,
                 "world_size": dist.get_world_size() if use_dist else 1,
                 "collective_backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if use_dist else None,
@@ -297,6 +327,7 @@ def main():
                 "kernel": "basis_rowpair_kernel (vp_basis: stand-alone Phi/dPhi evaluation; one thread per row pair of a problem)",
                 "bound": "hbm", "achieved": gbs_phi, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs_phi / HBM_PEAK_GBS, "traffic": committed_traffic("basis_rowpair_kernel") or committed_traffic("basis_kernel"),
+                "traffic_source": traffic_source("basis_rowpair_kernel") or traffic_source("basis_kernel"),
                 "bytes_per_launch": bytes_phi, "avg_launch_ms": basis_ms, "back_to_back_ms_per_launch": basis_ms_back_to_back,
             },
             "roofline_fit": {
@@ -304,6 +335,8 @@ def main():
                 "bound": "fp64_valu", "achieved": tflops_fit, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops_fit / FP64_VALU_PEAK_TFLOPS, "flops_per_evaluation": flops_eval,
                 "hbm_achieved_GBps": gbs_fit, "hbm_frac": gbs_fit / HBM_PEAK_GBS, "traffic": committed_traffic("fit2_kernel"),
+                "traffic_source": traffic_source("fit2_kernel"),
+                "valu_issue_frac": committed_valu_issue("fit2_kernel")[0], "valu_issue_source": committed_valu_issue("fit2_kernel")[1],
                 "bytes_per_launch": bytes_fit, "avg_launch_ms": fit_ms, "fits_per_s_kernel_only": B / (fit_ms * 1e-3),
             },
         }
@@ -348,6 +381,39 @@ def main():
                 }
                 bp1.close()
 
+            # ---- configs[3] emulated on ONE device: the G per-GPU shards of the G x B problem set, one after another ----
+            # The multi-GPU run is weak-scaled with no data-path collective: rank g fits shard g (problems g*B ..
+            # (g+1)*B-1) and the step ends with a 32-byte all-reduce, so its step time is the SLOWEST shard's.  The only
+            # scaling loss this design has is the imbalance of the shards' work (evaluation counts are heavy-tailed):
+            # predicted efficiency = mean / max of the per-shard step times.
+            G = args.emulate_shards
+            if G > 1:
+                shard_ms, shard_evals, shard_max = [], [], []
+                for g in range(G):
+                    fg, cg = vd.shard_range(G * B, g, G)
+                    dg = d if g == 0 else synth.double_exp_batch(cg, m=m, first_problem=fg, noise=args.noise)
+                    if g > 0:
+                        bp.set_observations(torch.from_numpy(dg["Y"]).to(dev))
+                    gg = torch.from_numpy(dg["tau_guess"]).to(dev)
+                    shard_ms.append(event_ms(lambda: bp.fit(gg, want_coefficients=False), 5, 1))
+                    _ag, _cg, repg = bp.fit(gg, want_coefficients=False)
+                    ng = bp.report_to_numpy(repg)["n_evals"]
+                    shard_evals.append(int(ng.sum()))
+                    shard_max.append(int(ng.max()))
+                    del dg
+                bp.set_observations(Y)
+                sm, se = np.array(shard_ms), np.array(shard_evals, dtype=np.float64)
+                out["configs3_emulated"] = {
+                    "workload": "BASELINE configs[3]: %d problems = %d shards of %d (contiguous split, varpro_amd/distributed.py"
+                                ":shard_range), each shard fitted alone on this one device" % (G * B, G, B),
+                    "shards": G, "per_shard_ms_per_step": [float(v) for v in sm],
+                    "per_shard_sum_evaluations": shard_evals, "per_shard_max_evaluations": shard_max,
+                    "predicted_efficiency": float(sm.mean() / sm.max()),
+                    "predicted_efficiency_from_evaluation_counts": float(se.mean() / se.max()),
+                    "predicted_fits_per_s_at_%d_gpus" % G: float(G * B / (sm.max() * 1e-3)),
+                    "note": "kernel time only (HIP events); the real run adds one RCCL all-reduce of 4 doubles per step",
+                }
+
             # ---- configs[2]: one alpha shared by S = 16384 right-hand sides, m = 2048, triple-exp + offset ----
             S2, m2 = 16384, 2048
             d2 = synth.mrhs_triple_exp(S=S2, m=m2)
@@ -378,7 +444,8 @@ def main():
                 "roofline": {"kernel": "mrhs_stream_kernel<MODE 1> (+ mrhs_factor_kernel): y in, r and J out", "bound": "hbm",
                              "achieved": bytes_ev2 / (ev2_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": bytes_ev2 / (ev2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bytes_ev2,
-                             "traffic": committed_traffic("mrhs_stream_kernel_mode1")},
+                             "traffic": committed_traffic("mrhs_stream_kernel_mode1"),
+                             "traffic_source": traffic_source("mrhs_stream_kernel_mode1")},
                 "roofline_fit": {"kernel": "mrhs_stream_kernel<MODE 0>: y re-read once per LM evaluation", "bound": "hbm",
                                  "achieved": T * m2 * S2 * int(r2["n_evals"][0]) / (fit2_ms * 1e-3) / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -398,19 +465,24 @@ def main():
             ms4 = event_ms(lambda: bp4.fit(g4, want_coefficients=False), 5, 2)
             _a4, _c4, rep4 = bp4.fit(g4, want_coefficients=False)
             r4 = bp4.report_to_numpy(rep4)
-            # the fit runs on the fp64 Gram matrix of [Phi | y | dPhi] (vp_fitg.hpp): per row 66 fp64 FMAs + 11 adds
-            # (77 accumulators), 5 recurrence + 10 derivative multiplies = 158 fp64 flops
+            # the fit runs on the fp64 Gram matrix of [Phi | y | dPhi] (vp_fitg.hpp).  ALGORITHMIC flops of one Gram
+            # evaluation, as priced since round 2: per row the 66 + 11 inner products of the 11 columns + constant
+            # (66 FMAs + 11 adds), 5 exponential + 10 derivative multiplies = 158 fp64 flops.  The round-3 kernel EXECUTES
+            # fewer: the moment form needs 56 FMAs + 11 adds + 10 multiplies = 133 per row (both fractions reported).
             flops4 = m4 * 158
+            flops4_exec = m4 * 133
             tf4 = float(r4["n_evals"].sum()) * flops4 / (ms4 * 1e-3) / 1e12
             out["configs4"] = {
                 "workload": "BASELINE configs[4]: %d fp32 fits, five exponentials + offset (n=6, q=5), m=%d" % (B4, m4),
                 "fits_per_s": B4 / (ms4 * 1e-3), "ms_per_step": ms4, "mean_evaluations_per_fit": float(r4["n_evals"].mean()),
                 "fraction_failed": float((r4["termination"] <= 0).mean()),
-                "roofline": {"kernel": "fitg_kernel<5 exp + offset> (fp32 data, fp64 Gram pass + Cholesky-based LM; 4 wavefronts per "
-                                       "problem, 8 slots per group)", "bound": "fp64_valu",
+                "roofline": {"kernel": "fitg_kernel<5 exp + offset> (fp32 data, fp64 moment/Gram pass + Cholesky-based LM; "
+                                       "independent persistent wavefronts, 3 problem slots each)", "bound": "fp64_valu",
                              "achieved": tf4, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf4 / FP64_VALU_PEAK_TFLOPS, "flops_per_evaluation": flops4,
-                             "hbm_bytes_per_evaluation": 4 * m4},
+                             "flops_executed_per_evaluation": flops4_exec, "frac_executed": tf4 * flops4_exec / flops4 / FP64_VALU_PEAK_TFLOPS,
+                             "hbm_bytes_per_evaluation": 4 * m4, "traffic": committed_traffic("fitg_kernel"),
+                             "traffic_source": traffic_source("fitg_kernel")},
             }
             bp4.close()
             del Y4
@@ -430,7 +502,7 @@ def main():
         G0 = np.tile(c0["tau_guess"][None, :], (reps0, 1))
         _a, _c, rep0, secs0 = O.fit_batch(mdl0, c0["x"], Y0, G0, n_threads=1)
         # (ii) single thread on the batch workload (the yardstick for the parallel efficiency)
-        n1 = 256
+        n1 = min(B, 6144)  # >= 2 s of single-thread work: a yardstick long enough that parallel_efficiency <= 1
         t1 = time.perf_counter()
         _a, _c, rep1, secs1 = O.fit_batch(mdl, d["x"], d["Y"][:n1], d["tau_guess"][:n1], n_threads=1)
         rate1 = n1 / secs1
@@ -455,7 +527,7 @@ def main():
                          ", capped by the container's cgroup CPU quota of %g CPUs" % quota, wall),
             "fits_per_s_inside_fits": n_cpu / max(secs_fit, 1e-9),
             "mean_evaluations_per_fit": float(rep_cpu["n_evals"].mean()),
-            "single_thread_fits_per_s": rate1,
+            "single_thread_fits_per_s": rate1, "single_thread_sample": "%d problems, %.2f s" % (n1, secs1),
             "parallel_efficiency": (n_cpu / max(secs_fit, 1e-9)) / (threads * rate1),
             "configs0_single_thread": {"us_per_fit": secs0 / reps0 * 1e6, "evaluations_per_fit": float(rep0["n_evals"].mean()),
                                        "us_per_evaluation": secs0 / reps0 * 1e6 / float(rep0["n_evals"].mean())},

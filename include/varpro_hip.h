@@ -274,6 +274,16 @@ int vp_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, 
 int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep,
                  double *trace_out, int trace_rows);
 
+/*
+ * Diagnostics for the fixed-alpha parity tests of the fp64-Gram fit kernel (VP_F32 handles whose fit runs on the normal
+ * equations in double, see vp_set_fit_kernel): evaluates that kernel's formulation ONCE at alpha [B][q] and writes, per
+ * problem, out[b] = { 1/2 ||r||^2, c (n), J^T r (q), J^T J (q x q, row-major) } as f64 -- the quantities the kernel
+ * hands to its LM step, i.e. set_params + residuals + jacobian (src/solvers/levmar/mod.rs:42-73, 101-201) contracted
+ * the way the LM driver consumes them.  Does not touch the handle's cached state.  VP_ERR_UNSUPPORTED for handles whose
+ * fit does not use the Gram kernel.  `out` follows the handle's address space.
+ */
+int vp_debug_gram_evaluate(vp_batch *h, const void *alpha, double *out);
+
 /* == FitResult::best_fit (src/fit.rs:55-59,87-91): UNWEIGHTED Phi(alpha) * C, [B][S][m] */
 int vp_best_fit(vp_batch *h, void *fit_out);
 

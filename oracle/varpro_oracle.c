@@ -782,12 +782,18 @@ static void trace_row(double *trace, int max_rows, int *row, int n, const double
 
 void vpo_fit(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep) { vpo_fit_trace(p, opts, rep, NULL, 0); }
 
-/* same as vpo_fit; additionally records one row [x_trial(q), ||r(x_trial)||, ratio, delta, par] per
- * evaluation (row 0: the initial point with ratio = NaN) -- used by the per-iteration parity tests */
-int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double *trace, int max_rows) {
+/* == levenberg_marquardt::LevenbergMarquardt::minimize (call site src/solvers/levmar/mod.rs:247) over ANY
+ * LeastSquaresProblem given as callbacks (vpo_lsq): MINPACK lmder with the crate's termination semantics.  The
+ * problem is only touched through set_params / residuals / jacobian, exactly as the crate touches the trait
+ * (src/solvers/levmar/mod.rs:22-202) -- so the same driver can run on the CPU restatement (vpo_fit_trace below) or,
+ * in tests, on the C ABI of the device library (tests/c/test_trait_lm.c).  Records one row [x_trial(q),
+ * ||r(x_trial)||, ratio, delta, par] per evaluation (row 0: the initial point with ratio = NaN).
+ * fvec, fwork: mr doubles each; fjac: mr*n doubles (workspace owned by the caller). */
+int vpo_lm_minimize(const vpo_lsq *P, const vp_lm_opts *opts, vp_report *rep, double *trace, int max_rows,
+                    double *fvec, double *fwork, double *fjac) {
     int trow = 0;
-    const int n = p->model.n_params;       /* LM "n" = number of parameters q */
-    const int mr = p->m * p->S;            /* LM "m" = number of residuals */
+    const int n = P->n;                    /* LM "n" = number of parameters q */
+    const int mr = P->mr;                  /* LM "m" = number of residuals */
     const double epsmch = DBL_EPSILON;
     vp_report report;
     report.termination = VP_TERM_NO_PARAMETERS;
@@ -798,16 +804,12 @@ int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double
     double rdiag[VP_MAX_PARAMS], acnorm[VP_MAX_PARAMS], wa[VP_MAX_PARAMS];
     double rmat[VP_MAX_PARAMS * VP_MAX_PARAMS];
     int ipvt[VP_MAX_PARAMS];
-    double *fvec = NULL, *fjac = NULL, *fwork = NULL;
     double fnorm = 0, delta = 0, par = 0, xnorm = 0, gnorm = 0;
     int first_tr = 1, first_update = 1;
     const int max_fev = opts->patience * (n + 1);
     if (n == 0) goto done;
-    fvec = p->ws_fvec;
-    fwork = p->ws_fwork;
-    fjac = p->ws_fjac;
-    memcpy(x, p->alpha, sizeof(double) * n);
-    if (!vpo_residuals(p, fvec)) {
+    P->params(P->user, x);
+    if (!P->residuals(P->user, fvec)) {
         report.termination = VP_TERM_USER;
         goto done;
     }
@@ -833,7 +835,7 @@ int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double
     for (int j = 0; j < n; ++j) diag[j] = 1.0;
 
     for (;;) { /* outer loop: new Jacobian */
-        if (!vpo_jacobian(p, fjac)) {
+        if (!P->jacobian(P->user, fjac)) {
             report.termination = VP_TERM_USER;
             goto done;
         }
@@ -917,9 +919,9 @@ int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double
             if (first_tr && pnorm < delta) delta = pnorm;
             first_tr = 0;
             for (int j = 0; j < n; ++j) xt[j] = x[j] - step[j];
-            vpo_set_params(p, xt);
+            P->set_params(P->user, xt);
             report.n_evals += 1;
-            if (!vpo_residuals(p, fwork)) {
+            if (!P->residuals(P->user, fwork)) {
                 report.termination = VP_TERM_USER;
                 goto done;
             }
@@ -969,7 +971,7 @@ int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double
             if (!term && delta <= epsmch * xnorm) term = VP_TERM_NO_IMPROVEMENT;
             if (!term && gnorm <= epsmch) term = VP_TERM_NO_IMPROVEMENT;
             if (term) {
-                if (!good) vpo_set_params(p, x); /* reset_params_if(!update_considered_good) */
+                if (!good) P->set_params(P->user, x); /* reset_params_if(!update_considered_good) */
                 report.termination = term;
                 goto done;
             }
@@ -979,6 +981,28 @@ int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double
 done:
     if (rep) *rep = report;
     return trow;
+}
+
+/* the CPU restatement as a LeastSquaresProblem */
+static void lsq_set_params(void *u, const double *x) { vpo_set_params((vpo_problem *)u, x); }
+static void lsq_params(void *u, double *x) {
+    vpo_problem *p = (vpo_problem *)u;
+    memcpy(x, p->alpha, sizeof(double) * p->model.n_params);
+}
+static int lsq_residuals(void *u, double *r) { return vpo_residuals((vpo_problem *)u, r); }
+static int lsq_jacobian(void *u, double *J) { return vpo_jacobian((vpo_problem *)u, J); }
+
+/* same as vpo_fit; additionally records the per-evaluation trace -- used by the per-iteration parity tests */
+int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double *trace, int max_rows) {
+    vpo_lsq P;
+    P.n = p->model.n_params;
+    P.mr = p->m * p->S;
+    P.user = p;
+    P.set_params = lsq_set_params;
+    P.params = lsq_params;
+    P.residuals = lsq_residuals;
+    P.jacobian = lsq_jacobian;
+    return vpo_lm_minimize(&P, opts, rep, trace, max_rows, p->ws_fvec, p->ws_fwork, p->ws_fjac);
 }
 
 /* ------------------------------------------------------------------------------------------- */

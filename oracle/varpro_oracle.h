@@ -92,6 +92,22 @@ void vpo_fit(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep);
 /* vpo_fit + per-evaluation trace rows [x_trial(q), ||r||, ratio, delta, par]; returns rows written */
 int vpo_fit_trace(vpo_problem *p, const vp_lm_opts *opts, vp_report *rep, double *trace, int max_rows);
 
+/* A LeastSquaresProblem as the levenberg-marquardt crate sees it (src/solvers/levmar/mod.rs:22-202): the driver below
+ * touches the problem through these four calls only.  residuals / jacobian return 0 for the trait's `None`. */
+typedef struct vpo_lsq {
+    int n;  /* number of parameters */
+    int mr; /* number of residuals (m * S) */
+    void *user;
+    void (*set_params)(void *user, const double *x);
+    void (*params)(void *user, double *x);
+    int (*residuals)(void *user, double *r);  /* mr */
+    int (*jacobian)(void *user, double *J);   /* mr x n, column-major */
+} vpo_lsq;
+/* == LevenbergMarquardt::minimize over callbacks; vpo_fit_trace is this driver on the CPU restatement.  Workspace:
+ * fvec, fwork mr doubles each, fjac mr*n doubles.  Returns the trace rows written. */
+int vpo_lm_minimize(const vpo_lsq *P, const vp_lm_opts *opts, vp_report *rep, double *trace, int max_rows,
+                    double *fvec, double *fwork, double *fjac);
+
 /* thin SVD A (m x n, col-major, m >= n) = U diag(sigma) V^T, sigma descending */
 void vpo_thin_svd(int m, int n, const double *A, double *U, double *sigma, double *V);
 

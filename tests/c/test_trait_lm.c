@@ -1,0 +1,241 @@
+/* The trait-level drop-in, end to end (stand-in for the Rust shim that cannot be compiled in this image).
+ *
+ * In the reference the UNCHANGED levenberg_marquardt::LevenbergMarquardt::minimize
+ * (/root/reference/src/solvers/levmar/mod.rs:247) drives a SeparableProblem through the LeastSquaresProblem trait:
+ * set_params -> residuals -> jacobian (/root/reference/src/solvers/levmar/mod.rs:22-202).  Here an EXTERNAL
+ * MINPACK-style driver -- the oracle's lmder loop (oracle/varpro_oracle.c: vpo_lm_minimize), compiled into THIS TEST,
+ * never into the product -- calls vp_set_params / vp_residuals / vp_jacobian on a device handle through the C ABI
+ * only, exactly as minimize() calls the trait, and runs to convergence.  Checked against
+ *   (1) vp_fit on the same data (the fused device-resident LM), and
+ *   (2) the oracle's own fit (the same driver on the CPU restatement):
+ * same termination reason, evaluation counts within +-2, the leading trial points of the trajectory, the final
+ * parameters and objective.
+ * Cases: S = 1 on the configs[0] quirk grid; S = 2 (Jacobian branch S <= q) and S = 3 (branch S > q); weights; a
+ * failing set_params (status != 0 <=> residuals() == None -> TerminationReason::User).
+ * usage: test_trait_lm            (prints "no device" and exits 0 without a GPU) */
+#include "varpro_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    vp_batch *h;
+    int q, mr;
+    int calls_set, calls_res, calls_jac;
+} dev_problem;
+
+static void d_set_params(void *u, const double *x) {
+    dev_problem *p = (dev_problem *)u;
+    p->calls_set++;
+    if (vp_set_params(p->h, x) != 0) {
+        printf("vp_set_params: %s\n", vp_last_error());
+        exit(2);
+    }
+}
+static void d_params(void *u, double *x) {
+    dev_problem *p = (dev_problem *)u;
+    if (vp_params(p->h, x) != 0) {
+        printf("vp_params: %s\n", vp_last_error());
+        exit(2);
+    }
+}
+static int d_residuals(void *u, double *r) {
+    dev_problem *p = (dev_problem *)u;
+    int32_t st = -1;
+    p->calls_res++;
+    if (vp_residuals(p->h, r, &st) != 0) {
+        printf("vp_residuals: %s\n", vp_last_error());
+        exit(2);
+    }
+    return st == VP_ST_OK; /* status != 0 <=> None */
+}
+static int d_jacobian(void *u, double *J) {
+    dev_problem *p = (dev_problem *)u;
+    int32_t st = -1;
+    p->calls_jac++;
+    if (vp_jacobian(p->h, J, &st) != 0) {
+        printf("vp_jacobian: %s\n", vp_last_error());
+        exit(2);
+    }
+    return st == VP_ST_OK;
+}
+
+static void double_exp_model(vp_model_desc *d, int offset) {
+    memset(d, 0, sizeof *d);
+    d->n_basis = offset ? 3 : 2;
+    d->n_params = 2;
+    d->kind[0] = VP_BASIS_EXP_DECAY; d->param[0][0] = 0; d->param[0][1] = -1;
+    d->kind[1] = VP_BASIS_EXP_DECAY; d->param[1][0] = 1; d->param[1][1] = -1;
+    if (offset) { d->kind[2] = VP_BASIS_CONST; d->param[2][0] = -1; d->param[2][1] = -1; }
+}
+
+#define ROWS 64
+
+static int run_case(const char *name, const vp_model_desc *mdl, int m, int S, const double *t, const double *Y,
+                    const double *w, const double *alpha0, int expect_user, double tol_alpha) {
+    const int q = mdl->n_params, n = mdl->n_basis, mr = m * S, W = q + 4;
+    int failures = 0, i, k, rows_ext, rows_fit, rows_orc, build_err = 0;
+    vp_lm_opts o;
+    vp_report rep_ext, rep_fit, rep_orc;
+    double a_ext[VP_MAX_PARAMS], a_fit[VP_MAX_PARAMS], a_orc[VP_MAX_PARAMS];
+    double *tr_ext = (double *)malloc(sizeof(double) * ROWS * W), *tr_fit = (double *)malloc(sizeof(double) * ROWS * W);
+    double *tr_orc = (double *)malloc(sizeof(double) * ROWS * W);
+    double *fvec = (double *)malloc(sizeof(double) * mr), *fwork = (double *)malloc(sizeof(double) * mr);
+    double *fjac = (double *)malloc(sizeof(double) * mr * q), *C = (double *)malloc(sizeof(double) * n * S);
+    vp_batch *h1 = 0, *h2 = 0;
+    dev_problem dp;
+    vpo_lsq P;
+    vpo_problem *op;
+    vp_lm_opts_default(&o, VP_F64);
+    for (i = 0; i < ROWS * W; ++i) tr_ext[i] = tr_fit[i] = tr_orc[i] = NAN;
+
+    /* (a) the external driver over the C ABI: build (= create + the builder's initial set_params), then minimize */
+    if (vp_batch_create(&h1, mdl, VP_F64, m, S, 1, t, Y, w, -1.0, VP_FLAG_OWN_STREAM, 0, 0) != 0) {
+        printf("%s: create failed: %s\n", name, vp_last_error());
+        return 1;
+    }
+    if (vp_set_params(h1, alpha0) != 0) return 1; /* SeparableProblemBuilder::build, src/problem/builder.rs:321 */
+    dp.h = h1; dp.q = q; dp.mr = mr; dp.calls_set = dp.calls_res = dp.calls_jac = 0;
+    P.n = q; P.mr = mr; P.user = &dp;
+    P.set_params = d_set_params; P.params = d_params; P.residuals = d_residuals; P.jacobian = d_jacobian;
+    rows_ext = vpo_lm_minimize(&P, &o, &rep_ext, tr_ext, ROWS, fvec, fwork, fjac);
+    vp_params(h1, a_ext); /* FitResult::nonlinear_parameters reads the problem's current parameters */
+    /* the trait calls the crate makes: one residuals() up front, then one set_params + one residuals per trial point
+     * (n_evals counts both kinds), plus one restoring set_params if the last trial was rejected
+     * (reset_params_if(!good)) */
+    if (!expect_user && !(dp.calls_res == rep_ext.n_evals &&
+                          (dp.calls_set == rep_ext.n_evals - 1 || dp.calls_set == rep_ext.n_evals))) {
+        printf("%s: unexpected call pattern set=%d res=%d jac=%d evals=%d\n", name, dp.calls_set, dp.calls_res, dp.calls_jac,
+               rep_ext.n_evals);
+        ++failures;
+    }
+
+    /* (b) the fused device LM on the same data */
+    if (vp_batch_create(&h2, mdl, VP_F64, m, S, 1, t, Y, w, -1.0, VP_FLAG_OWN_STREAM, 0, 0) != 0) return 1;
+    memcpy(a_fit, alpha0, sizeof(double) * q);
+    if (vp_fit_trace(h2, &o, a_fit, C, &rep_fit, tr_fit, ROWS) != 0) {
+        printf("%s: vp_fit_trace failed: %s\n", name, vp_last_error());
+        return 1;
+    }
+    rows_fit = 0;
+    for (i = 0; i < ROWS; ++i) if (tr_fit[i * W] == tr_fit[i * W]) rows_fit = i + 1;
+
+    /* (c) the oracle's fit: the same driver on the CPU restatement */
+    op = vpo_problem_create(mdl, m, S, t, Y, w, -1.0, &build_err);
+    if (!op) return 1;
+    vpo_set_params(op, alpha0);
+    rows_orc = vpo_fit_trace(op, &o, &rep_orc, tr_orc, ROWS);
+    memcpy(a_orc, op->alpha, sizeof(double) * q);
+
+    printf("%-28s external: term %2d evals %3d | vp_fit: term %2d evals %3d | oracle: term %2d evals %3d | trait calls set/res/jac %d/%d/%d\n",
+           name, rep_ext.termination, rep_ext.n_evals, rep_fit.termination, rep_fit.n_evals, rep_orc.termination,
+           rep_orc.n_evals, dp.calls_set, dp.calls_res, dp.calls_jac);
+    if (expect_user) {
+        if (rep_ext.termination != VP_TERM_USER || rep_fit.termination != VP_TERM_USER || rep_orc.termination != VP_TERM_USER) ++failures;
+        if (rep_ext.n_evals != rep_orc.n_evals || rep_fit.n_evals != rep_orc.n_evals) ++failures;
+    } else {
+        double amax = 0.0;
+        int lead;
+        /* same termination reason (success class and code) */
+        if (rep_ext.termination <= 0 || rep_ext.termination != rep_fit.termination || rep_ext.termination != rep_orc.termination) {
+            /* ftol / xtol / both may swap at the last evaluation: accept equal success, report the codes */
+            if (!(rep_ext.termination > 0 && rep_fit.termination > 0 && rep_orc.termination > 0)) ++failures;
+        }
+        if (abs(rep_ext.n_evals - rep_fit.n_evals) > 2 || abs(rep_ext.n_evals - rep_orc.n_evals) > 2) ++failures;
+        /* trajectory: the leading trial points (before rounding differences of the noise-level tail accumulate) */
+        lead = rows_ext < rows_fit ? rows_ext : rows_fit;
+        if (rows_orc < lead) lead = rows_orc;
+        if (lead > 6) lead = 6;
+        if (lead < 2) ++failures;
+        for (i = 0; i < lead; ++i) {
+            for (k = 0; k <= q; ++k) { /* alpha_trial (q) and ||r|| */
+                const double e = tr_ext[i * W + k], f = tr_fit[i * W + k], g = tr_orc[i * W + k];
+                const double sc = fabs(g) > 1e-300 ? fabs(g) : 1.0;
+                if (fabs(e - f) > 1e-8 * sc + 1e-12 || fabs(e - g) > 1e-8 * sc + 1e-12) {
+                    printf("  trajectory row %d col %d: external %.15g vp_fit %.15g oracle %.15g\n", i, k, e, f, g);
+                    ++failures;
+                }
+            }
+        }
+        for (k = 0; k < q; ++k) amax = fabs(a_orc[k]) > amax ? fabs(a_orc[k]) : amax;
+        for (k = 0; k < q; ++k) {
+            if (fabs(a_ext[k] - a_orc[k]) > tol_alpha * amax || fabs(a_fit[k] - a_orc[k]) > tol_alpha * amax) {
+                printf("  alpha[%d]: external %.15g vp_fit %.15g oracle %.15g\n", k, a_ext[k], a_fit[k], a_orc[k]);
+                ++failures;
+            }
+        }
+        {
+            double ysum = 0.0, dtol;
+            for (i = 0; i < mr; ++i) ysum += Y[i] * Y[i] * (w ? w[i % m] * w[i % m] : 1.0);
+            dtol = 1e-9 * rep_orc.objective + 1e-20 * 0.5 * ysum;
+            if (fabs(rep_ext.objective - rep_orc.objective) > dtol || fabs(rep_fit.objective - rep_orc.objective) > dtol) {
+                printf("  objective: external %.15g vp_fit %.15g oracle %.15g\n", rep_ext.objective, rep_fit.objective, rep_orc.objective);
+                ++failures;
+            }
+        }
+    }
+    vpo_problem_destroy(op);
+    vp_batch_destroy(h1);
+    vp_batch_destroy(h2);
+    free(tr_ext); free(tr_fit); free(tr_orc); free(fvec); free(fwork); free(fjac); free(C);
+    if (failures) printf("  %s: %d failure(s)\n", name, failures);
+    return failures;
+}
+
+static double lcg(unsigned long long *s) {
+    *s = *s * 6364136223846793005ULL + 1442695040888963407ULL;
+    return (double)(*s >> 11) / 9007199254740992.0;
+}
+
+int main(void) {
+    int failures = 0, i, s;
+    vp_model_desc m3, m2;
+    static double t[1024], y[3 * 1024], w[1024];
+    unsigned long long seed = 12345;
+    if (vp_device_count() <= 0) {
+        printf("no device: the trait-level LM test needs a GPU (the C ABI has no CPU path)\n");
+        return 0;
+    }
+    double_exp_model(&m3, 1);
+    double_exp_model(&m2, 0);
+    /* 1: configs[0] -- benches/double_exponential_without_noise.rs:97-112 incl. the linspace quirk (grid 0 -> -12.5) */
+    for (i = 0; i < 1024; ++i) {
+        t[i] = 0.0 + (0.0 - 12.5) / 1023.0 * (double)i;
+        y[i] = 4.0 * exp(-t[i] / 1.0) + 2.5 * exp(-t[i] / 3.0) + 1.0;
+    }
+    {
+        const double a0[2] = {2.0, 6.5};
+        failures += run_case("S=1 configs[0] quirk grid", &m3, 1024, 1, t, y, 0, a0, 0, 1e-8);
+    }
+    /* 2, 3: multiple right-hand sides on 20 samples (tests/integration_tests/main.rs:399-551 pattern): S = 2 takes the
+     * Jacobian branch S <= q (mod.rs:156-171), S = 3 the branch S > q (:172-186) */
+    for (i = 0; i < 20; ++i) t[i] = 12.5 * (double)i / 19.0;
+    for (s = 0; s < 3; ++s) {
+        const double c1 = 2.0 + 3.0 * s, c2 = 5.0 - 1.5 * s;
+        for (i = 0; i < 20; ++i) y[s * 20 + i] = c1 * exp(-t[i] / 1.0) + c2 * exp(-t[i] / 3.0);
+    }
+    {
+        const double a0[2] = {2.0, 6.5};
+        failures += run_case("S=2 (branch S<=q)", &m2, 20, 2, t, y, 0, a0, 0, 1e-8);
+        failures += run_case("S=3 (branch S>q)", &m2, 20, 3, t, y, 0, a0, 0, 1e-8);
+    }
+    /* 4: weighted, noisy, m = 1000 (not a multiple of the kernels' row blocks) */
+    for (i = 0; i < 1000; ++i) {
+        t[i] = 20.0 * (double)i / 999.0;
+        w[i] = 0.5 + lcg(&seed);
+        y[i] = 2.2 * exp(-t[i] / 2.4) + 6.8 * exp(-t[i] / 6.0) + 1.6 + 0.01 * (lcg(&seed) + lcg(&seed) + lcg(&seed) - 1.5);
+    }
+    {
+        const double a0[2] = {1.0, 8.0};
+        failures += run_case("S=1 weighted noisy m=1000", &m3, 1000, 1, t, y, w, a0, 0, 1e-6);
+    }
+    /* 5: set_params fails (tau = 0 -> non-finite basis): residuals() == None at once -> TerminationReason::User */
+    {
+        const double a0[2] = {0.0, 3.0};
+        failures += run_case("failing set_params -> User", &m3, 1000, 1, t, y, w, a0, 1, 0.0);
+    }
+    printf("%d failure(s)\n", failures);
+    return failures != 0;
+}

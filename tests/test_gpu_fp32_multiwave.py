@@ -128,8 +128,7 @@ def test_fp32_config4_full_size_properties():
     bp.close()
 
 
-@pytest.mark.parametrize("kernel", ["wave", "slots"])
-def test_fp32_config4_fit_against_the_fp32_and_fp64_oracles(kernel):
+def test_fp32_config4_fit_against_the_fp32_and_fp64_oracles():
     # BASELINE configs[4] (five exponentials + offset, fp32, m = 4096) on a 384-problem sample, against
     #   (a) the fp32-storage build of the oracle (oracle/Makefile: the reference ALGORITHM in single precision) and
     #   (b) the fp64 oracle on the same (float -> double converted) inputs.
@@ -143,7 +142,6 @@ def test_fp32_config4_fit_against_the_fp32_and_fp64_oracles(kernel):
     d = synth.multi_exp_batch(B, 5, m, taus, noise=1e-3, spread=0.1, guess_spread=0.05, dtype=np.float32)
     mdl32 = vp.multi_exponential_model(d["x"], d["tau_guess"][0], dtype=np.float32)
     bp = vp.BatchProblem(mdl32, d["Y"], x=d["x"])
-    bp.set_fit_kernel(kernel)
     alpha, C, rep = bp.fit(d["tau_guess"])
     bp.close()
     a32, c32, r32, _ = O.fit_batch_f32(mdl32, d["x"], d["Y"], d["tau_guess"], n_threads=8)

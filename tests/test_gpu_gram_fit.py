@@ -72,7 +72,7 @@ def test_gram_fit_does_not_depend_on_scheduling():
 
 
 def test_gram_fit_on_a_general_grid():
-    # non-uniform grid: no recurrence, one fp32 exponential per element
+    # non-uniform grid: no recurrence, one fp64 exponential per element
     B, m = 48, 2048
     rng = np.random.default_rng(11)
     x = np.sort(rng.uniform(0.0, 12.5, m)).astype(np.float32)
@@ -115,24 +115,22 @@ def test_gram_fit_survives_rank_deficient_trial_points():
         assert np.median(excess) <= 0.5
 
 
-def test_gram_and_householder_fp32_fits_agree_where_both_succeed():
-    # the same handle, fit once by the Gram kernel (automatic) and once by the fp32 Householder kernel ("wave")
+def test_wave_selection_runs_the_gram_kernel_too():
+    # there is no fp32 Householder FIT kernel for this shape any more (it lost 15 % of the fits): every selection of
+    # vp_set_fit_kernel runs the Gram kernel, bit-identically
     B, m = 128, 4096
     d = synth.multi_exp_batch(B, 5, m, TAUS, noise=1e-3, spread=0.1, guess_spread=0.05, dtype=np.float32)
     _, ag, cg, rg = _fit(d)
     _, ah, ch, rh = _fit(d, kernel="wave")
-    both = (rg["termination"] > 0) & (rh["termination"] > 0)
-    assert both.mean() >= 0.7 and (rg["termination"] > 0).mean() >= (rh["termination"] > 0).mean()
-    rel = np.abs(rg["objective"] - rh["objective"])[both] / rh["objective"][both]
-    assert np.median(rel) <= 1e-2
-    # the Gram kernel's objective is never noticeably above the Householder one's (it resolves what fp32 cannot)
-    assert ((rg["objective"] - rh["objective"])[both] <= 0.05 * rh["objective"][both]).mean() >= 0.9
+    assert np.array_equal(ag, ah, equal_nan=True) and np.array_equal(cg, ch, equal_nan=True)
+    assert np.array_equal(rg["n_evals"], rh["n_evals"]) and np.array_equal(rg["termination"], rh["termination"])
 
 
-def test_gram_fit_options_and_weighted_fallback():
-    # non-default LM options reach the kernel (patience -> LostPatience), and a weighted problem takes the Householder
-    # kernels (the Gram kernel handles unit weights only) with the same API
-    B, m = 16, 4096
+def test_gram_fit_options_and_weighted_problems():
+    # non-default LM options reach the kernel (patience -> LostPatience); weighted problems (shared and per-problem
+    # weights, src/problem/builder.rs:261-266, src/util/weights.rs:82-99) are fitted by the Gram kernel as well and reach
+    # the fp64 oracle's weighted minimum
+    B, m = 48, 4096
     d = synth.multi_exp_batch(B, 5, m, TAUS, noise=1e-3, spread=0.1, guess_spread=0.05, dtype=np.float32)
     s = vp.LevenbergMarquardt(np.float32).with_patience(1)
     _, a, c, rep = _fit(d, solver=s)
@@ -140,10 +138,31 @@ def test_gram_fit_options_and_weighted_fallback():
     assert (rep["n_evals"] <= 1 * 6 + 1).all()
     mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0], dtype=np.float32)
     w = np.linspace(1.0, 2.0, m).astype(np.float32)
-    bp = vp.BatchProblem(mdl, d["Y"], x=d["x"], weights=w)
-    a2, c2, r2 = bp.fit(d["tau_guess"])
+    x64, Y64, g64 = d["x"].astype(np.float64), d["Y"].astype(np.float64), d["tau_guess"].astype(np.float64)
+    a64, c64, r64, _ = O.fit_batch(mdl, x64, Y64, g64, w=w.astype(np.float64), n_threads=8)
+    scale = 0.5 * ((w.astype(np.float64) * Y64) ** 2).sum(1)
+    for weights in (w, np.tile(w, (B, 1))):
+        bp = vp.BatchProblem(mdl, d["Y"], x=d["x"], weights=weights)
+        a2, c2, r2 = bp.fit(d["tau_guess"])
+        bp.close()
+        ok, ok64 = r2["termination"] > 0, r64["termination"] > 0
+        assert ok.mean() >= 0.9 and ok.mean() >= ok64.mean() - 0.08
+        both = ok & ok64
+        excess = (r2["objective"] - r64["objective"])[both] / np.maximum(r64["objective"][both], 1e-9 * scale[both])
+        assert np.median(np.abs(excess)) <= 1e-4 and (excess <= 2e-2).mean() >= 0.95
+
+
+def test_gram_fit_on_per_problem_grids():
+    # VP_FLAG_T_PER_PROBLEM: every problem on its own grid (here: the same sampling stretched per problem)
+    B, m = 32, 2048
+    d = synth.multi_exp_batch(B, 5, m, TAUS, noise=1e-3, spread=0.1, guess_spread=0.05, dtype=np.float32)
+    X = np.tile(d["x"], (B, 1))
+    mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0], dtype=np.float32)
+    bp = vp.BatchProblem(mdl, d["Y"], x=X)
+    a1, c1, r1 = bp.fit(d["tau_guess"])
     bp.close()
-    assert (r2["termination"] != 0).all()
+    _, a0, c0, r0 = _fit(d)                                   # the same problems on the shared grid
+    assert np.array_equal(a0, a1, equal_nan=True) and np.array_equal(r0["n_evals"], r1["n_evals"])
 
 
 def test_gram_fit_single_problem_and_device_pointers():

@@ -189,6 +189,7 @@ class BatchProblem:
         check(self.lib.vp_batch_create(C.byref(h), C.byref(desc), self.vp_dtype, self.m, self.S, self.B,
                                        self._ptr(x), self._ptr(Y), self._ptr(w), eps, flags, self.device, stream))
         self._h = h
+        self._have_params = False  # mirrors the handle: set_params / evaluate / fit has run on the current data
         self._keep = None  # the handle owns copies (Y_w = W*Y, t, w)
 
     # ---- plumbing ----
@@ -248,6 +249,7 @@ class BatchProblem:
         """== SeparableProblem::set_params (src/solvers/levmar/mod.rs:42-73)"""
         a = self._as_array(alpha).reshape(self.B, self.q)
         check(self.lib.vp_set_params(self._h, self._ptr(a)))
+        self._have_params = True
 
     @_device_entry
     def params(self):
@@ -267,7 +269,7 @@ class BatchProblem:
         r = self._empty((self.B, self.S * self.m))
         st = self._empty((self.B,), np.int32)
         check(self.lib.vp_residuals(self._h, self._ptr(r), self._ptr(st)))
-        if self._never_evaluated(st):
+        if not self._have_params:
             r = None  # residuals() before any set_params(): the reference returns None (cached is None)
         return (r, st) if with_status else r
 
@@ -277,15 +279,11 @@ class BatchProblem:
         J = self._empty((self.B, self.q, self.S * self.m))
         st = self._empty((self.B,), np.int32)
         check(self.lib.vp_jacobian(self._h, self._ptr(J), self._ptr(st)))
-        if self._never_evaluated(st):
+        if not self._have_params:
             J = None  # jacobian() before any set_params(): None, not an uninitialised buffer
         return (J, st) if with_status else J
 
     @_device_entry
-    def _never_evaluated(self, st):
-        first = int(st[0].item()) if _is_torch(st) else int(st[0])
-        return first == _lib.VP_ST_NOT_EVALUATED
-
     def linear_coefficients(self):
         """(B, n) for single RHS, (B, S, n) for MRHS (each [b] is the reference's n x S matrix, column-major)"""
         Cm = self._empty((self.B, self.S, self.n))
@@ -315,6 +313,7 @@ class BatchProblem:
         st = self._empty((self.B,), np.int32)
         check(self.lib.vp_evaluate(self._h, self._ptr(a), self._ptr(r), self._ptr(J), self._ptr(Cm), self._ptr(cost),
                                    self._ptr(st)))
+        self._have_params = True
         return dict(r=r, J=J, C=Cm.reshape(self.B, self.n) if self.single_rhs else Cm, cost=cost, status=st)
 
     # ---- model surface ----
@@ -339,6 +338,7 @@ class BatchProblem:
         a = self._as_array(alpha0).reshape(self.B, self.q)
         a = a.clone() if _is_torch(a) else a.copy()
         Cm = self._empty((self.B, self.S, self.n)) if want_coefficients else None
+        self._have_params = True
         if self.device_mode:
             rep_t = torch.empty((self.B, 16), dtype=torch.uint8, device=self._torch_device())
             check(self.lib.vp_fit(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), self._ptr(rep_t)))
@@ -363,6 +363,7 @@ class BatchProblem:
         Cm = self._empty((self.B, self.S, self.n))
         rep = np.zeros(self.B, dtype=REPORT_DTYPE)
         tr = np.zeros((self.B, max_rows, self.q + 4))
+        self._have_params = True
         check(self.lib.vp_fit_trace(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), C.c_void_p(rep.ctypes.data),
                                     C.c_void_p(tr.ctypes.data), int(max_rows)))
         if self.single_rhs:
@@ -374,6 +375,18 @@ class BatchProblem:
         if _is_torch(rep):
             return rep.cpu().numpy().view(REPORT_DTYPE).reshape(-1)
         return rep
+
+    @_device_entry
+    def debug_gram_evaluate(self, alpha):
+        """diagnostics (vp_debug_gram_evaluate): the fp64-Gram fit kernel's formulation evaluated once at alpha ->
+        dict(cost (B,), C (B, n), Jtr (B, q), JtJ (B, q, q)), all float64"""
+        a = self._as_array(alpha).reshape(self.B, self.q)
+        per = 1 + self.n + self.q + self.q * self.q
+        out = self._empty((self.B, per), np.float64)
+        check(self.lib.vp_debug_gram_evaluate(self._h, self._ptr(a), self._ptr(out)))
+        n, q = self.n, self.q
+        return dict(cost=out[:, 0], C=out[:, 1:1 + n], Jtr=out[:, 1 + n:1 + n + q],
+                    JtJ=out[:, 1 + n + q:].reshape(self.B, q, q))
 
     @_device_entry
     def best_fit(self):
@@ -405,6 +418,7 @@ class BatchProblem:
         if self.device_mode and not Y.is_contiguous():
             Y = Y.contiguous()
         check(self.lib.vp_set_observations(self._h, self._ptr(Y)))
+        self._have_params = False
 
     def set_rhs_allreduce(self, global_rhs_count, group=None):
         """Shard ONE global fit over ranks by right-hand sides (vp_set_rhs_allreduce): this handle

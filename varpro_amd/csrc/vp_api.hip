@@ -993,6 +993,28 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
     return VP_ERR_OK;
 }
 
+int vp_debug_gram_evaluate(vp_batch *h, const void *alpha, double *out) {
+    VP_ENTER(h);
+    if (!alpha || !out) return fail(VP_ERR_INVALID, "null argument");
+    if (h->S != 1 || !h->kern->gram_fit || !h->kern->fit)
+        return fail(VP_ERR_UNSUPPORTED, "the handle's fit does not run on the Gram kernel (fp32, exponentials + offset beyond one wavefront)");
+    const size_t ts = tsize(h->dtype);
+    const int per = 1 + h->n + h->q + h->q * h->q;
+    InBuf a;
+    if (int rc = a.init(h, alpha, (size_t)h->B * h->q * ts)) return rc;
+    OutBuf o;
+    if (int rc = o.init(h, out, (size_t)h->B * per * sizeof(double))) return rc;
+    vp_lm_opts opt;
+    vp_lm_opts_default(&opt, h->dtype);
+    LaunchParams p;
+    fill_params(h, p);
+    p.alpha_out = const_cast<void *>(a.dptr); // read only in this mode
+    p.opts = &opt;
+    p.gram_dbg = (double *)o.dptr;
+    if (int rc = h->kern->fit(p)) return fail(rc, "Gram evaluation launch failed");
+    return o.finish(h);
+}
+
 int vp_set_rhs_allreduce(vp_batch *h, vp_allreduce_fn fn, void *user, int64_t global_rhs_count) {
     VP_ENTER(h);
     if (fn) {

@@ -3,28 +3,37 @@
 //
 // == LevMarSolver::fit -> LevenbergMarquardt::minimize (src/solvers/levmar/mod.rs:238-254) for a batch of fp32
 // problems, with the linear algebra of one evaluation (src/solvers/levmar/mod.rs:42-73, 101-201: thin decomposition of
-// Phi_w, coefficients, projected residual, Kaufman Jacobian) restated on the normal equations IN DOUBLE:
+// Phi_w, coefficients, projected residual, Kaufman Jacobian) restated on the normal equations IN DOUBLE.
 //
-//     X = [e_1 .. e_NE | y | d_1 .. d_NE]   (fp32 data and grid, columns evaluated and multiplied in fp64),   const column implicit
-//     ONE pass over the m rows accumulates the NX(NX+1)/2 inner products and NX column sums per lane (fp64 FMAs: the
-//     product of two fp32 values is exact in fp64), ONE packed wave reduction delivers them -- no column is ever
-//     resident, no per-reflector reduction round, no multi-wave group;
+// MOMENT form of the Gram matrix.  With e_k = w exp(-t/tau_k) (w = the row weight, src/util/weights.rs:82-99; 1 for
+// Weights::Unit) and u_k = t e_k the weighted derivative column is d_k = u_k / tau_k^2
+// (shared_test_code/src/lib.rs:109-114), so every inner product of X = [e_1..e_NE | w | y_w | d_1..d_NE] is one of
+//     A0[i,k] = sum e_i e_k    A1[i,k] = sum e_i u_k (symmetric: t w^2 e_i e_k)    A2[i,k] = sum u_i u_k
+//     B0[k] = sum e_k y        B1[k] = sum u_k y       YY = sum y^2
+//     S0[k] = sum w e_k        S1[k] = sum w u_k       SY = sum w y       SW = sum w^2 (= m for unit weights)
+// times powers of 1/tau_k^2 that are applied AFTER the pass: 3 NE(NE+1)/2 + 4 NE + 2 = 67 accumulators for NE = 5
+// where the plain Gram of the 11 columns needs 77, and no per-row scaling of the derivative columns.
+// ONE pass over the m rows accumulates them per lane (fp64 FMAs: the product of two fp32 values is exact in fp64), ONE
+// packed wave reduction delivers them -- no column is ever resident, no per-reflector reduction round.  Then, per slot
+// on one lane (gram_phase):
 //     A = Phi^T Phi = L L^T,  z = L^-1 Phi^T y,  c = L^-T z,  ||r||^2 = y^T y - z^T z,
 //     W = L^-1 Phi^T D,  D^T P_perp D = D^T D - W^T W,  D^T r = D^T y - W^T z,
 //     J^T J = diag(c) (D^T P_perp D) diag(c),  J^T r = -c_k (D^T r)_k   (Kaufman, pair p = (basis p, parameter p)),
 //     pivoted Cholesky of J^T J -> (R_J, acnorm, ipvt, qtf) exactly as the multiple-right-hand-side path (gram_to_qr).
 //
 // Why this is legitimate for fp32 and only for fp32: the Householder path in fp32 loses kappa(Phi)*eps32 (6e-8) of the
-// coefficients -- at cfg4's kappa ~ 1e6 that is 6 %, and 15 % of the fits end non-finite; the Gram matrix in fp64 loses
-// kappa^2*eps64 = 1e12*1e-16 = 1e-4.  For fp64 data the same trick would square the conditioning with nothing in
-// reserve, so fp64 handles never come here.  Rank-deficient Phi at a trial point (two decay times collide, a column
-// degenerates into the constant): columns whose Cholesky pivot vanishes are dropped, the counterpart of the reference's
-// truncated SVD (gram_phase).
+// coefficients -- at cfg4's kappa ~ 1e3..1e6 that is up to 6 %, and 15 % of the fits end non-finite; the Gram matrix in
+// fp64 loses kappa^2*eps64.  For fp64 data the same trick would square the conditioning with nothing in reserve, so fp64
+// handles never come here.  Rank-deficient Phi at a trial point (two decay times collide, a column degenerates into the
+// constant): columns whose Cholesky pivot vanishes are dropped, the counterpart of the reference's truncated SVD.
 //
-// Execution: the persistent-slot machinery of vp_fit2.hpp with W = 1 -- a wave owns GS slots, the VECTOR phase of a
-// slot is the streaming Gram pass (y re-read from HBM/L2 per evaluation, coalesced 16 B per lane; the grid sits in LDS),
-// then lane s turns slot s's Gram into the evaluation results (gram_phase) and runs the LM bookkeeping
-// (slot_scalar_phase<double>), all in fp64; results are stored as fp32.
+// Execution (round 3): every wavefront is an independent persistent worker that owns GS problem slots.  Per loop
+// iteration it streams the rows of each occupied slot ONCE (y_w -- and the grid / weights where they are not implied --
+// re-read from HBM / L2, 16 B per lane and stream, coalesced, the next chunk prefetched), then lane s turns slot s's
+// moments into the evaluation results (gram_phase) and runs the LM bookkeeping (slot_scalar_phase<double>), all in
+// fp64; finished slots refill from the device-side queue.  There are no workgroup barriers in the loop: while one wave
+// of a SIMD is in its latency-bound scalar phase the other streams.  Results do not depend on which wave or slot ran a
+// problem, nor on what ran beside it.
 #pragma once
 #include "vp_fit2.hpp"
 #include "vp_lm_core.hpp"
@@ -32,13 +41,22 @@
 namespace vp {
 
 template <int NE> struct GramIdx {
-    static constexpr int NX = 2 * NE + 1;        // e_0..e_{NE-1}, y (index NE), d_0..d_{NE-1} (index NE+1+k)
-    static constexpr int NP = NX * (NX + 1) / 2; // products a <= b, row-major upper triangle
-    static constexpr int NV = NP + NX;           // + column sums (products with the implicit constant column)
-    __host__ __device__ static constexpr int prod(int a, int b) {
-        return a <= b ? a * NX - a * (a - 1) / 2 + (b - a) : b * NX - b * (b - 1) / 2 + (a - b);
+    static constexpr int NT = NE * (NE + 1) / 2;
+    __host__ __device__ static constexpr int tri(int i, int k) { // i <= k, row-major upper triangle
+        return i * NE - i * (i - 1) / 2 + (k - i);
     }
-    __host__ __device__ static constexpr int sum(int a) { return NP + a; }
+    __host__ __device__ static constexpr int sym(int i, int k) { return i <= k ? tri(i, k) : tri(k, i); }
+    __host__ __device__ static constexpr int A0(int i, int k) { return sym(i, k); }
+    __host__ __device__ static constexpr int A1(int i, int k) { return NT + sym(i, k); }
+    __host__ __device__ static constexpr int A2(int i, int k) { return 2 * NT + sym(i, k); }
+    __host__ __device__ static constexpr int B0(int k) { return 3 * NT + k; }
+    __host__ __device__ static constexpr int B1(int k) { return 3 * NT + NE + k; }
+    static constexpr int YY = 3 * NT + 2 * NE;
+    __host__ __device__ static constexpr int S0(int k) { return YY + 1 + k; }
+    __host__ __device__ static constexpr int S1(int k) { return YY + 1 + NE + k; }
+    static constexpr int SY = YY + 1 + 2 * NE;
+    static constexpr int SW = SY + 1; // accumulated for weighted problems only
+    static constexpr int NV = SW + 1; // LDS stride of one slot's moments
 };
 
 // Packed wave reduction of V values whose totals are STORED to LDS by the lanes that end up holding them (dst[v]) --
@@ -64,19 +82,27 @@ template <int V, typename T> __device__ __forceinline__ void wave_reduce_store(T
     }
 }
 
-template <class M> struct FitgArgs {
-    const float *t;   // [m] shared grid
-    const float *yw;  // [B][m]
+__device__ __forceinline__ double uni_d(double x) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
+struct FitgArgs {
+    const float *t;   // [m] or [B][m]
+    const float *w;   // null (unit weights), [m] or [B][m]
+    const float *yw;  // [B][m] weighted data
     float *alpha;     // [B][q] in: guesses, out: parameters
     float *C_out;     // [B][n] or null
     double *cost_out;
     int32_t *status;
     vp_report *report;
     double *trace;
+    double *dbg;      // null, or [B][1 + n + q + q*q]: evaluate the Gram formulation ONCE at alpha and write
+                      // {1/2||r||^2, c, J^T r, J^T J} per problem instead of fitting (vp_debug_gram_evaluate)
     int *queue;
     int64_t B;
-    int m, mp;        // rows, rows padded to a multiple of 256
-    int trace_rows, scale_diag, patience, grid_uniform;
+    int64_t t_stride, w_stride;
+    int m;
+    int trace_rows, scale_diag, patience;
     int gs_used;      // slots per wave taken by the static first assignment (<= GS)
     double eps, ftol, xtol, gtol, stepbound;
 };
@@ -120,24 +146,33 @@ __device__ __noinline__ void slotg_fill(VP_LDS SlotRec<double, N, Q> *rec, VP_LD
     rec->trow = 0;
 }
 
-// Lane s: Gram of slot s -> results of the evaluation in the slot's record (what the vector phase of fit2_kernel posts).
-//   gram: [GS][NV] Grams of the slots (partial 0 of the [W][GS][NV] area, already totalled over the waves)
-template <int NE, int GS, int W>
-__device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs, VP_LDS double *gram,
-                                        VP_LDS const SlotConsts<double, float> *k) {
+// Lane s: moments of slot s -> results of the evaluation in the slot's record (what the vector phase of fit2_kernel
+// posts).  gram: [GS][GI::NV].  dbg != null: additionally write {1/2||r||^2, c, J^T r, J^T J} of the slot's problem.
+template <int NE, int GS, bool WEIGHTED>
+__device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs, VP_LDS const double *gram,
+                                        VP_LDS const SlotConsts<double, float> *k, double *dbg) {
     constexpr int N = NE + 1, Q = NE;
     using GI = GramIdx<NE>;
     const int lane = lane_id();
     if (!(lane < GS && recs[lane].prob >= 0)) return;
     VP_LDS SlotRec<double, N, Q> *rec = recs + lane;
-    VP_LDS double *g = gram + (size_t)lane * GI::NV;
-    // (the W per-wave partial Grams were totalled into partial 0 by the whole group before this call)
+    VP_LDS const double *g = gram + (size_t)lane * GI::NV;
     const double eps = k->eps;
+    double it2[NE]; // 1 / tau_k^2: the derivative columns are u_k / tau_k^2
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const double rt = frcp(rec->xt[i]);
+        it2[i] = rt * rt;
+    }
     // ---- A = Phi^T Phi (basis order e_0..e_{NE-1}, const) = L L^T ----
     // A column whose pivot d_i (its squared distance from the span of the columns before it) is <= max(eps^2,
-    // 1e-13 A_ii) is DROPPED (c_i = 0, the projector is that of the remaining columns): the counterpart of the
-    // reference's truncated SVD (singular values <= eps) at trial points where two decay times collide or a column
-    // degenerates into the constant -- the step is then judged by its residual like any other instead of ending the fit.
+    // VP_GRAM_NOISE A_ii) is DROPPED (c_i = 0, the projector is that of the remaining columns): the counterpart of the
+    // reference's truncated SVD (singular values <= eps, src/solvers/levmar/mod.rs:52-54) at trial points where two decay
+    // times collide or a column degenerates into the constant -- the step is then judged by its residual like any other
+    // instead of ending the fit.  eps is the handle's svd_epsilon (absolute, like the reference's); the relative term is
+    // NOT a user parameter but the resolution of the method: a pivot of a Gram matrix accumulated in fp64 carries
+    // rounding noise of a few hundred eps64 A_ii, below which it is indistinguishable from 0.
+    constexpr double VP_GRAM_NOISE = 1.0e-13;
     double Lm[N][N], iL[N]; // L (strict lower part) and the reciprocals of its diagonal (0 for a dropped column)
     bool ok = true;
 #pragma unroll
@@ -145,15 +180,15 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
             double aij;
-            if (i == NE) aij = (j == NE) ? (double)k->m : g[GI::sum(j)];
-            else aij = g[GI::prod(j, i)];
+            if (i == NE) aij = (j == NE) ? (WEIGHTED ? g[GI::SW] : (double)k->m) : g[GI::S0(j)];
+            else aij = g[GI::A0(j, i)];
             double acc = aij;
 #pragma unroll
             for (int p = 0; p < j; ++p) acc = tfma(-Lm[i][p], Lm[j][p], acc);
             if (i == j) {
                 ok = ok && is_finite(acc);
-                const bool keep = acc > tmax(eps * eps, 1.0e-13 * aij);
-                iL[i] = keep ? 1.0 / tsqrt(acc) : 0.0;
+                const bool keep = acc > tmax(eps * eps, VP_GRAM_NOISE * aij);
+                iL[i] = keep ? frsqrt(acc) : 0.0; // (Newton-refined v_rsq: 1-2 ulp, against kappa^2 eps64 of the method)
             } else {
                 Lm[i][j] = acc * iL[j]; // (a dropped column j has no sub-diagonal entries)
             }
@@ -163,12 +198,12 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
     double z[N], c[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        double acc = (i == NE) ? g[GI::sum(NE)] : g[GI::prod(i, NE)];
+        double acc = (i == NE) ? g[GI::SY] : g[GI::B0(i)];
 #pragma unroll
         for (int p = 0; p < i; ++p) acc = tfma(-Lm[i][p], z[p], acc);
         z[i] = acc * iL[i];
     }
-    double fn2 = g[GI::prod(NE, NE)];
+    double fn2 = g[GI::YY];
 #pragma unroll
     for (int i = 0; i < N; ++i) fn2 = tfma(-z[i], z[i], fn2);
 #pragma unroll
@@ -180,7 +215,7 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
         ok = ok && is_finite(c[i]);
     }
     ok = ok && is_finite(fn2);
-    const double fnorm1 = tsqrt(tmax(fn2, 0.0));
+    const double fnorm1 = usqrt(tmax(fn2, 0.0));
 
     const int fl_in = rec->flags;
     const bool first = (fl_in & 1) != 0;
@@ -188,9 +223,9 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
     double actred = 0.0, ratio = 0.0;
     bool good = false;
     if (!first) {
-        const double q1 = fnorm1 / fnorm;
+        const double q1 = fnorm1 * frcp(fnorm);
         actred = (fnorm1 * 0.1 < fnorm) ? 1.0 - q1 * q1 : -1.0;
-        ratio = (prered == 0.0) ? 0.0 : actred / prered;
+        ratio = (prered == 0.0) ? 0.0 : actred * frcp(prered);
         good = ratio >= 1.0e-4;
     }
     const bool need_jac = ok && (first || good);
@@ -201,6 +236,12 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
     for (int i = 0; i < N; ++i) rec->cnew[i] = c[i];
     int fl = fl_in & 7;
     if (ok) fl |= 8;
+    double *dbo = dbg ? dbg + (size_t)rec->prob * (1 + N + Q + Q * Q) : nullptr;
+    if (dbo) {
+        dbo[0] = ok ? 0.5 * tmax(fn2, 0.0) : 0.0 / 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) dbo[1 + i] = c[i];
+    }
     if (need_jac) {
         // ---- W = L^-1 Phi^T D;  G2 = D^T P_perp D;  v = D^T r ----
         double Wm[N][Q];
@@ -208,7 +249,7 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
         for (int kk = 0; kk < Q; ++kk)
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                double acc = (i == NE) ? g[GI::sum(NE + 1 + kk)] : g[GI::prod(i, NE + 1 + kk)];
+                double acc = ((i == NE) ? g[GI::S1(kk)] : g[GI::A1(i, kk)]) * it2[kk];
 #pragma unroll
                 for (int p = 0; p < i; ++p) acc = tfma(-Lm[i][p], Wm[p][kk], acc);
                 Wm[i][kk] = acc * iL[i];
@@ -216,18 +257,26 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
         double Aj[Q][Q], bv[Q];
 #pragma unroll
         for (int kk = 0; kk < Q; ++kk) {
-            double vk = g[GI::prod(NE, NE + 1 + kk)];
+            double vk = g[GI::B1(kk)] * it2[kk];
 #pragma unroll
             for (int i = 0; i < N; ++i) vk = tfma(-Wm[i][kk], z[i], vk);
             bv[kk] = -c[kk] * vk;
 #pragma unroll
             for (int l = kk; l < Q; ++l) {
-                double gkl = g[GI::prod(NE + 1 + kk, NE + 1 + l)];
+                double gkl = g[GI::A2(kk, l)] * (it2[kk] * it2[l]);
 #pragma unroll
                 for (int i = 0; i < N; ++i) gkl = tfma(-Wm[i][kk], Wm[i][l], gkl);
                 const double a = c[kk] * c[l] * gkl;
                 Aj[kk][l] = a;
                 Aj[l][kk] = a;
+            }
+        }
+        if (dbo) {
+#pragma unroll
+            for (int kk = 0; kk < Q; ++kk) {
+                dbo[1 + N + kk] = bv[kk];
+#pragma unroll
+                for (int l = 0; l < Q; ++l) dbo[1 + N + Q + kk * Q + l] = Aj[kk][l];
             }
         }
         double Rd[Q][Q], acd[Q], qd[Q];
@@ -242,33 +291,74 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
 #pragma unroll
             for (int j = 0; j < Q; ++j) rec->Rj[kk][j] = Rd[kk][j];
         }
+    } else if (dbo) {
+        for (int i = 0; i < Q + Q * Q; ++i) dbo[1 + N + i] = 0.0 / 0.0;
     }
     if (good) fl |= 32;
     rec->flags = fl;
+    if (dbg) rec->term = VP_TERM_USER; // evaluate-only: the slot is done (nothing else is written for it)
 }
 
-// One workgroup = one GROUP of W waves that owns GS slots: the waves stream interleaved 256-row chunks of a slot's rows
-// (the latency of one evaluation is what bounds a launch once the queue is empty), wave 0 runs the lane-parallel phases.
-template <class M, int GS, int W>
-__global__ void __launch_bounds__(64 * W, (2 * W) / 4 > 0 ? (2 * W) / 4 : 1) fitg_kernel(const FitgArgs<M> a) {
+// One chunk = 256 consecutive rows: lane l owns rows 256 ch + 4 l .. + 3 (16 B per lane and stream, 1 KiB per wave
+// instruction).  UNIFORM: the grid is t_0 + i dt to rounding (grid_check_kernel) -- t is never read, exp(-t/tau) of
+// a lane's rows follows from one anchor per lane by a recurrence (ratio per row, ratio per chunk).
+template <bool UNIFORM, bool WEIGHTED> struct GramChunk {
+    float4 y, t, w;
+};
+
+template <bool UNIFORM, bool WEIGHTED>
+__device__ __forceinline__ void gram_load_chunk(GramChunk<UNIFORM, WEIGHTED> &c, const float *yp, const float *tp, const float *wp,
+                                                const int row0, const int m, const bool vec) {
+    auto ld4 = [&](const float *p) __attribute__((always_inline)) -> float4 {
+        float4 v;
+        if (vec && row0 + 3 < m) {
+            v = *reinterpret_cast<const float4 *>(p + row0);
+        } else {
+            v.x = (row0 < m) ? p[row0] : 0.0f;
+            v.y = (row0 + 1 < m) ? p[row0 + 1] : 0.0f;
+            v.z = (row0 + 2 < m) ? p[row0 + 2] : 0.0f;
+            v.w = (row0 + 3 < m) ? p[row0 + 3] : 0.0f;
+        }
+        return v;
+    };
+    c.y = ld4(yp);
+    if constexpr (!UNIFORM) c.t = ld4(tp);
+    if constexpr (WEIGHTED) {
+        if (wp) {
+            c.w = ld4(wp);
+        } else { // unit weights with a ragged last row group: the row mask plays the weights
+            c.w.x = (row0 < m) ? 1.0f : 0.0f;
+            c.w.y = (row0 + 1 < m) ? 1.0f : 0.0f;
+            c.w.z = (row0 + 2 < m) ? 1.0f : 0.0f;
+            c.w.w = (row0 + 3 < m) ? 1.0f : 0.0f;
+        }
+    }
+}
+
+#ifndef VP_FITG_GS
+#define VP_FITG_GS 3
+#endif
+constexpr int VP_FITG_WAVES = 4; // independent waves per workgroup (they share the launch constants only)
+
+template <class M, int GS, bool UNIFORM, bool WEIGHTED>
+__global__ void __launch_bounds__(64 * VP_FITG_WAVES, 2) fitg_kernel(const FitgArgs a) {
     constexpr int N = M::N, Q = M::Q, NE = M::N - 1;
     static_assert(M::kStatic && M::kConstLast && M::kDiagonalPairs && M::Q == NE, "exponentials + offset");
     using GI = GramIdx<NE>;
     using Rec = SlotRec<double, N, Q>;
     using KC = SlotConsts<double, float>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *s_t = reinterpret_cast<float *>(smem_raw);                                   // [mp]
-    double *gram = reinterpret_cast<double *>(smem_raw + (size_t)a.mp * sizeof(float)); // [W][GS][NV]
-    Rec *recs = reinterpret_cast<Rec *>(gram + (size_t)W * GS * GI::NV);
-    KC *kc = reinterpret_cast<KC *>(recs + GS);
-    double *s_u = reinterpret_cast<double *>(kc + 1); // [W][4*NE] per-wave column constants of the running Gram pass
-    int *s_pop = reinterpret_cast<int *>(s_u + (size_t)W * 4 * NE); // [GS] queue pops
+    constexpr int NVR = WEIGHTED ? GI::NV : GI::NV - 1; // moments accumulated and reduced
+    constexpr int NW = VP_FITG_WAVES;
+    __shared__ __attribute__((aligned(16))) double s_gram[NW][GS][GI::NV];
+    __shared__ __attribute__((aligned(16))) Rec s_recs[NW][GS];
+    __shared__ __attribute__((aligned(16))) KC s_kc;
+    __shared__ double s_grid[NW][GS][2]; // UNIFORM: t_0 and dt of the slot's grid
     const int lane = lane_id();
     const int wv = (int)(threadIdx.x >> 6);
-    const int gw = (int)blockIdx.x; // persistent group index
+    const int gw = (int)blockIdx.x * NW + wv; // persistent wave index
     const int m = a.m;
-    for (int i = threadIdx.x; i < a.mp; i += blockDim.x) s_t[i] = (i < m) ? a.t[i] : 0.0f;
     if (threadIdx.x == 0) {
+        KC *kc = &s_kc;
         kc->ftol = a.ftol;
         kc->xtol = a.xtol;
         kc->gtol = a.gtol;
@@ -289,24 +379,38 @@ __global__ void __launch_bounds__(64 * W, (2 * W) / 4 > 0 ? (2 * W) / 4 : 1) fit
         kc->eps = a.eps;
     }
     __syncthreads();
+    VP_LDS Rec *recs = (VP_LDS Rec *)&s_recs[wv][0];
+    VP_LDS double *gram = (VP_LDS double *)&s_gram[wv][0][0];
+    VP_LDS const KC *kc = (VP_LDS const KC *)&s_kc;
     auto wave_sync = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    const bool uniform = a.grid_uniform != 0 && m >= 3;
-    const double t0 = (double)s_t[0];
-    const double dt = uniform ? ((double)s_t[m - 1] - t0) / (double)(m - 1) : 0.0;
-    const int nchunk = a.mp / 256;
+    const int nchunk = (m + 255) / 256;
+    // 16-byte row groups: every stream of the handle is 16-byte aligned per problem when m % 4 == 0 (hipMalloc'd bases)
+    const bool vec = (m & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.yw) | reinterpret_cast<uintptr_t>(a.t) |
+                                       reinterpret_cast<uintptr_t>(a.w)) & 15) == 0;
 
+    auto fill = [&](int s, int prob) __attribute__((always_inline)) {
+        slotg_fill<N, Q>(recs + s, kc, prob);
+        if constexpr (UNIFORM) {
+            if (prob >= 0 && lane == 0) {
+                const float *tp = a.t + (int64_t)prob * a.t_stride;
+                const double t0 = (double)tp[0];
+                s_grid[wv][s][0] = t0;
+                s_grid[wv][s][1] = ((double)tp[m - 1] - t0) / (double)(m - 1);
+            }
+        }
+    };
     int nactive = 0;
 #pragma nounroll
     for (int s = 0; s < GS; ++s) {
         const int64_t prob = (int64_t)gw * a.gs_used + s;
         const bool have = s < a.gs_used && prob < a.B;
-        if (wv == 0) slotg_fill<N, Q>((VP_LDS Rec *)(recs + s), (VP_LDS const KC *)kc, have ? (int)prob : -1);
+        fill(s, have ? (int)prob : -1);
         nactive += have ? 1 : 0;
     }
-    __syncthreads();
+    wave_sync();
 
 #ifdef VP_FITG_CLOCKS
     long long ck[4] = {0, 0, 0, 0};
@@ -322,145 +426,155 @@ __global__ void __launch_bounds__(64 * W, (2 * W) / 4 > 0 ? (2 * W) / 4 : 1) fit
 #define VP_CK(i)
 #endif
     while (nactive > 0) {
-        // ================= VECTOR phase: the Gram pass of every occupied slot =================
+        // ================= VECTOR phase: the moment pass of every occupied slot =================
 #pragma nounroll
         for (int s = 0; s < GS; ++s) {
-            Rec *rec = recs + s;
-            const int prob = uni(rec->prob);
+            const int prob = uni(recs[s].prob);
             if (prob < 0) continue;
-            // wave-uniform per-column constants live in LDS (su: 1/tau, 1/tau^2, ratio per row, ratio per chunk step), not
-            // in registers: the 77 fp64 accumulators own the register file
-            VP_LDS double *su = (VP_LDS double *)(s_u + (size_t)wv * 4 * NE);
-            double fa[NE];
-            {
-                double rt[NE];
+            double rt[NE];
 #pragma unroll
-                for (int kx = 0; kx < NE; ++kx) rt[kx] = 1.0 / rec->xt[kx];
+            for (int kx = 0; kx < NE; ++kx) rt[kx] = frcp(recs[s].xt[kx]);
+            double t0 = 0.0, dt = 0.0;
+            double fa[NE], q1[NE], qc[NE];
+            if constexpr (UNIFORM) {
+                t0 = uni_d(s_grid[wv][s][0]);
+                dt = uni_d(s_grid[wv][s][1]);
+                // anchor at the lane's first row, ratio per row, ratio per chunk: 3 NE exponentials per evaluation
+                double ax[3 * NE], ex[3 * NE];
+                const double tl = tfma((double)(4 * lane), dt, t0);
 #pragma unroll
                 for (int kx = 0; kx < NE; ++kx) {
-                    // uniform grid: exp(-t/tau) of a lane's rows by recurrence (anchor at the first row of the wave's first
-                    // chunk, ratio per row, ratio per W chunks)
-                    fa[kx] = uniform ? texp(-(t0 + (double)(256 * wv + 4 * lane) * dt) * rt[kx]) : 0.0;
-                    const double q1 = uniform ? texp(-dt * rt[kx]) : 0.0, qc = uniform ? texp(-((256.0 * W) * dt) * rt[kx]) : 0.0;
-                    if (lane == 0) {
-                        su[kx] = rt[kx];
-                        su[NE + kx] = rt[kx] * rt[kx];
-                        su[2 * NE + kx] = q1;
-                        su[3 * NE + kx] = qc;
-                    }
+                    ax[kx] = -tl * rt[kx];
+                    ax[NE + kx] = -dt * rt[kx];
+                    ax[2 * NE + kx] = -(256.0 * dt) * rt[kx];
+                }
+                texp_n<3 * NE>(ax, ex);
+#pragma unroll
+                for (int kx = 0; kx < NE; ++kx) {
+                    fa[kx] = ex[kx];
+                    q1[kx] = uni_d(ex[NE + kx]);
+                    qc[kx] = uni_d(ex[2 * NE + kx]);
                 }
             }
-            wave_sync();
             const float *yp = a.yw + (int64_t)prob * m;
-            const bool yvec = (reinterpret_cast<uintptr_t>(yp) & 15) == 0;
-            double acc[GI::NV];
+            const float *tp = a.t + (int64_t)prob * a.t_stride;
+            const float *wp = a.w ? a.w + (int64_t)prob * a.w_stride : nullptr;
+            double acc[NVR];
 #pragma unroll
-            for (int i = 0; i < GI::NV; ++i) acc[i] = 0.0;
+            for (int i = 0; i < NVR; ++i) acc[i] = 0.0;
+            GramChunk<UNIFORM, WEIGHTED> nxt;
+            gram_load_chunk(nxt, yp, tp, wp, 4 * lane, m, vec);
 #pragma nounroll
-            for (int ch = wv; ch < nchunk; ch += W) {
+            for (int ch = 0; ch < nchunk; ++ch) {
+                const GramChunk<UNIFORM, WEIGHTED> cur = nxt;
                 const int row0 = ch * 256 + 4 * lane;
-                const float4 t4 = *reinterpret_cast<const float4 *>(s_t + row0);
-                float4 y4;
-                if (yvec && row0 + 3 < m) {
-                    y4 = *reinterpret_cast<const float4 *>(yp + row0);
-                } else {
-                    y4.x = (row0 < m) ? yp[row0] : 0.0f;
-                    y4.y = (row0 + 1 < m) ? yp[row0 + 1] : 0.0f;
-                    y4.z = (row0 + 2 < m) ? yp[row0 + 2] : 0.0f;
-                    y4.w = (row0 + 3 < m) ? yp[row0 + 3] : 0.0f;
+                if (ch + 1 < nchunk) gram_load_chunk(nxt, yp, tp, wp, row0 + 256, m, vec);
+                const float yv[4] = {cur.y.x, cur.y.y, cur.y.z, cur.y.w};
+                float tv[4] = {0.f, 0.f, 0.f, 0.f}, wv4[4] = {1.f, 1.f, 1.f, 1.f};
+                if constexpr (!UNIFORM) {
+                    tv[0] = cur.t.x, tv[1] = cur.t.y, tv[2] = cur.t.z, tv[3] = cur.t.w;
                 }
-                const float tv[4] = {t4.x, t4.y, t4.z, t4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
+                if constexpr (WEIGHTED) {
+                    wv4[0] = cur.w.x, wv4[1] = cur.w.y, wv4[2] = cur.w.z, wv4[3] = cur.w.w;
+                }
+                // unit weights: m % 4 == 0 (host dispatch), so a lane's row group is valid or padding as a whole
+                const bool gvalid = row0 < m;
                 double f[NE];
+                if constexpr (UNIFORM) {
 #pragma unroll
-                for (int kx = 0; kx < NE; ++kx) f[kx] = fa[kx];
+                    for (int kx = 0; kx < NE; ++kx) f[kx] = (WEIGHTED || gvalid) ? fa[kx] : 0.0;
+                }
+                const double tb = UNIFORM ? tfma((double)row0, dt, t0) : 0.0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const bool valid = row0 + e < m;
-                    const double td = (double)tv[e];
-                    double X[GI::NX];
-                    if (uniform) {
+                    const double td = UNIFORM ? tfma((double)e, dt, tb) : (double)tv[e];
+                    const double yd = (double)yv[e];
+                    double eh[NE], uh[NE];
+                    if constexpr (UNIFORM) {
 #pragma unroll
                         for (int kx = 0; kx < NE; ++kx) {
-                            X[kx] = f[kx];
-                            f[kx] *= su[2 * NE + kx];
+                            eh[kx] = f[kx];
+                            if (e < 3) f[kx] *= q1[kx];
                         }
-                    } else { // general grid: one fp32 exponential per element (the accuracy class of the data)
+                    } else { // general grid: one fp64 exponential per element
+                        double ax[NE];
 #pragma unroll
-                        for (int kx = 0; kx < NE; ++kx) X[kx] = (double)texp(-(tv[e] * (float)su[kx]));
+                        for (int kx = 0; kx < NE; ++kx) ax[kx] = -td * rt[kx];
+                        texp_n<NE>(ax, eh);
+                        if constexpr (!WEIGHTED) {
+#pragma unroll
+                            for (int kx = 0; kx < NE; ++kx) eh[kx] = gvalid ? eh[kx] : 0.0;
+                        }
                     }
+                    double wd = 1.0;
+                    if constexpr (WEIGHTED) {
+                        wd = (double)wv4[e];
+#pragma unroll
+                        for (int kx = 0; kx < NE; ++kx) eh[kx] *= wd; // (padding rows: w = 0)
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < NE; ++kx) uh[kx] = td * eh[kx];
+#pragma unroll
+                    for (int i = 0; i < NE; ++i)
+#pragma unroll
+                        for (int k2 = i; k2 < NE; ++k2) {
+                            acc[GI::A0(i, k2)] = tfma(eh[i], eh[k2], acc[GI::A0(i, k2)]);
+                            acc[GI::A1(i, k2)] = tfma(eh[i], uh[k2], acc[GI::A1(i, k2)]);
+                            acc[GI::A2(i, k2)] = tfma(uh[i], uh[k2], acc[GI::A2(i, k2)]);
+                        }
 #pragma unroll
                     for (int kx = 0; kx < NE; ++kx) {
-                        X[kx] = valid ? X[kx] : 0.0;
-                        X[NE + 1 + kx] = X[kx] * (td * su[NE + kx]); // d/dtau exp(-t/tau) = exp(-t/tau) t / tau^2
+                        acc[GI::B0(kx)] = tfma(eh[kx], yd, acc[GI::B0(kx)]);
+                        acc[GI::B1(kx)] = tfma(uh[kx], yd, acc[GI::B1(kx)]);
                     }
-                    X[NE] = valid ? (double)yv[e] : 0.0;
-                    int idx = 0;
+                    acc[GI::YY] = tfma(yd, yd, acc[GI::YY]);
+                    if constexpr (WEIGHTED) {
 #pragma unroll
-                    for (int p = 0; p < GI::NX; ++p)
-#pragma unroll
-                        for (int q = p; q < GI::NX; ++q) {
-                            acc[idx] = tfma(X[p], X[q], acc[idx]);
-                            ++idx;
+                        for (int kx = 0; kx < NE; ++kx) {
+                            acc[GI::S0(kx)] = tfma(wd, eh[kx], acc[GI::S0(kx)]);
+                            acc[GI::S1(kx)] = tfma(wd, uh[kx], acc[GI::S1(kx)]);
                         }
+                        acc[GI::SY] = tfma(wd, yd, acc[GI::SY]);
+                        acc[GI::SW] = tfma(wd, wd, acc[GI::SW]);
+                    } else {
 #pragma unroll
-                    for (int p = 0; p < GI::NX; ++p) acc[GI::NP + p] += X[p];
+                        for (int kx = 0; kx < NE; ++kx) {
+                            acc[GI::S0(kx)] += eh[kx];
+                            acc[GI::S1(kx)] += uh[kx];
+                        }
+                        acc[GI::SY] += yd;
+                    }
                 }
+                if constexpr (UNIFORM) {
 #pragma unroll
-                for (int kx = 0; kx < NE; ++kx) fa[kx] *= su[3 * NE + kx];
+                    for (int kx = 0; kx < NE; ++kx) fa[kx] *= qc[kx];
+                }
             }
-            wave_reduce_store<GI::NV>(acc, (VP_LDS double *)(gram + ((size_t)wv * GS + s) * GI::NV));
+            wave_reduce_store<NVR>(acc, gram + (size_t)s * GI::NV);
         }
-        __syncthreads();
-        // total the W per-wave partial Grams in place (fixed order; all threads: one LDS round trip instead of 77 serial
-        // ones on the lanes of wave 0)
-        if constexpr (W > 1) {
-            for (int i = threadIdx.x; i < GS * GI::NV; i += 64 * W) {
-                double t = gram[i];
-#pragma unroll
-                for (int w = 1; w < W; ++w) t += gram[(size_t)w * GS * GI::NV + i];
-                gram[i] = t;
-            }
-            __syncthreads();
-        }
+        wave_sync();
         VP_CK(0);
-        // ===== wave 0, lane s: Gram -> evaluation results, then the LM bookkeeping of slot s; queue pops for finished slots =====
-        if (wv == 0) {
-            gram_phase<NE, GS, W>((VP_LDS Rec *)recs, (VP_LDS double *)gram, (VP_LDS const KC *)kc);
+        // ===== lane s: moments -> evaluation results, then the LM bookkeeping of slot s =====
+        gram_phase<NE, GS, WEIGHTED>(recs, gram, kc, a.dbg);
+        wave_sync();
+        VP_CK(1);
+        if (!a.dbg) {
+            slot_scalar_phase<double, N, Q, GS, float>(recs, kc);
             wave_sync();
-            VP_CK(1);
-            slot_scalar_phase<double, N, Q, GS, float>((VP_LDS Rec *)recs, (VP_LDS const KC *)kc);
-            wave_sync();
-            VP_CK(2);
-            if (lane == 0) {
-                for (int s = 0; s < GS; ++s)
-                    s_pop[s] = (recs[s].prob >= 0 && recs[s].term != 0)
-                                   ? __hip_atomic_fetch_add(kc->queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                   : -1;
-            }
         }
-        __syncthreads();
-        // ================= refill finished slots =================
-        bool refilled = false;
+        VP_CK(2);
+        // ================= refill finished slots from the queue =================
 #pragma nounroll
         for (int s = 0; s < GS; ++s) {
             if (uni(recs[s].prob) < 0 || uni(recs[s].term) == 0) continue;
-            const int next = uni(s_pop[s]);
+            int next = 0;
+            if (lane == 0) next = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            next = uni(next);
             const bool have = (int64_t)next < a.B;
-            refilled = true;
+            fill(s, have ? next : -1);
             if (!have) nactive -= 1;
         }
-        if (refilled) {
-            __syncthreads(); // every wave has read the finished records
-            if (wv == 0) {
-#pragma nounroll
-                for (int s = 0; s < GS; ++s) {
-                    if (uni(recs[s].prob) < 0 || uni(recs[s].term) == 0) continue;
-                    const int next = uni(s_pop[s]);
-                    slotg_fill<N, Q>((VP_LDS Rec *)(recs + s), (VP_LDS const KC *)kc, (int64_t)next < a.B ? next : -1);
-                }
-            }
-            __syncthreads();
-        }
+        wave_sync();
         VP_CK(3);
     }
 #ifdef VP_FITG_CLOCKS
@@ -471,16 +585,14 @@ __global__ void __launch_bounds__(64 * W, (2 * W) / 4 > 0 ? (2 * W) / 4 : 1) fit
 #endif
 }
 
-// fp32 handle, unit weights, one shared grid, single right-hand side: the Gram kernel; everything else: `fallback`
-template <class M> int launch_fitg(const LaunchParams &p, int (*fallback)(const LaunchParams &)) {
-    constexpr int W = 4, GS = 8, NE = M::N - 1;
-    using GI = GramIdx<NE>;
-    const int mp = ((p.m + 255) / 256) * 256;
-    const size_t lds = (size_t)mp * sizeof(float) + (size_t)GS * (W * GI::NV * sizeof(double) + sizeof(SlotRec<double, M::N, M::Q>)) +
-                       sizeof(SlotConsts<double, float>) + (size_t)W * 4 * NE * sizeof(double) + (size_t)GS * sizeof(int) + 16;
-    if (p.w || p.t_stride != 0 || !p.queue || p.fit_group == 1 || p.S != 1 || lds > 64 * 1024) return fallback(p);
-    FitgArgs<M> a;
+// fp32 handle, single right-hand side, NE exponentials + offset: the Gram kernel for every combination of grid
+// (shared / per problem, uniform or not) and weights (none / shared / per problem)
+template <class M> int launch_fitg(const LaunchParams &p, double *dbg = nullptr) {
+    constexpr int GS = VP_FITG_GS, NW = VP_FITG_WAVES;
+    if (p.S != 1 || !p.queue) return VP_ERR_UNSUPPORTED;
+    FitgArgs a;
     a.t = (const float *)p.t;
+    a.w = (const float *)p.w;
     a.yw = (const float *)p.yw;
     a.alpha = (float *)p.alpha_out;
     a.C_out = (float *)p.C_out;
@@ -488,30 +600,39 @@ template <class M> int launch_fitg(const LaunchParams &p, int (*fallback)(const 
     a.status = p.status;
     a.report = p.report;
     a.trace = p.trace;
+    a.dbg = dbg;
     a.queue = p.queue;
     a.B = p.B;
+    a.t_stride = p.t_stride;
+    a.w_stride = p.w_stride;
     a.m = p.m;
-    a.mp = mp;
     a.trace_rows = p.trace_rows;
     a.scale_diag = p.opts->scale_diag;
     a.patience = p.opts->patience;
-    a.grid_uniform = p.grid_uniform;
     a.eps = p.eps;
     a.ftol = p.opts->ftol;
     a.xtol = p.opts->xtol;
     a.gtol = p.opts->gtol;
     a.stepbound = p.opts->stepbound;
     if (a.B <= 0) return VP_ERR_OK;
-    // persistent grid: 2 groups of W waves per CU; the static first assignment spreads the batch over all groups
-    const int64_t cap_groups = (int64_t)p.num_cus * 2;
-    int64_t gs_used = (a.B + cap_groups - 1) / cap_groups;
+    // persistent grid: 2 workgroups of NW independent waves per CU (2 waves per SIMD); the static first assignment
+    // spreads the batch over all waves
+    const int64_t cap_waves = (int64_t)p.num_cus * 2 * NW;
+    int64_t gs_used = (a.B + cap_waves - 1) / cap_waves;
     if (gs_used > GS) gs_used = GS;
     if (gs_used < 1) gs_used = 1;
     a.gs_used = (int)gs_used;
-    int64_t blocks = (a.B + gs_used - 1) / gs_used;
-    if (blocks > cap_groups) blocks = cap_groups;
-    if (hipMemsetD32Async((hipDeviceptr_t)p.queue, (int)(blocks * gs_used), 1, p.stream) != hipSuccess) return VP_ERR_HIP;
-    hipLaunchKernelGGL((fitg_kernel<M, GS, W>), dim3((unsigned)blocks), dim3(64 * W), lds, p.stream, a);
+    int64_t waves = (a.B + gs_used - 1) / gs_used;
+    if (waves > cap_waves) waves = cap_waves;
+    const int64_t blocks = (waves + NW - 1) / NW;
+    if (hipMemsetD32Async((hipDeviceptr_t)p.queue, (int)(blocks * NW * gs_used), 1, p.stream) != hipSuccess) return VP_ERR_HIP;
+    const bool uniform = p.grid_uniform != 0 && p.m >= 3;
+    const bool weighted = p.w != nullptr || (p.m & 3) != 0; // a ragged last row group is masked through the weights
+    const dim3 grid((unsigned)blocks), block(64 * NW);
+    if (uniform && !weighted) hipLaunchKernelGGL((fitg_kernel<M, GS, true, false>), grid, block, 0, p.stream, a);
+    else if (uniform) hipLaunchKernelGGL((fitg_kernel<M, GS, true, true>), grid, block, 0, p.stream, a);
+    else if (!weighted) hipLaunchKernelGGL((fitg_kernel<M, GS, false, false>), grid, block, 0, p.stream, a);
+    else hipLaunchKernelGGL((fitg_kernel<M, GS, false, true>), grid, block, 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 

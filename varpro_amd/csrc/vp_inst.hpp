@@ -46,22 +46,20 @@
         &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0, \
         &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>});
 
-// fp32, many columns x many rows: the fit runs on the fp64 Gram matrix (vp_fitg.hpp; falls back to the slot kernel for
-// weighted problems / per-problem grids); evaluate / basis / statistics stay on the WW-wave Householder kernels
+// fp32, many columns x many rows: the FIT runs on the fp64 Gram matrix (vp_fitg.hpp: any grid, any weights; there is
+// no fp32 Householder fit kernel for these shapes -- it lost 15 % of the fits and spilled 230-250 VGPRs);
+// evaluate / basis / best_fit / statistics stay on the WW-wave Householder kernels
 namespace vp {
-template <class M, int R, int W> int launch_fitg_or_slots(const LaunchParams &p) {
-    return launch_fitg<M>(p, &launch_fit2<float, M, R, W>);
-}
+template <class M> int launch_fitg_entry(const LaunchParams &p) { return launch_fitg<M>(p, p.gram_dbg); }
 } // namespace vp
 #define VP_REGISTER_MULTIEXP_W_GRAM(NEXP, OFF, RR, WW)                                                                 \
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
         VP_F32, ::vp::FAMILY_MULTIEXP, NEXP, OFF, 0, RR, WW,                                                           \
         &::vp::launch_evaluate<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                 \
         &::vp::launch_basis<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                    \
-        &::vp::launch_fitg_or_slots<::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                   \
-        &::vp::launch_fit<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                      \
+        &::vp::launch_fitg_entry<::vp::MultiExpModel<NEXP, (OFF) != 0>>, nullptr,                                     \
         &::vp::launch_best_fit<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0, \
-        &::vp::launch_stats<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>});
+        &::vp::launch_stats<float, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, 1});
 
 // run-time-descriptor models at larger m (WW waves per problem): single-RHS kernel set only
 #define VP_REGISTER_RT_W(T, DT, NN, QQ, PP, RR, WW)                                                                    \

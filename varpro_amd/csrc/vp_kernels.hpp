@@ -46,6 +46,7 @@ struct LaunchParams {
     int trace_rows;
     int fit_group;      // fit: kernel selection (VP_FIT_KERNEL_*): 0 = automatic, 1 = one problem per wave, 2 = slots
     int *queue;         // fit (slot kernel): device int, the problem queue head
+    double *gram_dbg;   // Gram fit kernel: evaluate-only diagnostics output (vp_debug_gram_evaluate) or null
     int num_cus;        // compute units of the device
     void *gen_ws;       // generic fallback kernels (vp_generic.hpp): workspace, gen_blocks slots
     int gen_blocks;

@@ -26,6 +26,7 @@ struct KernelEntry {
     size_t mrhs_state_bytes;
     launch_fn stats; // batched fit statistics (vp_stats.hpp)
     launch_fn mrhs_fit_whole; // S > 1 fit as ONE launch (generic fallback kernels only; null elsewhere)
+    int gram_fit;       // 1: `fit` is the fp64-Gram kernel (vp_fitg.hpp), which also serves vp_debug_gram_evaluate
 };
 
 std::vector<KernelEntry> &registry();
