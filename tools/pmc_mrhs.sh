@@ -14,7 +14,7 @@ for sub in ("a","b"):
     for fn in f:
         for row in csv.DictReader(open(fn)):
             k=row["Kernel_Name"]
-            if "mrhs_stream" not in k: continue
+            if "mrhs_stream" not in k and "mrhs_coop" not in k: continue
             k="mode0" if k.rstrip(")").split(",")[-1].strip().startswith("0") or "0>(" in k else "mode1"
             agg[k][row["Counter_Name"]]+=float(row["Counter_Value"])
             key=(k,row["Dispatch_Id"])

@@ -448,7 +448,8 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         if (h->rhs_allreduce) {
             const int64_t total = h->B * nacc;
             hipLaunchKernelGGL(mrhs_reduce_partials_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                               lp.stream, (const double *)h->mrhs.acc, mrhs_gx(h->S), nacc, h->B, h->d_mrhs_tot);
+                               lp.stream, (const double *)h->mrhs.acc, mrhs_gx(h->S, h->kern->mrhs_gx_cap > 0 ? h->kern->mrhs_gx_cap : 256), nacc, h->B,
+                               h->d_mrhs_tot);
             VP_HIP(hipGetLastError());
             if (h->rhs_allreduce(h->d_mrhs_tot, total, (void *)lp.stream, h->rhs_allreduce_user) != 0)
                 return fail(VP_ERR_INVALID, "the right-hand-side all-reduce callback reported an error");
@@ -717,7 +718,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         VP_TRY(hipMalloc(&h->mrhs.g, (size_t)B * std::max(1, p_) * m * ts));
         VP_TRY(hipMalloc((void **)&h->mrhs.small, (size_t)B * mrhs_small_stride_rt(n_, p_) * sizeof(double)));
         VP_TRY(hipMalloc((void **)&h->mrhs.statusA, (size_t)B * sizeof(int32_t)));
-        VP_TRY(hipMalloc((void **)&h->mrhs.acc, (size_t)B * 256 * (1 + n_ * n_ + p_) * sizeof(double)));
+        VP_TRY(hipMalloc((void **)&h->mrhs.acc, (size_t)B * VP_MRHS_GX_MAX * (1 + n_ * n_ + p_) * sizeof(double)));
         VP_TRY(hipMalloc(&h->mrhs.lm_state, (size_t)B * kern->mrhs_state_bytes));
         VP_TRY(hipMalloc((void **)&h->mrhs.nactive, sizeof(int32_t)));
         VP_TRY(hipMalloc((void **)&h->mrhs.done, (size_t)B * sizeof(int32_t)));

@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// LDS-typed pointers (address space 3): accesses through them stay ds_* instructions in out-of-line functions
+#define VP_LDS __attribute__((address_space(3)))
+
 namespace vp {
 
 template <typename T> struct num;

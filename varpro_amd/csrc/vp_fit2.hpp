@@ -61,7 +61,6 @@ template <typename T, class M> struct Fit2Args {
     int waves_total;   // persistent waves in the grid
 };
 
-#define VP_LDS __attribute__((address_space(3)))
 
 // Launch-wide constants of the slot kernel, staged ONCE per workgroup in LDS: the scalar phase and the refill path
 // (both out of line, see below) read them from there, so they do not occupy SGPRs -- i.e. spill slots -- across the
@@ -429,6 +428,321 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
     }
 }
 
+// LONE TAIL (W = 1).  Once the problem queue is dry a wave that holds ONE unfinished fit has nobody to share the scalar
+// phase with: the lane-parallel bookkeeping (one dependent fp64 chain issued for a single lane, an LDS record round
+// trip and a call per evaluation) is then pure latency -- 5.6 us per evaluation against the 3.9 us of fit_kernel, whose
+// bookkeeping is inline and wave-uniform -- and the end of a launch IS a few hundred waves each
+// finishing one long fit.  This function takes the slot's record and runs the REST of that fit the fit_kernel way:
+// same evaluation (the slot's H_0 y column), same arithmetic, results bit-identical to either kernel.  Out of line: its
+// register allocation must not touch the slot loop's.
+template <typename T, class M, int R, int PADM>
+__device__ __noinline__ void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q> *rec, VP_LDS const T *s_col, VP_LDS const T *s_t,
+                                            VP_LDS const SlotConsts<T> *kc, const M mdl, const T eps, const int uniform,
+                                            const T h0_beta, const T h0_u, const T h0_g) {
+    constexpr int N = M::N, P = M::P, Q = M::Q;
+    constexpr int NC = N + P, YC = N - 1, DC = YC + 1;
+    using G = Grp<1>;
+    G grp = G::make(nullptr);
+    const int lane = grp.gl;
+    using Src = RowSource<T, R, true, 0, 1, 1, true, PADM>;
+    Src src;
+    src.t = (const T *)s_t;
+    src.w = nullptr;
+    src.m = kc->m;
+    src.lane = lane;
+    src.vec = true;
+    src.set_uniform(uniform != 0);
+    ConstReflector<T> h0;
+    h0.beta = h0_beta;
+    h0.u = h0_u;
+    h0.g = h0_g;
+    h0.live = true;
+    const T ftol = kc->ftol, xtol = kc->xtol, gtol = kc->gtol, stepbound = kc->stepbound;
+    const int scale_diag = uni(kc->scale_diag), max_fev = uni(kc->max_fev), mres = uni(kc->m);
+    const int64_t prob = uni(rec->prob);
+    const T qty0 = rec->qty0;
+    T x[Q], xt[Q], diag[Q], qtf[Q], step[Q], acnorm[Q], cbest[N];
+    T Rj[Q][Q];
+    int ipvt[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        xt[k] = rec->xt[k];
+        step[k] = T(0);
+    }
+    T fnorm, delta, par, xnorm, gnorm, pnorm, prered, dirder, objective;
+    bool first, first_tr, first_update;
+    int nfev, term = VP_TERM_NOT_RUN, st_best = uni(rec->status), trow = uni(rec->trow);
+    auto trace_row = [&](const T(&xx)[Q], T fn, T ratio) {
+        double *trace = kc->trace;
+        const int trace_rows = kc->trace_rows;
+        if (trace && trow < trace_rows && lane == 0) {
+            double *tr = trace + ((size_t)prob * trace_rows + trow) * (Q + 4);
+#pragma unroll
+            for (int k = 0; k < Q; ++k) tr[k] = (double)xx[k];
+            tr[Q] = (double)fn;
+            tr[Q + 1] = (double)ratio;
+            tr[Q + 2] = (double)delta;
+            tr[Q + 3] = (double)par;
+        }
+        ++trow;
+    };
+    for (;;) {
+        // the LM state stays parked in the slot's record during the sweep (the register-pressure peak); only the trial
+        // parameters are live across it
+        T C[NC][R];
+        EvalUniform<T, N> u;
+        load_rows_lds<T, R, 1>((const T *)s_col, lane, C[YC]);
+        evaluate_core_const_first<T, M, R, NC, Src, G, true>(mdl, xt, src, eps, grp, h0, C, u, nullptr, qty0);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            x[k] = rec->x[k];
+            diag[k] = rec->diag[k];
+            qtf[k] = rec->qtf[k];
+            acnorm[k] = rec->acnorm[k];
+            ipvt[k] = uni(rec->ipvt[k]);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) Rj[k][j] = rec->Rj[k][j];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) cbest[k] = rec->cbest[k];
+        fnorm = rec->fnorm;
+        delta = rec->delta;
+        par = rec->par;
+        xnorm = rec->xnorm;
+        gnorm = rec->gnorm;
+        pnorm = rec->pnorm;
+        prered = rec->prered;
+        dirder = rec->dirder;
+        objective = rec->objective;
+        {
+            const int fl = uni(rec->flags);
+            first = (fl & 1) != 0;
+            first_tr = (fl & 2) != 0;
+            first_update = (fl & 4) != 0;
+            nfev = uni(rec->nfev);
+        }
+        const T fnorm1 = usqrt(u.fn2);
+        bool need_jac = false;
+        if (first) {
+            first = false;
+            nfev = 1;
+            st_best = u.ok ? VP_ST_OK : VP_ST_NONFINITE;
+            if (!u.ok) {
+                term = VP_TERM_USER;
+                break;
+            }
+            fnorm = fnorm1;
+            objective = T(0.5) * fnorm * fnorm;
+            trace_row(xt, fnorm1, T(0) / T(0));
+#pragma unroll
+            for (int k = 0; k < N; ++k) cbest[k] = u.c[k];
+            if (Q > mres) {
+                term = VP_TERM_WRONG_DIMENSIONS;
+                break;
+            }
+            if (uni(!is_finite(fnorm))) {
+                term = VP_TERM_NUMERICAL;
+                break;
+            }
+            if (uni(fnorm <= num<T>::tiny)) {
+                term = VP_TERM_RESIDUALS_ZERO;
+                break;
+            }
+            need_jac = true;
+        } else {
+            nfev += 1;
+            if (!u.ok) {
+                term = VP_TERM_USER;
+#pragma unroll
+                for (int k = 0; k < Q; ++k) x[k] = xt[k];
+#pragma unroll
+                for (int k = 0; k < N; ++k) cbest[k] = u.c[k];
+                st_best = VP_ST_NONFINITE;
+                break;
+            }
+            const T q1 = fnorm1 * frcp(fnorm);
+            const T actred = (fnorm1 * T(0.1) < fnorm) ? T(1) - q1 * q1 : T(-1);
+            const T ratio = (prered == T(0)) ? T(0) : actred * frcp(prered);
+            if (ratio <= T(0.25)) {
+                T temp = !(actred < T(0)) ? T(0.5) : T(0.5) * dirder * frcp(dirder + T(0.5) * actred);
+                if (fnorm1 * T(0.1) >= fnorm || temp < T(0.1)) temp = T(0.1);
+                delta = temp * tmin(delta, pnorm * T(10));
+                par = par * frcp(temp);
+            } else if (par == T(0) || ratio >= T(0.75)) {
+                delta = pnorm * T(2);
+                par = par * T(0.5);
+            }
+            const bool good = uni(ratio >= T(1.0e-4));
+            trace_row(xt, fnorm1, ratio);
+            if (good) {
+#pragma unroll
+                for (int k = 0; k < Q; ++k) x[k] = xt[k];
+#pragma unroll
+                for (int k = 0; k < N; ++k) cbest[k] = u.c[k];
+                T tmpv[Q];
+#pragma unroll
+                for (int k = 0; k < Q; ++k) tmpv[k] = scale_diag ? diag[k] * x[k] : x[k];
+                xnorm = enorm_small<T, Q>(tmpv);
+                fnorm = fnorm1;
+                objective = T(0.5) * fnorm1 * fnorm1;
+                if (uni(!is_finite(xnorm))) {
+                    term = VP_TERM_NUMERICAL;
+                    break;
+                }
+            }
+            int tcode = 0;
+            if (fnorm <= num<T>::tiny) tcode = VP_TERM_RESIDUALS_ZERO;
+            if (!tcode) {
+                const bool ftol_check = tabs(actred) <= ftol && prered <= ftol && ratio * T(0.5) <= T(1);
+                const bool xtol_check = delta <= xtol * xnorm;
+                if (ftol_check || xtol_check)
+                    tcode = (ftol_check && xtol_check) ? VP_TERM_CONVERGED_BOTH
+                                                       : (ftol_check ? VP_TERM_CONVERGED_FTOL : VP_TERM_CONVERGED_XTOL);
+            }
+            if (!tcode && nfev >= max_fev) tcode = VP_TERM_LOST_PATIENCE;
+            if (!tcode && tabs(actred) <= num<T>::eps && prered <= num<T>::eps && ratio * T(0.5) <= T(1))
+                tcode = VP_TERM_NO_IMPROVEMENT;
+            if (!tcode && delta <= num<T>::eps * xnorm) tcode = VP_TERM_NO_IMPROVEMENT;
+            if (!tcode && gnorm <= num<T>::eps) tcode = VP_TERM_NO_IMPROVEMENT;
+            tcode = uni(tcode);
+            if (tcode) {
+                term = tcode;
+                break;
+            }
+            need_jac = good;
+        }
+        if (need_jac) {
+            residual_qcoords<T, R, N>(C[YC], u.e, grp);
+            T zs[Q];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
+            jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
+            T gmax = T(0);
+            bool degenerate = false;
+            const T ifn = frcp(fnorm);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const T an = dyn_get<Q>(acnorm, ipvt[j]);
+                if (an != T(0)) {
+                    T sum = T(0);
+#pragma unroll
+                    for (int i = 0; i <= j; ++i) sum = tfma(Rj[i][j], qtf[i], sum);
+                    const T temp = tabs(sum * frcp(an) * ifn);
+                    if (temp != temp) degenerate = true;
+                    gmax = tmax(gmax, temp);
+                }
+            }
+            gnorm = gmax;
+            if (uni(degenerate)) {
+                term = VP_TERM_NUMERICAL;
+                break;
+            }
+            if (uni(gnorm <= gtol)) {
+                term = VP_TERM_ORTHOGONAL;
+                break;
+            }
+            if (first_update) {
+                T tmpv[Q];
+#pragma unroll
+                for (int k = 0; k < Q; ++k) {
+                    if (scale_diag) diag[k] = (acnorm[k] == T(0)) ? T(1) : acnorm[k];
+                    tmpv[k] = scale_diag ? diag[k] * x[k] : x[k];
+                }
+                xnorm = enorm_small<T, Q>(tmpv);
+                if (uni(!is_finite(xnorm))) {
+                    term = VP_TERM_NUMERICAL;
+                    break;
+                }
+                delta = (xnorm == T(0)) ? stepbound : stepbound * xnorm;
+                first_update = false;
+            } else if (scale_diag) {
+#pragma unroll
+                for (int k = 0; k < Q; ++k) diag[k] = tmax(diag[k], acnorm[k]);
+            }
+        }
+        par = lmpar<T, Q>(Rj, ipvt, diag, qtf, delta, par, step, pnorm);
+        if (uni(!is_finite(pnorm))) {
+            term = VP_TERM_NUMERICAL;
+            break;
+        }
+        {
+            T wa[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) wa[i] = T(0);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const T pj = dyn_get<Q>(step, ipvt[j]);
+#pragma unroll
+                for (int i = 0; i <= j; ++i) wa[i] = tfma(Rj[i][j], pj, wa[i]);
+            }
+            const T ifn = frcp(fnorm);
+            const T t1 = enorm_small<T, Q>(wa) * ifn;
+            const T temp1 = t1 * t1;
+            const T t2 = (usqrt(par) * pnorm) * ifn;
+            const T temp2 = t2 * t2;
+            if (uni(!is_finite(temp1) || !is_finite(temp2))) {
+                term = VP_TERM_NUMERICAL;
+                break;
+            }
+            prered = temp1 + temp2 * T(2);
+            dirder = -(temp1 + temp2);
+        }
+        if (first_tr && pnorm < delta) delta = pnorm;
+        first_tr = false;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) xt[k] = x[k] - step[k];
+        // park for the next sweep
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                rec->x[k] = x[k];
+                rec->diag[k] = diag[k];
+                rec->qtf[k] = qtf[k];
+                rec->acnorm[k] = acnorm[k];
+                rec->ipvt[k] = ipvt[k];
+#pragma unroll
+                for (int j = 0; j < Q; ++j) rec->Rj[k][j] = Rj[k][j];
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) rec->cbest[k] = cbest[k];
+            rec->fnorm = fnorm;
+            rec->delta = delta;
+            rec->par = par;
+            rec->xnorm = xnorm;
+            rec->gnorm = gnorm;
+            rec->pnorm = pnorm;
+            rec->prered = prered;
+            rec->dirder = dirder;
+            rec->objective = objective;
+            rec->flags = (first ? 1 : 0) | (first_tr ? 2 : 0) | (first_update ? 4 : 0);
+            rec->nfev = nfev;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // results of the finished problem
+    if (lane == 0) {
+        vp_report rep;
+        rep.termination = term;
+        rep.n_evals = nfev;
+        rep.objective = (double)objective;
+        kc->report[prob] = rep;
+        double *cost_out = kc->cost_out;
+        int32_t *status_out = kc->status;
+        T *alpha_out = kc->alpha, *C_out = kc->C_out;
+        if (cost_out) cost_out[prob] = (double)objective;
+        if (status_out) status_out[prob] = st_best;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) alpha_out[prob * Q + k] = x[k];
+        if (C_out) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) C_out[prob * N + k] = cbest[k];
+        }
+        rec->term = term;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // A workgroup = NG groups of W waves (W = 1: NG = 4 independent waves; W > 1: ONE group, whose reductions use
 // workgroup barriers).  The groups share one LDS copy of the grid; each owns GS slots.  With W > 1 the scalar phase
 // runs on wave 0 of the group only -- the one-problem-per-group kernel has all W waves repeat the bookkeeping.
@@ -518,6 +832,7 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
 
     // ---- initial, static assignment: group gw takes problems gw*GS .. gw*GS+GS-1 ----
     int nactive = 0;
+    bool queue_dry = false;
 #pragma nounroll
     for (int s = 0; s < GS; ++s) {
         const int64_t prob = (int64_t)gw * GS + s;
@@ -632,11 +947,34 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
             }
             const bool have = (int64_t)next < B_;
             fill(s, have ? next : -1);
-            if (!have) nactive -= 1;
+            if (!have) {
+                nactive -= 1;
+                queue_dry = true; // learnt for free: the pop this wave had to make anyway came back empty
+            }
         }
         group_sync();
         VP_CK2(2);
+#ifndef VP_NO_LONE_TAIL
+        if constexpr (W == 1) {
+            if (queue_dry && nactive == 1) break; // ONE fit left and nothing to refill from: finish it below
+        }
+#endif
     }
+#ifndef VP_NO_LONE_TAIL
+    if constexpr (W == 1) {
+        // the wave's last fit runs the fit_kernel way (fit2_lone_tail) -- as the kernel's exit path: nothing of the slot
+        // loop is live across the call
+        if (nactive == 1) {
+#pragma nounroll
+            for (int s = 0; s < GS; ++s) {
+                if (uni(recs[s].prob) < 0) continue;
+                fit2_lone_tail<T, M, R, PADM>((VP_LDS Rec *)(recs + s), (VP_LDS const T *)(s_y + (size_t)s * MP),
+                                              (VP_LDS const T *)s_t, (VP_LDS const SlotConsts<T> *)kc, mdl, eps_, uniform_,
+                                              h0.beta, h0.u, h0.g);
+            }
+        }
+    }
+#endif
 #ifdef VP_FIT2_CLOCKS
     if (args.f.trace && blockIdx.x == 0 && threadIdx.x == 0) {
         double *tr = args.f.trace + (size_t)(args.f.trace_rows - 1) * (Q + 4);

@@ -22,7 +22,7 @@
         &::vp::launch_mrhs_lm<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                          \
         &::vp::launch_mrhs_finish<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                      \
         ::vp::mrhs_state_bytes<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>>(),                                          \
-        &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>});
+        &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>, nullptr, 0, ::vp::mrhs_gx_cap<T, RR>()});
 
 #define VP_REGISTER_RT(T, DT, NN, QQ, PP, RR)                                                                          \
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
@@ -33,7 +33,7 @@
         &::vp::launch_mrhs_factor<T, ::vp::RtModel<NN, QQ, PP>, RR>,                                                  \
         &::vp::launch_mrhs_stream<T, ::vp::RtModel<NN, QQ, PP>, RR>, &::vp::launch_mrhs_lm<T, ::vp::RtModel<NN, QQ, PP>, RR>, \
         &::vp::launch_mrhs_finish<T, ::vp::RtModel<NN, QQ, PP>, RR>, ::vp::mrhs_state_bytes<T, ::vp::RtModel<NN, QQ, PP>>(), \
-        &::vp::launch_stats<T, ::vp::RtModel<NN, QQ, PP>, RR>});
+        &::vp::launch_stats<T, ::vp::RtModel<NN, QQ, PP>, RR>, nullptr, 0, ::vp::mrhs_gx_cap<T, RR>()});
 
 // multi-wave groups (WW waves per problem): problems whose columns do not fit the registers of one wave
 #define VP_REGISTER_MULTIEXP_W(T, DT, NEXP, OFF, RR, WW)                                                               \

@@ -220,6 +220,28 @@ __global__ void __launch_bounds__(64 * W) mrhs_factor_kernel(const MrhsFactorArg
     }
 }
 
+// Packed wave reduction of V values whose totals are STORED by the lanes that end up holding them: dst[v] = total of
+// value v (same packing as wave_allreduce, vp_device.hpp; no broadcast, i.e. no 2V SGPRs)
+template <int V, typename T> __device__ __forceinline__ void wave_reduce_store_g(T (&x)[V], T *dst) {
+    constexpr int V1 = (V + 1) / 2, V2 = (V1 + 1) / 2, V3 = (V2 + 1) / 2, V4 = (V3 + 1) / 2;
+    T y1[V1], y2[V2], y3[V3], y4[V4];
+    pack_level<0>(x, y1);
+    pack_level<1>(y1, y2);
+    pack_level<2>(y2, y3);
+    pack_level<3>(y3, y4);
+#pragma unroll
+    for (int i = 0; i < V4; ++i) y4[i] += dpp<DPP_ROR4>(y4[i]);
+#pragma unroll
+    for (int i = 0; i < V4; ++i) y4[i] += dpp<DPP_ROR8>(y4[i]);
+    const int L = lane_id();
+    const int v = ((L >> 5) & 1) | (((L >> 4) & 1) << 1) | ((L & 1) << 2) | (((L >> 1) & 1) << 3);
+    if ((L & 0xC) == 0) {
+#pragma unroll
+        for (int i = 0; i < V4; ++i)
+            if (16 * i + v < V) dst[16 * i + v] = y4[i];
+    }
+}
+
 template <typename T, int N, int P> struct MrhsStreamArgs {
     const T *yw;   // [B][S][m]
     MrhsWs ws;
@@ -477,6 +499,337 @@ __global__ void __launch_bounds__(64 * VP_MRHS_WAVES) mrhs_stream_kernel(const M
     }
 }
 
+// ---- MODE 0 (fit), workgroup-cooperative with LDS-DMA prefetch (round 3) ------------------------------------------------
+// The one-wave-per-column kernel above re-reads Q and G from LDS for every column (176 ds_read_b128 per column: the LDS
+// pipe alone is ~38 us of a pass at configs[2]) and waits for its 16 KiB column before it computes (SQ_WAIT_ANY 75 %,
+// profiles/r02_mrhs_stream_pmc.json).  Here the NW waves of a workgroup share EVERY column: group lane gl owns
+// RW = R / NW rows (Layout<RW, NW>: row pairs dealt round-robin over the 64 NW lanes, so each wave-level access is 1 KiB
+// contiguous and a column is one 16 KiB burst per workgroup) and the lane's slice of Q lives in REGISTERS for the whole
+// launch -- no LDS reads of Q or G in the loop.  y streams through a per-wave LDS ring of 2 batches of NB columns filled by
+// global_load_lds_dwordx4 (asynchronous global -> LDS DMA: no VGPRs, lane-linear destination = this layout), i.e. batches
+// k+1 and k+2 are in flight while batch k is computed.  Per batch ONE cross-wave reduction (packed wave reduction -> LDS
+// -> one bare s_barrier): T = Q^T y for the NB columns, plus the squared residual norms of the PREVIOUS batch (they need T
+// first), so the per-column cost / status trail one batch.  The fit's other sums need no per-column reduction:
+//     sum_s c_{j(p),s} (G_p^T r_s) = G_p^T (sum_s c_{j(p),s} r_s):  P accumulator rows per lane, ONE dot with G at the end;
+//     c = R^{-1} T and sum c c^T are wave-uniform, accumulated one per lane by wave 0.
+// The DMA is issued from inline asm (the compiler would drain it with vmcnt(0) at every LDS read it cannot disambiguate),
+// so the waits are counted by hand: a wave issues KL = NB * RW/2 = 8 DMA instructions per batch, in order, and NOTHING else
+// that counts in vmcnt inside the loop -- the per-column results (c, cost, status) are staged in LDS and written by wave 0
+// in bursts, after a full drain; selections out of the coefficient vector are one-hot dot products (a select chain would
+// become a dynamically indexed vector in scratch, whose accesses count in vmcnt too).
+// Measured at configs[2] (profiles/r03_mrhs_stream.json): the pass is bound by the length of each wave's instruction stream
+// (VALU + SALU, in-order, 2 waves per SIMD), not by HBM: 82 us with 8 waves per column group, 66 us with 4 (half the
+// redundant wave-uniform work per column), 55 us of it with the loads switched off; a pure read of the same 268 MB takes
+// 41 us (tools/read_pattern.hip).
+template <typename T, int N, int P, int RW, int NW, int NB>
+__global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStreamArgs<T, N, P> a) {
+    static_assert(sizeof(T) == 8 && RW >= 2 && RW % 2 == 0, "fp64, row pairs");
+    constexpr int NPAIR = RW / 2, KL = NB * NPAIR;
+    constexpr int D = 2; // ring depth
+    constexpr int NRED = N * NB + NB;
+    constexpr int NACC = 1 + N * N + P;
+    constexpr int FB = 16;            // batches between two result bursts
+    constexpr int FC = FB * NB;       // columns staged
+    static_assert(NACC <= 64 && NRED <= 64 && (KL == 8 || KL == 16), "one lane per value; the wait counts below are written for KL = 8 / 16");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // ring[NW][D][NB][NPAIR][64] double2 | s_x[2][NW][NRED] | s_ri[2 N N] | s_c[FC][N] | s_cost[FC] | s_st[FC]
+    double2 *ring = reinterpret_cast<double2 *>(smem_raw);
+    double *s_x = reinterpret_cast<double *>(ring + (size_t)NW * D * NB * NPAIR * 64);
+    double *s_ri = s_x + 2 * NW * NRED;
+    double *s_c = s_ri + 2 * N * N;
+    double *s_cost = s_c + FC * N;
+    int *s_st = reinterpret_cast<int *>(s_cost + FC);
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int gl = (int)threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const int m = a.m;
+    if (a.ws.done[b] != 0) return; // (uniform per workgroup)
+    const T *qsrc = (const T *)a.ws.qthin + b * (int64_t)N * m;
+    const T *gsrc = (const T *)a.ws.g + b * (int64_t)P * m;
+    const double *small = a.ws.small + b * mrhs_small_stride<N, P>();
+    T q[N][RW];
+#pragma unroll
+    for (int j = 0; j < N; ++j) load_rows<T, RW, NW>(qsrc + (int64_t)j * m, m, gl, true, q[j]);
+    T gv[P > 0 ? P : 1][RW]; // v_p = sum_s c_{j(p),s} r_s
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) gv[p][r] = T(0);
+    if (threadIdx.x < N * N) {
+        s_ri[threadIdx.x] = small[threadIdx.x];
+        s_ri[N * N + threadIdx.x] = small[N * N + P * P + threadIdx.x];
+    }
+    const int stA = a.ws.statusA[b];
+    const int wsel = uni(a.ws.widx[b]) & 1;
+    const bool truncated = uni(small[2 * N * N + P * P] != 0.0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // every compiler-issued load has landed: vmcnt is ours now
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    T accv = T(0);
+    const int ak = lane < NACC ? lane : 0;
+    const int ai = (ak >= 1 && ak <= N * N) ? (ak - 1) / N : 0, aj = (ak >= 1 && ak <= N * N) ? (ak - 1) % N : 0;
+    // Selections out of the N coefficients of a column are written as ONE-HOT dot products: a chain of selects over a
+    // small array is folded by the compiler into a dynamically indexed vector, which it then keeps in SCRATCH -- scratch
+    // accesses count in vmcnt and would both stall on and miscount the DMA queue of this loop.
+    T ohi[N], ohj[N], ohp[P > 0 ? P : 1][N];
+#pragma unroll
+    for (int j2 = 0; j2 < N; ++j2) {
+        ohi[j2] = (ak >= 1 && ak <= N * N && ai == j2) ? T(1) : T(0);
+        ohj[j2] = (ak >= 1 && ak <= N * N && aj == j2) ? T(1) : T(0);
+#pragma unroll
+        for (int p = 0; p < P; ++p) ohp[p][j2] = (a.pb[p] == j2) ? T(1) : T(0);
+    }
+    const int64_t nbatch = (a.S + NB - 1) / NB;
+    const int64_t nloc = (nbatch > (int64_t)blockIdx.x) ? (nbatch - 1 - blockIdx.x) / gridDim.x + 1 : 0; // batches of this workgroup
+    const unsigned ring_lds = (unsigned)(uintptr_t)(VP_LDS unsigned char *)smem_raw + (unsigned)wave * (D * KL * 1024u);
+    // rows of this lane: pair k covers rows (k * 512 + gl) * 2, +1; rows >= m (m even) are clamped for the DMA and zeroed after
+    bool rvalid[NPAIR];
+    int64_t roff[NPAIR];
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+        const int row = (k * 64 * NW + gl) * 2;
+        rvalid[k] = row < m;
+        roff[k] = rvalid[k] ? row : 0;
+    }
+    // issue the KL DMA instructions of local batch i into ring slot i % D (columns past S re-read column S-1: the count of
+    // instructions per batch must not depend on the data)
+    auto issue = [&](const int64_t i) __attribute__((always_inline)) {
+        const int64_t bt = blockIdx.x + i * (int64_t)gridDim.x;
+        const unsigned slot = ring_lds + (unsigned)(i % D) * (KL * 1024u);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            int64_t s = bt * NB + c;
+            s = s < a.S ? s : a.S - 1;
+            const T *col = a.yw + (b * a.S + s) * (int64_t)m;
+#pragma unroll
+            for (int k = 0; k < NPAIR; ++k) {
+                const T *src = col + roff[k];
+                const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)(c * NPAIR + k) * 1024u);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src), "s"(dst)
+                             : "memory");
+            }
+        }
+    };
+    T r2prev[NB];
+    bool cfin_prev[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        r2prev[c] = T(0);
+        cfin_prev[c] = true;
+    }
+    int ph = 0;
+    // staged results of local batch i live in rows (i % FB) * NB + c of s_c / s_cost / s_st
+    auto emit_prev = [&](const T tot, const int64_t i) __attribute__((always_inline)) {
+        if (i < 0) return;
+        const int64_t bt = blockIdx.x + i * (int64_t)gridDim.x;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const int64_t s = bt * NB + c;
+            if (s >= a.S) continue;
+            const T r2 = readlane(tot, N * NB + c);
+            const bool ok = is_finite(r2) && stA == VP_ST_OK && cfin_prev[c];
+            if (wave == 0) {
+                if (lane == 0) {
+                    s_cost[(int)(i % FB) * NB + c] = 0.5 * (double)r2;
+                    s_st[(int)(i % FB) * NB + c] = ok ? VP_ST_OK : (stA != VP_ST_OK ? stA : VP_ST_NONFINITE);
+                }
+                accv += (ak == 0) ? r2 : T(0);
+            }
+        }
+    };
+    // wave 0 writes the staged results of local batches [i0, i1) (after draining its DMA: stores and loads share vmcnt)
+    auto burst = [&](const int64_t i0, const int64_t i1) __attribute__((always_inline)) {
+        if (wave != 0 || i1 <= i0) return;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        for (int64_t i = i0; i < i1; ++i) {
+            const int64_t bt = blockIdx.x + i * (int64_t)gridDim.x;
+            const int c = lane / N, jn = lane % N; // lanes 0 .. NB*N-1: coefficient jn of column c
+            const int64_t s = bt * NB + c;
+            if (lane < NB * N && s < a.S) ((T *)a.ws.cbuf[wsel])[(b * a.S + s) * N + jn] = (T)s_c[((int)(i % FB) * NB + c) * N + jn];
+            const int64_t s2 = bt * NB + lane;
+            if (lane < NB && s2 < a.S) {
+                a.ws.costbuf[wsel][b * a.S + s2] = s_cost[(int)(i % FB) * NB + lane];
+                a.ws.stbuf[wsel][b * a.S + s2] = s_st[(int)(i % FB) * NB + lane];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores are out before the next DMA is counted
+    };
+    if (nloc > 0) issue(0);
+    if (D > 1 && nloc > 1) issue(1);
+    int64_t flushed = 0; // local batches whose cost / status / c have been written
+    for (int64_t i = 0; i < nloc; ++i) {
+        const int64_t bt = blockIdx.x + i * (int64_t)gridDim.x;
+        // ---- batch i has landed once at most the KL instructions of batch i+1 are outstanding ----
+#ifdef VP_MRHS_NOLOAD
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        if (D > 1 && i + 1 < nloc) {
+            if constexpr (KL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#endif
+        T y[NB][RW];
+        {
+            const double2 *slot = ring + ((size_t)wave * D + (size_t)(i % D)) * KL * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const bool cvalid = bt * NB + c < a.S;
+#pragma unroll
+                for (int k = 0; k < NPAIR; ++k) {
+                    const double2 v = slot[(c * NPAIR + k) * 64];
+                    y[c][2 * k] = (cvalid && rvalid[k]) ? v.x : T(0);
+                    y[c][2 * k + 1] = (cvalid && rvalid[k]) ? v.y : T(0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot has been read: it may be refilled
+#ifdef VP_MRHS_NOLOAD // developer A/B: compute + synchronisation alone (the ring keeps the first two batches)
+        (void)issue;
+#else
+        if (i + D < nloc) issue(i + D);
+#endif
+        // ---- partial T = Q^T y | carried squared norms ----
+        T red[NRED];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                T acc = T(0);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc = tfma(q[j][r], y[c][r], acc);
+                red[c * N + j] = acc;
+            }
+            red[N * NB + c] = r2prev[c];
+        }
+        wave_reduce_store_g<NRED>(red, s_x + ((size_t)ph * NW + wave) * NRED);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // (a bare barrier: __syncthreads() would carry a full memory fence, i.e. drain the DMA)
+        asm volatile("" ::: "memory");
+        T tot = T(0);
+        if (lane < NRED) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += s_x[((size_t)ph * NW + w) * NRED + lane];
+        }
+        ph ^= 1;
+        emit_prev(tot, i - 1);
+        // a burst of FB batches is complete once the cost of its last batch has been emitted (one batch late)
+        if (i > 0 && (i % FB) == 0) {
+            burst(flushed, i);
+            flushed = i;
+        }
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const bool valid = bt * NB + c < a.S; // (uniform)
+            T tq[N], cc[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) tq[j] = readlane(tot, c * N + j);
+            if (truncated) {
+                T tp[N];
+#pragma unroll
+                for (int i2 = 0; i2 < N; ++i2) {
+                    T acc = T(0), accp = T(0);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        acc = tfma((T)s_ri[i2 * N + j], tq[j], acc);
+                        accp = tfma((T)s_ri[N * N + i2 * N + j], tq[j], accp);
+                    }
+                    cc[i2] = acc;
+                    tp[i2] = accp;
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < N; ++i2) tq[i2] = tp[i2];
+            } else {
+#pragma unroll
+                for (int i2 = 0; i2 < N; ++i2) {
+                    T acc = T(0);
+#pragma unroll
+                    for (int j = i2; j < N; ++j) acc = tfma((T)s_ri[i2 * N + j], tq[j], acc);
+                    cc[i2] = acc;
+                }
+            }
+            bool cfin = true;
+#pragma unroll
+            for (int i2 = 0; i2 < N; ++i2) cfin = cfin && is_finite(cc[i2]);
+            cfin_prev[c] = uni(cfin);
+            T r2 = T(0);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                T v = y[c][r];
+#pragma unroll
+                for (int j = 0; j < N; ++j) v = tfma(-tq[j], q[j][r], v);
+                y[c][r] = v;
+                r2 = tfma(v, v, r2);
+            }
+            r2prev[c] = valid ? r2 : T(0);
+            if (!valid) continue;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                T cp = T(0);
+#pragma unroll
+                for (int j2 = 0; j2 < N; ++j2) cp = tfma(ohp[p][j2], cc[j2], cp);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) gv[p][r] = tfma(cp, y[c][r], gv[p][r]);
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int j2 = 0; j2 < N; ++j2)
+                    if (lane == j2) s_c[((int)(i % FB) * NB + c) * N + j2] = (double)cc[j2];
+                T fa_ = T(0), fb_ = T(0);
+#pragma unroll
+                for (int j2 = 0; j2 < N; ++j2) {
+                    fa_ = tfma(ohi[j2], cc[j2], fa_);
+                    fb_ = tfma(ohj[j2], cc[j2], fb_);
+                }
+                accv = tfma(fa_, fb_, accv);
+            }
+        }
+    }
+    // ---- flush: squared norms of the last batch, the P dots G_p^T v_p, the remaining staged results ----
+    {
+        T red[NRED];
+#pragma unroll
+        for (int i2 = 0; i2 < NRED; ++i2) red[i2] = T(0);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) red[N * NB + c] = r2prev[c];
+        if constexpr (P > 0) {
+            static_assert(P <= N * NB, "the dots ride in the T slots of the flush round");
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                T gs[RW];
+                load_rows<T, RW, NW>(gsrc + (int64_t)p * m, m, gl, true, gs);
+                T acc = T(0);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc = tfma(gs[r], gv[p][r], acc);
+                red[p] = acc;
+            }
+        }
+        wave_reduce_store_g<NRED>(red, s_x + ((size_t)ph * NW + wave) * NRED);
+        __syncthreads();
+        T tot = T(0);
+        if (lane < NRED) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += s_x[((size_t)ph * NW + w) * NRED + lane];
+        }
+        emit_prev(tot, nloc - 1);
+        burst(flushed, nloc);
+        if (wave == 0) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const T dp = readlane(tot, p);
+                accv = (ak == 1 + N * N + p) ? dp : accv;
+            }
+            if (lane < NACC) a.ws.acc[(b * gridDim.x + blockIdx.x) * NACC + lane] = (double)accv;
+        }
+    }
+}
+
 template <typename T, int N, int Q, int P> struct MrhsLmArgs {
     MrhsWs ws;
     LmOpts<T> opts;
@@ -619,11 +972,21 @@ template <class M> inline void pair_maps(const vp_model_desc &d, int (&pb)[M::P 
 
 // workgroups per problem of the streaming kernel: one persistent 8-wave workgroup per CU at most (its LDS copy
 // of Q and G is ~100 KiB)
-inline int mrhs_gx(int64_t S) {
+constexpr int VP_MRHS_GX_MAX = 512; // partial-sum slots per problem the handle allocates
+inline int mrhs_gx(int64_t S, int cap = 256) {
     int64_t gx = (S + 7) / 8;
-    if (gx > 256) gx = 256;
+    if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     return (int)gx;
+}
+// workgroups per problem of the MODE 0 streaming pass of a (scalar type, rows per lane) kernel set: the LDS-DMA kernel runs
+// two 4-wave workgroups per CU, the one-wave-per-column kernel one 8-wave workgroup
+template <typename T, int R> constexpr int mrhs_gx_cap() {
+#ifndef VP_NO_MRHS_DMA
+    return (sizeof(T) == 8 && R == 32) ? 512 : 256;
+#else
+    return 256;
+#endif
 }
 
 template <typename T, class M, int R> int launch_mrhs_factor(const LaunchParams &p) {
@@ -665,9 +1028,30 @@ template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams 
     a.m = p.m;
     a.S = p.S;
     a.B = p.B;
+    // MODE 0 leaves one partial-sum record per workgroup for the LM step: the grid must be the (T, R) kernel set's own
+    // mrhs_gx_cap; MODE 1 has no such coupling
+    const int gx = (p.mrhs_mode == 0) ? mrhs_gx(p.S, mrhs_gx_cap<T, R>()) : mrhs_gx(p.S);
+#ifndef VP_NO_MRHS_DMA
+    if constexpr (sizeof(T) == 8 && R == 32) {
+        // 16-byte row pairs (m even, aligned bases); NW waves share a column (R / NW rows per lane), NB columns per batch
+        // (8 DMA instructions per batch and wave), ring of 2 batches per wave; two workgroups per CU
+        const bool vec = (p.m & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.yw) | reinterpret_cast<uintptr_t>(a.ws.qthin) |
+                                             reinterpret_cast<uintptr_t>(a.ws.g)) & 15) == 0;
+        if (p.mrhs_mode == 0 && vec) {
+            constexpr int NWd = 4, RWd = R / NWd, NBd = 16 / RWd;
+            const size_t dlds = (size_t)NWd * 2 * NBd * (RWd / 2) * 1024 +
+                                (size_t)(2 * NWd * (N * NBd + NBd) + 2 * N * N + 16 * NBd * N + 16 * NBd) * 8 + 16 * NBd * 4;
+            if (hipFuncSetAttribute((const void *)mrhs_coop_dma_kernel<T, N, P, RWd, NWd, NBd>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds) != hipSuccess)
+                return VP_ERR_HIP;
+            hipLaunchKernelGGL((mrhs_coop_dma_kernel<T, N, P, RWd, NWd, NBd>), dim3((unsigned)gx, (unsigned)p.B), dim3(64 * NWd), dlds,
+                               p.stream, a);
+            return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+        }
+    }
+#endif
     const size_t lds = (size_t)(N + P) * 64 * R * sizeof(T) + (size_t)N * N * sizeof(T);
     const int waves_per_wg = VP_MRHS_WAVES;
-    const int gx = mrhs_gx(p.S);
     dim3 grid((unsigned)gx, (unsigned)p.B), block(64 * waves_per_wg);
     hipError_t e;
     if (p.mrhs_mode == 0) {
@@ -701,7 +1085,7 @@ template <typename T, class M, int R> int launch_mrhs_lm(const LaunchParams &p) 
     a.B = p.B;
     a.S_global = p.mrhs_S_global > 0 ? p.mrhs_S_global : p.S;
     a.init = p.mrhs_init;
-    a.gx = p.mrhs_gx > 0 ? p.mrhs_gx : mrhs_gx(p.S);
+    a.gx = p.mrhs_gx > 0 ? p.mrhs_gx : mrhs_gx(p.S, mrhs_gx_cap<T, R>());
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
     hipLaunchKernelGGL((mrhs_lm_kernel<T, N, Q, P>), dim3((unsigned)p.B), dim3(64), 0, p.stream, a);

@@ -27,6 +27,7 @@ struct KernelEntry {
     launch_fn stats; // batched fit statistics (vp_stats.hpp)
     launch_fn mrhs_fit_whole; // S > 1 fit as ONE launch (generic fallback kernels only; null elsewhere)
     int gram_fit;       // 1: `fit` is the fp64-Gram kernel (vp_fitg.hpp), which also serves vp_debug_gram_evaluate
+    int mrhs_gx_cap;    // MRHS streaming kernel: max workgroups (partial-sum slots) per problem; 0 = 256
 };
 
 std::vector<KernelEntry> &registry();
