@@ -107,9 +107,12 @@ enum {
 enum {
     VP_ERR_OK = 0,
     VP_ERR_INVALID = -1,     /* bad handle / argument / shape (builder errors, src/problem/builder.rs:15-46) */
-    VP_ERR_UNSUPPORTED = -2, /* operation not available for this handle (every MODEL the descriptor can express is
-                              * accepted -- shapes without a specialised kernel run on generic kernels, global fits
-                              * included; what remains unsupported: right-hand-side sharding for such shapes, m < n) */
+    VP_ERR_UNSUPPORTED = -2, /* operation not available for this handle.  Every MODEL the descriptor can express is
+                              * accepted for every entry point -- shapes without a specialised kernel set run on generic
+                              * kernels, global fits (S > 1) and any batch size included.  What remains unsupported:
+                              * m < n (an underdetermined linear sub-problem), right-hand-side sharding
+                              * (vp_set_rhs_allreduce) on a shape that runs on the generic kernels, fit statistics with
+                              * S > 1 (as in the reference), vp_debug_gram_evaluate on handles without the Gram kernel */
     VP_ERR_HIP = -3,         /* HIP runtime failure */
     VP_ERR_NO_DEVICE = -4    /* no gfx950 device / library built without device code */
 };

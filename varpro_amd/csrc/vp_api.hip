@@ -591,6 +591,10 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     // fallback kernels (vp_generic.hpp): any descriptor, any m -- slower, but never a CPU path and never "unsupported"
     const KernelEntry *kern = find_kernels(dtype, *model, m);
     if (!kern) kern = generic_kernels(dtype);
+    // a global fit (S > 1) on a specialised set WITHOUT multiple-right-hand-side kernels (the multi-wave sets: double
+    // exponential at 2048 < m <= 4096, the fp32 Gram shape) runs on the generic kernels as well
+    if (S > 1 && !(kern->mrhs_factor && kern->mrhs_stream && kern->mrhs_lm && kern->mrhs_finish) && !kern->mrhs_fit_whole)
+        kern = generic_kernels(dtype);
 
     vp_batch *h = new vp_batch();
     std::memset(h, 0, sizeof(*h));
@@ -709,10 +713,6 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     VP_TRY(hipEventCreate(&h->ev0));
     VP_TRY(hipEventCreate(&h->ev1));
     if (S > 1 && kern->mrhs_factor && kern->mrhs_stream && kern->mrhs_lm && kern->mrhs_finish) {
-        if (B > 65535) { // the streaming kernel's grid is (workgroups per problem, problems): gridDim.y <= 65535
-            vp_batch_destroy(h);
-            return fail(VP_ERR_UNSUPPORTED, "at most 65535 problems per handle with multiple right-hand sides");
-        }
         const int n_ = h->n, p_ = h->p, q_ = h->q;
         VP_TRY(hipMalloc(&h->mrhs.qthin, (size_t)B * n_ * m * ts));
         VP_TRY(hipMalloc(&h->mrhs.g, (size_t)B * std::max(1, p_) * m * ts));

@@ -751,9 +751,11 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_basis_kernel(con
     }
 }
 
-template <typename T> __global__ void __launch_bounds__(TB) gen_best_fit_kernel(const GenArgs<T> a) {
+template <typename T> __global__ void __launch_bounds__(TB) gen_best_fit_kernel(const GenArgs<T> a, const int S) {
+    // prob = b * S + s: right-hand side s of problem b shares the grid and the parameters of b (src/fit.rs:87-91)
     const int m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params;
-    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+    for (int64_t prob = blockIdx.x; prob < a.B * S; prob += gridDim.x) {
+        const int64_t b = prob / S;
         const T *tp = a.t + b * a.t_stride;
         for (int i = (int)threadIdx.x; i < m; i += TB) {
             const T t = tp[i];
@@ -763,9 +765,9 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_best_fit_kernel(
                 T f, d0, d1;
                 basis_eval<T>(a.mdl.kind[j], t, i0 >= 0 ? a.alpha[b * q + i0] : T(0), i1 >= 0 ? a.alpha[b * q + i1] : T(0), f,
                               d0, d1);
-                acc = tfma(f, a.C_in[b * n + j], acc);
+                acc = tfma(f, a.C_in[prob * n + j], acc);
             }
-            a.r_out[b * (int64_t)m + i] = acc;
+            a.r_out[prob * (int64_t)m + i] = acc;
         }
     }
 }
@@ -990,11 +992,11 @@ template <typename T> int launch_basis(const LaunchParams &p) {
 template <typename T> int launch_best_fit(const LaunchParams &p) {
     GenArgs<T> a;
     if (!fill_args(p, a)) return VP_ERR_UNSUPPORTED;
-    if (p.S != 1) return VP_ERR_UNSUPPORTED;
     a.C_in = (const T *)p.C_out;
     if (a.B <= 0) return VP_ERR_OK;
-    const unsigned grid = (unsigned)(a.B < 4096 ? a.B : 4096);
-    hipLaunchKernelGGL((gen_best_fit_kernel<T>), dim3(grid), dim3(TB), 0, p.stream, a);
+    const int64_t nprob = a.B * p.S;
+    const unsigned grid = (unsigned)(nprob < 4096 ? nprob : 4096);
+    hipLaunchKernelGGL((gen_best_fit_kernel<T>), dim3(grid), dim3(TB), 0, p.stream, a, (int)p.S);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 

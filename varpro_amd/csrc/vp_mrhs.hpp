@@ -255,6 +255,7 @@ template <typename T, int N, int P> struct MrhsStreamArgs {
     int m;
     int S;
     int64_t B;
+    int gx; // workgroups per problem: the grid is ONE-dimensional, gx * B workgroups (no 65535 limit on B)
 };
 
 #ifndef VP_MRHS_WAVES
@@ -272,7 +273,8 @@ __global__ void __launch_bounds__(64 * VP_MRHS_WAVES) mrhs_stream_kernel(const M
     T *s_g = s_q + N * MP;                    // [P][MP]
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6), nwave = (int)(blockDim.x >> 6);
-    const int64_t b = blockIdx.y;
+    const int64_t b = blockIdx.x / a.gx;
+    const int wgi = (int)(blockIdx.x - b * a.gx); // workgroup within the problem
     const int m = a.m;
     if constexpr (MODE == 0) {
         if (a.ws.done[b] != 0) return; // the LM loop of this problem has terminated (uniform per workgroup)
@@ -334,7 +336,7 @@ __global__ void __launch_bounds__(64 * VP_MRHS_WAVES) mrhs_stream_kernel(const M
     const int ai = (ak >= 1 && ak <= N * N) ? (ak - 1) / N : 0, aj = (ak >= 1 && ak <= N * N) ? (ak - 1) % N : 0;
     const int ap = ak > N * N ? ak - 1 - N * N : 0;
 
-    const int64_t gw = (int64_t)blockIdx.x * nwave + wave, nw = (int64_t)gridDim.x * nwave;
+    const int64_t gw = (int64_t)wgi * nwave + wave, nw = (int64_t)a.gx * nwave;
     for (int64_t s = gw; s < a.S; s += nw) {
         const int64_t prob = b * a.S + s;
         const T *yp = a.yw + prob * (int64_t)m;
@@ -494,7 +496,7 @@ __global__ void __launch_bounds__(64 * VP_MRHS_WAVES) mrhs_stream_kernel(const M
         if (threadIdx.x < NACC) {
             double tot = 0.0;
             for (int w = 0; w < nwave; ++w) tot += s_part[w * NACC + threadIdx.x];
-            a.ws.acc[(b * gridDim.x + blockIdx.x) * NACC + threadIdx.x] = tot;
+            a.ws.acc[(b * a.gx + wgi) * NACC + threadIdx.x] = tot;
         }
     }
 }
@@ -542,7 +544,8 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const int gl = (int)threadIdx.x;
-    const int64_t b = blockIdx.y;
+    const int64_t b = blockIdx.x / a.gx;
+    const int wgi = (int)(blockIdx.x - b * a.gx); // workgroup within the problem
     const int m = a.m;
     if (a.ws.done[b] != 0) return; // (uniform per workgroup)
     const T *qsrc = (const T *)a.ws.qthin + b * (int64_t)N * m;
@@ -582,7 +585,7 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
         for (int p = 0; p < P; ++p) ohp[p][j2] = (a.pb[p] == j2) ? T(1) : T(0);
     }
     const int64_t nbatch = (a.S + NB - 1) / NB;
-    const int64_t nloc = (nbatch > (int64_t)blockIdx.x) ? (nbatch - 1 - blockIdx.x) / gridDim.x + 1 : 0; // batches of this workgroup
+    const int64_t nloc = (nbatch > (int64_t)wgi) ? (nbatch - 1 - wgi) / a.gx + 1 : 0; // batches of this workgroup
     const unsigned ring_lds = (unsigned)(uintptr_t)(VP_LDS unsigned char *)smem_raw + (unsigned)wave * (D * KL * 1024u);
     // rows of this lane: pair k covers rows (k * 512 + gl) * 2, +1; rows >= m (m even) are clamped for the DMA and zeroed after
     bool rvalid[NPAIR];
@@ -596,7 +599,7 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
     // issue the KL DMA instructions of local batch i into ring slot i % D (columns past S re-read column S-1: the count of
     // instructions per batch must not depend on the data)
     auto issue = [&](const int64_t i) __attribute__((always_inline)) {
-        const int64_t bt = blockIdx.x + i * (int64_t)gridDim.x;
+        const int64_t bt = wgi + i * (int64_t)a.gx;
         const unsigned slot = ring_lds + (unsigned)(i % D) * (KL * 1024u);
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
@@ -626,7 +629,7 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
     // staged results of local batch i live in rows (i % FB) * NB + c of s_c / s_cost / s_st
     auto emit_prev = [&](const T tot, const int64_t i) __attribute__((always_inline)) {
         if (i < 0) return;
-        const int64_t bt = blockIdx.x + i * (int64_t)gridDim.x;
+        const int64_t bt = wgi + i * (int64_t)a.gx;
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             const int64_t s = bt * NB + c;
@@ -647,7 +650,7 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
         if (wave != 0 || i1 <= i0) return;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         for (int64_t i = i0; i < i1; ++i) {
-            const int64_t bt = blockIdx.x + i * (int64_t)gridDim.x;
+            const int64_t bt = wgi + i * (int64_t)a.gx;
             const int c = lane / N, jn = lane % N; // lanes 0 .. NB*N-1: coefficient jn of column c
             const int64_t s = bt * NB + c;
             if (lane < NB * N && s < a.S) ((T *)a.ws.cbuf[wsel])[(b * a.S + s) * N + jn] = (T)s_c[((int)(i % FB) * NB + c) * N + jn];
@@ -663,7 +666,7 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
     if (D > 1 && nloc > 1) issue(1);
     int64_t flushed = 0; // local batches whose cost / status / c have been written
     for (int64_t i = 0; i < nloc; ++i) {
-        const int64_t bt = blockIdx.x + i * (int64_t)gridDim.x;
+        const int64_t bt = wgi + i * (int64_t)a.gx;
         // ---- batch i has landed once at most the KL instructions of batch i+1 are outstanding ----
 #ifdef VP_MRHS_NOLOAD
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -825,7 +828,7 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
                 const T dp = readlane(tot, p);
                 accv = (ak == 1 + N * N + p) ? dp : accv;
             }
-            if (lane < NACC) a.ws.acc[(b * gridDim.x + blockIdx.x) * NACC + lane] = (double)accv;
+            if (lane < NACC) a.ws.acc[(b * a.gx + wgi) * NACC + lane] = (double)accv;
         }
     }
 }
@@ -1031,6 +1034,8 @@ template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams 
     // MODE 0 leaves one partial-sum record per workgroup for the LM step: the grid must be the (T, R) kernel set's own
     // mrhs_gx_cap; MODE 1 has no such coupling
     const int gx = (p.mrhs_mode == 0) ? mrhs_gx(p.S, mrhs_gx_cap<T, R>()) : mrhs_gx(p.S);
+    a.gx = gx;
+    if ((int64_t)gx * p.B > 0x7fffffffLL) return VP_ERR_UNSUPPORTED;
 #ifndef VP_NO_MRHS_DMA
     if constexpr (sizeof(T) == 8 && R == 32) {
         // 16-byte row pairs (m even, aligned bases); NW waves share a column (R / NW rows per lane), NB columns per batch
@@ -1044,7 +1049,7 @@ template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams 
             if (hipFuncSetAttribute((const void *)mrhs_coop_dma_kernel<T, N, P, RWd, NWd, NBd>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds) != hipSuccess)
                 return VP_ERR_HIP;
-            hipLaunchKernelGGL((mrhs_coop_dma_kernel<T, N, P, RWd, NWd, NBd>), dim3((unsigned)gx, (unsigned)p.B), dim3(64 * NWd), dlds,
+            hipLaunchKernelGGL((mrhs_coop_dma_kernel<T, N, P, RWd, NWd, NBd>), dim3((unsigned)((int64_t)gx * p.B)), dim3(64 * NWd), dlds,
                                p.stream, a);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
         }
@@ -1052,7 +1057,7 @@ template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams 
 #endif
     const size_t lds = (size_t)(N + P) * 64 * R * sizeof(T) + (size_t)N * N * sizeof(T);
     const int waves_per_wg = VP_MRHS_WAVES;
-    dim3 grid((unsigned)gx, (unsigned)p.B), block(64 * waves_per_wg);
+    dim3 grid((unsigned)((int64_t)gx * p.B)), block(64 * waves_per_wg);
     hipError_t e;
     if (p.mrhs_mode == 0) {
         e = hipFuncSetAttribute((const void *)mrhs_stream_kernel<T, N, P, R, 0>,
@@ -1110,14 +1115,16 @@ __global__ void mrhs_finish_kernel(const LmVars<T, N, Q> *st, int64_t B, T *alph
 
 // (C, cost, status) of every column at the final parameters = the best point's buffer
 template <typename T>
-__global__ void mrhs_gather_kernel(const MrhsWs ws, int64_t B, int S, int n, T *C_out, double *cost_bs, int32_t *status_bs) {
-    const int64_t b = blockIdx.y;
+__global__ void mrhs_gather_kernel(const MrhsWs ws, int64_t B, int S, int n, T *C_out, double *cost_bs, int32_t *status_bs,
+                                   const int gx) {
+    const int64_t b = blockIdx.x / gx;
+    const int wgi = (int)(blockIdx.x - b * gx), nwg = gx;
     if (b >= B) return;
     const int sel = ws.bidx[b] & 1;
     const T *cs = (const T *)ws.cbuf[sel] + b * (int64_t)S * n;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)S * n; i += (int64_t)gridDim.x * blockDim.x)
+    for (int64_t i = wgi * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)S * n; i += (int64_t)nwg * blockDim.x)
         C_out[b * (int64_t)S * n + i] = cs[i];
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < S; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = wgi * (int64_t)blockDim.x + threadIdx.x; i < S; i += (int64_t)nwg * blockDim.x) {
         cost_bs[b * S + i] = ws.costbuf[sel][b * S + i];
         status_bs[b * S + i] = ws.stbuf[sel][b * S + i];
     }
@@ -1132,8 +1139,8 @@ template <typename T, class M, int R> int launch_mrhs_finish(const LaunchParams 
         const int64_t per = (int64_t)p.S * M::N;
         unsigned gx = (unsigned)((per + 255) / 256);
         if (gx > 64) gx = 64;
-        hipLaunchKernelGGL((mrhs_gather_kernel<T>), dim3(gx, (unsigned)p.B), dim3(256), 0, p.stream, ws, p.B, p.S, (int)M::N,
-                           (T *)p.C_out, p.cost_out, p.status);
+        hipLaunchKernelGGL((mrhs_gather_kernel<T>), dim3((unsigned)((int64_t)gx * p.B)), dim3(256), 0, p.stream, ws, p.B, p.S, (int)M::N,
+                           (T *)p.C_out, p.cost_out, p.status, (int)gx);
     }
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
