@@ -446,7 +446,10 @@ def main():
                              "frac": bytes_ev2 / (ev2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bytes_ev2,
                              "traffic": committed_traffic("mrhs_stream_kernel_mode1"),
                              "traffic_source": traffic_source("mrhs_stream_kernel_mode1")},
-                "roofline_fit": {"kernel": "mrhs_stream_kernel<MODE 0>: y re-read once per LM evaluation", "bound": "hbm",
+                "roofline_fit": {"kernel": "mrhs_coop_dma_kernel (MODE 0: workgroup-cooperative, LDS-DMA prefetch): y re-read once per LM "
+                                           "evaluation; fraction over the WHOLE global fit incl. the factor / LM-step kernels between passes",
+                                 "bound": "hbm", "traffic": committed_traffic("mrhs_coop_dma_kernel"),
+                                 "traffic_source": traffic_source("mrhs_coop_dma_kernel"),
                                  "achieved": T * m2 * S2 * int(r2["n_evals"][0]) / (fit2_ms * 1e-3) / 1e9,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": T * m2 * S2 * int(r2["n_evals"][0]) / (fit2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -476,13 +479,14 @@ def main():
                 "workload": "BASELINE configs[4]: %d fp32 fits, five exponentials + offset (n=6, q=5), m=%d" % (B4, m4),
                 "fits_per_s": B4 / (ms4 * 1e-3), "ms_per_step": ms4, "mean_evaluations_per_fit": float(r4["n_evals"].mean()),
                 "fraction_failed": float((r4["termination"] <= 0).mean()),
-                "roofline": {"kernel": "fitg_kernel<5 exp + offset> (fp32 data, fp64 moment/Gram pass + Cholesky-based LM; "
-                                       "independent persistent wavefronts, 3 problem slots each)", "bound": "fp64_valu",
+                "roofline": {"kernel": "fitg2_kernel<5 exp + offset> (fp32 data, fp64 moment/Gram pass + Cholesky-based LM; per CU one "
+                                       "8-wave workgroup = 7 streaming waves + 1 bookkeeping wave over a pool of 32 problem slots)",
+                             "bound": "fp64_valu",
                              "achieved": tf4, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf4 / FP64_VALU_PEAK_TFLOPS, "flops_per_evaluation": flops4,
                              "flops_executed_per_evaluation": flops4_exec, "frac_executed": tf4 * flops4_exec / flops4 / FP64_VALU_PEAK_TFLOPS,
-                             "hbm_bytes_per_evaluation": 4 * m4, "traffic": committed_traffic("fitg_kernel"),
-                             "traffic_source": traffic_source("fitg_kernel")},
+                             "hbm_bytes_per_evaluation": 4 * m4, "y_reread_bytes_per_launch": 4.0 * m4 * float(r4["n_evals"].sum()),
+                             "traffic": committed_traffic("fitg2_kernel"), "traffic_source": traffic_source("fitg2_kernel")},
             }
             bp4.close()
             del Y4

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profile of the bench command on the GPU box (bash tools/profile_round2.sh [tag]):
+# Profile of the bench command on the GPU box (bash tools/profile_round2.sh [tag]; round 3: tag r03):
 #   1. rocprofv3 --kernel-trace --stats           -> per-kernel durations + the timestamped trace of the pipelined leg
 #   2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE    -> HBM traffic per kernel (separate passes, counters only)
 #   3. rocprofv3 --pmc SQ_* (tools/pmc_fit.sh)    -> VALU instruction counts of the fit kernels
@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT/summary
-CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --emulate-shards 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $CMD > $OUT/summary/${TAG}_bench_under_rocprof_stdout.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o $TAG -- $CMD > $OUT/bench_pmc_fetch_stdout.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o $TAG -- $CMD > $OUT/bench_pmc_write_stdout.log 2>&1

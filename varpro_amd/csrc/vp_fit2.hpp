@@ -188,9 +188,9 @@ __device__ __noinline__ void slot_fill(VP_LDS SlotRec<T, N, Q> *rec, VP_LDS T *s
 // termination tests, gradient test, lmpar, predicted reduction, next trial point) and writes the results of a fit that
 // terminated.  == the body of LevenbergMarquardt::minimize between two evaluations.  Out of line (see slot_fill).
 template <typename T, int N, int Q, int GS, typename TO = T>
-__device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP_LDS const SlotConsts<T, TO> *k) {
+__device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP_LDS const SlotConsts<T, TO> *k, const bool act = true) {
     const int lane = lane_id();
-    if (!(lane < GS && recs[lane].prob >= 0)) return;
+    if (!(act && lane < GS && recs[lane].prob >= 0)) return;
     VP_LDS SlotRec<T, N, Q> *s = recs + lane;
     const T ftol = k->ftol, xtol = k->xtol, gtol = k->gtol, stepbound = k->stepbound;
     const int scale_diag = k->scale_diag, max_fev = k->max_fev, m = k->m;

@@ -27,13 +27,18 @@
 // handles never come here.  Rank-deficient Phi at a trial point (two decay times collide, a column degenerates into the
 // constant): columns whose Cholesky pivot vanishes are dropped, the counterpart of the reference's truncated SVD.
 //
-// Execution (round 3): every wavefront is an independent persistent worker that owns GS problem slots.  Per loop
-// iteration it streams the rows of each occupied slot ONCE (y_w -- and the grid / weights where they are not implied --
-// re-read from HBM / L2, 16 B per lane and stream, coalesced, the next chunk prefetched), then lane s turns slot s's
-// moments into the evaluation results (gram_phase) and runs the LM bookkeeping (slot_scalar_phase<double>), all in
-// fp64; finished slots refill from the device-side queue.  There are no workgroup barriers in the loop: while one wave
-// of a SIMD is in its latency-bound scalar phase the other streams.  Results do not depend on which wave or slot ran a
-// problem, nor on what ran beside it.
+// Execution (round 3): a workgroup of 8 waves owns a POOL of NS = 32 problem slots.  Waves 1..7 (stream waves) do nothing
+// but moment passes: each claims the next slot that has a trial point, streams the rows of its problem ONCE (y_w -- and the
+// grid / weights where they are not implied -- re-read from HBM / L2, 16 B per lane and stream, coalesced, the next chunk
+// prefetched) and leaves the moments in LDS.  Wave 0 (the scalar wave) does nothing but the lane-serial part, lane s <->
+// slot s, for every slot whose moments are ready: gram_phase (moments -> c, ||r||, J^T J, J^T r) and the LM bookkeeping
+// (slot_scalar_phase<double>), all in fp64, and the refill of finished slots from the device-side queue.  Slot states live
+// in LDS, claims are LDS compare-and-swaps, there is no barrier in the loop: the ~33 k issue cycles of one bookkeeping
+// pass serve up to NS evaluations instead of one wave's own 2-3, and no stream wave ever waits for them.  Results do not
+// depend on which wave served a slot, nor on what ran beside it (tested bit for bit under a permutation of the batch).
+// Round-3 history at configs[4] (8192 fits): round 2's 4-wave groups 5.7 ms -> independent waves on the moment form 4.0 ms
+// -> role-specialised waves 3.4 ms; measured without a gain: serving the oldest fit first, raised priority of the scalar
+// wave, 4 / 5 / 6 waves per workgroup, 16 / 24 / 48 slots.
 #pragma once
 #include "vp_fit2.hpp"
 #include "vp_lm_core.hpp"
@@ -107,54 +112,15 @@ struct FitgArgs {
     double eps, ftol, xtol, gtol, stepbound;
 };
 
-// (re)fill a slot: only the LM record -- no data is staged
-template <int N, int Q>
-__device__ __noinline__ void slotg_fill(VP_LDS SlotRec<double, N, Q> *rec, VP_LDS const SlotConsts<double, float> *k, const int prob) {
-    if (lane_id() != 0) return;
-    if (prob < 0) {
-        rec->prob = -1;
-        rec->term = VP_TERM_NOT_RUN;
-        return;
-    }
-    const float *a0 = k->alpha + (int64_t)prob * Q;
-#pragma unroll
-    for (int i = 0; i < Q; ++i) {
-        const double v = (double)a0[i];
-        rec->xt[i] = v;
-        rec->x[i] = v;
-        rec->diag[i] = 1.0;
-        rec->qtf[i] = 0.0;
-        rec->acnorm[i] = 0.0;
-        rec->ipvt[i] = i;
-#pragma unroll
-        for (int j = 0; j < Q; ++j) rec->Rj[i][j] = 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        rec->cbest[i] = 0.0;
-        rec->cnew[i] = 0.0;
-    }
-    rec->fnorm = rec->delta = rec->par = rec->xnorm = rec->gnorm = rec->pnorm = rec->prered = rec->dirder = 0.0;
-    rec->objective = 0.0 / 0.0;
-    rec->fnorm1 = rec->actred = rec->ratio = 0.0;
-    rec->qty0 = 0.0;
-    rec->flags = 1 | 2 | 4;
-    rec->nfev = 0;
-    rec->term = VP_TERM_NOT_RUN;
-    rec->status = VP_ST_NOT_EVALUATED;
-    rec->prob = prob;
-    rec->trow = 0;
-}
-
 // Lane s: moments of slot s -> results of the evaluation in the slot's record (what the vector phase of fit2_kernel
 // posts).  gram: [GS][GI::NV].  dbg != null: additionally write {1/2||r||^2, c, J^T r, J^T J} of the slot's problem.
 template <int NE, int GS, bool WEIGHTED>
 __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs, VP_LDS const double *gram,
-                                        VP_LDS const SlotConsts<double, float> *k, double *dbg) {
+                                        VP_LDS const SlotConsts<double, float> *k, double *dbg, const bool act = true) {
     constexpr int N = NE + 1, Q = NE;
     using GI = GramIdx<NE>;
     const int lane = lane_id();
-    if (!(lane < GS && recs[lane].prob >= 0)) return;
+    if (!(act && lane < GS && recs[lane].prob >= 0)) return;
     VP_LDS SlotRec<double, N, Q> *rec = recs + lane;
     VP_LDS const double *g = gram + (size_t)lane * GI::NV;
     const double eps = k->eps;
@@ -335,260 +301,332 @@ __device__ __forceinline__ void gram_load_chunk(GramChunk<UNIFORM, WEIGHTED> &c,
     }
 }
 
-#ifndef VP_FITG_GS
-#define VP_FITG_GS 3
-#endif
-constexpr int VP_FITG_WAVES = 4; // independent waves per workgroup (they share the launch constants only)
+// The MOMENT PASS of one slot by one wavefront: streams the rows of problem `prob` once and leaves the NVR moments in
+// gram_out (LDS).  rec->xt holds the trial parameters; grid2 = {t_0, dt} of the slot's grid (UNIFORM).
+template <int NE, bool UNIFORM, bool WEIGHTED>
+__device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRec<double, NE + 1, NE> *rec, VP_LDS const double *grid2,
+                                          VP_LDS double *gram_out, const int prob, const int lane, const int m, const int nchunk,
+                                          const bool vec) {
+    using GI = GramIdx<NE>;
+    constexpr int NVR = WEIGHTED ? GI::NV : GI::NV - 1;
+    double rt[NE];
+#pragma unroll
+    for (int kx = 0; kx < NE; ++kx) rt[kx] = frcp(rec->xt[kx]);
+    double t0 = 0.0, dt = 0.0;
+    double fa[NE], q1[NE], qc[NE];
+    if constexpr (UNIFORM) {
+        t0 = uni_d(grid2[0]);
+        dt = uni_d(grid2[1]);
+        // anchor at the lane's first row, ratio per row, ratio per chunk: 3 NE exponentials per evaluation
+        double ax[3 * NE], ex[3 * NE];
+        const double tl = tfma((double)(4 * lane), dt, t0);
+#pragma unroll
+        for (int kx = 0; kx < NE; ++kx) {
+            ax[kx] = -tl * rt[kx];
+            ax[NE + kx] = -dt * rt[kx];
+            ax[2 * NE + kx] = -(256.0 * dt) * rt[kx];
+        }
+        texp_n<3 * NE>(ax, ex);
+#pragma unroll
+        for (int kx = 0; kx < NE; ++kx) {
+            fa[kx] = ex[kx];
+            q1[kx] = uni_d(ex[NE + kx]);
+            qc[kx] = uni_d(ex[2 * NE + kx]);
+        }
+    }
+    const float *yp = a.yw + (int64_t)prob * m;
+    const float *tp = a.t + (int64_t)prob * a.t_stride;
+    const float *wp = a.w ? a.w + (int64_t)prob * a.w_stride : nullptr;
+    double acc[NVR];
+#pragma unroll
+    for (int i = 0; i < NVR; ++i) acc[i] = 0.0;
+    GramChunk<UNIFORM, WEIGHTED> nxt;
+    gram_load_chunk(nxt, yp, tp, wp, 4 * lane, m, vec);
+#pragma nounroll
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const GramChunk<UNIFORM, WEIGHTED> cur = nxt;
+        const int row0 = ch * 256 + 4 * lane;
+        if (ch + 1 < nchunk) gram_load_chunk(nxt, yp, tp, wp, row0 + 256, m, vec);
+        const float yv[4] = {cur.y.x, cur.y.y, cur.y.z, cur.y.w};
+        float tv[4] = {0.f, 0.f, 0.f, 0.f}, wv4[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (!UNIFORM) {
+            tv[0] = cur.t.x, tv[1] = cur.t.y, tv[2] = cur.t.z, tv[3] = cur.t.w;
+        }
+        if constexpr (WEIGHTED) {
+            wv4[0] = cur.w.x, wv4[1] = cur.w.y, wv4[2] = cur.w.z, wv4[3] = cur.w.w;
+        }
+        // unit weights: m % 4 == 0 (host dispatch), so a lane's row group is valid or padding as a whole
+        const bool gvalid = row0 < m;
+        double f[NE];
+        if constexpr (UNIFORM) {
+#pragma unroll
+            for (int kx = 0; kx < NE; ++kx) f[kx] = (WEIGHTED || gvalid) ? fa[kx] : 0.0;
+        }
+        const double tb = UNIFORM ? tfma((double)row0, dt, t0) : 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double td = UNIFORM ? tfma((double)e, dt, tb) : (double)tv[e];
+            const double yd = (double)yv[e];
+            double eh[NE], uh[NE];
+            if constexpr (UNIFORM) {
+#pragma unroll
+                for (int kx = 0; kx < NE; ++kx) {
+                    eh[kx] = f[kx];
+                    if (e < 3) f[kx] *= q1[kx];
+                }
+            } else { // general grid: one fp64 exponential per element
+                double ax[NE];
+#pragma unroll
+                for (int kx = 0; kx < NE; ++kx) ax[kx] = -td * rt[kx];
+                texp_n<NE>(ax, eh);
+                if constexpr (!WEIGHTED) {
+#pragma unroll
+                    for (int kx = 0; kx < NE; ++kx) eh[kx] = gvalid ? eh[kx] : 0.0;
+                }
+            }
+            double wd = 1.0;
+            if constexpr (WEIGHTED) {
+                wd = (double)wv4[e];
+#pragma unroll
+                for (int kx = 0; kx < NE; ++kx) eh[kx] *= wd; // (padding rows: w = 0)
+            }
+#pragma unroll
+            for (int kx = 0; kx < NE; ++kx) uh[kx] = td * eh[kx];
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+#pragma unroll
+                for (int k2 = i; k2 < NE; ++k2) {
+                    acc[GI::A0(i, k2)] = tfma(eh[i], eh[k2], acc[GI::A0(i, k2)]);
+                    acc[GI::A1(i, k2)] = tfma(eh[i], uh[k2], acc[GI::A1(i, k2)]);
+                    acc[GI::A2(i, k2)] = tfma(uh[i], uh[k2], acc[GI::A2(i, k2)]);
+                }
+#pragma unroll
+            for (int kx = 0; kx < NE; ++kx) {
+                acc[GI::B0(kx)] = tfma(eh[kx], yd, acc[GI::B0(kx)]);
+                acc[GI::B1(kx)] = tfma(uh[kx], yd, acc[GI::B1(kx)]);
+            }
+            acc[GI::YY] = tfma(yd, yd, acc[GI::YY]);
+            if constexpr (WEIGHTED) {
+#pragma unroll
+                for (int kx = 0; kx < NE; ++kx) {
+                    acc[GI::S0(kx)] = tfma(wd, eh[kx], acc[GI::S0(kx)]);
+                    acc[GI::S1(kx)] = tfma(wd, uh[kx], acc[GI::S1(kx)]);
+                }
+                acc[GI::SY] = tfma(wd, yd, acc[GI::SY]);
+                acc[GI::SW] = tfma(wd, wd, acc[GI::SW]);
+            } else {
+#pragma unroll
+                for (int kx = 0; kx < NE; ++kx) {
+                    acc[GI::S0(kx)] += eh[kx];
+                    acc[GI::S1(kx)] += uh[kx];
+                }
+                acc[GI::SY] += yd;
+            }
+        }
+        if constexpr (UNIFORM) {
+#pragma unroll
+            for (int kx = 0; kx < NE; ++kx) fa[kx] *= qc[kx];
+        }
+    }
+    wave_reduce_store<NVR>(acc, gram_out);
+}
 
-template <class M, int GS, bool UNIFORM, bool WEIGHTED>
-__global__ void __launch_bounds__(64 * VP_FITG_WAVES, 2) fitg_kernel(const FitgArgs a) {
+// ---- role-specialised waves ------------------------------------------------------------------------------------------
+// If every wave alternated moment passes and bookkeeping (measured: 4.0 ms per 8192 fits) the lane-serial LM bookkeeping --
+// ~33 k cycles of issue per pass however few lanes are active (tools/gram_clocks.py: gram_phase 7 k + slot_scalar_phase
+// 26 k) -- would be paid once per 2-3 evaluations and stretch every fit's round.  Here a workgroup of 8 waves owns a POOL
+// of NS slots: wave 0 (the scalar wave) does nothing but the bookkeeping, lane s <-> slot s, for every slot whose moments
+// are ready -- one pass serves up to NS evaluations -- and waves 1..7 (the stream waves) do nothing but moment passes, each
+// claiming the next slot that has a trial point.  Slots move through 1 (needs a pass) -> 2 (being streamed) -> 3 (moments
+// ready; bookkeeping) -> 1 | refill | 0 (empty); the state words live in LDS, claims are LDS compare-and-swaps, there is no
+// barrier in the loop.  A fit's result is independent of who processed it and when.
+// (re)fill the slot of THIS lane: only the LM record -- no data is staged
+template <int N, int Q>
+__device__ __forceinline__ void slotg_fill_lane(VP_LDS SlotRec<double, N, Q> *rec, VP_LDS const SlotConsts<double, float> *k,
+                                                const int prob) {
+    const float *a0 = k->alpha + (int64_t)prob * Q;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const double v = (double)a0[i];
+        rec->xt[i] = v;
+        rec->x[i] = v;
+        rec->diag[i] = 1.0;
+        rec->qtf[i] = 0.0;
+        rec->acnorm[i] = 0.0;
+        rec->ipvt[i] = i;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) rec->Rj[i][j] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        rec->cbest[i] = 0.0;
+        rec->cnew[i] = 0.0;
+    }
+    rec->fnorm = rec->delta = rec->par = rec->xnorm = rec->gnorm = rec->pnorm = rec->prered = rec->dirder = 0.0;
+    rec->objective = 0.0 / 0.0;
+    rec->fnorm1 = rec->actred = rec->ratio = 0.0;
+    rec->qty0 = 0.0;
+    rec->flags = 1 | 2 | 4;
+    rec->nfev = 0;
+    rec->term = VP_TERM_NOT_RUN;
+    rec->status = VP_ST_NOT_EVALUATED;
+    rec->prob = prob;
+    rec->trow = 0;
+}
+
+#ifndef VP_FITG_NS
+#define VP_FITG_NS 32
+#endif
+#ifndef VP_FITG2_NWAVES
+#define VP_FITG2_NWAVES 8
+#endif
+constexpr int VP_FITG2_WAVES = VP_FITG2_NWAVES;
+
+template <class M, int NS, bool UNIFORM, bool WEIGHTED>
+__global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 : 1) fitg2_kernel(const FitgArgs a) {
     constexpr int N = M::N, Q = M::Q, NE = M::N - 1;
     static_assert(M::kStatic && M::kConstLast && M::kDiagonalPairs && M::Q == NE, "exponentials + offset");
+    static_assert(NS <= 64, "one lane of the scalar wave per slot");
     using GI = GramIdx<NE>;
     using Rec = SlotRec<double, N, Q>;
     using KC = SlotConsts<double, float>;
-    constexpr int NVR = WEIGHTED ? GI::NV : GI::NV - 1; // moments accumulated and reduced
-    constexpr int NW = VP_FITG_WAVES;
-    __shared__ __attribute__((aligned(16))) double s_gram[NW][GS][GI::NV];
-    __shared__ __attribute__((aligned(16))) Rec s_recs[NW][GS];
+    __shared__ __attribute__((aligned(16))) double s_gram[NS][GI::NV];
+    __shared__ __attribute__((aligned(16))) Rec s_recs[NS];
     __shared__ __attribute__((aligned(16))) KC s_kc;
-    __shared__ double s_grid[NW][GS][2]; // UNIFORM: t_0 and dt of the slot's grid
+    __shared__ double s_grid[NS][2];
+    __shared__ int s_state[NS]; // 0 empty | 1 needs a moment pass | 2 being streamed | 3 moments ready / bookkeeping
+    __shared__ int s_live;      // slots that hold a fit
     const int lane = lane_id();
     const int wv = (int)(threadIdx.x >> 6);
-    const int gw = (int)blockIdx.x * NW + wv; // persistent wave index
     const int m = a.m;
+    VP_LDS Rec *recs = (VP_LDS Rec *)&s_recs[0];
+    VP_LDS double *gram = (VP_LDS double *)&s_gram[0][0];
+    VP_LDS const KC *kc = (VP_LDS const KC *)&s_kc;
     if (threadIdx.x == 0) {
-        KC *kc = &s_kc;
-        kc->ftol = a.ftol;
-        kc->xtol = a.xtol;
-        kc->gtol = a.gtol;
-        kc->stepbound = a.stepbound;
-        kc->alpha = a.alpha;
-        kc->C_out = a.C_out;
-        kc->cost_out = a.cost_out;
-        kc->status = a.status;
-        kc->report = a.report;
-        kc->trace = a.trace;
-        kc->yw = a.yw;
-        kc->queue = a.queue;
-        kc->B = a.B;
-        kc->trace_rows = a.trace_rows;
-        kc->scale_diag = a.scale_diag;
-        kc->max_fev = a.patience * (Q + 1);
-        kc->m = a.m;
-        kc->eps = a.eps;
+        KC *k = &s_kc;
+        k->ftol = a.ftol;
+        k->xtol = a.xtol;
+        k->gtol = a.gtol;
+        k->stepbound = a.stepbound;
+        k->alpha = a.alpha;
+        k->C_out = a.C_out;
+        k->cost_out = a.cost_out;
+        k->status = a.status;
+        k->report = a.report;
+        k->trace = a.trace;
+        k->yw = a.yw;
+        k->queue = a.queue;
+        k->B = a.B;
+        k->trace_rows = a.trace_rows;
+        k->scale_diag = a.scale_diag;
+        k->max_fev = a.patience * (Q + 1);
+        k->m = a.m;
+        k->eps = a.eps;
+        s_live = 0;
     }
     __syncthreads();
-    VP_LDS Rec *recs = (VP_LDS Rec *)&s_recs[wv][0];
-    VP_LDS double *gram = (VP_LDS double *)&s_gram[wv][0][0];
-    VP_LDS const KC *kc = (VP_LDS const KC *)&s_kc;
-    auto wave_sync = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto grid_of = [&](const int s, const int prob) __attribute__((always_inline)) {
+        if constexpr (UNIFORM) {
+            const float *tp = a.t + (int64_t)prob * a.t_stride;
+            const double t0 = (double)tp[0];
+            s_grid[s][0] = t0;
+            s_grid[s][1] = ((double)tp[m - 1] - t0) / (double)(m - 1);
+        }
     };
+    // static first assignment: workgroup g takes problems g * ns_used .. + ns_used - 1 (lane s of wave 0 fills slot s)
+    if (wv == 0 && lane < NS) {
+        const int64_t prob = (int64_t)blockIdx.x * a.gs_used + lane;
+        const bool have = lane < a.gs_used && prob < a.B;
+        if (have) {
+            slotg_fill_lane<N, Q>(recs + lane, kc, (int)prob);
+            grid_of(lane, (int)prob);
+            __hip_atomic_fetch_add(&s_live, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            s_recs[lane].prob = -1;
+            s_recs[lane].term = VP_TERM_NOT_RUN;
+        }
+        s_state[lane] = have ? 1 : 0;
+    }
+    __syncthreads();
     const int nchunk = (m + 255) / 256;
-    // 16-byte row groups: every stream of the handle is 16-byte aligned per problem when m % 4 == 0 (hipMalloc'd bases)
     const bool vec = (m & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.yw) | reinterpret_cast<uintptr_t>(a.t) |
                                        reinterpret_cast<uintptr_t>(a.w)) & 15) == 0;
+    auto lds_release = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
-    auto fill = [&](int s, int prob) __attribute__((always_inline)) {
-        slotg_fill<N, Q>(recs + s, kc, prob);
-        if constexpr (UNIFORM) {
-            if (prob >= 0 && lane == 0) {
-                const float *tp = a.t + (int64_t)prob * a.t_stride;
-                const double t0 = (double)tp[0];
-                s_grid[wv][s][0] = t0;
-                s_grid[wv][s][1] = ((double)tp[m - 1] - t0) / (double)(m - 1);
+    if (wv == 0) {
+        // ======================= the scalar wave: lane s <-> slot s =======================
+        for (;;) {
+            const int st = (lane < NS) ? __hip_atomic_load(&s_state[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+            asm volatile("" ::: "memory");
+            const bool act = st == 3;
+            if (!uni(act)) {
+                if (uni(__hip_atomic_load(&s_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= 0) break;
+                __builtin_amdgcn_s_sleep(8);
+                continue;
             }
-        }
-    };
-    int nactive = 0;
-#pragma nounroll
-    for (int s = 0; s < GS; ++s) {
-        const int64_t prob = (int64_t)gw * a.gs_used + s;
-        const bool have = s < a.gs_used && prob < a.B;
-        fill(s, have ? (int)prob : -1);
-        nactive += have ? 1 : 0;
-    }
-    wave_sync();
-
-#ifdef VP_FITG_CLOCKS
-    long long ck[4] = {0, 0, 0, 0};
-    long long c0 = 0;
-#define VP_CK(i)                                                                                                       \
-    do {                                                                                                               \
-        const long long c1 = __builtin_amdgcn_s_memtime();                                                             \
-        ck[i] += c1 - c0;                                                                                              \
-        c0 = c1;                                                                                                       \
-    } while (0)
-    c0 = __builtin_amdgcn_s_memtime();
-#else
-#define VP_CK(i)
-#endif
-    while (nactive > 0) {
-        // ================= VECTOR phase: the moment pass of every occupied slot =================
-#pragma nounroll
-        for (int s = 0; s < GS; ++s) {
-            const int prob = uni(recs[s].prob);
-            if (prob < 0) continue;
-            double rt[NE];
-#pragma unroll
-            for (int kx = 0; kx < NE; ++kx) rt[kx] = frcp(recs[s].xt[kx]);
-            double t0 = 0.0, dt = 0.0;
-            double fa[NE], q1[NE], qc[NE];
-            if constexpr (UNIFORM) {
-                t0 = uni_d(s_grid[wv][s][0]);
-                dt = uni_d(s_grid[wv][s][1]);
-                // anchor at the lane's first row, ratio per row, ratio per chunk: 3 NE exponentials per evaluation
-                double ax[3 * NE], ex[3 * NE];
-                const double tl = tfma((double)(4 * lane), dt, t0);
-#pragma unroll
-                for (int kx = 0; kx < NE; ++kx) {
-                    ax[kx] = -tl * rt[kx];
-                    ax[NE + kx] = -dt * rt[kx];
-                    ax[2 * NE + kx] = -(256.0 * dt) * rt[kx];
-                }
-                texp_n<3 * NE>(ax, ex);
-#pragma unroll
-                for (int kx = 0; kx < NE; ++kx) {
-                    fa[kx] = ex[kx];
-                    q1[kx] = uni_d(ex[NE + kx]);
-                    qc[kx] = uni_d(ex[2 * NE + kx]);
-                }
+            gram_phase<NE, NS, WEIGHTED>(recs, gram, kc, a.dbg, act);
+            lds_release();
+            if (!a.dbg) {
+                slot_scalar_phase<double, N, Q, NS, float>(recs, kc, act);
+                lds_release();
             }
-            const float *yp = a.yw + (int64_t)prob * m;
-            const float *tp = a.t + (int64_t)prob * a.t_stride;
-            const float *wp = a.w ? a.w + (int64_t)prob * a.w_stride : nullptr;
-            double acc[NVR];
-#pragma unroll
-            for (int i = 0; i < NVR; ++i) acc[i] = 0.0;
-            GramChunk<UNIFORM, WEIGHTED> nxt;
-            gram_load_chunk(nxt, yp, tp, wp, 4 * lane, m, vec);
-#pragma nounroll
-            for (int ch = 0; ch < nchunk; ++ch) {
-                const GramChunk<UNIFORM, WEIGHTED> cur = nxt;
-                const int row0 = ch * 256 + 4 * lane;
-                if (ch + 1 < nchunk) gram_load_chunk(nxt, yp, tp, wp, row0 + 256, m, vec);
-                const float yv[4] = {cur.y.x, cur.y.y, cur.y.z, cur.y.w};
-                float tv[4] = {0.f, 0.f, 0.f, 0.f}, wv4[4] = {1.f, 1.f, 1.f, 1.f};
-                if constexpr (!UNIFORM) {
-                    tv[0] = cur.t.x, tv[1] = cur.t.y, tv[2] = cur.t.z, tv[3] = cur.t.w;
-                }
-                if constexpr (WEIGHTED) {
-                    wv4[0] = cur.w.x, wv4[1] = cur.w.y, wv4[2] = cur.w.z, wv4[3] = cur.w.w;
-                }
-                // unit weights: m % 4 == 0 (host dispatch), so a lane's row group is valid or padding as a whole
-                const bool gvalid = row0 < m;
-                double f[NE];
-                if constexpr (UNIFORM) {
-#pragma unroll
-                    for (int kx = 0; kx < NE; ++kx) f[kx] = (WEIGHTED || gvalid) ? fa[kx] : 0.0;
-                }
-                const double tb = UNIFORM ? tfma((double)row0, dt, t0) : 0.0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const double td = UNIFORM ? tfma((double)e, dt, tb) : (double)tv[e];
-                    const double yd = (double)yv[e];
-                    double eh[NE], uh[NE];
-                    if constexpr (UNIFORM) {
-#pragma unroll
-                        for (int kx = 0; kx < NE; ++kx) {
-                            eh[kx] = f[kx];
-                            if (e < 3) f[kx] *= q1[kx];
-                        }
-                    } else { // general grid: one fp64 exponential per element
-                        double ax[NE];
-#pragma unroll
-                        for (int kx = 0; kx < NE; ++kx) ax[kx] = -td * rt[kx];
-                        texp_n<NE>(ax, eh);
-                        if constexpr (!WEIGHTED) {
-#pragma unroll
-                            for (int kx = 0; kx < NE; ++kx) eh[kx] = gvalid ? eh[kx] : 0.0;
-                        }
-                    }
-                    double wd = 1.0;
-                    if constexpr (WEIGHTED) {
-                        wd = (double)wv4[e];
-#pragma unroll
-                        for (int kx = 0; kx < NE; ++kx) eh[kx] *= wd; // (padding rows: w = 0)
-                    }
-#pragma unroll
-                    for (int kx = 0; kx < NE; ++kx) uh[kx] = td * eh[kx];
-#pragma unroll
-                    for (int i = 0; i < NE; ++i)
-#pragma unroll
-                        for (int k2 = i; k2 < NE; ++k2) {
-                            acc[GI::A0(i, k2)] = tfma(eh[i], eh[k2], acc[GI::A0(i, k2)]);
-                            acc[GI::A1(i, k2)] = tfma(eh[i], uh[k2], acc[GI::A1(i, k2)]);
-                            acc[GI::A2(i, k2)] = tfma(uh[i], uh[k2], acc[GI::A2(i, k2)]);
-                        }
-#pragma unroll
-                    for (int kx = 0; kx < NE; ++kx) {
-                        acc[GI::B0(kx)] = tfma(eh[kx], yd, acc[GI::B0(kx)]);
-                        acc[GI::B1(kx)] = tfma(uh[kx], yd, acc[GI::B1(kx)]);
-                    }
-                    acc[GI::YY] = tfma(yd, yd, acc[GI::YY]);
-                    if constexpr (WEIGHTED) {
-#pragma unroll
-                        for (int kx = 0; kx < NE; ++kx) {
-                            acc[GI::S0(kx)] = tfma(wd, eh[kx], acc[GI::S0(kx)]);
-                            acc[GI::S1(kx)] = tfma(wd, uh[kx], acc[GI::S1(kx)]);
-                        }
-                        acc[GI::SY] = tfma(wd, yd, acc[GI::SY]);
-                        acc[GI::SW] = tfma(wd, wd, acc[GI::SW]);
+            if (act) {
+                int next_state = 1;
+                if (s_recs[lane].term != 0) { // the fit of this slot is finished (results written): next problem, or empty
+                    const int next = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int64_t)next < a.B) {
+                        slotg_fill_lane<N, Q>(recs + lane, kc, next);
+                        grid_of(lane, next);
                     } else {
-#pragma unroll
-                        for (int kx = 0; kx < NE; ++kx) {
-                            acc[GI::S0(kx)] += eh[kx];
-                            acc[GI::S1(kx)] += uh[kx];
-                        }
-                        acc[GI::SY] += yd;
+                        s_recs[lane].prob = -1;
+                        s_recs[lane].term = VP_TERM_NOT_RUN;
+                        next_state = 0;
+                        __hip_atomic_fetch_add(&s_live, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-                if constexpr (UNIFORM) {
-#pragma unroll
-                    for (int kx = 0; kx < NE; ++kx) fa[kx] *= qc[kx];
-                }
+                lds_release(); // the record is complete before the slot is handed to a stream wave
+                __hip_atomic_store(&s_state[lane], next_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            wave_reduce_store<NVR>(acc, gram + (size_t)s * GI::NV);
         }
-        wave_sync();
-        VP_CK(0);
-        // ===== lane s: moments -> evaluation results, then the LM bookkeeping of slot s =====
-        gram_phase<NE, GS, WEIGHTED>(recs, gram, kc, a.dbg);
-        wave_sync();
-        VP_CK(1);
-        if (!a.dbg) {
-            slot_scalar_phase<double, N, Q, GS, float>(recs, kc);
-            wave_sync();
+    } else {
+        // ======================= stream waves: claim a slot with a trial point, stream its rows =======================
+        int start = (wv - 1) * (NS / (VP_FITG2_WAVES - 1)); // spread the first claims over the pool
+        for (;;) {
+            // lanes look at one slot each; the first slot at or after `start` (cyclically) that has a trial point is claimed
+            // (serving the OLDEST fit first instead was measured: no gain -- a fit's round is the pass + the bookkeeping, not
+            // the queueing)
+            int sl = lane + start;
+            sl = sl >= NS ? sl - NS : sl;
+            const int st = (lane < NS) ? __hip_atomic_load(&s_state[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+            const unsigned long long ready = __builtin_amdgcn_ballot_w64(lane < NS && st == 1);
+            if (ready == 0ull) {
+                if (uni(__hip_atomic_load(&s_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= 0) break;
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            int s = (int)__builtin_ctzll(ready) + start;
+            s = s >= NS ? s - NS : s;
+            int won = 0;
+            if (lane == 0) {
+                int expect = 1;
+                won = __hip_atomic_compare_exchange_strong(&s_state[s], &expect, 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+            }
+            if (!uni(won)) continue; // another stream wave was faster
+            asm volatile("" ::: "memory");
+            const int prob = uni(s_recs[s].prob);
+            gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0], gram + (size_t)s * GI::NV, prob, lane, m,
+                                             nchunk, vec);
+            lds_release(); // the moments are in LDS before the slot is handed to the scalar wave
+            if (lane == 0) __hip_atomic_store(&s_state[s], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            start = s + 1 >= NS ? 0 : s + 1;
         }
-        VP_CK(2);
-        // ================= refill finished slots from the queue =================
-#pragma nounroll
-        for (int s = 0; s < GS; ++s) {
-            if (uni(recs[s].prob) < 0 || uni(recs[s].term) == 0) continue;
-            int next = 0;
-            if (lane == 0) next = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            next = uni(next);
-            const bool have = (int64_t)next < a.B;
-            fill(s, have ? next : -1);
-            if (!have) nactive -= 1;
-        }
-        wave_sync();
-        VP_CK(3);
     }
-#ifdef VP_FITG_CLOCKS
-    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) {
-        double *tr = a.trace + (size_t)(a.trace_rows - 1) * (Q + 4);
-        for (int i = 0; i < 4; ++i) tr[i] = (double)ck[i];
-    }
-#endif
 }
 
 // fp32 handle, single right-hand side, NE exponentials + offset: the Gram kernel for every combination of grid
 // (shared / per problem, uniform or not) and weights (none / shared / per problem)
 template <class M> int launch_fitg(const LaunchParams &p, double *dbg = nullptr) {
-    constexpr int GS = VP_FITG_GS, NW = VP_FITG_WAVES;
     if (p.S != 1 || !p.queue) return VP_ERR_UNSUPPORTED;
     FitgArgs a;
     a.t = (const float *)p.t;
@@ -615,24 +653,24 @@ template <class M> int launch_fitg(const LaunchParams &p, double *dbg = nullptr)
     a.gtol = p.opts->gtol;
     a.stepbound = p.opts->stepbound;
     if (a.B <= 0) return VP_ERR_OK;
-    // persistent grid: 2 workgroups of NW independent waves per CU (2 waves per SIMD); the static first assignment
-    // spreads the batch over all waves
-    const int64_t cap_waves = (int64_t)p.num_cus * 2 * NW;
-    int64_t gs_used = (a.B + cap_waves - 1) / cap_waves;
-    if (gs_used > GS) gs_used = GS;
-    if (gs_used < 1) gs_used = 1;
-    a.gs_used = (int)gs_used;
-    int64_t waves = (a.B + gs_used - 1) / gs_used;
-    if (waves > cap_waves) waves = cap_waves;
-    const int64_t blocks = (waves + NW - 1) / NW;
-    if (hipMemsetD32Async((hipDeviceptr_t)p.queue, (int)(blocks * NW * gs_used), 1, p.stream) != hipSuccess) return VP_ERR_HIP;
     const bool uniform = p.grid_uniform != 0 && p.m >= 3;
     const bool weighted = p.w != nullptr || (p.m & 3) != 0; // a ragged last row group is masked through the weights
-    const dim3 grid((unsigned)blocks), block(64 * NW);
-    if (uniform && !weighted) hipLaunchKernelGGL((fitg_kernel<M, GS, true, false>), grid, block, 0, p.stream, a);
-    else if (uniform) hipLaunchKernelGGL((fitg_kernel<M, GS, true, true>), grid, block, 0, p.stream, a);
-    else if (!weighted) hipLaunchKernelGGL((fitg_kernel<M, GS, false, false>), grid, block, 0, p.stream, a);
-    else hipLaunchKernelGGL((fitg_kernel<M, GS, false, true>), grid, block, 0, p.stream, a);
+    // role-specialised waves: one 8-wave workgroup per CU (1 scalar wave + 7 stream waves) with a pool of NS slots; the
+    // static first assignment spreads the batch over all workgroups
+    constexpr int NS = VP_FITG_NS;
+    const int64_t cap_groups = (int64_t)p.num_cus;
+    int64_t ns_used = (a.B + cap_groups - 1) / cap_groups;
+    if (ns_used > NS) ns_used = NS;
+    if (ns_used < 1) ns_used = 1;
+    a.gs_used = (int)ns_used;
+    int64_t blocks = (a.B + ns_used - 1) / ns_used;
+    if (blocks > cap_groups) blocks = cap_groups;
+    if (hipMemsetD32Async((hipDeviceptr_t)p.queue, (int)(blocks * ns_used), 1, p.stream) != hipSuccess) return VP_ERR_HIP;
+    const dim3 grid((unsigned)blocks), block(64 * VP_FITG2_WAVES);
+    if (uniform && !weighted) hipLaunchKernelGGL((fitg2_kernel<M, NS, true, false>), grid, block, 0, p.stream, a);
+    else if (uniform) hipLaunchKernelGGL((fitg2_kernel<M, NS, true, true>), grid, block, 0, p.stream, a);
+    else if (!weighted) hipLaunchKernelGGL((fitg2_kernel<M, NS, false, false>), grid, block, 0, p.stream, a);
+    else hipLaunchKernelGGL((fitg2_kernel<M, NS, false, true>), grid, block, 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
