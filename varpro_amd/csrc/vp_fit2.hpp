@@ -428,6 +428,9 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
     }
 }
 
+#ifndef VP_LONE_TAIL_LINKAGE
+#define VP_LONE_TAIL_LINKAGE __forceinline__
+#endif
 // LONE TAIL (W = 1).  Once the problem queue is dry a wave that holds ONE unfinished fit has nobody to share the scalar
 // phase with: the lane-parallel bookkeeping (one dependent fp64 chain issued for a single lane, an LDS record round
 // trip and a call per evaluation) is then pure latency -- 5.6 us per evaluation against the 3.9 us of fit_kernel, whose
@@ -436,7 +439,7 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
 // same evaluation (the slot's H_0 y column), same arithmetic, results bit-identical to either kernel.  Out of line: its
 // register allocation must not touch the slot loop's.
 template <typename T, class M, int R, int PADM>
-__device__ __noinline__ void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q> *rec, VP_LDS const T *s_col, VP_LDS const T *s_t,
+__device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q> *rec, VP_LDS const T *s_col, VP_LDS const T *s_t,
                                             VP_LDS const SlotConsts<T> *kc, const M mdl, const T eps, const int uniform,
                                             const T h0_beta, const T h0_u, const T h0_g) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
@@ -740,7 +743,6 @@ __device__ __noinline__ void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q> *rec, 
         }
         rec->term = term;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // A workgroup = NG groups of W waves (W = 1: NG = 4 independent waves; W > 1: ONE group, whose reductions use
