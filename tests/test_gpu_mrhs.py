@@ -259,3 +259,55 @@ def test_mrhs_gram_based_lm_step_conditioning_sweep():
         assert r["ok_device"] == r["ok_oracle"], r
         if r["ok_oracle"]:
             assert r["objective_rel_dev"] <= 1e-6, r
+
+
+def test_mrhs_gram_based_lm_step_beyond_cond_1e2():
+    # The sweep above cannot push the scaled cond(J) past ~1e2 (two decay times whose GUESSES differ by 6 % keep the
+    # Jacobian columns apart).  Here the initial decay times themselves are 2 (1 -+ e): cond(J) ~ 0.4 / e as the LM driver
+    # sees it, cond(Phi) ~ 7 / e.  Recorded per e: the first trial point of the device (pivoted Cholesky of the streamed
+    # J^T J) against the oracle's (MINPACK qrfac of the tall J, src/solvers/levmar/mod.rs:172-186 + the LM crate), and
+    # the end of the fit.  Stated bound on the first step: 10 cond(J)^2 eps + 100 cond(J) cond(Phi) eps (the second term
+    # is what the two SOLVES of the linear sub-problem -- Householder here, thin SVD there -- differ by, amplified by the
+    # step); asserted up to cond(J) = 1e5.  Past cond(Phi) ~ 1e6 the first step is rounding noise in BOTH drivers; what
+    # must still hold: the same success flag and the same minimum.
+    import json
+    import os
+    rng = np.random.default_rng(7)
+    S, m = 8, 1024
+    x = 12.5 * np.arange(m) / (m - 1)
+    Cm = rng.uniform(10, 100, (S, 3))
+    Y = Cm[:, 0:1] * np.exp(-x / 1.5) + Cm[:, 1:2] * np.exp(-x / 3.0) + Cm[:, 2:3]
+    Y = Y + 1e-4 * np.abs(Y).max() * rng.standard_normal(Y.shape)
+    eps = np.finfo(float).eps
+    rows = []
+    for e in (1e-2, 1e-3, 1e-4, 1e-5, 1e-6, 3e-7):
+        guess = np.array([[2.0 * (1 - e), 2.0 * (1 + e)]])
+        mdl = double_exp_builder_model(x, guess[0])
+        ref = O.Problem(mdl, x, Y)
+        ref.set_params(guess[0])
+        J = ref.jacobian().T
+        sv = np.linalg.svd(J / np.linalg.norm(J, axis=0), compute_uv=False)
+        cond_phi = np.linalg.cond(O.eval_phi(mdl, x, guess[0]).T)
+        rr, tr_ref = ref.fit_trace(max_rows=4)
+        bp = vp.BatchProblem(mdl, Y[None], x=x)
+        alpha, C, rep, tr = bp.fit_trace(guess, max_rows=4)
+        bp.close()
+        dev = np.abs(tr[0, 1, :2] - tr_ref[1, :2]).max() / np.abs(tr_ref[1, :2] - tr_ref[0, :2]).max()
+        rows.append(dict(guess_separation=e, cond_J=float(sv[0] / sv[-1]), cond_Phi=float(cond_phi), first_step_rel_dev=float(dev),
+                         objective_rel_dev=float(abs(rep["objective"][0] - rr.objective) / rr.objective),
+                         ok_device=bool(rep["termination"][0] > 0), ok_oracle=bool(rr.termination > 0),
+                         evals_device=int(rep["n_evals"][0]), evals_oracle=int(rr.n_evals),
+                         alpha_dev=float(np.abs(np.sort(alpha[0]) - np.sort(ref.params())).max())))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        json.dump(rows, open(os.path.join(out, "mrhs_conditioning_sweep_close_guesses.json"), "w"), indent=1)
+    except OSError:
+        pass
+    assert max(r["cond_J"] for r in rows) >= 1e4          # the sweep does reach the regime the first one could not
+    for r in rows:
+        if r["cond_Phi"] <= 1e6:
+            bound = 10.0 * r["cond_J"] ** 2 * eps + 100.0 * r["cond_J"] * r["cond_Phi"] * eps
+            assert r["first_step_rel_dev"] <= max(1e-9, bound), r
+        assert r["ok_device"] == r["ok_oracle"], r
+        assert r["objective_rel_dev"] <= 1e-9 and r["alpha_dev"] <= 1e-6, r
