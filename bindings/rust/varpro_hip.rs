@@ -73,6 +73,8 @@ extern "C" {
     pub fn vp_fit(h: *mut vp_batch, opts: *const vp_lm_opts, alpha_inout: *mut c_void, c_out: *mut c_void,
         rep: *mut vp_report) -> i32;
     pub fn vp_best_fit(h: *mut vp_batch, fit_out: *mut c_void) -> i32;
+    /// parity diagnostics of the fp64-Gram fit kernel: {1/2||r||^2, c, J^T r, J^T J} at alpha, per problem
+    pub fn vp_debug_gram_evaluate(h: *mut vp_batch, alpha: *const c_void, out: *mut f64) -> i32;
     pub fn vp_summary(h: *mut vp_batch, out: *mut f64) -> i32;
     pub fn vp_summary_device(h: *mut vp_batch, dev_out4: *mut f64) -> i32;
     pub fn vp_fit_trace(h: *mut vp_batch, opts: *const vp_lm_opts, alpha_inout: *mut c_void, c_out: *mut c_void,

@@ -340,10 +340,10 @@ int vp_set_rhs_allreduce(vp_batch *h, vp_allreduce_fn fn, void *user, int64_t gl
  *   SLOTS : the slot kernel whenever it covers the problem, regardless of the batch size
  * All three implement LevenbergMarquardt::minimize (src/solvers/levmar/mod.rs:247) with identical arithmetic per
  * problem; results do not depend on which wavefront or slot ran a problem.
- * One exception to "identical arithmetic": VP_F32 handles whose model needs more than one wavefront's registers (five
- * exponentials + offset beyond 128 rows, BASELINE.json configs[4]) are fitted under AUTO / SLOTS on the fp64 Gram matrix
- * of [Phi | y | dPhi] (normal equations in double; unit weights, shared grid) -- more accurate than an fp32 Householder
- * sweep and deterministic, but not bit-identical to WAVE, which keeps the fp32 Householder kernels. */
+ * VP_F32 handles whose model needs more than one wavefront's registers (five exponentials + offset beyond 128 rows,
+ * BASELINE.json configs[4]) are fitted on the fp64 Gram matrix of [Phi | y | dPhi] (normal equations in double, any grid,
+ * any weights) WHATEVER the selection: there is no fp32 Householder fit kernel for these shapes (it lost 15 % of the fits
+ * to non-finite evaluations); vp_evaluate / vp_residuals / vp_jacobian / vp_statistics keep the fp32 Householder kernels. */
 enum { VP_FIT_KERNEL_AUTO = 0, VP_FIT_KERNEL_WAVE = 1, VP_FIT_KERNEL_SLOTS = 2 };
 int vp_set_fit_kernel(vp_batch *h, int which);
 
