@@ -528,25 +528,28 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
     static_assert(sizeof(T) == 8 && RW >= 2 && RW % 2 == 0, "fp64, row pairs");
     constexpr int NPAIR = RW / 2, KL = NB * NPAIR;
     constexpr int D = 2; // ring depth
-    constexpr int NRED = N * NB + NB;
+    constexpr int NRED = N * NB + NB;                 // per batch: T of the NB columns | ||r||^2 of the previous batch
+    constexpr int NFL = P * N + NB;                   // flush round: the P x N dots G_p^T W_j | ||r||^2 of the last batch
+    constexpr int NX = NRED > NFL ? NRED : NFL;
     constexpr int NACC = 1 + N * N + P;
     constexpr int FB = 16;            // batches between two result bursts
     constexpr int FC = FB * NB;       // columns staged
-    static_assert(NACC <= 64 && NRED <= 64 && (KL == 8 || KL == 16), "one lane per value; the wait counts below are written for KL = 8 / 16");
+    static_assert(NACC <= 64 && NX <= 64 && KL == 8, "one lane per value; the wait counts below are written for KL = 8");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // ring[NW][D][NB][NPAIR][64] double2 | s_x[2][NW][NRED] | s_ri[2 N N] | s_c[FC][N] | s_cost[FC] | s_st[FC]
+    // ring[NW][D][KL][64] double2 | s_x[2][NW][NX] | s_ri[2 N N] | s_t[FC][N] | s_cost[FC] | s_st[FC] | s_fin[N N + P N]
     double2 *ring = reinterpret_cast<double2 *>(smem_raw);
-    double *s_x = reinterpret_cast<double *>(ring + (size_t)NW * D * NB * NPAIR * 64);
-    double *s_ri = s_x + 2 * NW * NRED;
-    double *s_c = s_ri + 2 * N * N;
-    double *s_cost = s_c + FC * N;
-    int *s_st = reinterpret_cast<int *>(s_cost + FC);
+    double *s_x = reinterpret_cast<double *>(ring + (size_t)NW * D * KL * 64);
+    double *s_ri = s_x + 2 * NW * NX;
+    double *s_t = s_ri + 2 * N * N;
+    double *s_cost = s_t + FC * N;
+    double *s_fin = s_cost + FC;
+    int *s_st = reinterpret_cast<int *>(s_fin + N * N + P * N);
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const int gl = (int)threadIdx.x;
     const int64_t b = blockIdx.x / a.gx;
     const int wgi = (int)(blockIdx.x - b * a.gx); // workgroup within the problem
-    const int m = a.m;
+    const int m = a.m, S = a.S, gx = a.gx;
     if (a.ws.done[b] != 0) return; // (uniform per workgroup)
     const T *qsrc = (const T *)a.ws.qthin + b * (int64_t)N * m;
     const T *gsrc = (const T *)a.ws.g + b * (int64_t)P * m;
@@ -554,14 +557,15 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
     T q[N][RW];
 #pragma unroll
     for (int j = 0; j < N; ++j) load_rows<T, RW, NW>(qsrc + (int64_t)j * m, m, gl, true, q[j]);
-    T gv[P > 0 ? P : 1][RW]; // v_p = sum_s c_{j(p),s} r_s
+    // W_j = sum_s T_{j,s} r_s  (row space; c = R^-1 T is linear in T, so sum_s c_{i,s} r_s = sum_j Rinv[i][j] W_j at the end)
+    T wacc[N][RW];
 #pragma unroll
-    for (int p = 0; p < P; ++p)
+    for (int j = 0; j < N; ++j)
 #pragma unroll
-        for (int r = 0; r < RW; ++r) gv[p][r] = T(0);
+        for (int r = 0; r < RW; ++r) wacc[j][r] = T(0);
     if (threadIdx.x < N * N) {
-        s_ri[threadIdx.x] = small[threadIdx.x];
-        s_ri[N * N + threadIdx.x] = small[N * N + P * P + threadIdx.x];
+        s_ri[threadIdx.x] = small[threadIdx.x];                          // R^-1 (or R^+), row-major
+        s_ri[N * N + threadIdx.x] = small[N * N + P * P + threadIdx.x];  // P_n
     }
     const int stA = a.ws.statusA[b];
     const int wsel = uni(a.ws.widx[b]) & 1;
@@ -570,127 +574,123 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    // wave 0, one sum per lane: lane 0 sum ||r||^2, lane 1 + i N + j sum T_i T_j (one-hot selections: a select chain over
+    // a small array is folded into a dynamically indexed vector kept in SCRATCH, whose accesses count in vmcnt)
     T accv = T(0);
     const int ak = lane < NACC ? lane : 0;
-    const int ai = (ak >= 1 && ak <= N * N) ? (ak - 1) / N : 0, aj = (ak >= 1 && ak <= N * N) ? (ak - 1) % N : 0;
-    // Selections out of the N coefficients of a column are written as ONE-HOT dot products: a chain of selects over a
-    // small array is folded by the compiler into a dynamically indexed vector, which it then keeps in SCRATCH -- scratch
-    // accesses count in vmcnt and would both stall on and miscount the DMA queue of this loop.
-    T ohi[N], ohj[N], ohp[P > 0 ? P : 1][N];
+    const bool ak_tt = ak >= 1 && ak <= N * N;
+    T ohi[N], ohj[N];
 #pragma unroll
     for (int j2 = 0; j2 < N; ++j2) {
-        ohi[j2] = (ak >= 1 && ak <= N * N && ai == j2) ? T(1) : T(0);
-        ohj[j2] = (ak >= 1 && ak <= N * N && aj == j2) ? T(1) : T(0);
-#pragma unroll
-        for (int p = 0; p < P; ++p) ohp[p][j2] = (a.pb[p] == j2) ? T(1) : T(0);
+        ohi[j2] = (ak_tt && (ak - 1) / N == j2) ? T(1) : T(0);
+        ohj[j2] = (ak_tt && (ak - 1) % N == j2) ? T(1) : T(0);
     }
-    const int64_t nbatch = (a.S + NB - 1) / NB;
-    const int64_t nloc = (nbatch > (int64_t)wgi) ? (nbatch - 1 - wgi) / a.gx + 1 : 0; // batches of this workgroup
+    const int nbatch = (S + NB - 1) / NB;
+    const int nloc = (nbatch > wgi) ? (nbatch - 1 - wgi) / gx + 1 : 0; // batches of this workgroup
+    const bool ragged = (S % NB) != 0;                                  // the last batch has columns past S
+    const bool fullrows = m == 64 * RW * NW;
     const unsigned ring_lds = (unsigned)(uintptr_t)(VP_LDS unsigned char *)smem_raw + (unsigned)wave * (D * KL * 1024u);
-    // rows of this lane: pair k covers rows (k * 512 + gl) * 2, +1; rows >= m (m even) are clamped for the DMA and zeroed after
+    // rows of this lane: pair k covers rows (k * 64 NW + gl) * 2, +1; rows >= m (m even) are clamped for the DMA and zeroed after
     bool rvalid[NPAIR];
-    int64_t roff[NPAIR];
+    unsigned roffb[NPAIR]; // byte offset of the pair within a column
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
         const int row = (k * 64 * NW + gl) * 2;
         rvalid[k] = row < m;
-        roff[k] = rvalid[k] ? row : 0;
+        roffb[k] = (unsigned)(rvalid[k] ? row : 0) * (unsigned)sizeof(T);
     }
-    // issue the KL DMA instructions of local batch i into ring slot i % D (columns past S re-read column S-1: the count of
-    // instructions per batch must not depend on the data)
-    auto issue = [&](const int64_t i) __attribute__((always_inline)) {
-        const int64_t bt = wgi + i * (int64_t)a.gx;
-        const unsigned slot = ring_lds + (unsigned)(i % D) * (KL * 1024u);
+    const T *ybase = a.yw + b * (int64_t)S * m;
+    // the KL DMA instructions of local batch i into ring slot i % D: wave-uniform column base in SGPRs, per-lane byte
+    // offset in one VGPR (columns past S re-read column S - 1: the instruction count per batch must not depend on the data)
+    auto issue = [&](const int i) __attribute__((always_inline)) {
+        const int bt = wgi + i * gx;
+        const unsigned slot = ring_lds + (unsigned)(i & (D - 1)) * (KL * 1024u);
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
-            int64_t s = bt * NB + c;
-            s = s < a.S ? s : a.S - 1;
-            const T *col = a.yw + (b * a.S + s) * (int64_t)m;
+            int s = bt * NB + c;
+            s = s < S ? s : S - 1;
+            const T *col = ybase + (int64_t)s * m;
 #pragma unroll
             for (int k = 0; k < NPAIR; ++k) {
-                const T *src = col + roff[k];
                 const unsigned dst = __builtin_amdgcn_readfirstlane(slot + (unsigned)(c * NPAIR + k) * 1024u);
                 unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep)
-                             : "v"(src), "s"(dst)
+                             : "v"(roffb[k]), "s"(col), "s"(dst)
                              : "memory");
             }
         }
     };
     T r2prev[NB];
-    bool cfin_prev[NB];
+    unsigned badprev = 0u; // bit c: T of column c of the previous batch was not finite
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
-        r2prev[c] = T(0);
-        cfin_prev[c] = true;
-    }
+    for (int c = 0; c < NB; ++c) r2prev[c] = T(0);
     int ph = 0;
-    // staged results of local batch i live in rows (i % FB) * NB + c of s_c / s_cost / s_st
-    auto emit_prev = [&](const T tot, const int64_t i) __attribute__((always_inline)) {
+    // cost / status of local batch i (its squared norms arrive one batch late) -> staging rows (i % FB) * NB + c
+    auto emit_prev = [&](const T tot, const int i) __attribute__((always_inline)) {
         if (i < 0) return;
-        const int64_t bt = wgi + i * (int64_t)a.gx;
+        const int bt = wgi + i * gx;
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
-            const int64_t s = bt * NB + c;
-            if (s >= a.S) continue;
+            if (bt * NB + c >= S) continue;
             const T r2 = readlane(tot, N * NB + c);
-            const bool ok = is_finite(r2) && stA == VP_ST_OK && cfin_prev[c];
+            const bool ok = is_finite(r2) && stA == VP_ST_OK && ((badprev >> c) & 1u) == 0u;
             if (wave == 0) {
                 if (lane == 0) {
-                    s_cost[(int)(i % FB) * NB + c] = 0.5 * (double)r2;
-                    s_st[(int)(i % FB) * NB + c] = ok ? VP_ST_OK : (stA != VP_ST_OK ? stA : VP_ST_NONFINITE);
+                    s_cost[(i & (FB - 1)) * NB + c] = 0.5 * (double)r2;
+                    s_st[(i & (FB - 1)) * NB + c] = ok ? VP_ST_OK : (stA != VP_ST_OK ? stA : VP_ST_NONFINITE);
                 }
                 accv += (ak == 0) ? r2 : T(0);
             }
         }
     };
-    // wave 0 writes the staged results of local batches [i0, i1) (after draining its DMA: stores and loads share vmcnt)
-    auto burst = [&](const int64_t i0, const int64_t i1) __attribute__((always_inline)) {
+    // wave 0 writes the staged results of local batches [i0, i1): c = R^-1 T per column, cost, status (after draining its
+    // DMA: stores and loads share vmcnt)
+    auto burst = [&](const int i0, const int i1) __attribute__((always_inline)) {
         if (wave != 0 || i1 <= i0) return;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        for (int64_t i = i0; i < i1; ++i) {
-            const int64_t bt = wgi + i * (int64_t)a.gx;
-            const int c = lane / N, jn = lane % N; // lanes 0 .. NB*N-1: coefficient jn of column c
-            const int64_t s = bt * NB + c;
-            if (lane < NB * N && s < a.S) ((T *)a.ws.cbuf[wsel])[(b * a.S + s) * N + jn] = (T)s_c[((int)(i % FB) * NB + c) * N + jn];
-            const int64_t s2 = bt * NB + lane;
-            if (lane < NB && s2 < a.S) {
-                a.ws.costbuf[wsel][b * a.S + s2] = s_cost[(int)(i % FB) * NB + lane];
-                a.ws.stbuf[wsel][b * a.S + s2] = s_st[(int)(i % FB) * NB + lane];
+        const int c = lane / N, jn = lane % N; // lanes 0 .. NB*N-1: coefficient jn of column c
+        for (int i = i0; i < i1; ++i) {
+            const int bt = wgi + i * gx;
+            const int s = bt * NB + c;
+            if (lane < NB * N && s < S) {
+                const double *tt = s_t + ((i & (FB - 1)) * NB + c) * N;
+                double cv = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) cv = tfma(s_ri[jn * N + j], tt[j], cv);
+                ((T *)a.ws.cbuf[wsel])[(b * S + s) * N + jn] = (T)cv;
+            }
+            const int s2 = bt * NB + lane;
+            if (lane < NB && s2 < S) {
+                a.ws.costbuf[wsel][b * S + s2] = s_cost[(i & (FB - 1)) * NB + lane];
+                a.ws.stbuf[wsel][b * S + s2] = s_st[(i & (FB - 1)) * NB + lane];
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores are out before the next DMA is counted
     };
     if (nloc > 0) issue(0);
-    if (D > 1 && nloc > 1) issue(1);
-    int64_t flushed = 0; // local batches whose cost / status / c have been written
-    for (int64_t i = 0; i < nloc; ++i) {
-        const int64_t bt = wgi + i * (int64_t)a.gx;
+    if (nloc > 1) issue(1);
+    int flushed = 0; // local batches whose cost / status / c have been written
+    for (int i = 0; i < nloc; ++i) {
+        const int bt = wgi + i * gx;
         // ---- batch i has landed once at most the KL instructions of batch i+1 are outstanding ----
 #ifdef VP_MRHS_NOLOAD
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-        if (D > 1 && i + 1 < nloc) {
-            if constexpr (KL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (i + 1 < nloc) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         T y[NB][RW];
         {
-            const double2 *slot = ring + ((size_t)wave * D + (size_t)(i % D)) * KL * 64 + lane;
+            const double2 *slot = ring + ((size_t)wave * D + (size_t)(i & (D - 1))) * KL * 64 + lane;
 #pragma unroll
-            for (int c = 0; c < NB; ++c) {
-                const bool cvalid = bt * NB + c < a.S;
+            for (int c = 0; c < NB; ++c)
 #pragma unroll
                 for (int k = 0; k < NPAIR; ++k) {
                     const double2 v = slot[(c * NPAIR + k) * 64];
-                    y[c][2 * k] = (cvalid && rvalid[k]) ? v.x : T(0);
-                    y[c][2 * k + 1] = (cvalid && rvalid[k]) ? v.y : T(0);
+                    y[c][2 * k] = v.x;
+                    y[c][2 * k + 1] = v.y;
                 }
-            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot has been read: it may be refilled
 #ifdef VP_MRHS_NOLOAD // developer A/B: compute + synchronisation alone (the ring keeps the first two batches)
@@ -698,8 +698,25 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
 #else
         if (i + D < nloc) issue(i + D);
 #endif
+        if (!fullrows) { // padding rows of a partially filled row block
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+#pragma unroll
+                for (int k = 0; k < NPAIR; ++k) {
+                    y[c][2 * k] = rvalid[k] ? y[c][2 * k] : T(0);
+                    y[c][2 * k + 1] = rvalid[k] ? y[c][2 * k + 1] : T(0);
+                }
+        }
+        if (ragged && bt == nbatch - 1) { // columns past S in the very last batch
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (bt * NB + c >= S) {
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) y[c][r] = T(0);
+                }
+        }
         // ---- partial T = Q^T y | carried squared norms ----
-        T red[NRED];
+        T red[NX];
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
 #pragma unroll
@@ -711,124 +728,130 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
             }
             red[N * NB + c] = r2prev[c];
         }
-        wave_reduce_store_g<NRED>(red, s_x + ((size_t)ph * NW + wave) * NRED);
+#pragma unroll
+        for (int v = NRED; v < NX; ++v) red[v] = T(0);
+        wave_reduce_store_g<NX>(red, s_x + ((size_t)ph * NW + wave) * NX);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier(); // (a bare barrier: __syncthreads() would carry a full memory fence, i.e. drain the DMA)
         asm volatile("" ::: "memory");
         T tot = T(0);
         if (lane < NRED) {
 #pragma unroll
-            for (int w = 0; w < NW; ++w) tot += s_x[((size_t)ph * NW + w) * NRED + lane];
+            for (int w = 0; w < NW; ++w) tot += s_x[((size_t)ph * NW + w) * NX + lane];
         }
         ph ^= 1;
         emit_prev(tot, i - 1);
         // a burst of FB batches is complete once the cost of its last batch has been emitted (one batch late)
-        if (i > 0 && (i % FB) == 0) {
+        if (i > 0 && (i & (FB - 1)) == 0) {
             burst(flushed, i);
             flushed = i;
         }
+        // non-finite T (lanes c N .. c N + N - 1 of tot) -> status of that column
+        {
+            const unsigned long long bad = __builtin_amdgcn_ballot_w64(lane < N * NB && !is_finite(tot));
+            badprev = 0u;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) badprev |= ((bad >> (c * N)) & ((1ull << N) - 1ull)) != 0ull ? (1u << c) : 0u;
+        }
+        if (wave == 0 && lane < N * NB) s_t[(i & (FB - 1)) * NB * N + lane] = (double)tot; // T of the batch, for the burst
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
-            const bool valid = bt * NB + c < a.S; // (uniform)
-            T tq[N], cc[N];
+            T tq[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) tq[j] = readlane(tot, c * N + j);
-            if (truncated) {
-                T tp[N];
+            if (wave == 0) { // sum T T^T (columns past S carry T = 0)
+                T fa_ = T(0), fb_ = T(0);
 #pragma unroll
-                for (int i2 = 0; i2 < N; ++i2) {
-                    T acc = T(0), accp = T(0);
-#pragma unroll
-                    for (int j = 0; j < N; ++j) {
-                        acc = tfma((T)s_ri[i2 * N + j], tq[j], acc);
-                        accp = tfma((T)s_ri[N * N + i2 * N + j], tq[j], accp);
-                    }
-                    cc[i2] = acc;
-                    tp[i2] = accp;
+                for (int j2 = 0; j2 < N; ++j2) {
+                    fa_ = tfma(ohi[j2], tq[j2], fa_);
+                    fb_ = tfma(ohj[j2], tq[j2], fb_);
                 }
+                accv = tfma(fa_, fb_, accv);
+            }
+            T tr[N]; // what the residual subtracts: T itself, or P_n T for a rank-deficient Phi_w (rare)
 #pragma unroll
-                for (int i2 = 0; i2 < N; ++i2) tq[i2] = tp[i2];
-            } else {
+            for (int j = 0; j < N; ++j) tr[j] = tq[j];
+            if (truncated) {
 #pragma unroll
                 for (int i2 = 0; i2 < N; ++i2) {
-                    T acc = T(0);
+                    T accp = T(0);
 #pragma unroll
-                    for (int j = i2; j < N; ++j) acc = tfma((T)s_ri[i2 * N + j], tq[j], acc);
-                    cc[i2] = acc;
+                    for (int j = 0; j < N; ++j) accp = tfma((T)s_ri[N * N + i2 * N + j], tq[j], accp);
+                    tr[i2] = accp;
                 }
             }
-            bool cfin = true;
-#pragma unroll
-            for (int i2 = 0; i2 < N; ++i2) cfin = cfin && is_finite(cc[i2]);
-            cfin_prev[c] = uni(cfin);
             T r2 = T(0);
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
                 T v = y[c][r];
 #pragma unroll
-                for (int j = 0; j < N; ++j) v = tfma(-tq[j], q[j][r], v);
-                y[c][r] = v;
+                for (int j = 0; j < N; ++j) v = tfma(-tr[j], q[j][r], v);
                 r2 = tfma(v, v, r2);
+#pragma unroll
+                for (int j = 0; j < N; ++j) wacc[j][r] = tfma(tq[j], v, wacc[j][r]);
             }
-            r2prev[c] = valid ? r2 : T(0);
-            if (!valid) continue;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                T cp = T(0);
-#pragma unroll
-                for (int j2 = 0; j2 < N; ++j2) cp = tfma(ohp[p][j2], cc[j2], cp);
-#pragma unroll
-                for (int r = 0; r < RW; ++r) gv[p][r] = tfma(cp, y[c][r], gv[p][r]);
-            }
-            if (wave == 0) {
-#pragma unroll
-                for (int j2 = 0; j2 < N; ++j2)
-                    if (lane == j2) s_c[((int)(i % FB) * NB + c) * N + j2] = (double)cc[j2];
-                T fa_ = T(0), fb_ = T(0);
-#pragma unroll
-                for (int j2 = 0; j2 < N; ++j2) {
-                    fa_ = tfma(ohi[j2], cc[j2], fa_);
-                    fb_ = tfma(ohj[j2], cc[j2], fb_);
-                }
-                accv = tfma(fa_, fb_, accv);
-            }
+            r2prev[c] = r2;
         }
     }
-    // ---- flush: squared norms of the last batch, the P dots G_p^T v_p, the remaining staged results ----
+    // ---- flush: squared norms of the last batch, the P x N dots G_p^T W_j, the remaining staged results ----
     {
-        T red[NRED];
+        T red[NX];
 #pragma unroll
-        for (int i2 = 0; i2 < NRED; ++i2) red[i2] = T(0);
+        for (int v = 0; v < NX; ++v) red[v] = T(0);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) red[N * NB + c] = r2prev[c];
-        if constexpr (P > 0) {
-            static_assert(P <= N * NB, "the dots ride in the T slots of the flush round");
+        for (int c = 0; c < NB; ++c) red[P * N + c] = r2prev[c];
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                T gs[RW];
-                load_rows<T, RW, NW>(gsrc + (int64_t)p * m, m, gl, true, gs);
+        for (int p = 0; p < P; ++p) {
+            T gs[RW];
+            load_rows<T, RW, NW>(gsrc + (int64_t)p * m, m, gl, true, gs);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
                 T acc = T(0);
 #pragma unroll
-                for (int r = 0; r < RW; ++r) acc = tfma(gs[r], gv[p][r], acc);
-                red[p] = acc;
+                for (int r = 0; r < RW; ++r) acc = tfma(gs[r], wacc[j][r], acc);
+                red[p * N + j] = acc;
             }
         }
-        wave_reduce_store_g<NRED>(red, s_x + ((size_t)ph * NW + wave) * NRED);
+        wave_reduce_store_g<NX>(red, s_x + ((size_t)ph * NW + wave) * NX);
         __syncthreads();
         T tot = T(0);
-        if (lane < NRED) {
+        if (lane < NFL) {
 #pragma unroll
-            for (int w = 0; w < NW; ++w) tot += s_x[((size_t)ph * NW + w) * NRED + lane];
+            for (int w = 0; w < NW; ++w) tot += s_x[((size_t)ph * NW + w) * NX + lane];
         }
-        emit_prev(tot, nloc - 1);
+        // the squared norms of the last batch sit in lanes P N .. here: move them to where emit_prev expects them
+        {
+            T shifted = T(0);
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const T v = readlane(tot, P * N + c);
+                shifted = (lane == N * NB + c) ? v : shifted;
+            }
+            emit_prev(shifted, nloc - 1);
+        }
         burst(flushed, nloc);
         if (wave == 0) {
+            // back from T-space: sum c c^T = Rinv (sum T T^T) Rinv^T;  sum_s c_{j(p),s} u_{p,s} = sum_j Rinv[j(p)][j] (G_p^T W_j)
+            if (ak_tt) s_fin[ak - 1] = (double)accv;
+            if (lane < P * N) s_fin[N * N + lane] = (double)tot;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double outv = (double)accv; // lane 0: sum ||r||^2
+            if (ak_tt) {
+                const int ci = (ak - 1) / N, cj = (ak - 1) % N;
+                double acc2 = 0.0;
+                for (int i2 = 0; i2 < N; ++i2)
+                    for (int j2 = 0; j2 < N; ++j2) acc2 = tfma(s_ri[ci * N + i2] * s_ri[cj * N + j2], s_fin[i2 * N + j2], acc2);
+                outv = acc2;
+            } else if (ak > N * N) {
+                const int p = ak - 1 - N * N;
+                int jb = 0;
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const T dp = readlane(tot, p);
-                accv = (ak == 1 + N * N + p) ? dp : accv;
+                for (int pp = 0; pp < P; ++pp) jb = (pp == p) ? a.pb[pp] : jb;
+                double acc2 = 0.0;
+                for (int j2 = 0; j2 < N; ++j2) acc2 = tfma(s_ri[jb * N + j2], s_fin[N * N + p * N + j2], acc2);
+                outv = acc2;
             }
-            if (lane < NACC) a.ws.acc[(b * a.gx + wgi) * NACC + lane] = (double)accv;
+            if (lane < NACC) a.ws.acc[(b * gx + wgi) * NACC + lane] = outv;
         }
     }
 }
@@ -1044,8 +1067,9 @@ template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams 
                                              reinterpret_cast<uintptr_t>(a.ws.g)) & 15) == 0;
         if (p.mrhs_mode == 0 && vec) {
             constexpr int NWd = 4, RWd = R / NWd, NBd = 16 / RWd;
+            constexpr int NXd = (N * NBd + NBd) > (P * N + NBd) ? (N * NBd + NBd) : (P * N + NBd);
             const size_t dlds = (size_t)NWd * 2 * NBd * (RWd / 2) * 1024 +
-                                (size_t)(2 * NWd * (N * NBd + NBd) + 2 * N * N + 16 * NBd * N + 16 * NBd) * 8 + 16 * NBd * 4;
+                                (size_t)(2 * NWd * NXd + 2 * N * N + 16 * NBd * N + 16 * NBd + N * N + P * N) * 8 + 16 * NBd * 4 + 64;
             if (hipFuncSetAttribute((const void *)mrhs_coop_dma_kernel<T, N, P, RWd, NWd, NBd>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds) != hipSuccess)
                 return VP_ERR_HIP;
