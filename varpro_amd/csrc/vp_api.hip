@@ -589,7 +589,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
 
     // a specialised (register-resident) kernel set if one is instantiated for this (dtype, model, m), else the generic
     // fallback kernels (vp_generic.hpp): any descriptor, any m -- slower, but never a CPU path and never "unsupported"
-    const KernelEntry *kern = find_kernels(dtype, *model, m);
+    const KernelEntry *kern = find_kernels(dtype, *model, m, S);
     if (!kern) kern = generic_kernels(dtype);
     // a global fit (S > 1) on a specialised set WITHOUT multiple-right-hand-side kernels (the multi-wave sets: double
     // exponential at 2048 < m <= 4096, the fp32 Gram shape) runs on the generic kernels as well
@@ -1191,7 +1191,7 @@ int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out) {
     return FAMILY_RT;
 }
 
-const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m) {
+const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m, int64_t S) {
     int a, b, c, p;
     const int fam = classify_model(d, a, b, c, p);
     if (fam < 0) return nullptr;
@@ -1209,8 +1209,17 @@ const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m) {
         for (const KernelEntry &e : registry()) {
             if (e.dtype != dtype || e.family != f || e.a != ka || e.b != kb || e.c != kc) continue;
             if ((int64_t)64 * e.R * e.W < m) continue;
-            // smallest capacity first; among equal capacities the fewest waves per problem
-            if (!best || e.R * e.W < best->R * best->W || (e.R * e.W == best->R * best->W && e.W < best->W)) best = &e;
+            // smallest capacity first.  Among equal capacities: a multiple-RHS handle takes the set that has MRHS kernels;
+            // a single-RHS handle the one whose columns fit the registers (R <= 16 rows per lane -- the R = 32 sets spill
+            // hundreds of VGPRs: triple exponential at m = 2048, 0.71 vs 0.10 ms per 16384 evaluations at m = 1024), else
+            // the fewest waves per problem
+            auto better = [&](const KernelEntry &x, const KernelEntry &y) {
+                if (x.R * x.W != y.R * y.W) return x.R * x.W < y.R * y.W;
+                if (S > 1 && (x.mrhs_stream != nullptr) != (y.mrhs_stream != nullptr)) return x.mrhs_stream != nullptr;
+                if (S == 1 && (x.R <= 16) != (y.R <= 16)) return x.R <= 16;
+                return x.W < y.W;
+            };
+            if (!best || better(e, *best)) best = &e;
         }
     }
     return best;
