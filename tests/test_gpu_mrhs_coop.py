@@ -1,0 +1,112 @@
+"""The workgroup-cooperative MRHS kernels (fp64, 1024 < m <= 2048, m even: `mrhs_coop_out_kernel` for the trait-level
+outputs r / J, `mrhs_coop_dma_kernel` for the fit pass) against the CPU oracle -- and the shapes just outside their
+window (odd m, m <= 1024), which take the one-wave-per-column kernel: same numbers either way.
+Reference: src/solvers/levmar/mod.rs:42-73 (set_params), :91-95 (residuals), :101-201 (Jacobian, MRHS branch :172-186)."""
+import numpy as np
+import pytest
+
+import varpro_amd as vp
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _data(rng, S, m, tau, noise=1e-3):
+    x = np.linspace(0.0, 12.5, m)
+    Cm = rng.uniform(1, 50, (S, len(tau) + 1))
+    Y = sum(Cm[:, j:j + 1] * np.exp(-x / tau[j]) for j in range(len(tau))) + Cm[:, -1:]
+    return x, Y + noise * np.abs(Y).max() * rng.standard_normal(Y.shape)
+
+
+@pytest.mark.parametrize("nexp", [2, 3])
+@pytest.mark.parametrize("S,m,weighted", [(2, 2048, False), (3, 1026, True), (33, 1500, False), (64, 2048, True),
+                                          (7, 1501, False), (129, 1030, False), (5, 2046, True)])
+def test_trait_outputs_match_oracle(nexp, S, m, weighted):
+    rng = np.random.default_rng(1000 * nexp + S + m)
+    tau = [1.0, 3.0, 7.0][:nexp]
+    guess = np.array([1.3, 3.6, 8.1][:nexp])
+    x, Y = _data(rng, S, m, tau)
+    w = rng.uniform(0.3, 2.0, m) if weighted else None
+    mdl = vp.multi_exponential_model(x, guess, offset=True)
+    bp = vp.BatchProblem(mdl, Y[None], x=x, weights=w)
+    ev = bp.evaluate(guess[None])
+    ref = O.Problem(mdl, x, Y, w=w)
+    ref.set_params(guess)
+    yw = Y if w is None else Y * w
+    Cr = ref.linear_coefficients()
+    assert ev["status"][0] == 0
+    assert np.abs(ev["C"][0] - Cr).max() <= TOL * np.abs(Cr).max()
+    assert np.abs(ev["r"][0] - ref.residuals()).max() <= TOL * np.abs(yw).max()
+    Jr = ref.jacobian()
+    for k in range(nexp):
+        assert np.abs(ev["J"][0, k] - Jr[k]).max() <= 1e-9 * np.abs(Jr[k]).max()
+    assert abs(ev["cost"][0] - 0.5 * (ref.residuals() ** 2).sum()) <= 1e-10 * ev["cost"][0]
+    # residuals alone and the Jacobian alone (each output pointer may be absent)
+    e2 = bp.evaluate(guess[None], want_jacobian=False)
+    assert np.array_equal(e2["r"], ev["r"]) and np.array_equal(e2["C"], ev["C"])
+    bp.close()
+
+
+def test_trait_outputs_several_problems_each_with_its_own_parameters():
+    rng = np.random.default_rng(5)
+    B, S, m = 3, 19, 1400
+    tau = [1.0, 3.0, 7.0]
+    xs, Ys = zip(*[_data(rng, S, m, tau) for _ in range(B)])
+    x = xs[0]
+    Y = np.stack(Ys)
+    guesses = np.array([[1.3, 3.6, 8.1], [0.9, 2.7, 6.0], [1.1, 3.3, 9.0]])
+    mdl = vp.multi_exponential_model(x, guesses[0], offset=True)
+    bp = vp.BatchProblem(mdl, Y, x=x)
+    ev = bp.evaluate(guesses)
+    for b in range(B):
+        ref = O.Problem(mdl, x, Y[b])
+        ref.set_params(guesses[b])
+        assert np.abs(ev["C"][b] - ref.linear_coefficients()).max() <= TOL * np.abs(ref.linear_coefficients()).max()
+        assert np.abs(ev["r"][b] - ref.residuals()).max() <= TOL * np.abs(Y[b]).max()
+        Jr = ref.jacobian()
+        for k in range(3):
+            assert np.abs(ev["J"][b, k] - Jr[k]).max() <= 1e-9 * np.abs(Jr[k]).max()
+    bp.close()
+
+
+@pytest.mark.parametrize("S,m", [(9, 1500), (40, 2048)])
+def test_rank_deficient_basis_minimum_norm_solution_in_the_cooperative_kernel(S, m):
+    # tau1 == tau2 (src/solvers/levmar/mod.rs:51-54: svd.solve(eps) -> minimum-norm coefficients for every column)
+    rng = np.random.default_rng(S + m)
+    x = np.linspace(0.0, 10.0, m)
+    Y = rng.uniform(1, 5, (S, 1)) * np.exp(-x / 2.0) + rng.uniform(0, 1, (S, 1)) + 1e-3 * rng.standard_normal((S, m))
+    mdl = vp.multi_exponential_model(x, [2.0, 2.0], offset=True)
+    bp = vp.BatchProblem(mdl, Y[None], x=x, epsilon=1e-8)
+    ev = bp.evaluate(np.array([[2.0, 2.0]]), want_jacobian=False)
+    ref = O.Problem(mdl, x, Y, eps=1e-8)
+    ref.set_params([2.0, 2.0])
+    Cr = ref.linear_coefficients()
+    assert ev["status"][0] == 0
+    assert np.abs(ev["C"][0] - Cr).max() <= 1e-9 * np.abs(Cr).max()
+    assert np.abs(ev["r"][0] - ref.residuals()).max() <= TOL * np.abs(Y).max()
+    assert abs(ev["cost"][0] - 0.5 * (ref.residuals() ** 2).sum()) <= 1e-9 * ev["cost"][0]
+    bp.close()
+
+
+@pytest.mark.parametrize("S,m,weighted", [(24, 1500, False), (70, 2048, True)])
+def test_global_fit_trajectory_matches_oracle(S, m, weighted):
+    rng = np.random.default_rng(S * m)
+    tau = [1.0, 3.0, 7.0]
+    x, Y = _data(rng, S, m, tau)
+    w = rng.uniform(0.5, 1.5, m) if weighted else None
+    guess = np.array([[1.2, 3.5, 8.0]])
+    mdl = vp.multi_exponential_model(x, guess[0], offset=True)
+    bp = vp.BatchProblem(mdl, Y[None], x=x, weights=w)
+    alpha, C, rep, tr = bp.fit_trace(guess, max_rows=12)
+    ref = O.Problem(mdl, x, Y, w=w)
+    ref.set_params(guess[0])
+    rr, tr_ref = ref.fit_trace(max_rows=12)
+    assert rep["termination"][0] > 0 and rr.termination > 0
+    for i in range(min(5, len(tr_ref), int(rep["n_evals"][0]))):
+        assert np.abs(tr[0, i, :3] - tr_ref[i, :3]).max() <= 1e-6 * np.abs(tr_ref[i, :3]).max(), i
+    assert abs(rep["objective"][0] - rr.objective) <= 1e-8 * rr.objective
+    assert np.abs(alpha[0] - ref.params()).max() <= 1e-6 * np.abs(ref.params()).max()
+    r = bp.residuals()
+    assert abs(0.5 * (r ** 2).sum() - rep["objective"][0]) <= 1e-9 * rep["objective"][0]
+    bp.close()

@@ -856,6 +856,194 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
     }
 }
 
+// ---- MODE 1 (trait-level outputs), workgroup-cooperative --------------------------------------------------------------
+// The same column-sharing layout as mrhs_coop_dma_kernel for the pass that WRITES r and J (4 of its 5 streams are stores):
+// slices of Q and G in registers, the next batch of y prefetched into registers by ordinary loads (stores and loads share
+// vmcnt, so the hand-counted LDS-DMA of the fit pass is not an option here; the compiler's own counting is), one cross-wave
+// reduction per batch, r = y - Q T and J_k = -sum_{p in k} c_{j(p)} G_p written as 1 KiB bursts per wave instruction.
+template <typename T, int N, int P, int RW, int NW, int NB>
+__global__ void __launch_bounds__(64 * NW) mrhs_coop_out_kernel(const MrhsStreamArgs<T, N, P> a) {
+    static_assert(sizeof(T) == 8 && RW >= 2 && RW % 2 == 0, "fp64, row pairs");
+    constexpr int NRED = N * NB + NB;
+    static_assert(NRED <= 64, "one lane per value");
+    __shared__ __attribute__((aligned(16))) double s_x[2][NW][NRED];
+    __shared__ double s_ri[2 * N * N];
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int gl = (int)threadIdx.x;
+    const int64_t b = blockIdx.x / a.gx;
+    const int wgi = (int)(blockIdx.x - b * a.gx);
+    const int m = a.m, S = a.S, gx = a.gx;
+    const T *qsrc = (const T *)a.ws.qthin + b * (int64_t)N * m;
+    const T *gsrc = (const T *)a.ws.g + b * (int64_t)P * m;
+    const double *small = a.ws.small + b * mrhs_small_stride<N, P>();
+    T q[N][RW], g[P > 0 ? P : 1][RW];
+#pragma unroll
+    for (int j = 0; j < N; ++j) load_rows<T, RW, NW>(qsrc + (int64_t)j * m, m, gl, true, q[j]);
+#pragma unroll
+    for (int p = 0; p < P; ++p) load_rows<T, RW, NW>(gsrc + (int64_t)p * m, m, gl, true, g[p]);
+    if (threadIdx.x < N * N) {
+        s_ri[threadIdx.x] = small[threadIdx.x];
+        s_ri[N * N + threadIdx.x] = small[N * N + P * P + threadIdx.x];
+    }
+    const int stA = a.ws.statusA[b];
+    const bool truncated = uni(small[2 * N * N + P * P] != 0.0);
+    // which coefficient scales pair p, as a one-hot row (a select chain over the coefficient array would be folded into a
+    // dynamically indexed vector kept in scratch)
+    T ohp[P > 0 ? P : 1][N];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int j2 = 0; j2 < N; ++j2) ohp[p][j2] = (a.pb[p] == j2) ? T(1) : T(0);
+    __syncthreads();
+    const int nbatch = (S + NB - 1) / NB;
+    const T *ybase = a.yw + b * (int64_t)S * m;
+    T ynext[NB][RW];
+    auto load_batch = [&](const int bt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const int s = bt * NB + c;
+            if (s < S) {
+                load_rows<T, RW, NW>(ybase + (int64_t)s * m, m, gl, true, ynext[c]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < RW; ++r) ynext[c][r] = T(0);
+            }
+        }
+    };
+    T r2prev[NB];
+    unsigned badprev = 0u;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) r2prev[c] = T(0);
+    int ph = 0, prev_bt = -1;
+    auto emit_prev = [&](const T tot, const int bt) __attribute__((always_inline)) {
+        if (bt < 0) return;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const int s = bt * NB + c;
+            if (s >= S) continue;
+            const T r2 = readlane(tot, N * NB + c);
+            const bool ok = is_finite(r2) && stA == VP_ST_OK && ((badprev >> c) & 1u) == 0u;
+            if (wave == 0 && lane == 0) {
+                const int64_t prob = b * S + s;
+                if (a.cost_bs) a.cost_bs[prob] = 0.5 * (double)r2;
+                if (a.status_bs) a.status_bs[prob] = ok ? VP_ST_OK : (stA != VP_ST_OK ? stA : VP_ST_NONFINITE);
+            }
+        }
+    };
+    int bt = wgi;
+    if (bt < nbatch) load_batch(bt);
+    for (; bt < nbatch; bt += gx) {
+        T y[NB][RW];
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int r = 0; r < RW; ++r) y[c][r] = ynext[c][r];
+        if (bt + gx < nbatch) load_batch(bt + gx); // in flight while this batch is computed and written
+        T red[NRED];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                T acc = T(0);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc = tfma(q[j][r], y[c][r], acc);
+                red[c * N + j] = acc;
+            }
+            red[N * NB + c] = r2prev[c];
+        }
+        wave_reduce_store_g<NRED>(red, &s_x[ph][wave][0]);
+        __syncthreads();
+        T tot = T(0);
+        if (lane < NRED) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += s_x[ph][w][lane];
+        }
+        ph ^= 1;
+        emit_prev(tot, prev_bt);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const int s = bt * NB + c;
+            const bool valid = s < S; // (uniform)
+            T tq[N], cc[N], tr[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) tq[j] = readlane(tot, c * N + j);
+#pragma unroll
+            for (int i2 = 0; i2 < N; ++i2) {
+                T acc = T(0), accp = T(0);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    if (truncated || j >= i2) acc = tfma((T)s_ri[i2 * N + j], tq[j], acc);
+                    if (truncated) accp = tfma((T)s_ri[N * N + i2 * N + j], tq[j], accp);
+                }
+                cc[i2] = acc;
+                tr[i2] = truncated ? accp : tq[i2];
+            }
+            bool cfin = true;
+#pragma unroll
+            for (int i2 = 0; i2 < N; ++i2) cfin = cfin && is_finite(cc[i2]);
+            badprev = (badprev & ~(1u << c)) | (uni(cfin) ? 0u : (1u << c));
+            T r2 = T(0);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                T v = y[c][r];
+#pragma unroll
+                for (int j = 0; j < N; ++j) v = tfma(-tr[j], q[j][r], v);
+                y[c][r] = v;
+                r2 = tfma(v, v, r2);
+            }
+            r2prev[c] = valid ? r2 : T(0);
+            if (!valid) continue;
+            const int64_t prob = b * S + s;
+            if (a.C_out && wave == 0) {
+#pragma unroll
+                for (int j2 = 0; j2 < N; ++j2)
+                    if (lane == j2) a.C_out[prob * N + j2] = cc[j2];
+            }
+            if (a.r_out) store_rows<T, RW, NW>(a.r_out + prob * (int64_t)m, m, gl, true, y[c]);
+            if (a.J_out) {
+                T cp[P > 0 ? P : 1];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    T v = T(0);
+#pragma unroll
+                    for (int j2 = 0; j2 < N; ++j2) v = tfma(ohp[p][j2], cc[j2], v);
+                    cp[p] = -v;
+                }
+                for (int k2 = 0; k2 < a.q; ++k2) {
+                    T jk[RW];
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) jk[r] = T(0);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        if (a.pp[p] == k2) {
+#pragma unroll
+                            for (int r = 0; r < RW; ++r) jk[r] = tfma(cp[p], g[p][r], jk[r]);
+                        }
+                    }
+                    store_rows<T, RW, NW>(a.J_out + ((b * a.q + k2) * (int64_t)S + s) * (int64_t)m, m, gl, true, jk);
+                }
+            }
+        }
+        prev_bt = bt;
+    }
+    { // flush: the squared norms of the last batch
+        T red[NRED];
+#pragma unroll
+        for (int v = 0; v < NRED; ++v) red[v] = T(0);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) red[N * NB + c] = r2prev[c];
+        wave_reduce_store_g<NRED>(red, &s_x[ph][wave][0]);
+        __syncthreads();
+        T tot = T(0);
+        if (lane < NRED) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += s_x[ph][w][lane];
+        }
+        emit_prev(tot, prev_bt);
+    }
+}
+
 template <typename T, int N, int Q, int P> struct MrhsLmArgs {
     MrhsWs ws;
     LmOpts<T> opts;
@@ -1065,6 +1253,15 @@ template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams 
         // (8 DMA instructions per batch and wave), ring of 2 batches per wave; two workgroups per CU
         const bool vec = (p.m & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.yw) | reinterpret_cast<uintptr_t>(a.ws.qthin) |
                                              reinterpret_cast<uintptr_t>(a.ws.g)) & 15) == 0;
+#ifndef VP_NO_MRHS_COOP_OUT
+        if (p.mrhs_mode != 0 && vec && (a.r_out || a.J_out) && (reinterpret_cast<uintptr_t>(a.r_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.J_out) & 15) == 0) {
+            constexpr int NWd = 4, RWd = R / NWd, NBd = 2;
+            const int gxo = mrhs_gx(p.S, 512);
+            a.gx = gxo;
+            hipLaunchKernelGGL((mrhs_coop_out_kernel<T, N, P, RWd, NWd, NBd>), dim3((unsigned)((int64_t)gxo * p.B)), dim3(64 * NWd), 0, p.stream, a);
+            return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+        }
+#endif
         if (p.mrhs_mode == 0 && vec) {
             constexpr int NWd = 4, RWd = R / NWd, NBd = 16 / RWd;
             constexpr int NXd = (N * NBd + NBd) > (P * N + NBd) ? (N * NBd + NBd) : (P * N + NBd);
