@@ -59,13 +59,25 @@ __global__ void reduce_rhs_kernel(const double *__restrict__ cost_bs, const int3
     if (b >= B) return;
     double acc = 0.0;
     int st = 0;
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        acc += cost_bs[b * S + s];
-        const int v = status_bs[b * S + s];
-        st = v > st ? v : st;
+    // eight loads in flight per thread and trip (one dependent load per trip made this 24 us for S = 16384)
+    for (int s0 = threadIdx.x; s0 < S; s0 += 8 * blockDim.x) {
+        double c[8];
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int s = s0 + k * (int)blockDim.x;
+            const bool in = s < S;
+            c[k] = in ? cost_bs[b * S + s] : 0.0;
+            v[k] = in ? status_bs[b * S + s] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            acc += c[k];
+            st = v[k] > st ? v[k] : st;
+        }
     }
-    __shared__ double sh[256];
-    __shared__ int shs[256];
+    __shared__ double sh[1024];
+    __shared__ int shs[1024];
     sh[threadIdx.x] = acc;
     shs[threadIdx.x] = st;
     __syncthreads();
@@ -194,6 +206,11 @@ struct vp_batch {
     // MRHS fit: a captured HIP graph of VP_MRHS_GRAPH_ITERS {factor, stream, LM step} iterations (replayed per batch
     // of iterations: one graph launch instead of 3 x ITERS kernel launches), the options it was captured with
     hipGraphExec_t mrhs_graph;
+    hipGraphExec_t mrhs_graph_tail; // 12 further iterations + finish, for a fit that outlasts mrhs_graph
+    int mrhs_graph_len;     // LM iterations mrhs_graph holds
+    int mrhs_graph_iters;   // ... and what the next capture should hold (evaluations of the previous fit + 1, >= 6)
+    int32_t *h_nactive;     // pinned, device-mapped: the active count as the graph's last kernel leaves it
+    int32_t *h_nactive_dev; // its device address
     vp_lm_opts mrhs_graph_opts;
     hipStream_t cap_stream;
     bool mrhs_graph_failed;
@@ -310,7 +327,7 @@ struct Timer {
 
 int reduce_rhs(vp_batch *h) {
     if (h->S == 1) return 0; // d_cost / d_status alias the per-(b,s) arrays
-    hipLaunchKernelGGL(reduce_rhs_kernel, dim3((unsigned)h->B), dim3(256), 0, h->stream, h->d_cost_bs,
+    hipLaunchKernelGGL(reduce_rhs_kernel, dim3((unsigned)h->B), dim3(h->S > 2048 ? 1024 : 256), 0, h->stream, h->d_cost_bs,
                        h->d_status_bs, h->d_cost, h->d_status, (int)h->S, h->B);
     VP_HIP(hipGetLastError());
     return 0;
@@ -417,12 +434,7 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         if (int rc = tr.finish(h)) return rc;
         return VP_ERR_OK;
     }
-    VP_HIP(hipMemsetAsync(h->mrhs.nactive, 0, sizeof(int32_t), h->stream));
     Timer tm(h, VP_KERNEL_FIT);
-    p.mrhs_init = 1;
-    p.alpha = h->d_alpha;
-    if (int rc = h->kern->mrhs_lm(p)) return fail(rc, "mrhs_lm (init) launch failed");
-    p.mrhs_init = 0;
     const int max_iter = o.patience * (h->q + 1) + 2;
     // right-hand sides sharded over ranks: the reduced sums of this rank's columns are totalled in a fixed order,
     // summed over the ranks by the caller's collective (RCCL all-reduce of B*(1+n*n+p) doubles per evaluation) and
@@ -434,16 +446,21 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         ws_tot.acc = h->d_mrhs_tot;
         p.mrhs_S_global = h->rhs_global;
     }
-    // The loop is device-driven: iterations are ENQUEUED in batches with no host synchronisation in between -- a
-    // problem whose LM loop has terminated is skipped on the device (MrhsWs::done), so an iteration enqueued past the
-    // end costs three empty launches (~microseconds), while every read-back of the active count costs a full stream
-    // drain.  The host looks at the count after 12 iterations (a typical global fit needs fewer than that many
-    // evaluations), then after every further 24.
-    constexpr int GRAPH_ITERS = 12;
+    // the first launch: LM state from alpha0 (the active count is SET there, no memset) + factorisation of alpha0
+    auto enqueue_init = [&](LaunchParams &lp) -> int {
+        lp.mrhs_init = 1;
+        lp.alpha = h->d_alpha;
+        const int rc = h->kern->mrhs_lm(lp);
+        lp.mrhs_init = 0;
+        return rc ? fail(rc, "mrhs_step (init) launch failed") : 0;
+    };
+    // one LM iteration = TWO launches: the streaming pass at the trial point, then the LM step on its sums fused with the
+    // factorisation of the next trial point (mrhs_step_kernel).  The loop is device-driven: iterations are ENQUEUED with
+    // no host synchronisation in between -- a problem whose LM loop has terminated is skipped on the device
+    // (MrhsWs::done), so an iteration enqueued past the end costs two empty launches (~10 us).
     auto enqueue_iteration = [&](LaunchParams &lp) -> int {
         lp.alpha = h->mrhs.alpha_trial;
         lp.mrhs_mode = 0;
-        if (int rc = h->kern->mrhs_factor(lp)) return fail(rc, "mrhs_factor launch failed");
         if (int rc = h->kern->mrhs_stream(lp)) return fail(rc, "mrhs_stream launch failed");
         if (h->rhs_allreduce) {
             const int64_t total = h->B * nacc;
@@ -454,23 +471,44 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
             if (h->rhs_allreduce(h->d_mrhs_tot, total, (void *)lp.stream, h->rhs_allreduce_user) != 0)
                 return fail(VP_ERR_INVALID, "the right-hand-side all-reduce callback reported an error");
             lp.mrhs_ws = &ws_tot;
+            lp.mrhs_fws = &h->mrhs;
             lp.mrhs_gx = 1;
         }
-        if (int rc = h->kern->mrhs_lm(lp)) return fail(rc, "mrhs_lm launch failed");
+        // the LM step on the sums of this pass + the factorisation of the next trial point (one launch)
+        if (int rc = h->kern->mrhs_lm(lp)) return fail(rc, "mrhs_step launch failed");
         lp.mrhs_ws = &h->mrhs;
+        lp.mrhs_fws = nullptr;
         lp.mrhs_gx = 0;
         return 0;
     };
-    // A batch of GRAPH_ITERS iterations as ONE captured HIP graph (no trace, no all-reduce callback: both put host
-    // state into the launch sequence).  Captured on a private stream -- the handle's stream may be the null stream,
-    // which cannot be captured -- and replayed on the handle's stream.  The graph holds the LM options by value: it
-    // is re-captured when they change.
+    // final parameters + reports; coefficients, cost and status of every column at the final point come from the best
+    // point's pass (double-buffered per-column results, MrhsWs::cbuf) -- no further pass over Y.  The m x S residual
+    // matrix is produced on demand by vp_residuals, as after a single-RHS fit.  The finish kernel also leaves the active
+    // count in pinned host memory (no copy kernel for the host's look at it).
+    auto enqueue_finish = [&](LaunchParams &lp) -> int {
+        lp.alpha_out = h->d_alpha;
+        lp.report = h->d_report;
+        lp.C_out = h->d_C;
+        lp.cost_out = h->d_cost_bs;
+        lp.status = h->d_status_bs;
+        lp.mrhs_hflag = h->h_nactive_dev;
+        if (int rc = h->kern->mrhs_finish(lp)) return fail(rc, "mrhs_finish launch failed");
+        return 0;
+    };
+    if (!h->h_nactive) {
+        VP_HIP(hipHostMalloc((void **)&h->h_nactive, 2 * sizeof(int32_t), hipHostMallocMapped));
+        VP_HIP(hipHostGetDevicePointer((void **)&h->h_nactive_dev, h->h_nactive, 0));
+    }
+    // The WHOLE fit as ONE captured HIP graph: init, `iters` iterations, finish (no trace, no all-reduce callback: both
+    // put host state into the launch sequence).  Captured on a private stream -- the handle's stream may be the null
+    // stream, which cannot be captured -- and replayed on the handle's stream.  The graph holds the LM options by
+    // value: it is re-captured when they change.  Its length follows the handle's previous fit (evaluations + 1 spare
+    // iteration, at least 6; 12 for the first fit): repeated fits of similar data -- the streaming use this path is
+    // built for -- enqueue almost no idle iterations, and a fit that needs more continues with further replays of the
+    // iteration-only tail graph.
     const bool want_graph = !p.trace && !h->rhs_allreduce && !h->mrhs_graph_failed;
-    if (want_graph && (!h->mrhs_graph || std::memcmp(&h->mrhs_graph_opts, &o, sizeof(o)) != 0)) {
-        if (h->mrhs_graph) {
-            (void)hipGraphExecDestroy(h->mrhs_graph);
-            h->mrhs_graph = nullptr;
-        }
+    int want_iters = h->mrhs_graph_iters > 0 ? h->mrhs_graph_iters : 12;
+    auto capture = [&](hipGraphExec_t &exec, const bool head, const int iters) -> bool {
         bool ok = true;
         if (!h->cap_stream) ok = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
         hipGraph_t g = nullptr;
@@ -478,46 +516,60 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         if (ok) {
             LaunchParams gp = p;
             gp.stream = h->cap_stream;
-            for (int it = 0; it < GRAPH_ITERS && ok; ++it) ok = enqueue_iteration(gp) == 0;
+            if (head) ok = enqueue_init(gp) == 0;
+            for (int it = 0; it < iters && ok; ++it) ok = enqueue_iteration(gp) == 0;
+            if (ok) ok = enqueue_finish(gp) == 0;
             const bool ended = hipStreamEndCapture(h->cap_stream, &g) == hipSuccess;
             ok = ok && ended && g != nullptr;
         }
-        if (ok) ok = hipGraphInstantiate(&h->mrhs_graph, g, nullptr, nullptr, 0) == hipSuccess;
+        if (ok) ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
         if (g) (void)hipGraphDestroy(g);
         if (!ok) {
             (void)hipGetLastError();
+            exec = nullptr;
+        }
+        return ok;
+    };
+    if (want_graph && (!h->mrhs_graph || h->mrhs_graph_len != want_iters || std::memcmp(&h->mrhs_graph_opts, &o, sizeof(o)) != 0)) {
+        if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
+        if (h->mrhs_graph_tail) (void)hipGraphExecDestroy(h->mrhs_graph_tail);
+        h->mrhs_graph = h->mrhs_graph_tail = nullptr;
+        if (capture(h->mrhs_graph, true, want_iters) && capture(h->mrhs_graph_tail, false, 12)) {
+            h->mrhs_graph_opts = o;
+            h->mrhs_graph_len = want_iters;
+        } else {
+            if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
             h->mrhs_graph = nullptr;
             h->mrhs_graph_failed = true; // fall back to plain launches for the rest of this handle's life
-        } else {
-            h->mrhs_graph_opts = o;
         }
     }
-    int next_check = GRAPH_ITERS;
-    for (int it = 0; it < max_iter;) {
-        if (want_graph && h->mrhs_graph) {
-            VP_HIP(hipGraphLaunch(h->mrhs_graph, h->stream));
-            it += GRAPH_ITERS;
-        } else {
+    if (want_graph && h->mrhs_graph) {
+        VP_HIP(hipGraphLaunch(h->mrhs_graph, h->stream));
+        VP_HIP(hipStreamSynchronize(h->stream));
+        for (int it = h->mrhs_graph_len; *(volatile int32_t *)h->h_nactive > 0 && it < max_iter; it += 12) {
+            VP_HIP(hipGraphLaunch(h->mrhs_graph_tail, h->stream));
+            VP_HIP(hipStreamSynchronize(h->stream));
+        }
+        // the next capture: as many iterations as this fit's longest problem took evaluations, plus one spare
+        const int nfev_max = ((volatile int32_t *)h->h_nactive)[1];
+        int it_next = nfev_max + 1;
+        it_next = it_next < 6 ? 6 : (it_next > 24 ? 24 : it_next);
+        h->mrhs_graph_iters = it_next;
+    } else {
+        if (int rc = enqueue_init(p)) return rc;
+        int next_check = 12;
+        for (int it = 0; it < max_iter;) {
             if (int rc = enqueue_iteration(p)) return rc;
             ++it;
             if (it < next_check && it < max_iter) continue;
-            next_check += 2 * GRAPH_ITERS;
+            next_check += 24;
+            int32_t nact = 0;
+            VP_HIP(hipMemcpyAsync(&nact, h->mrhs.nactive, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            VP_HIP(hipStreamSynchronize(h->stream));
+            if (nact <= 0) break;
         }
-        int32_t nact = 0;
-        VP_HIP(hipMemcpyAsync(&nact, h->mrhs.nactive, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        VP_HIP(hipStreamSynchronize(h->stream));
-        if (nact <= 0) break;
+        if (int rc = enqueue_finish(p)) return rc;
     }
-    // final parameters + reports, then one trait-level evaluation at the final point (C, cost, status, R cache)
-    // final parameters + reports; coefficients, cost and status of every column at the final point come from the best
-    // point's pass (double-buffered per-column results, MrhsWs::cbuf) -- no further pass over Y.  The m x S residual
-    // matrix is produced on demand by vp_residuals, as after a single-RHS fit.
-    p.alpha_out = h->d_alpha;
-    p.report = h->d_report;
-    p.C_out = h->d_C;
-    p.cost_out = h->d_cost_bs;
-    p.status = h->d_status_bs;
-    if (int rc = h->kern->mrhs_finish(p)) return fail(rc, "mrhs_finish launch failed");
     tm.stop();
     if (int rc = reduce_rhs(h)) return rc;
     h->have_params = true;
@@ -720,7 +772,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         VP_TRY(hipMalloc((void **)&h->mrhs.statusA, (size_t)B * sizeof(int32_t)));
         VP_TRY(hipMalloc((void **)&h->mrhs.acc, (size_t)B * VP_MRHS_GX_MAX * (1 + n_ * n_ + p_) * sizeof(double)));
         VP_TRY(hipMalloc(&h->mrhs.lm_state, (size_t)B * kern->mrhs_state_bytes));
-        VP_TRY(hipMalloc((void **)&h->mrhs.nactive, sizeof(int32_t)));
+        VP_TRY(hipMalloc((void **)&h->mrhs.nactive, 2 * sizeof(int32_t)));
         VP_TRY(hipMalloc((void **)&h->mrhs.done, (size_t)B * sizeof(int32_t)));
         VP_TRY(hipMemsetAsync(h->mrhs.done, 0, (size_t)B * sizeof(int32_t), h->stream));
         VP_TRY(hipMalloc(&h->mrhs.alpha_trial, (size_t)std::max<int64_t>(1, B * q_) * ts));
@@ -781,6 +833,8 @@ void vp_batch_destroy(vp_batch *h) {
     (void)hipFree(h->mrhs.widx);
     (void)hipFree(h->mrhs.bidx);
     if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
+    if (h->mrhs_graph_tail) (void)hipGraphExecDestroy(h->mrhs_graph_tail);
+    if (h->h_nactive) (void)hipHostFree(h->h_nactive);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

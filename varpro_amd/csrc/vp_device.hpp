@@ -308,6 +308,38 @@ template <int N, typename T> __device__ __forceinline__ void dyn_set(T (&a)[N], 
 #pragma unroll
     for (int j = 0; j < N; ++j) a[j] = (idx == j) ? val : a[j];
 }
+// Opaque variants (O = true): every element passes through an empty asm, so that the optimiser cannot fold the select chain
+// back into a dynamically indexed load / store on the array (select of loads -> load of a selected address), which pins the
+// array -- and any struct it is a member of -- in scratch memory.  Needed where the arrays are members of a state struct
+// (LmVars, vp_lm_core.hpp: 512 B of scratch and ~260 scratch accesses in mrhs_lm_kernel without it); the single-RHS fit
+// kernels keep the plain form (their arrays are small locals and end up in registers either way).
+__device__ __forceinline__ double dyn_opq(double x) {
+    asm("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float dyn_opq(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ int dyn_opq(int x) {
+    asm("" : "+v"(x));
+    return x;
+}
+template <int N, bool O, typename T> __device__ __forceinline__ T dyn_get_o(const T (&a)[N], int idx) {
+    if constexpr (!O) return dyn_get<N>(a, idx);
+    T v = dyn_opq(a[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) v = (idx == j) ? dyn_opq(a[j]) : v;
+    return v;
+}
+template <int N, bool O, typename T> __device__ __forceinline__ void dyn_set_o(T (&a)[N], int idx, T val) {
+    if constexpr (!O) {
+        dyn_set<N>(a, idx, val);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) a[j] = (idx == j) ? val : dyn_opq(a[j]);
+}
 
 template <typename T> __device__ __forceinline__ bool is_finite(T x) { return (x - x) == T(0); }
 template <typename T> __device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }

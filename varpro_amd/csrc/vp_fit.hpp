@@ -57,7 +57,7 @@ template <typename T, int Q, bool U = true> __device__ __forceinline__ T enorm_s
 // MINPACK qrsolv on wave-uniform registers.  r[row][col]: upper triangle incl. diagonal = R of the
 // pivoted QR; the strict lower triangle is scratch (receives S^T).  Solves
 // min || [R P^T; D] x - [qtb; 0] ||.
-template <typename T, int Q, bool U = true>
+template <typename T, int Q, bool U = true, bool O = false>
 __device__ __forceinline__ void qrsolv(T (&r)[Q][Q], const int (&ipvt)[Q], const T (&diag)[Q], const T (&qtb)[Q],
                                        T (&x)[Q], T (&sdiag)[Q]) {
     T wa[Q];
@@ -70,7 +70,7 @@ __device__ __forceinline__ void qrsolv(T (&r)[Q][Q], const int (&ipvt)[Q], const
     }
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
-        const T dl = dyn_get<Q>(diag, ipvt[j]);
+        const T dl = dyn_get_o<Q, O>(diag, ipvt[j]);
         if (pol<U>(dl != T(0))) {
 #pragma unroll
             for (int k = j; k < Q; ++k) sdiag[k] = T(0);
@@ -119,11 +119,11 @@ __device__ __forceinline__ void qrsolv(T (&r)[Q][Q], const int (&ipvt)[Q], const
         }
     }
 #pragma unroll
-    for (int j = 0; j < Q; ++j) dyn_set<Q>(x, ipvt[j], wa[j]);
+    for (int j = 0; j < Q; ++j) dyn_set_o<Q, O>(x, ipvt[j], wa[j]);
 }
 
 // MINPACK lmpar.  Returns par; step = p (new point is x - p); dxnorm = ||diag .* p||.
-template <typename T, int Q, bool U = true>
+template <typename T, int Q, bool U = true, bool O = false>
 __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (&diag)[Q], const T (&qtb)[Q],
                                    const T delta, T par, T (&x)[Q], T &dxnorm_out) {
     const T p1 = T(0.1), p001 = T(0.001), dwarf = num<T>::tiny;
@@ -135,7 +135,7 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
         if (r[j][j] == T(0) && nsing == Q) nsing = j;
         if (nsing < Q) wa1[j] = T(0);
         rinv[j] = (r[j][j] != T(0)) ? frcp(r[j][j]) : T(0);
-        dperm[j] = dyn_get<Q>(diag, ipvt[j]);
+        dperm[j] = dyn_get_o<Q, O>(diag, ipvt[j]);
     }
     nsing = pol<U>(nsing);
 #pragma unroll
@@ -149,7 +149,7 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
         }
     }
 #pragma unroll
-    for (int j = 0; j < Q; ++j) dyn_set<Q>(x, ipvt[j], wa1[j]);
+    for (int j = 0; j < Q; ++j) dyn_set_o<Q, O>(x, ipvt[j], wa1[j]);
 #pragma unroll
     for (int j = 0; j < Q; ++j) wa2[j] = diag[j] * x[j];
     T dxnorm = enorm_small<T, Q, U>(wa2);
@@ -163,7 +163,7 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
     if (nsing >= Q) {
         const T idx = frcp(dxnorm);
 #pragma unroll
-        for (int j = 0; j < Q; ++j) wa1[j] = dperm[j] * (dyn_get<Q>(wa2, ipvt[j]) * idx);
+        for (int j = 0; j < Q; ++j) wa1[j] = dperm[j] * (dyn_get_o<Q, O>(wa2, ipvt[j]) * idx);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
             T sum = T(0);
@@ -194,7 +194,7 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
         const T sq = usqrt(par);
 #pragma unroll
         for (int j = 0; j < Q; ++j) wa1[j] = sq * diag[j];
-        qrsolv<T, Q, U>(r, ipvt, wa1, qtb, x, sdiag);
+        qrsolv<T, Q, U, O>(r, ipvt, wa1, qtb, x, sdiag);
 #pragma unroll
         for (int j = 0; j < Q; ++j) wa2[j] = diag[j] * x[j];
         dxnorm = enorm_small<T, Q, U>(wa2);
@@ -203,7 +203,7 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
         if (pol<U>(tabs(fp) <= p1 * delta || (parl == T(0) && fp <= temp && temp < T(0)) || iter == 10)) break;
         const T idx = frcp(dxnorm);
 #pragma unroll
-        for (int j = 0; j < Q; ++j) wa1[j] = dperm[j] * (dyn_get<Q>(wa2, ipvt[j]) * idx);
+        for (int j = 0; j < Q; ++j) wa1[j] = dperm[j] * (dyn_get_o<Q, O>(wa2, ipvt[j]) * idx);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
             wa1[j] = wa1[j] * frcp(sdiag[j]);

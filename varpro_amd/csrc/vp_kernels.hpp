@@ -51,6 +51,8 @@ struct LaunchParams {
     void *gen_ws;       // generic fallback kernels (vp_generic.hpp): workspace, gen_blocks slots
     int gen_blocks;
     const void *mrhs_ws; // MRHS path: pointer to the handle's MrhsWs
+    const void *mrhs_fws; // MRHS LM step + factorisation: the workspace the factorisation writes when it is not mrhs_ws (null: mrhs_ws)
+    int32_t *mrhs_hflag; // MRHS finish: pinned host words [active count, max evaluations] (device address) or null
     int mrhs_mode;      // MRHS stream: 0 = reduced quantities (fit), 1 = trait-level outputs
     int mrhs_init;      // MRHS LM step: 1 = initialise the state
     int mrhs_gx;        // MRHS LM step: partial-sum slots per problem (0 = the streaming kernel's grid)

@@ -140,7 +140,7 @@ __device__ __forceinline__ void lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T>
         const T ifn = frcp(s.fnorm);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            const T an = dyn_get<Q>(s.acnorm, s.ipvt[j]);
+            const T an = dyn_get_o<Q, true>(s.acnorm, s.ipvt[j]);
             if (an != T(0)) {
                 T sum = T(0);
 #pragma unroll
@@ -184,7 +184,7 @@ __device__ __forceinline__ void lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T>
     for (int i = 0; i < Q; ++i)
 #pragma unroll
         for (int j = 0; j < Q; ++j) Rwork[i][j] = s.Rj[i][j];
-    s.par = lmpar<T, Q, U>(Rwork, s.ipvt, s.diag, s.qtf, s.delta, s.par, step, s.pnorm);
+    s.par = lmpar<T, Q, U, true>(Rwork, s.ipvt, s.diag, s.qtf, s.delta, s.par, step, s.pnorm);
     if (pol<U>(!is_finite(s.pnorm))) {
         s.term = VP_TERM_NUMERICAL;
         return;
@@ -194,7 +194,7 @@ __device__ __forceinline__ void lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T>
     for (int i = 0; i < Q; ++i) wa[i] = T(0);
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
-        const T pj = dyn_get<Q>(step, s.ipvt[j]);
+        const T pj = dyn_get_o<Q, true>(step, s.ipvt[j]);
 #pragma unroll
         for (int i = 0; i <= j; ++i) wa[i] = tfma(s.Rj[i][j], pj, wa[i]);
     }

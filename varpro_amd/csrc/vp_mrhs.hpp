@@ -40,7 +40,7 @@ struct MrhsWs {
     int32_t *statusA; // [B]
     double *acc;      // [B][gx][1 + N*N + P]  per-workgroup partials of sum ||r||^2, sum c c^T, sum c_{j(p)} u_p
     void *lm_state;   // [B] LmVars
-    int32_t *nactive; // [1]
+    int32_t *nactive; // [2]  problems whose LM loop is still running | most evaluations any finished problem took
     int32_t *done;    // [B] 1 once the problem's LM loop has terminated: later factor / stream launches skip it
     void *alpha_trial; // [B][q] T
     // per-column results of the fit's passes, double-buffered: the pass at a trial point writes buffer widx[b]; when the LM
@@ -67,21 +67,14 @@ template <typename T, class M> struct MrhsFactorArgs {
 
 // W waves per problem: W = 1 for batches that fill the GPU with one wave per problem; W = 4 (R/4 rows per lane) when
 // there are few problems and the factorisation of ONE tall Phi is on the critical path of every LM iteration.
-template <typename T, class M, int R, int W = 1>
-__global__ void __launch_bounds__(64 * W) mrhs_factor_kernel(const MrhsFactorArgs<T, M> a) {
-    constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + P;
+// the factorisation of problem b at `alpha` by the calling group of W waves (results -> a.ws)
+template <typename T, class M, int R, int W>
+__device__ __forceinline__ void mrhs_factor_body(const MrhsFactorArgs<T, M> &a, const int64_t b, const T (&alpha)[M::Q], Grp<W> &grp) {
+    constexpr int N = M::N, P = M::P, NC = N + P;
     using L = Layout<R, W>;
     using G = Grp<W>;
-    __shared__ __attribute__((aligned(16))) unsigned char s_xch[group_xch_bytes<W>() > 0 ? group_xch_bytes<W>() : 16];
-    G grp = G::make(s_xch);
     const int lane = grp.gl; // group lane
-    const int64_t b = blockIdx.x;
-    if (b >= a.B) return;
-    if (a.skip_done && uni(a.ws.done[b]) != 0) return;
     const int m = a.m;
-    T alpha[Q];
-#pragma unroll
-    for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
     using Src = RowSource<T, R, false, 2, 2, W>;
     Src src;
     src.t = a.t + b * a.t_stride;
@@ -218,6 +211,21 @@ __global__ void __launch_bounds__(64 * W) mrhs_factor_kernel(const MrhsFactorArg
             store_rows<T, R, W>(qout + (int64_t)j * m, m, lane, false, Z[0]);
         }
     }
+}
+
+template <typename T, class M, int R, int W = 1>
+__global__ void __launch_bounds__(64 * W) mrhs_factor_kernel(const MrhsFactorArgs<T, M> a) {
+    constexpr int Q = M::Q;
+    using G = Grp<W>;
+    __shared__ __attribute__((aligned(16))) unsigned char s_xch[group_xch_bytes<W>() > 0 ? group_xch_bytes<W>() : 16];
+    G grp = G::make(s_xch);
+    const int64_t b = blockIdx.x;
+    if (b >= a.B) return;
+    if (a.skip_done && uni(a.ws.done[b]) != 0) return;
+    T alpha[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
+    mrhs_factor_body<T, M, R, W>(a, b, alpha, grp);
 }
 
 // Packed wave reduction of V values whose totals are STORED by the lanes that end up holding them: dst[v] = total of
@@ -861,8 +869,11 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
 // slices of Q and G in registers, the next batch of y prefetched into registers by ordinary loads (stores and loads share
 // vmcnt, so the hand-counted LDS-DMA of the fit pass is not an option here; the compiler's own counting is), one cross-wave
 // reduction per batch, r = y - Q T and J_k = -sum_{p in k} c_{j(p)} G_p written as 1 KiB bursts per wave instruction.
-template <typename T, int N, int P, int RW, int NW, int NB>
-__global__ void __launch_bounds__(64 * NW) mrhs_coop_out_kernel(const MrhsStreamArgs<T, N, P> a) {
+// Two shapes are instantiated (A/B on the GPU, cfg2): batches of NB = 2 columns with one workgroup per CU (270 VGPRs) for
+// the pass that writes r AND J (0.247 ms against 0.26-0.27 for the other shape), and NB = 1 with two workgroups per CU
+// (<= 256 VGPRs) for the pass that writes r alone (0.106 ms against 0.142).
+template <typename T, int N, int P, int RW, int NW, int NB, int WPE>
+__global__ void __launch_bounds__(64 * NW, WPE) mrhs_coop_out_kernel(const MrhsStreamArgs<T, N, P> a) {
     static_assert(sizeof(T) == 8 && RW >= 2 && RW % 2 == 0, "fp64, row pairs");
     constexpr int NRED = N * NB + NB;
     static_assert(NRED <= 64, "one lane per value");
@@ -1058,61 +1069,96 @@ template <typename T, int N, int Q, int P> struct MrhsLmArgs {
     int trace_rows;
 };
 
-// one wavefront per problem; wave-uniform arithmetic
-template <typename T, int N, int Q, int P>
-__global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P> a) {
+// ONE kernel between two streaming passes of the fit: the LM step on the sums the pass left, then -- unless the loop has
+// terminated -- the factorisation of the new trial point, by the same group of W waves (W = 4 when few problems make both
+// pure latency on the critical path of every iteration; the LM arithmetic is wave-uniform and every wave carries it).
+// Everything the step reads from global memory is REQUESTED before anything is waited for: the LM state, the partial sums
+// (one record per thread in flight, the whole group reduces), G^T G, the status and the buffer index -- one round trip
+// instead of five dependent ones (phase clocks at configs[2]: 4.6 us of a 10 us LM step were the serial loop over the 512
+// partial records, 4.2 us the dependent loads of the accept / Gram phase).  `init`: set the state up and factorise alpha0.
+template <typename T, class M, int R, int W>
+__global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<T, M> fa, const MrhsLmArgs<T, M::N, M::Q, M::P> a) {
+    constexpr int N = M::N, P = M::P, Q = M::Q;
+    using G = Grp<W>;
+    __shared__ __attribute__((aligned(16))) unsigned char s_xch[group_xch_bytes<W>() > 0 ? group_xch_bytes<W>() : 16];
+    G grp = G::make(s_xch);
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
-    const int lane = lane_id();
+    const int gl = grp.gl;
     using Vars = LmVars<T, N, Q>;
     Vars *gs = reinterpret_cast<Vars *>(a.ws.lm_state) + b;
     T *trial = (T *)a.ws.alpha_trial + b * Q;
     constexpr int NACC = 1 + N * N + P;
-    static_assert(NACC <= 64, "one lane per accumulator");
     Vars s;
     if (a.init) {
         T a0[Q];
 #pragma unroll
         for (int k = 0; k < Q; ++k) a0[k] = a.alpha0[b * Q + k];
         lm_init<T, N, Q>(s, a0);
-        if (lane == 0) {
+        if (gl == 0) {
             *gs = s;
 #pragma unroll
             for (int k = 0; k < Q; ++k) trial[k] = s.xt[k];
-            atomicAdd(a.ws.nactive, 1);
+            if (b == 0) { // (every decrement happens in a later launch)
+                a.ws.nactive[0] = (int32_t)a.B;
+                a.ws.nactive[1] = 0;
+            }
             a.ws.done[b] = 0;
             a.ws.widx[b] = 0;
             a.ws.bidx[b] = 0;
         }
-        return;
-    }
+    } else {
+    // ---- every load first ----
     s = *gs;
-    if (s.term != 0) return; // finished earlier
-    // total the per-workgroup partial sums: lane i owns accumulator i, then broadcast
+    const int stA = a.ws.statusA[b];
+    const int wold = a.ws.widx[b];
+    const double *small = a.ws.small + b * mrhs_small_stride<N, P>();
+    double gtg[P > 0 ? P * P : 1];
+#pragma unroll
+    for (int i = 0; i < P * P; ++i) gtg[i] = small[N * N + i];
     double acc[NACC];
     {
-        // lanes stride over the gx partial records (independent loads in flight), then wave all-reduce
+        // group lanes stride over the gx partial records, two records per lane and trip in flight; then one group all-reduce
         const double *part = a.ws.acc + (size_t)b * a.gx * NACC;
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-        for (int g = lane; g < a.gx; g += 64) {
+        constexpr int NT = 64 * W;
+        for (int g = gl; g < a.gx; g += 2 * NT) {
+            const bool two = g + NT < a.gx;
+            const double *r0 = part + (size_t)g * NACC, *r1 = part + (size_t)(two ? g + NT : g) * NACC;
+            double v0[NACC], v1[NACC];
 #pragma unroll
-            for (int i = 0; i < NACC; ++i) acc[i] += part[(size_t)g * NACC + i];
+            for (int i = 0; i < NACC; ++i) v0[i] = r0[i];
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) v1[i] = r1[i];
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] += v0[i] + (two ? v1[i] : 0.0);
         }
-        wave_allreduce(acc);
     }
-    const int stA = a.ws.statusA[b];
+    if (uni(s.term != 0)) return; // finished earlier (uniform over the group)
+    // group all-reduce of the NACC sums, VP_XV values per exchange
+#pragma unroll
+    for (int c0 = 0; c0 < NACC; c0 += VP_XV) {
+        constexpr int CH = VP_XV;
+        double part[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) part[i] = (c0 + i < NACC) ? acc[c0 + i < NACC ? c0 + i : 0] : 0.0;
+        group_allreduce(grp, part);
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (c0 + i < NACC) acc[c0 + i] = part[i];
+    }
     const T cost2 = (T)acc[0];
     const bool ok = uni(stA == VP_ST_OK && is_finite(cost2));
     const T fnorm1 = tsqrt(cost2);
     const bool first_eval = s.first != 0;
     const bool need_jac = lm_after_eval<T, N, Q, true>(s, a.opts, fnorm1, ok, (long)a.m * (long)a.S_global);
-    if (lane == 0 && (s.accepted || first_eval)) { // the pass that just ran evaluated the new best point: keep its buffer
-        const int w = a.ws.widx[b] & 1;
+    if (gl == 0 && (s.accepted || first_eval)) { // the pass that just ran evaluated the new best point: keep its buffer
+        const int w = wold & 1;
         a.ws.bidx[b] = w;
         a.ws.widx[b] = w ^ 1;
     }
-    if (a.trace && lane == 0 && s.nfev - 1 < a.trace_rows) {
+    if (a.trace && gl == 0 && s.nfev - 1 < a.trace_rows) {
         double *tr = a.trace + ((size_t)b * a.trace_rows + (s.nfev - 1)) * (Q + 4);
         for (int k = 0; k < Q; ++k) tr[k] = (double)s.xt[k];
         tr[Q] = (double)fnorm1;
@@ -1121,7 +1167,6 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
         tr[Q + 3] = (double)s.par;
     }
     if (need_jac) {
-        const double *small = a.ws.small + b * mrhs_small_stride<N, P>();
         // J^T J and J^T r are assembled and factored in DOUBLE for both dtypes (the accumulators are double): an fp32
         // handle would otherwise square the conditioning of J in fp32 and drop columns from cond(J) ~ 3e3 on
         double A[Q][Q], bv[Q];
@@ -1134,11 +1179,14 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int kp = a.pp[p], jp = a.pb[p];
-            dyn_set<Q>(bv, kp, dyn_get<Q>(bv, kp) - acc[1 + N * N + p]);
+            dyn_set_o<Q, true>(bv, kp, dyn_get_o<Q, true>(bv, kp) - acc[1 + N * N + p]);
 #pragma unroll
             for (int p2 = 0; p2 < P; ++p2) {
                 const int kp2 = a.pp[p2], jp2 = a.pb[p2];
-                const double contrib = acc[1 + jp * N + jp2] * small[N * N + p * P + p2];
+                double ccv = acc[1]; // sum c_jp c_jp2 (a select chain: a run-time index would pin acc[] in scratch)
+#pragma unroll
+                for (int e = 1; e < N * N; ++e) ccv = (jp * N + jp2 == e) ? dyn_opq(acc[1 + e]) : ccv;
+                const double contrib = ccv * gtg[p * P + p2];
 #pragma unroll
                 for (int k = 0; k < Q; ++k)
 #pragma unroll
@@ -1157,15 +1205,22 @@ __global__ void __launch_bounds__(64) mrhs_lm_kernel(const MrhsLmArgs<T, N, Q, P
         }
     }
     lm_next_step<T, N, Q, true>(s, a.opts, need_jac);
-    if (lane == 0) {
+    if (gl == 0) {
         *gs = s;
 #pragma unroll
         for (int k = 0; k < Q; ++k) trial[k] = s.xt[k];
         if (s.term != 0) {
             atomicAdd(a.ws.nactive, -1);
+            atomicMax(a.ws.nactive + 1, s.nfev);
             a.ws.done[b] = 1;
         }
     }
+    if (uni(s.term != 0)) return;
+    }
+    T xt[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) xt[k] = s.xt[k];
+    mrhs_factor_body<T, M, R, W>(fa, b, xt, grp);
 }
 
 } // namespace vp
@@ -1203,19 +1258,24 @@ template <typename T, int R> constexpr int mrhs_gx_cap() {
 #endif
 }
 
-template <typename T, class M, int R> int launch_mrhs_factor(const LaunchParams &p) {
-    MrhsFactorArgs<T, M> a;
-    if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+template <typename T, class M> inline bool fill_factor_args(const LaunchParams &p, MrhsFactorArgs<T, M> &a) {
+    if (!bind_model(*p.model, a.mdl)) return false;
     a.t = (const T *)p.t;
     a.w = (const T *)p.w;
     a.alpha = (const T *)p.alpha;
-    a.ws = *reinterpret_cast<const MrhsWs *>(p.mrhs_ws);
+    a.ws = *reinterpret_cast<const MrhsWs *>(p.mrhs_fws ? p.mrhs_fws : p.mrhs_ws);
     a.m = p.m;
     a.B = p.B;
     a.t_stride = p.t_stride;
     a.w_stride = p.w_stride;
     a.eps = (T)p.eps;
     a.skip_done = (p.mrhs_mode == 0) ? 1 : 0; // fit loop (reduced sums) vs trait-level evaluation
+    return true;
+}
+
+template <typename T, class M, int R> int launch_mrhs_factor(const LaunchParams &p) {
+    MrhsFactorArgs<T, M> a;
+    if (!fill_factor_args<T, M>(p, a)) return VP_ERR_UNSUPPORTED;
     // few problems: the factorisation is pure latency -> 4 waves per problem (R/4 rows per lane)
     if constexpr (R % 4 == 0 && R / 4 >= 2) {
         if (a.B <= 1024) {
@@ -1255,10 +1315,13 @@ template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams 
                                              reinterpret_cast<uintptr_t>(a.ws.g)) & 15) == 0;
 #ifndef VP_NO_MRHS_COOP_OUT
         if (p.mrhs_mode != 0 && vec && (a.r_out || a.J_out) && (reinterpret_cast<uintptr_t>(a.r_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.J_out) & 15) == 0) {
-            constexpr int NWd = 4, RWd = R / NWd, NBd = 2;
+            constexpr int NWd = 4, RWd = R / NWd;
             const int gxo = mrhs_gx(p.S, 512);
             a.gx = gxo;
-            hipLaunchKernelGGL((mrhs_coop_out_kernel<T, N, P, RWd, NWd, NBd>), dim3((unsigned)((int64_t)gxo * p.B)), dim3(64 * NWd), 0, p.stream, a);
+            if (a.J_out)
+                hipLaunchKernelGGL((mrhs_coop_out_kernel<T, N, P, RWd, NWd, 2, 1>), dim3((unsigned)((int64_t)gxo * p.B)), dim3(64 * NWd), 0, p.stream, a);
+            else
+                hipLaunchKernelGGL((mrhs_coop_out_kernel<T, N, P, RWd, NWd, 1, 2>), dim3((unsigned)((int64_t)gxo * p.B)), dim3(64 * NWd), 0, p.stream, a);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
         }
 #endif
@@ -1294,8 +1357,13 @@ template <typename T, class M, int R> int launch_mrhs_stream(const LaunchParams 
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
+// the LM step + the factorisation of the next trial point (mrhs_step_kernel); p.mrhs_ws = the workspace the LM step reads
+// its sums from, p.mrhs_fws (or p.mrhs_ws when null) the one the factorisation writes
 template <typename T, class M, int R> int launch_mrhs_lm(const LaunchParams &p) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
+    MrhsFactorArgs<T, M> fa;
+    if (!fill_factor_args<T, M>(p, fa)) return VP_ERR_UNSUPPORTED;
+    fa.skip_done = 1;
     MrhsLmArgs<T, N, Q, P> a;
     a.ws = *reinterpret_cast<const MrhsWs *>(p.mrhs_ws);
     a.opts.ftol = (T)p.opts->ftol;
@@ -1314,7 +1382,14 @@ template <typename T, class M, int R> int launch_mrhs_lm(const LaunchParams &p) 
     a.gx = p.mrhs_gx > 0 ? p.mrhs_gx : mrhs_gx(p.S, mrhs_gx_cap<T, R>());
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
-    hipLaunchKernelGGL((mrhs_lm_kernel<T, N, Q, P>), dim3((unsigned)p.B), dim3(64), 0, p.stream, a);
+    // few problems: LM step and factorisation are pure latency -> 4 waves per problem (R/4 rows per lane)
+    if constexpr (R % 4 == 0 && R / 4 >= 2) {
+        if (a.B <= 1024) {
+            hipLaunchKernelGGL((mrhs_step_kernel<T, M, R / 4, 4>), dim3((unsigned)a.B), dim3(256), 0, p.stream, fa, a);
+            return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL((mrhs_step_kernel<T, M, R, 1>), dim3((unsigned)p.B), dim3(64), 0, p.stream, fa, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
@@ -1322,8 +1397,13 @@ template <typename T, class M, int R> int launch_mrhs_lm(const LaunchParams &p) 
 template <typename T, class M> size_t mrhs_state_bytes() { return sizeof(LmVars<T, M::N, M::Q>); }
 
 template <typename T, int N, int Q>
-__global__ void mrhs_finish_kernel(const LmVars<T, N, Q> *st, int64_t B, T *alpha_out, vp_report *rep) {
+__global__ void mrhs_finish_kernel(const LmVars<T, N, Q> *st, int64_t B, T *alpha_out, vp_report *rep, const int32_t *nactive,
+                                   int32_t *hflag) {
     const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (b == 0 && hflag) { // pinned host memory: what the host looks at after the stream has drained
+        hflag[0] = nactive[0];
+        hflag[1] = nactive[1];
+    }
     if (b >= B) return;
     const LmVars<T, N, Q> s = st[b];
     for (int k = 0; k < Q; ++k) alpha_out[b * Q + k] = s.x[k];
@@ -1355,7 +1435,8 @@ template <typename T, class M, int R> int launch_mrhs_finish(const LaunchParams 
     const MrhsWs &ws = *reinterpret_cast<const MrhsWs *>(p.mrhs_ws);
     const unsigned grid = (unsigned)((p.B + 63) / 64);
     hipLaunchKernelGGL((mrhs_finish_kernel<T, M::N, M::Q>), dim3(grid), dim3(64), 0, p.stream,
-                       (const LmVars<T, M::N, M::Q> *)ws.lm_state, p.B, (T *)p.alpha_out, p.report);
+                       (const LmVars<T, M::N, M::Q> *)ws.lm_state, p.B, (T *)p.alpha_out, p.report, (const int32_t *)ws.nactive,
+                       p.mrhs_hflag);
     if (p.C_out && p.cost_out && p.status) {
         const int64_t per = (int64_t)p.S * M::N;
         unsigned gx = (unsigned)((per + 255) / 256);
