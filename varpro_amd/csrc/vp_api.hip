@@ -128,7 +128,7 @@ __global__ void mrhs_reduce_partials_kernel(const double *part, int gx, int nacc
     const int64_t b = idx / nacc;
     const int i = (int)(idx - b * nacc);
     double s = 0.0;
-    for (int g = 0; g < gx; ++g) s += part[((size_t)b * gx + g) * nacc + i];
+    for (int g = 0; g < gx; ++g) s += part[((size_t)b * nacc + i) * gx + g]; // [b][accumulator][workgroup]
     tot[idx] = s;
 }
 
@@ -325,9 +325,9 @@ struct Timer {
     }
 };
 
-int reduce_rhs(vp_batch *h) {
+int reduce_rhs(vp_batch *h, hipStream_t stream_override = nullptr, bool use_override = false) {
     if (h->S == 1) return 0; // d_cost / d_status alias the per-(b,s) arrays
-    hipLaunchKernelGGL(reduce_rhs_kernel, dim3((unsigned)h->B), dim3(h->S > 2048 ? 1024 : 256), 0, h->stream, h->d_cost_bs,
+    hipLaunchKernelGGL(reduce_rhs_kernel, dim3((unsigned)h->B), dim3(h->S > 2048 ? 1024 : 256), 0, use_override ? stream_override : h->stream, h->d_cost_bs,
                        h->d_status_bs, h->d_cost, h->d_status, (int)h->S, h->B);
     VP_HIP(hipGetLastError());
     return 0;
@@ -493,7 +493,7 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         lp.status = h->d_status_bs;
         lp.mrhs_hflag = h->h_nactive_dev;
         if (int rc = h->kern->mrhs_finish(lp)) return fail(rc, "mrhs_finish launch failed");
-        return 0;
+        return reduce_rhs(h, lp.stream, true); // per-problem cost / status from the per-column ones
     };
     if (!h->h_nactive) {
         VP_HIP(hipHostMalloc((void **)&h->h_nactive, 2 * sizeof(int32_t), hipHostMallocMapped));
@@ -543,11 +543,24 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
             h->mrhs_graph_failed = true; // fall back to plain launches for the rest of this handle's life
         }
     }
+    // device-pointer handles: the copies into the caller's arrays are enqueued right behind the graph, BEFORE the host
+    // waits for the active count (a fit that outlasts the graph repeats them after the tail graph)
+    bool outputs_done = false;
+    auto early_outputs = [&]() -> int {
+        if (!device_ptrs(h) || tr.tmp) return 0;
+        if (int rc = copy_out(h, alpha_inout, h->d_alpha, (size_t)h->B * h->q * ts)) return rc;
+        if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
+        if (int rc = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc;
+        outputs_done = true;
+        return 0;
+    };
     if (want_graph && h->mrhs_graph) {
         VP_HIP(hipGraphLaunch(h->mrhs_graph, h->stream));
+        if (int rc = early_outputs()) return rc;
         VP_HIP(hipStreamSynchronize(h->stream));
         for (int it = h->mrhs_graph_len; *(volatile int32_t *)h->h_nactive > 0 && it < max_iter; it += 12) {
             VP_HIP(hipGraphLaunch(h->mrhs_graph_tail, h->stream));
+            if (int rc = early_outputs()) return rc;
             VP_HIP(hipStreamSynchronize(h->stream));
         }
         // the next capture: as many iterations as this fit's longest problem took evaluations, plus one spare
@@ -571,13 +584,14 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         if (int rc = enqueue_finish(p)) return rc;
     }
     tm.stop();
-    if (int rc = reduce_rhs(h)) return rc;
     h->have_params = true;
     h->r_valid = false;
     h->have_report = true;
-    if (int rc = copy_out(h, alpha_inout, h->d_alpha, (size_t)h->B * h->q * ts)) return rc;
-    if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
-    if (int rc = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc;
+    if (!outputs_done) {
+        if (int rc = copy_out(h, alpha_inout, h->d_alpha, (size_t)h->B * h->q * ts)) return rc;
+        if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
+        if (int rc = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc;
+    }
     if (int rc = tr.finish(h)) return rc;
     return VP_ERR_OK;
 }

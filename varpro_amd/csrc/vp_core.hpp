@@ -148,6 +148,36 @@ __device__ __forceinline__ void apply_q_cols(T (&C)[NC][R], const T (&g)[N], G &
     }
 }
 
+// both at once: columns [C0, C1) of the unified array <- Q (.) and Z <- Q Z, ONE reduction round per reflector
+template <typename T, int R, int N, int NC, int C0, int C1, int NZ, class G>
+__device__ __forceinline__ void apply_q_cols_and_z(T (&C)[NC][R], const T (&g)[N], T (&Z)[NZ][R], G &grp) {
+    constexpr int NCZ = C1 - C0, NW = NCZ + NZ;
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+        T w[NW];
+#pragma unroll
+        for (int z = 0; z < NW; ++z) {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc = tfma(C[k][r], z < NCZ ? C[C0 + (z < NCZ ? z : 0)][r] : Z[z >= NCZ ? z - NCZ : 0][r], acc);
+            w[z] = acc;
+        }
+        group_allreduce(grp, w);
+#pragma unroll
+        for (int z = 0; z < NCZ; ++z) {
+            const T f = g[k] * w[z];
+#pragma unroll
+            for (int r = 0; r < R; ++r) C[C0 + z][r] = tfma(f, C[k][r], C[C0 + z][r]);
+        }
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) {
+            const T f = g[k] * w[NCZ + z];
+#pragma unroll
+            for (int r = 0; r < R; ++r) Z[z][r] = tfma(f, C[k][r], Z[z][r]);
+        }
+    }
+}
+
 // Slow path of the linear solve: truncated SVD of the N x N triangular factor (absolute threshold
 // eps, as nalgebra's SVD::solve at src/solvers/levmar/mod.rs:52-54).  All arithmetic wave-uniform.
 // Returns the minimum-norm c and e = qty - Rm c (the part of the residual that lives in range(Q)).

@@ -38,7 +38,7 @@ struct MrhsWs {
     void *g;          // [B][P][m]  T
     double *small;    // [B][mrhs_small_stride]   R^{-1} or R^+ (row-major), G^T G, P_n, truncated flag
     int32_t *statusA; // [B]
-    double *acc;      // [B][gx][1 + N*N + P]  per-workgroup partials of sum ||r||^2, sum c c^T, sum c_{j(p)} u_p
+    double *acc;      // [B][1 + N*N + P][gx]  per-workgroup partials of sum ||r||^2, sum c c^T, sum c_{j(p)} u_p
     void *lm_state;   // [B] LmVars
     int32_t *nactive; // [2]  problems whose LM loop is still running | most evaluations any finished problem took
     int32_t *done;    // [B] 1 once the problem's LM loop has terminated: later factor / stream launches skip it
@@ -63,29 +63,49 @@ template <typename T, class M> struct MrhsFactorArgs {
     int64_t t_stride, w_stride;
     T eps;
     int skip_done; // fit loop: problems whose LM loop has terminated are skipped
+    int grid_uniform; // every grid of the handle is uniform to rounding (grid_check_kernel)
 };
 
 // W waves per problem: W = 1 for batches that fill the GPU with one wave per problem; W = 4 (R/4 rows per lane) when
 // there are few problems and the factorisation of ONE tall Phi is on the critical path of every LM iteration.
 // the factorisation of problem b at `alpha` by the calling group of W waves (results -> a.ws)
+// the rows of problem b as the group's lanes see them (uniform grids: the exp recurrence of build_columns).  Built by the
+// caller BEFORE anything else it waits for: set_uniform reads the two ends of the grid, a dependent global round trip
+// that otherwise sits at the head of the column build
+template <typename T, int R, int W> using MrhsSrc = RowSource<T, R, false, 2, 2, W, true>;
 template <typename T, class M, int R, int W>
-__device__ __forceinline__ void mrhs_factor_body(const MrhsFactorArgs<T, M> &a, const int64_t b, const T (&alpha)[M::Q], Grp<W> &grp) {
+__device__ __forceinline__ MrhsSrc<T, R, W> mrhs_make_src(const MrhsFactorArgs<T, M> &a, const int64_t b, const int gl) {
+    MrhsSrc<T, R, W> src;
+    src.t = a.t + b * a.t_stride;
+    src.w = a.w ? a.w + b * a.w_stride : nullptr;
+    src.m = a.m;
+    src.lane = gl;
+    // 2-element accesses where every grid / weight array starts 16-byte (8-byte for fp32) aligned and m is even
+    src.vec = (a.m & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.t) | reinterpret_cast<uintptr_t>(a.w)) & (2 * sizeof(T) - 1)) == 0;
+    src.set_uniform(a.grid_uniform != 0);
+    return src;
+}
+template <typename T, class M, int R, int W>
+__device__ __forceinline__ void mrhs_factor_body(const MrhsFactorArgs<T, M> &a, const int64_t b, const T (&alpha)[M::Q], Grp<W> &grp,
+                                                 const MrhsSrc<T, R, W> &src, long long *clk = nullptr) {
+#ifdef VP_MRHS_STEP_CLOCKS
+#define VP_MTICK(i, dep) do { if (clk) clk[i] = (long long)__builtin_amdgcn_s_memtime() + ((dep) == T(-1.2345) ? 1 : 0); } while (0)
+#else
+#define VP_MTICK(i, dep) do { } while (0)
+#endif
     constexpr int N = M::N, P = M::P, NC = N + P;
     using L = Layout<R, W>;
     using G = Grp<W>;
     const int lane = grp.gl; // group lane
     const int m = a.m;
-    using Src = RowSource<T, R, false, 2, 2, W>;
-    Src src;
-    src.t = a.t + b * a.t_stride;
-    src.w = a.w ? a.w + b * a.w_stride : nullptr;
-    src.m = m;
-    src.lane = lane;
-    src.vec = false;
+    using Src = MrhsSrc<T, R, W>;
     T C[NC][R];
+    VP_MTICK(2, alpha[0]);
     build_columns<T, M, R, NC, Src, N>(a.mdl, alpha, src, C);
+    VP_MTICK(3, C[0][0] + C[NC - 1][R - 1]);
     T g[N], Rm[N][N], qdummy[N];
     house_qr<T, R, N, NC, 0, false, G>(C, g, Rm, qdummy, grp);
+    VP_MTICK(4, Rm[N - 1][N - 1]);
     // R^{-1} (upper triangular) and the rank test of solve_coeffs
     double *small = a.ws.small + b * mrhs_small_stride<N, P>();
     int st = VP_ST_OK;
@@ -95,6 +115,9 @@ __device__ __forceinline__ void mrhs_factor_body(const MrhsFactorArgs<T, M> &a, 
     T Ri[N][N];
     if (!uni(zero_diag)) {
         T inv_f2 = T(0);
+        T rdiag[N]; // one division per diagonal entry (N instead of N (N + 1) / 2)
+#pragma unroll
+        for (int i = 0; i < N; ++i) rdiag[i] = T(1) / Rm[i][i];
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
@@ -106,7 +129,7 @@ __device__ __forceinline__ void mrhs_factor_body(const MrhsFactorArgs<T, M> &a, 
                 T acc = (i == j) ? T(1) : T(0);
 #pragma unroll
                 for (int l = i + 1; l <= j; ++l) acc = tfma(-Rm[i][l], Ri[l][j], acc);
-                Ri[i][j] = acc / Rm[i][i];
+                Ri[i][j] = acc * rdiag[i];
                 inv_f2 = tfma(Ri[i][j], Ri[i][j], inv_f2);
             }
         if (!uni(inv_f2 * a.eps * a.eps < T(1))) st = VP_ST_SINGULAR;
@@ -168,47 +191,67 @@ __device__ __forceinline__ void mrhs_factor_body(const MrhsFactorArgs<T, M> &a, 
 #pragma unroll
         for (int r = 0; r < L::VW && r < R; ++r)
             if (L::row_of(r, lane) < N) C[N + p][r] = T(0);
-    if constexpr (P > 0) {
-        apply_q_cols<T, R, N, NC, N, NC>(C, g, grp);
-        T gg[P * P];
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int p2 = 0; p2 < P; ++p2) {
-                T acc = T(0);
-#pragma unroll
-                for (int r = 0; r < R; ++r) acc = tfma(C[N + p][r], C[N + p2][r], acc);
-                gg[p * P + p2] = acc;
-            }
-        group_allreduce(grp, gg);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < P * P; ++i) small[N * N + i] = (double)gg[i];
-        }
-        T *gout = (T *)a.ws.g + b * (int64_t)P * m;
-#pragma unroll
-        for (int p = 0; p < P; ++p) store_rows<T, R, W>(gout + (int64_t)p * m, m, lane, false, C[N + p]);
-    }
-    // explicit thin Q: column j = Q e_j -- all N unit vectors in one back-sweep (N rounds) when they fit the
-    // registers, else one by one (N*N rounds)
+    VP_MTICK(5, Ri[0][0]);
+    // 16-byte stores of the row pairs where the columns allow it (m even: every column starts 16-byte aligned)
+    const bool vst = sizeof(T) == 8 && (m & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.ws.qthin) | reinterpret_cast<uintptr_t>(a.ws.g)) & 15) == 0;
+    // G and the explicit thin Q (column j = Q e_j) from ONE back-sweep over the reflectors when the N unit vectors fit
+    // the registers next to the columns (N rounds instead of 2 N), else G first, then Q (N rounds, or N*N one by one)
     T *qout = (T *)a.ws.qthin + b * (int64_t)N * m;
-    if constexpr (N * R * (int)(sizeof(T) / 4) <= 96) {
+    constexpr bool Z_FITS = N * R * (int)(sizeof(T) / 4) <= 96;
+    auto gram_and_store_g = [&]() __attribute__((always_inline)) {
+        if constexpr (P > 0) {
+            T gg[P * P];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int p2 = 0; p2 < P; ++p2) {
+                    T acc = T(0);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc = tfma(C[N + p][r], C[N + p2][r], acc);
+                    gg[p * P + p2] = acc;
+                }
+            group_allreduce(grp, gg);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < P * P; ++i) small[N * N + i] = (double)gg[i];
+            }
+            T *gout = (T *)a.ws.g + b * (int64_t)P * m;
+#pragma unroll
+            for (int p = 0; p < P; ++p) store_rows<T, R, W>(gout + (int64_t)p * m, m, lane, vst, C[N + p]);
+        }
+    };
+    if constexpr (Z_FITS && P > 0 && P + N <= VP_XV && P * P <= VP_XV) {
         T Z[N][R];
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
             for (int r = 0; r < R; ++r) Z[j][r] = (L::row_of(r, lane) == j) ? T(1) : T(0);
-        apply_q<T, R, N, NC, N>(C, g, Z, grp);
+        apply_q_cols_and_z<T, R, N, NC, N, NC, N>(C, g, Z, grp);
+        VP_MTICK(6, Z[0][0]);
 #pragma unroll
-        for (int j = 0; j < N; ++j) store_rows<T, R, W>(qout + (int64_t)j * m, m, lane, false, Z[j]);
+        for (int j = 0; j < N; ++j) store_rows<T, R, W>(qout + (int64_t)j * m, m, lane, vst, Z[j]);
+        gram_and_store_g();
     } else {
+        if constexpr (P > 0) apply_q_cols<T, R, N, NC, N, NC>(C, g, grp);
+        gram_and_store_g();
+        if constexpr (Z_FITS) {
+            T Z[N][R];
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            T Z[1][R];
+            for (int j = 0; j < N; ++j)
 #pragma unroll
-            for (int r = 0; r < R; ++r) Z[0][r] = (L::row_of(r, lane) == j) ? T(1) : T(0);
-            apply_q<T, R, N, NC, 1>(C, g, Z, grp);
-            store_rows<T, R, W>(qout + (int64_t)j * m, m, lane, false, Z[0]);
+                for (int r = 0; r < R; ++r) Z[j][r] = (L::row_of(r, lane) == j) ? T(1) : T(0);
+            apply_q<T, R, N, NC, N>(C, g, Z, grp);
+#pragma unroll
+            for (int j = 0; j < N; ++j) store_rows<T, R, W>(qout + (int64_t)j * m, m, lane, vst, Z[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                T Z[1][R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) Z[0][r] = (L::row_of(r, lane) == j) ? T(1) : T(0);
+                apply_q<T, R, N, NC, 1>(C, g, Z, grp);
+                store_rows<T, R, W>(qout + (int64_t)j * m, m, lane, vst, Z[0]);
+            }
         }
     }
 }
@@ -222,10 +265,11 @@ __global__ void __launch_bounds__(64 * W) mrhs_factor_kernel(const MrhsFactorArg
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
     if (a.skip_done && uni(a.ws.done[b]) != 0) return;
+    const MrhsSrc<T, R, W> src = mrhs_make_src<T, M, R, W>(a, b, grp.gl);
     T alpha[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
-    mrhs_factor_body<T, M, R, W>(a, b, alpha, grp);
+    mrhs_factor_body<T, M, R, W>(a, b, alpha, grp, src);
 }
 
 // Packed wave reduction of V values whose totals are STORED by the lanes that end up holding them: dst[v] = total of
@@ -504,7 +548,7 @@ __global__ void __launch_bounds__(64 * VP_MRHS_WAVES) mrhs_stream_kernel(const M
         if (threadIdx.x < NACC) {
             double tot = 0.0;
             for (int w = 0; w < nwave; ++w) tot += s_part[w * NACC + threadIdx.x];
-            a.ws.acc[(b * a.gx + wgi) * NACC + threadIdx.x] = tot;
+            a.ws.acc[((size_t)b * NACC + threadIdx.x) * a.gx + wgi] = tot; // [b][accumulator][workgroup]
         }
     }
 }
@@ -562,37 +606,6 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
     const T *qsrc = (const T *)a.ws.qthin + b * (int64_t)N * m;
     const T *gsrc = (const T *)a.ws.g + b * (int64_t)P * m;
     const double *small = a.ws.small + b * mrhs_small_stride<N, P>();
-    T q[N][RW];
-#pragma unroll
-    for (int j = 0; j < N; ++j) load_rows<T, RW, NW>(qsrc + (int64_t)j * m, m, gl, true, q[j]);
-    // W_j = sum_s T_{j,s} r_s  (row space; c = R^-1 T is linear in T, so sum_s c_{i,s} r_s = sum_j Rinv[i][j] W_j at the end)
-    T wacc[N][RW];
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-#pragma unroll
-        for (int r = 0; r < RW; ++r) wacc[j][r] = T(0);
-    if (threadIdx.x < N * N) {
-        s_ri[threadIdx.x] = small[threadIdx.x];                          // R^-1 (or R^+), row-major
-        s_ri[N * N + threadIdx.x] = small[N * N + P * P + threadIdx.x];  // P_n
-    }
-    const int stA = a.ws.statusA[b];
-    const int wsel = uni(a.ws.widx[b]) & 1;
-    const bool truncated = uni(small[2 * N * N + P * P] != 0.0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // every compiler-issued load has landed: vmcnt is ours now
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    // wave 0, one sum per lane: lane 0 sum ||r||^2, lane 1 + i N + j sum T_i T_j (one-hot selections: a select chain over
-    // a small array is folded into a dynamically indexed vector kept in SCRATCH, whose accesses count in vmcnt)
-    T accv = T(0);
-    const int ak = lane < NACC ? lane : 0;
-    const bool ak_tt = ak >= 1 && ak <= N * N;
-    T ohi[N], ohj[N];
-#pragma unroll
-    for (int j2 = 0; j2 < N; ++j2) {
-        ohi[j2] = (ak_tt && (ak - 1) / N == j2) ? T(1) : T(0);
-        ohj[j2] = (ak_tt && (ak - 1) % N == j2) ? T(1) : T(0);
-    }
     const int nbatch = (S + NB - 1) / NB;
     const int nloc = (nbatch > wgi) ? (nbatch - 1 - wgi) / gx + 1 : 0; // batches of this workgroup
     const bool ragged = (S % NB) != 0;                                  // the last batch has columns past S
@@ -629,6 +642,49 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
             }
         }
     };
+    // The first two batches of y are requested BEFORE the workgroup fetches its slices of Q (they depend on nothing the
+    // factorisation wrote): one global round trip instead of two in front of the loop.  G is only needed by the flush at
+    // the very end: one dword per cache line is touched here so that the flush finds it in this XCD's L2.
+    if (nloc > 0) issue(0);
+    if (nloc > 1) issue(1);
+    if constexpr (P > 0) {
+        const int glines = (int)(((int64_t)P * m * (int64_t)sizeof(T) + 127) / 128);
+        for (int ln = gl; ln < glines; ln += 64 * NW) {
+            unsigned dummy;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(reinterpret_cast<const char *>(gsrc) + (size_t)ln * 128) : "memory");
+        }
+    }
+    T q[N][RW];
+#pragma unroll
+    for (int j = 0; j < N; ++j) load_rows<T, RW, NW>(qsrc + (int64_t)j * m, m, gl, true, q[j]);
+    // W_j = sum_s T_{j,s} r_s  (row space; c = R^-1 T is linear in T, so sum_s c_{i,s} r_s = sum_j Rinv[i][j] W_j at the end)
+    T wacc[N][RW];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) wacc[j][r] = T(0);
+    if (threadIdx.x < N * N) {
+        s_ri[threadIdx.x] = small[threadIdx.x];                          // R^-1 (or R^+), row-major
+        s_ri[N * N + threadIdx.x] = small[N * N + P * P + threadIdx.x];  // P_n
+    }
+    const int stA = a.ws.statusA[b];
+    const int wsel = uni(a.ws.widx[b]) & 1;
+    const bool truncated = uni(small[2 * N * N + P * P] != 0.0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // every compiler-issued load has landed: vmcnt is ours now
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // wave 0, one sum per lane: lane 0 sum ||r||^2, lane 1 + i N + j sum T_i T_j (one-hot selections: a select chain over
+    // a small array is folded into a dynamically indexed vector kept in SCRATCH, whose accesses count in vmcnt)
+    T accv = T(0);
+    const int ak = lane < NACC ? lane : 0;
+    const bool ak_tt = ak >= 1 && ak <= N * N;
+    T ohi[N], ohj[N];
+#pragma unroll
+    for (int j2 = 0; j2 < N; ++j2) {
+        ohi[j2] = (ak_tt && (ak - 1) / N == j2) ? T(1) : T(0);
+        ohj[j2] = (ak_tt && (ak - 1) % N == j2) ? T(1) : T(0);
+    }
     T r2prev[NB];
     unsigned badprev = 0u; // bit c: T of column c of the previous batch was not finite
 #pragma unroll
@@ -676,8 +732,6 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores are out before the next DMA is counted
     };
-    if (nloc > 0) issue(0);
-    if (nloc > 1) issue(1);
     int flushed = 0; // local batches whose cost / status / c have been written
     for (int i = 0; i < nloc; ++i) {
         const int bt = wgi + i * gx;
@@ -859,7 +913,7 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
                 for (int j2 = 0; j2 < N; ++j2) acc2 = tfma(s_ri[jb * N + j2], s_fin[N * N + p * N + j2], acc2);
                 outv = acc2;
             }
-            if (lane < NACC) a.ws.acc[(b * gx + wgi) * NACC + lane] = outv;
+            if (lane < NACC) a.ws.acc[((size_t)b * NACC + lane) * gx + wgi] = outv; // [b][accumulator][workgroup]
         }
     }
 }
@@ -1085,10 +1139,14 @@ __global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
     const int gl = grp.gl;
+    const MrhsSrc<T, R, W> src = mrhs_make_src<T, M, R, W>(fa, b, gl);
     using Vars = LmVars<T, N, Q>;
     Vars *gs = reinterpret_cast<Vars *>(a.ws.lm_state) + b;
     T *trial = (T *)a.ws.alpha_trial + b * Q;
     constexpr int NACC = 1 + N * N + P;
+#ifdef VP_MRHS_STEP_CLOCKS
+    long long clkv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     Vars s;
     if (a.init) {
         T a0[Q];
@@ -1108,6 +1166,9 @@ __global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<
             a.ws.bidx[b] = 0;
         }
     } else {
+#ifdef VP_MRHS_STEP_CLOCKS
+    clkv[0] = (long long)__builtin_amdgcn_s_memtime();
+#endif
     // ---- every load first ----
     s = *gs;
     const int stA = a.ws.statusA[b];
@@ -1118,19 +1179,21 @@ __global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<
     for (int i = 0; i < P * P; ++i) gtg[i] = small[N * N + i];
     double acc[NACC];
     {
-        // group lanes stride over the gx partial records, two records per lane and trip in flight; then one group all-reduce
+        // accumulator-major partials [NACC][gx]: group lane g reads workgroup g's (and g + 64 W's) value of every sum -- each
+        // wave-level load is 512 contiguous bytes (record-major, 64 lanes x 160-byte stride = 64 cache lines per
+        // instruction, made this phase 4 us); two values per lane and trip in flight, then one group all-reduce
         const double *part = a.ws.acc + (size_t)b * a.gx * NACC;
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
         constexpr int NT = 64 * W;
         for (int g = gl; g < a.gx; g += 2 * NT) {
             const bool two = g + NT < a.gx;
-            const double *r0 = part + (size_t)g * NACC, *r1 = part + (size_t)(two ? g + NT : g) * NACC;
+            const int g1 = two ? g + NT : g;
             double v0[NACC], v1[NACC];
 #pragma unroll
-            for (int i = 0; i < NACC; ++i) v0[i] = r0[i];
+            for (int i = 0; i < NACC; ++i) v0[i] = part[(size_t)i * a.gx + g];
 #pragma unroll
-            for (int i = 0; i < NACC; ++i) v1[i] = r1[i];
+            for (int i = 0; i < NACC; ++i) v1[i] = part[(size_t)i * a.gx + g1];
 #pragma unroll
             for (int i = 0; i < NACC; ++i) acc[i] += v0[i] + (two ? v1[i] : 0.0);
         }
@@ -1149,6 +1212,9 @@ __global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<
             if (c0 + i < NACC) acc[c0 + i] = part[i];
     }
     const T cost2 = (T)acc[0];
+#ifdef VP_MRHS_STEP_CLOCKS
+    clkv[1] = (long long)__builtin_amdgcn_s_memtime() + (cost2 == T(-1.2345) ? 1 : 0);
+#endif
     const bool ok = uni(stA == VP_ST_OK && is_finite(cost2));
     const T fnorm1 = tsqrt(cost2);
     const bool first_eval = s.first != 0;
@@ -1176,6 +1242,14 @@ __global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<
 #pragma unroll
             for (int l = 0; l < Q; ++l) A[k][l] = 0.0;
         }
+        if constexpr (M::kDiagonalPairs) { // pair p <-> (basis p, parameter p): everything static
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                bv[k] = -acc[1 + N * N + k];
+#pragma unroll
+                for (int l = 0; l < Q; ++l) A[k][l] = acc[1 + k * N + l] * gtg[k * P + l];
+            }
+        } else {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int kp = a.pp[p], jp = a.pb[p];
@@ -1193,6 +1267,7 @@ __global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<
                     for (int l = 0; l < Q; ++l)
                         if (k == kp && l == kp2) A[k][l] += contrib;
             }
+        }
         }
         double Rd[Q][Q], acd[Q], qd[Q];
         gram_to_qr<double, Q>(A, bv, Rd, acd, s.ipvt, qd);
@@ -1220,7 +1295,17 @@ __global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<
     T xt[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) xt[k] = s.xt[k];
-    mrhs_factor_body<T, M, R, W>(fa, b, xt, grp);
+#ifdef VP_MRHS_STEP_CLOCKS
+    mrhs_factor_body<T, M, R, W>(fa, b, xt, grp, src, clkv);
+    __syncthreads();
+    if (a.trace && gl == 0 && s.nfev - 1 < a.trace_rows && !a.init) { // the row of this step: phase durations in ticks
+        clkv[7] = (long long)__builtin_amdgcn_s_memtime();
+        double *tr = a.trace + ((size_t)b * a.trace_rows + (s.nfev - 1)) * (Q + 4);
+        for (int k = 0; k < 7 && k < Q + 4; ++k) tr[k] = (double)(clkv[k + 1] - clkv[k]);
+    }
+#else
+    mrhs_factor_body<T, M, R, W>(fa, b, xt, grp, src);
+#endif
 }
 
 } // namespace vp
@@ -1270,6 +1355,7 @@ template <typename T, class M> inline bool fill_factor_args(const LaunchParams &
     a.w_stride = p.w_stride;
     a.eps = (T)p.eps;
     a.skip_done = (p.mrhs_mode == 0) ? 1 : 0; // fit loop (reduced sums) vs trait-level evaluation
+    a.grid_uniform = p.grid_uniform;
     return true;
 }
 
