@@ -109,8 +109,9 @@ enum {
     VP_ERR_INVALID = -1,     /* bad handle / argument / shape (builder errors, src/problem/builder.rs:15-46) */
     VP_ERR_UNSUPPORTED = -2, /* operation not available for this handle.  Every MODEL the descriptor can express is
                               * accepted for every entry point -- shapes without a specialised kernel set run on generic
-                              * kernels, global fits (S > 1) and any batch size included.  What remains unsupported:
-                              * m < n (an underdetermined linear sub-problem), right-hand-side sharding
+                              * kernels, global fits (S > 1) and any batch size included; m < n (an underdetermined
+                              * linear sub-problem) takes the reference's minimum-norm solution.  What remains unsupported:
+                              * right-hand-side sharding
                               * (vp_set_rhs_allreduce) on a shape that runs on the generic kernels, fit statistics with
                               * S > 1 (as in the reference), vp_debug_gram_evaluate on handles without the Gram kernel */
     VP_ERR_HIP = -3,         /* HIP runtime failure */

@@ -170,6 +170,22 @@ void vpo_thin_svd(int m, int n, const double *A, double *U, double *sigma, doubl
 
 /* W: m x n workspace owned by the caller (the problem object: no allocation per evaluation) */
 static void thin_svd_ws(int m, int n, const double *A, double *U, double *sigma, double *V, double *W) {
+    if (m < n) {
+        /* a WIDE matrix (fewer samples than basis functions): nalgebra's svd(true, true) returns U m x m, m singular
+         * values, V^T m x n, and svd.solve the minimum-norm solution.  Realised here on [A; 0] (n x n): zero rows change
+         * neither the non-zero singular values nor their right vectors, and the left vectors of the non-zero singular
+         * values have zeros in the added rows.  Returned in the m >= n layout the callers use: n columns, those past
+         * rank(A) with sigma = 0 (pinned by numpy's minimum-norm lstsq in tests/test_oracle_reference_vectors.py). */
+        double Ap[VP_MAX_BASIS * VP_MAX_BASIS], Up[VP_MAX_BASIS * VP_MAX_BASIS], Wp[VP_MAX_BASIS * VP_MAX_BASIS];
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i) Ap[i + j * n] = (i < m) ? A[i + (size_t)j * m] : 0.0;
+        thin_svd_ws(n, n, Ap, Up, sigma, V, Wp);
+        for (int j = 0; j < n; ++j) {
+            if (j >= m) sigma[j] = 0.0; /* (rounding-level values of the n - m structural zeros) */
+            for (int i = 0; i < m; ++i) U[i + (size_t)j * m] = (j < m) ? Up[i + j * n] : 0.0;
+        }
+        return;
+    }
     double tau[VP_MAX_BASIS];
     long double Rm[VP_MAX_BASIS * VP_MAX_BASIS], Vr[VP_MAX_BASIS * VP_MAX_BASIS];
     memcpy(W, A, sizeof(double) * (size_t)m * n);

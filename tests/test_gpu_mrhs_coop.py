@@ -110,3 +110,39 @@ def test_global_fit_trajectory_matches_oracle(S, m, weighted):
     r = bp.residuals()
     assert abs(0.5 * (r ** 2).sum() - rep["objective"][0]) <= 1e-9 * rep["objective"][0]
     bp.close()
+
+
+def test_repeated_fits_on_one_handle_follow_the_graph_length_adaptation():
+    # the whole-fit graph is sized from the handle's PREVIOUS fit (evaluations + 1) and continued by a 12-iteration tail
+    # graph when a fit outlasts it: a sequence of fits of different lengths on ONE handle must give, fit by fit, exactly
+    # what a fresh handle gives (same kernels, same order of operations: bit-identical reports and parameters)
+    rng = np.random.default_rng(11)
+    m, S = 1500, 12
+    tau = [1.0, 3.0, 7.0]
+    x, Y_easy = _data(rng, S, m, tau, noise=1e-4)
+    _, Y_hard = _data(rng, S, m, [0.8, 1.1, 9.0], noise=5e-2)
+    guess_easy, guess_hard = np.array([[1.1, 3.2, 7.5]]), np.array([[0.3, 4.0, 20.0]])
+    mdl = vp.multi_exponential_model(x, guess_easy[0], offset=True)
+
+    def fresh(Y, g):
+        bp = vp.BatchProblem(mdl, Y[None], x=x)
+        out = bp.fit(g)
+        bp.close()
+        return out
+
+    ref_easy, ref_hard = fresh(Y_easy, guess_easy), fresh(Y_hard, guess_hard)
+    assert ref_hard[2]["n_evals"][0] > ref_easy[2]["n_evals"][0] + 3   # the sequence really changes length
+    bp = vp.BatchProblem(mdl, Y_easy[None], x=x)
+    for Y, g, ref in ((Y_easy, guess_easy, ref_easy), (Y_hard, guess_hard, ref_hard), (Y_easy, guess_easy, ref_easy),
+                      (Y_easy, guess_easy, ref_easy), (Y_hard, guess_hard, ref_hard)):
+        bp.set_observations(Y[None])
+        a, C, rep = bp.fit(g)
+        assert rep["n_evals"][0] == ref[2]["n_evals"][0] and rep["termination"][0] == ref[2]["termination"][0]
+        assert np.array_equal(a, ref[0]) and np.array_equal(C, ref[1])
+        assert rep["objective"][0] == ref[2]["objective"][0]
+    # changed LM options re-capture the graph: tighter patience ends the hard fit early with LostPatience
+    slv = vp.LevenbergMarquardt().with_patience(2)
+    bp.set_observations(Y_hard[None])
+    a, C, rep = bp.fit(guess_hard, solver=slv)
+    assert rep["n_evals"][0] <= 2 * 4 + 1
+    bp.close()

@@ -160,3 +160,26 @@ def test_lmfit_fixtures(weighted):
     assert rep.termination > 0
     assert np.abs(p.params() - exp["tau"]).max() < 1e-5
     assert np.abs(p.linear_coefficients() - exp["c"]).max() < 1e-5
+
+
+def test_wide_basis_matrix_takes_the_minimum_norm_solution():
+    """m < n (fewer samples than basis functions): nalgebra's `svd(true, true).solve(b, eps)` (src/solvers/levmar/mod.rs:51-54)
+    returns the minimum-norm solution of the underdetermined system.  The reference holds no vector for this branch; the
+    oracle's is pinned here against numpy's minimum-norm `lstsq` (LAPACK gelsd), for unit and general weights."""
+    import varpro_amd as vp
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    for m, S, weighted in ((2, 1, False), (1, 1, False), (3, 2, True), (2, 3, True)):
+        x = np.linspace(0.0, 1.5, m) if m > 1 else np.array([0.4])
+        Y = rng.uniform(1.0, 5.0, (S, m))
+        w = rng.uniform(0.5, 2.0, m) if weighted else None
+        alpha = np.array([1.0, 2.5, 6.0])
+        mdl = vp.multi_exponential_model(x, alpha, offset=True)                  # n = 4 > m
+        ref = O.Problem(mdl, x, Y, w=w)
+        assert ref.set_params(alpha) is not False
+        ww = np.ones(m) if w is None else w
+        Phi = np.stack([np.exp(-x / a) for a in alpha] + [np.ones(m)], axis=1) * ww[:, None]   # m x n
+        Cn = np.linalg.lstsq(Phi, (Y * ww).T, rcond=None)[0].T                                # S x n, minimum norm
+        assert np.abs(ref.linear_coefficients() - Cn).max() <= 1e-12 * np.abs(Cn).max()
+        assert np.abs(ref.residuals()).max() <= 1e-13 * np.abs(Y * ww).max()
+        assert np.abs(np.asarray(ref.jacobian())).max() <= 1e-12 * np.abs(Y * ww).max()

@@ -205,6 +205,7 @@ struct vp_batch {
     int gen_blocks;
     // MRHS fit: a captured HIP graph of VP_MRHS_GRAPH_ITERS {factor, stream, LM step} iterations (replayed per batch
     // of iterations: one graph launch instead of 3 x ITERS kernel launches), the options it was captured with
+    int64_t m_user;  // != 0: the caller's row count m < n; the handle works on m = n rows, the extra ones with zero weight
     hipGraphExec_t mrhs_graph;
     hipGraphExec_t mrhs_graph_tail; // 12 further iterations + finish, for a fit that outlasts mrhs_graph
     int mrhs_graph_len;     // LM iterations mrhs_graph holds
@@ -272,6 +273,87 @@ struct OutBuf {
     }
     ~OutBuf() {
         if (tmp) (void)hipFree(tmp);
+    }
+};
+
+int copy_out(vp_batch *h, void *user, const void *dev, size_t bytes);
+// ---- m < n (an underdetermined linear sub-problem; the reference's SVD solve accepts it, src/solvers/levmar/mod.rs:51-54)
+// The handle then works on n rows: the caller's m rows plus n - m rows of zero weight (zero rows change neither the
+// minimum-norm coefficients nor the residual nor any singular value > 0).  Everything with a row dimension that crosses the
+// ABI is padded on the way in and stripped on the way out.
+__global__ void strip_rows_kernel(const unsigned *__restrict__ src, unsigned *__restrict__ dst, int64_t blocks, int words_user,
+                                  int words_pad) {
+    const int64_t total = blocks * words_user;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t blk = i / words_user;
+        dst[i] = src[blk * words_pad + (i - blk * words_user)];
+    }
+}
+
+// the LM crate's answer when there are fewer residuals than nonlinear parameters: one evaluation at the initial point,
+// then TerminationReason::WrongDimensions (vp_lm_core.hpp lm_after_eval, first evaluation)
+__global__ void wrong_dimensions_report_kernel(const double *__restrict__ cost, const int32_t *__restrict__ status, int64_t B,
+                                               vp_report *__restrict__ rep) {
+    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    vp_report r;
+    const bool ok = status[b] == 0;
+    r.termination = ok ? VP_TERM_WRONG_DIMENSIONS : VP_TERM_USER;
+    r.n_evals = 1;
+    r.objective = ok ? cost[b] : 0.0 / 0.0;
+    rep[b] = r;
+}
+
+// `blocks` blocks of the handle's m rows in device memory -> the caller's array of `blocks` blocks of ITS m rows
+int copy_out_rows(vp_batch *h, void *user, const void *dev, size_t blocks) {
+    if (!user) return 0;
+    const size_t ts = tsize(h->dtype);
+    if (!h->m_user) return copy_out(h, user, dev, blocks * (size_t)h->m * ts);
+    const size_t bytes = blocks * (size_t)h->m_user * ts;
+    void *packed = device_ptrs(h) ? user : nullptr;
+    if (!packed) VP_HIP(hipMalloc(&packed, bytes ? bytes : 1));
+    const int wu = (int)(h->m_user * ts / 4), wp = (int)(h->m * ts / 4);
+    const int64_t total = (int64_t)blocks * wu;
+    hipLaunchKernelGGL(strip_rows_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), dim3(256), 0, h->stream,
+                       (const unsigned *)dev, (unsigned *)packed, (int64_t)blocks, wu, wp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && !device_ptrs(h)) {
+        e = hipMemcpyAsync(user, packed, bytes, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(packed);
+    }
+    if (e != hipSuccess) return fail(VP_ERR_HIP, std::string("copy_out_rows: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// an output with a row dimension: `blocks` blocks of m rows.  Not padded: OutBuf as is.  Padded: the kernels write a
+// private array of padded blocks, finish() strips it into the caller's
+struct RowOut {
+    OutBuf buf;
+    void *pad = nullptr;
+    void *user = nullptr;
+    size_t blocks = 0;
+    void *dptr = nullptr;
+    int init(vp_batch *h, void *user_, size_t blocks_) {
+        user = user_;
+        blocks = blocks_;
+        if (!h->m_user) {
+            const int rc = buf.init(h, user_, blocks_ * (size_t)h->m * tsize(h->dtype));
+            dptr = buf.dptr;
+            return rc;
+        }
+        if (!user) return 0;
+        VP_HIP(hipMalloc(&pad, blocks * (size_t)h->m * tsize(h->dtype)));
+        dptr = pad;
+        return 0;
+    }
+    int finish(vp_batch *h) {
+        if (!h->m_user) return buf.finish(h);
+        if (!user) return 0;
+        return copy_out_rows(h, user, pad, blocks);
+    }
+    ~RowOut() {
+        if (pad) (void)hipFree(pad);
     }
 };
 
@@ -624,9 +706,75 @@ void vp_lm_opts_default(vp_lm_opts *o, int dtype) {
     o->scale_diag = 1;
 }
 
+static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dtype, int64_t m, int64_t S, int64_t B,
+                             const void *t, const void *Y, const void *w, double svd_epsilon, int flags, int device,
+                             void *hip_stream, bool data_on_device);
+
+// pad the row dimension of `blocks` blocks from m to mp rows with `fill` (host arrays of 4- or 8-byte elements)
+static void pad_rows_host(const void *src, void *dst, size_t blocks, int64_t m, int64_t mp, size_t ts, double fill) {
+    for (size_t blk = 0; blk < blocks; ++blk) {
+        std::memcpy((char *)dst + blk * mp * ts, (const char *)src + blk * m * ts, (size_t)m * ts);
+        for (int64_t i = m; i < mp; ++i) {
+            if (ts == 8) ((double *)dst)[blk * mp + i] = fill;
+            else ((float *)dst)[blk * mp + i] = (float)fill;
+        }
+    }
+}
+
 int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64_t m, int64_t S, int64_t B,
                     const void *t, const void *Y, const void *w, double svd_epsilon, int flags, int device,
                     void *hip_stream) {
+    const bool dev_data = (flags & VP_FLAG_DEVICE_PTRS) != 0;
+    if (!out || !model || !Y || !t || m <= 0 || S <= 0 || B <= 0 || (dtype != VP_F64 && dtype != VP_F32) || m >= model->n_basis ||
+        model->n_basis > VP_MAX_BASIS)
+        return batch_create_impl(out, model, dtype, m, S, B, t, Y, w, svd_epsilon, flags, device, hip_stream, dev_data);
+    // m < n: the reference solves the underdetermined linear sub-problem by its truncated SVD (minimum-norm coefficients,
+    // src/solvers/levmar/mod.rs:51-54).  Here: n - m extra rows of ZERO weight (grid value = the last sample, data 0) --
+    // they change neither the minimum-norm solution, nor the residual, nor a non-zero singular value -- and the handle
+    // strips them from every array that crosses the ABI (m_user).  Tiny problems by construction: padded on the host.
+    const size_t ts = dtype == VP_F64 ? 8 : 4;
+    const int64_t mp = model->n_basis;
+    const size_t tb = (flags & VP_FLAG_T_PER_PROBLEM) ? (size_t)B : 1, wb = (flags & VP_FLAG_W_PER_PROBLEM) ? (size_t)B : 1;
+    std::vector<char> th(tb * m * ts), yh((size_t)B * S * m * ts), wh(w ? wb * m * ts : 0);
+    if (dev_data) {
+        if (vp_device_count() <= 0) return fail(VP_ERR_NO_DEVICE, "no HIP device visible");
+        DeviceGuard g__;
+        if (int rc = g__.enter(device)) return rc;
+        hipStream_t st = (flags & VP_FLAG_OWN_STREAM) ? nullptr : (hipStream_t)hip_stream;
+        VP_HIP(hipMemcpyAsync(th.data(), t, th.size(), hipMemcpyDeviceToHost, st));
+        VP_HIP(hipMemcpyAsync(yh.data(), Y, yh.size(), hipMemcpyDeviceToHost, st));
+        if (w) VP_HIP(hipMemcpyAsync(wh.data(), w, wh.size(), hipMemcpyDeviceToHost, st));
+        VP_HIP(hipStreamSynchronize(st));
+    } else {
+        std::memcpy(th.data(), t, th.size());
+        std::memcpy(yh.data(), Y, yh.size());
+        if (w) std::memcpy(wh.data(), w, wh.size());
+    }
+    std::vector<char> tp(tb * mp * ts), yp((size_t)B * S * mp * ts), wp(wb * mp * ts);
+    for (size_t blk = 0; blk < tb; ++blk) { // grid: repeat the last sample
+        const double last = ts == 8 ? ((const double *)th.data())[blk * m + m - 1] : (double)((const float *)th.data())[blk * m + m - 1];
+        pad_rows_host(th.data() + blk * m * ts, tp.data() + blk * mp * ts, 1, m, mp, ts, last);
+    }
+    pad_rows_host(yh.data(), yp.data(), (size_t)B * S, m, mp, ts, 0.0);
+    if (w) {
+        pad_rows_host(wh.data(), wp.data(), wb, m, mp, ts, 0.0);
+    } else { // unit weights on the caller's rows, zero on the padding
+        std::vector<char> ones(wb * m * ts);
+        for (size_t i = 0; i < wb * (size_t)m; ++i) {
+            if (ts == 8) ((double *)ones.data())[i] = 1.0;
+            else ((float *)ones.data())[i] = 1.0f;
+        }
+        pad_rows_host(ones.data(), wp.data(), wb, m, mp, ts, 0.0);
+    }
+    const int rc = batch_create_impl(out, model, dtype, mp, S, B, tp.data(), yp.data(), wp.data(), svd_epsilon, flags, device, hip_stream,
+                                     false);
+    if (rc == VP_ERR_OK) (*out)->m_user = m;
+    return rc;
+}
+
+static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dtype, int64_t m, int64_t S, int64_t B,
+                             const void *t, const void *Y, const void *w, double svd_epsilon, int flags, int device,
+                             void *hip_stream, const bool data_on_device) {
     if (!out) return fail(VP_ERR_INVALID, "null output handle");
     *out = nullptr;
     if (!model) return fail(VP_ERR_INVALID, "null model");
@@ -641,7 +789,6 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     int fa, fb, fc, npairs;
     if (classify_model(*model, fa, fb, fc, npairs) < 0) return fail(VP_ERR_INVALID, "malformed model descriptor");
     if (npairs > VP_MAX_PAIRS) return fail(VP_ERR_INVALID, "too many dependency pairs");
-    if (m < model->n_basis) return fail(VP_ERR_UNSUPPORTED, "m < n (underdetermined linear sub-problem) unsupported");
 
     int ndev = vp_device_count();
     if (ndev <= 0) return fail(VP_ERR_NO_DEVICE, "no HIP device visible");
@@ -702,7 +849,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
             return fail(VP_ERR_HIP, msg__);                                                                           \
         }                                                                                                             \
     } while (0)
-    const hipMemcpyKind kin = device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind kin = data_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     VP_TRY(hipMalloc(&h->d_t, t_elems * ts));
     VP_TRY(hipMemcpyAsync(h->d_t, t, t_elems * ts, kin, h->stream));
     if (w) {
@@ -730,7 +877,7 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
         // Y_w = W * Y
         void *&ytmp = h->tmp_b;
         const void *ysrc = Y;
-        if (!device_ptrs(h)) {
+        if (!data_on_device) {
             VP_TRY(hipMalloc(&ytmp, y_elems * ts));
             VP_TRY(hipMemcpyAsync(ytmp, Y, y_elems * ts, hipMemcpyHostToDevice, h->stream));
             ysrc = ytmp;
@@ -900,7 +1047,7 @@ int vp_residuals(vp_batch *h, void *r_out, int32_t *status) {
         if (int rc = run_evaluate(h, h->d_R, nullptr, nullptr)) return rc;
         h->r_valid = true;
     }
-    if (int rc = copy_out(h, r_out, h->d_R, (size_t)h->B * h->S * h->m * tsize(h->dtype))) return rc;
+    if (int rc = copy_out_rows(h, r_out, h->d_R, (size_t)h->B * h->S)) return rc;
     return copy_status(h, status);
 }
 
@@ -908,8 +1055,8 @@ int vp_jacobian(vp_batch *h, void *J_out, int32_t *status) {
     VP_ENTER(h);
     if (!h->have_params) return copy_status(h, status) ? VP_ERR_HIP : VP_ERR_OK;
     if (!J_out) return fail(VP_ERR_INVALID, "null J_out");
-    OutBuf J;
-    if (int rc = J.init(h, J_out, (size_t)h->B * h->q * h->S * h->m * tsize(h->dtype))) return rc;
+    RowOut J;
+    if (int rc = J.init(h, J_out, (size_t)h->B * h->q * h->S)) return rc;
     if (int rc = run_evaluate(h, nullptr, J.dptr, nullptr)) return rc;
     if (int rc = J.finish(h)) return rc;
     return copy_status(h, status);
@@ -924,7 +1071,7 @@ int vp_linear_coeffs(vp_batch *h, void *C_out, int32_t *status) {
 
 int vp_weighted_data(vp_batch *h, void *Yw_out) {
     VP_ENTER(h);
-    return copy_out(h, Yw_out, h->d_yw, (size_t)h->B * h->S * h->m * tsize(h->dtype));
+    return copy_out_rows(h, Yw_out, h->d_yw, (size_t)h->B * h->S);
 }
 
 int vp_set_observations(vp_batch *h, const void *Y) {
@@ -934,7 +1081,22 @@ int vp_set_observations(vp_batch *h, const void *Y) {
     const size_t y_elems = (size_t)h->B * h->S * h->m;
     // Y_w = W * Y straight into the handle's buffer; host pointers are staged through the buffer itself
     const void *ysrc = Y;
-    if (!device_ptrs(h)) {
+    std::vector<char> ypad;
+    if (h->m_user) { // m < n: pad the caller's rows on the host (tiny by construction), then as a host array
+        const size_t nb = (size_t)h->B * h->S;
+        std::vector<char> yh(nb * h->m_user * ts);
+        if (device_ptrs(h)) {
+            VP_HIP(hipMemcpyAsync(yh.data(), Y, yh.size(), hipMemcpyDeviceToHost, h->stream));
+            VP_HIP(hipStreamSynchronize(h->stream));
+        } else {
+            std::memcpy(yh.data(), Y, yh.size());
+        }
+        ypad.resize(y_elems * ts);
+        pad_rows_host(yh.data(), ypad.data(), nb, h->m_user, h->m, ts, 0.0);
+        VP_HIP(hipMemcpyAsync(h->d_yw, ypad.data(), y_elems * ts, hipMemcpyHostToDevice, h->stream));
+        VP_HIP(hipStreamSynchronize(h->stream));
+        ysrc = h->d_yw;
+    } else if (!device_ptrs(h)) {
         VP_HIP(hipMemcpyAsync(h->d_yw, Y, y_elems * ts, hipMemcpyHostToDevice, h->stream));
         ysrc = h->d_yw; // in place: every element is read once and written once by the same thread
     }
@@ -971,9 +1133,9 @@ int vp_evaluate(vp_batch *h, const void *alpha, void *r_out, void *J_out, void *
     const size_t ts = tsize(h->dtype);
     VP_HIP(hipMemcpyAsync(h->d_alpha, alpha, (size_t)h->B * h->q * ts,
                           device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
-    OutBuf r, J;
-    if (int rc = r.init(h, r_out, (size_t)h->B * h->S * h->m * ts)) return rc;
-    if (int rc = J.init(h, J_out, (size_t)h->B * h->q * h->S * h->m * ts)) return rc;
+    RowOut r, J;
+    if (int rc = r.init(h, r_out, (size_t)h->B * h->S)) return rc;
+    if (int rc = J.init(h, J_out, (size_t)h->B * h->q * h->S)) return rc;
     if (int rc = run_evaluate(h, r.dptr, J.dptr, h->d_C)) return rc;
     h->have_params = true;
     h->r_valid = false;
@@ -993,9 +1155,9 @@ int vp_basis(vp_batch *h, const void *alpha, void *Phi_out, void *dPhi_out, int 
         if (!((flags & VP_BASIS_SKIP_INVARIANT) && h->model.kind[j] == VP_BASIS_CONST)) ++ncols;
     InBuf a;
     if (int rc = a.init(h, alpha, (size_t)h->B * h->q * ts)) return rc;
-    OutBuf phi, dphi;
-    if (int rc = phi.init(h, Phi_out, (size_t)h->B * ncols * h->m * ts)) return rc;
-    if (int rc = dphi.init(h, dPhi_out, (size_t)h->B * h->p * h->m * ts)) return rc;
+    RowOut phi, dphi;
+    if (int rc = phi.init(h, Phi_out, (size_t)h->B * ncols)) return rc;
+    if (int rc = dphi.init(h, dPhi_out, (size_t)h->B * h->p)) return rc;
     LaunchParams p;
     fill_params(h, p);
     p.alpha = a.dptr;
@@ -1020,6 +1182,22 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
                  double *trace_out, int trace_rows) {
     VP_ENTER(h);
     if (!alpha_inout) return fail(VP_ERR_INVALID, "null alpha");
+    if (h->m_user && (int64_t)h->q > h->m_user * h->S) {
+        // m < n AND fewer residuals than nonlinear parameters (the padded handle would count its own n rows): the reference's
+        // LM driver evaluates once and reports WrongDimensions
+        const size_t ts = tsize(h->dtype);
+        VP_HIP(hipMemcpyAsync(h->d_alpha, alpha_inout, (size_t)h->B * h->q * ts,
+                              device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+        if (int rc = run_evaluate(h, nullptr, nullptr, h->d_C)) return rc;
+        hipLaunchKernelGGL(wrong_dimensions_report_kernel, dim3((unsigned)((h->B + 255) / 256)), dim3(256), 0, h->stream,
+                           (const double *)h->d_cost, (const int32_t *)h->d_status, h->B, h->d_report);
+        VP_HIP(hipGetLastError());
+        h->have_params = true;
+        h->r_valid = false;
+        h->have_report = true;
+        if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
+        return copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report));
+    }
     if (h->S != 1) return mrhs_fit(h, opts, alpha_inout, C_out, rep, trace_out, trace_rows);
     if (!h->kern->fit && !h->kern->fit_single) return fail(VP_ERR_UNSUPPORTED, "no fit kernel for this model");
     vp_lm_opts o;
@@ -1101,8 +1279,8 @@ int vp_best_fit(vp_batch *h, void *fit_out) {
     VP_ENTER(h);
     if (!h->have_params) return fail(VP_ERR_INVALID, "no parameters set yet");
     if (!h->kern->best_fit) return fail(VP_ERR_UNSUPPORTED, "no best_fit kernel for this model");
-    OutBuf f;
-    if (int rc = f.init(h, fit_out, (size_t)h->B * h->S * h->m * tsize(h->dtype))) return rc;
+    RowOut f;
+    if (int rc = f.init(h, fit_out, (size_t)h->B * h->S)) return rc;
     LaunchParams p;
     fill_params(h, p);
     p.C_out = h->d_C; // input here
@@ -1121,10 +1299,11 @@ int vp_statistics(vp_batch *h, void *cov_out, double *reduced_chi2_out, void *co
     if (!cov_out || !reduced_chi2_out) return fail(VP_ERR_INVALID, "null output");
     const size_t ts = tsize(h->dtype);
     const int k = h->n + h->q;
-    OutBuf cov, chi2, sig, st;
+    OutBuf cov, chi2, st;
+    RowOut sig;
     if (int rc = cov.init(h, cov_out, (size_t)h->B * k * k * ts)) return rc;
     if (int rc = chi2.init(h, reduced_chi2_out, (size_t)h->B * sizeof(double))) return rc;
-    if (int rc = sig.init(h, conf_sigma_out, (size_t)h->B * h->m * ts)) return rc;
+    if (int rc = sig.init(h, conf_sigma_out, (size_t)h->B)) return rc;
     void *st_tmp = nullptr;
     int32_t *st_dev = status && device_ptrs(h) ? status : nullptr;
     if (!st_dev) {
