@@ -110,9 +110,8 @@ enum {
     VP_ERR_UNSUPPORTED = -2, /* operation not available for this handle.  Every MODEL the descriptor can express is
                               * accepted for every entry point -- shapes without a specialised kernel set run on generic
                               * kernels, global fits (S > 1) and any batch size included; m < n (an underdetermined
-                              * linear sub-problem) takes the reference's minimum-norm solution.  What remains unsupported:
-                              * right-hand-side sharding
-                              * (vp_set_rhs_allreduce) on a shape that runs on the generic kernels, fit statistics with
+                              * linear sub-problem) takes the reference's minimum-norm solution; right-hand-side sharding
+                              * (vp_set_rhs_allreduce) works on every shape.  What remains unsupported: fit statistics with
                               * S > 1 (as in the reference), vp_debug_gram_evaluate on handles without the Gram kernel */
     VP_ERR_HIP = -3,         /* HIP runtime failure */
     VP_ERR_NO_DEVICE = -4    /* no gfx950 device / library built without device code */

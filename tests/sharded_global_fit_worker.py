@@ -15,12 +15,15 @@ import varpro_amd as vp  # noqa: E402
 from varpro_amd.distributed import ShardedGlobalFit, shard_range  # noqa: E402
 
 backend, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+shape = sys.argv[6] if len(sys.argv) > 6 else "specialised"
 torch.cuda.set_device(0)
 dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
 dev = torch.device("cuda", 0)
 
 rng = np.random.default_rng(1234)  # the same problem on every rank
-m, S, B = 512, 96, 2
+# "generic": m = 2500 rows, beyond every specialised kernel set of this model -> the generic kernels (vp_generic.hpp),
+# whose global fit runs in phases around the all-reduce
+m, S, B = (512, 96, 2) if shape == "specialised" else (2500, 24, 2)
 x = np.linspace(0.0, 12.5, m)
 tau_true = np.array([[1.0, 3.0, 7.0], [0.8, 2.5, 9.0]])
 Cm = rng.uniform(1, 100, (B, S, 4))

@@ -195,7 +195,9 @@ struct vp_batch {
     vp_allreduce_fn rhs_allreduce;
     void *rhs_allreduce_user;
     int64_t rhs_global; // right-hand sides of the whole problem
-    double *d_mrhs_tot; // [B][1 + n*n + p] totals of the reduced sums (all-reduced across ranks)
+    double *d_mrhs_tot; // [B][1 + n*n + p] totals of the reduced sums (all-reduced across ranks); generic kernels: [B][2 + q*q + q]
+    void *d_gen_lm;     // generic kernels, sharded right-hand sides: [B] LM state between the phases
+    int32_t *d_gen_nactive;
     // single-RHS fit kernel selection (vp_set_fit_kernel) and the slot kernel's problem queue
     int fit_kernel;
     int *d_queue;
@@ -495,13 +497,46 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
     if (!h->have_mrhs) {
         // generic fallback kernels: the whole global fit is one launch (vp_generic.hpp, gen_mrhs_fit_kernel), which also
         // leaves the coefficients / cost / status of every column at the final point
-        if (h->rhs_allreduce) return fail(VP_ERR_UNSUPPORTED, "right-hand-side sharding needs the MRHS kernel set");
         p.alpha_out = h->d_alpha;
         p.C_out = h->d_C;
         p.cost_out = h->d_cost_bs;
         p.status = h->d_status_bs;
         p.report = h->d_report;
-        {
+        if (h->rhs_allreduce) {
+            // right-hand sides sharded over ranks: the same kernel in phases -- init, then per evaluation {sums of this
+            // rank's columns, the caller's all-reduce of B*(2 + q*q + q) doubles, LM step on the totals (every rank takes
+            // bit-identical decisions)}, then the per-column results at the final point
+            const int nacc = 2 + h->q * h->q + h->q;
+            if (!h->d_gen_lm) VP_HIP(hipMalloc(&h->d_gen_lm, (size_t)h->B * h->kern->mrhs_state_bytes));
+            if (!h->d_mrhs_tot) VP_HIP(hipMalloc((void **)&h->d_mrhs_tot, (size_t)h->B * nacc * sizeof(double)));
+            if (!h->d_gen_nactive) VP_HIP(hipMalloc((void **)&h->d_gen_nactive, sizeof(int32_t)));
+            VP_HIP(hipMemsetAsync(h->d_gen_nactive, 0, sizeof(int32_t), h->stream));
+            p.gen_lm_state = h->d_gen_lm;
+            p.gen_acc = h->d_mrhs_tot;
+            p.gen_nactive = h->d_gen_nactive;
+            p.mrhs_S_global = h->rhs_global;
+            Timer tm(h, VP_KERNEL_FIT);
+            p.gen_phase = 1;
+            if (int rc = h->kern->mrhs_fit_whole(p)) return fail(rc, "generic global-fit (init) launch failed");
+            const int max_iter = o.patience * (h->q + 1) + 2;
+            for (int it = 0; it < max_iter; ++it) {
+                p.gen_phase = 2;
+                if (int rc = h->kern->mrhs_fit_whole(p)) return fail(rc, "generic global-fit (sums) launch failed");
+                if (h->rhs_allreduce(h->d_mrhs_tot, h->B * nacc, (void *)h->stream, h->rhs_allreduce_user) != 0)
+                    return fail(VP_ERR_INVALID, "the right-hand-side all-reduce callback reported an error");
+                p.gen_phase = 3;
+                if (int rc = h->kern->mrhs_fit_whole(p)) return fail(rc, "generic global-fit (step) launch failed");
+                if ((it & 3) == 3 || it + 1 == max_iter) {
+                    int32_t nact = 0;
+                    VP_HIP(hipMemcpyAsync(&nact, h->d_gen_nactive, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                    VP_HIP(hipStreamSynchronize(h->stream));
+                    if (nact <= 0) break;
+                }
+            }
+            p.gen_phase = 4;
+            if (int rc = h->kern->mrhs_fit_whole(p)) return fail(rc, "generic global-fit (results) launch failed");
+            tm.stop();
+        } else {
             Timer tm(h, VP_KERNEL_FIT);
             if (int rc = h->kern->mrhs_fit_whole(p)) return fail(rc, "generic global-fit launch failed");
             tm.stop();
@@ -958,6 +993,8 @@ void vp_batch_destroy(vp_batch *h) {
     (void)dev_guard__.enter(h->device);
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_mrhs_tot);
+    (void)hipFree(h->d_gen_lm);
+    (void)hipFree(h->d_gen_nactive);
     (void)hipFree(h->d_t);
     (void)hipFree(h->d_w);
     (void)hipFree(h->d_yw);
@@ -1265,8 +1302,8 @@ int vp_debug_gram_evaluate(vp_batch *h, const void *alpha, double *out) {
 int vp_set_rhs_allreduce(vp_batch *h, vp_allreduce_fn fn, void *user, int64_t global_rhs_count) {
     VP_ENTER(h);
     if (fn) {
-        if (h->S <= 1 || !h->have_mrhs)
-            return fail(VP_ERR_UNSUPPORTED, "right-hand-side sharding needs a handle with S > 1 and MRHS kernels");
+        if (h->S <= 1 || (!h->have_mrhs && !h->kern->mrhs_fit_whole))
+            return fail(VP_ERR_UNSUPPORTED, "right-hand-side sharding needs a handle with S > 1");
         if (global_rhs_count < h->S) return fail(VP_ERR_INVALID, "global_rhs_count smaller than the local S");
     }
     h->rhs_allreduce = fn;

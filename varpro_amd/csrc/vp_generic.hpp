@@ -50,7 +50,16 @@ template <typename T> struct GenArgs {
     LmOpts<T> lm;
     double *trace;
     int trace_rows;
+    // global fit with the right-hand sides sharded over ranks (gen_mrhs_fit_kernel in phases, the caller's collective
+    // between `sums` and `step`): 0 = the whole fit in one launch; 1 = init; 2 = sums at the trial point -> acc;
+    // 3 = LM step on the (all-reduced) acc; 4 = results at the final point
+    int phase;
+    void *lm_state;     // [B] LmAny<T>
+    double *acc;        // [B][gen_nacc(q)]: sum ||r||^2 | J^T J | J^T r | columns whose evaluation failed
+    int32_t *nactive;   // [1]
+    int64_t S_global;   // right-hand sides of the WHOLE problem (0: S)
 };
+__host__ __device__ constexpr int gen_nacc(int q) { return 2 + q * q + q; }
 
 template <typename T> __device__ __forceinline__ T g_exp(T x);
 template <> __device__ __forceinline__ double g_exp(double x) { return texp(x); }
@@ -600,68 +609,102 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_mrhs_fit_kernel(
     __shared__ GenShared<T> sh;
     __shared__ LmAny<T> lm;
     __shared__ int s_term, s_trow, s_okall;
-    __shared__ double s_acc[1 + VP_MAX_PARAMS * VP_MAX_PARAMS + VP_MAX_PARAMS]; // sum ||r||^2 | J^T J (q x q) | J^T r
+    __shared__ double s_acc[2 + VP_MAX_PARAMS * VP_MAX_PARAMS + VP_MAX_PARAMS]; // sum ||r||^2 | J^T J (q x q) | J^T r | failed columns
     const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params, P = a.P, NS = a.S; // (S names the LM state inside VP_GEN_DISPATCH)
     const int NCQ = n + 1 + P;
+    const int phase = a.phase;
+    const long mres = (long)m * (long)(a.S_global > 0 ? a.S_global : NS);
     T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
     auto col = [&](int c) { return ws + (int64_t)c * m; };
+    LmAny<T> *gstate = reinterpret_cast<LmAny<T> *>(a.lm_state);
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
         if (tid == 0) {
-            T a0[VP_MAX_PARAMS];
-            for (int k = 0; k < q; ++k) a0[k] = a.alpha_io[b * q + k];
-            VP_GEN_DISPATCH(q, (lm_init<T, VP_MAX_BASIS, QQ>(S, a0)));
-            for (int k = 0; k < q; ++k) sh.alpha[k] = a0[k];
-            s_term = (q == 0) ? VP_TERM_NO_PARAMETERS : 0;
+            if (phase <= 1) {
+                T a0[VP_MAX_PARAMS];
+                for (int k = 0; k < q; ++k) a0[k] = a.alpha_io[b * q + k];
+                VP_GEN_DISPATCH(q, (lm_init<T, VP_MAX_BASIS, QQ>(S, a0)));
+                for (int k = 0; k < q; ++k) sh.alpha[k] = a0[k];
+                s_term = (q == 0) ? VP_TERM_NO_PARAMETERS : 0;
+                if (phase == 1) {
+                    gstate[b] = lm;
+                    if (q > 0) atomicAdd(a.nactive, 1);
+                }
+            } else {
+                lm = gstate[b];
+                s_term = 0;
+                VP_GEN_DISPATCH(q, {
+                    s_term = S.term;
+                    for (int k = 0; k < QQ; ++k) sh.alpha[k] = (phase == 4) ? S.x[k] : S.xt[k];
+                });
+                if (q == 0) s_term = VP_TERM_NO_PARAMETERS;
+            }
             s_trow = 0;
         }
         __syncthreads();
-        while (s_term == 0) {
-            if (tid == 0) {
-                for (int i = 0; i < 1 + q * q + q; ++i) s_acc[i] = 0.0;
-                s_okall = 1;
-            }
-            __syncthreads();
-            for (int s = 0; s < NS; ++s) {
-                evaluate<T>(a, sh, ws, b, false, b * NS + s);
-                // Kaufman columns in Q-coordinates: z_k = -sum_{pairs p of parameter k} c_{basis(p)} (Q^T D_p), rows >= n
-                for (int k = 0; k < q; ++k) {
-                    T *zk = col(NCQ + k);
-                    for (int i = n + tid; i < m; i += TB) {
-                        T acc = T(0);
-                        for (int p = 0; p < P; ++p)
-                            if (a.pp[p] == k) acc = tfma(-sh.c[a.pb[p]], col(n + 1 + p)[i], acc);
-                        zk[i] = acc;
-                    }
+        if (phase == 1) continue;
+        while (s_term == 0 && phase != 4) {
+            if (phase != 3) { // ---- the sums of this rank's columns at the trial point ----
+                if (tid == 0) {
+                    for (int i = 0; i < gen_nacc(q); ++i) s_acc[i] = 0.0;
+                    s_okall = 1;
                 }
                 __syncthreads();
-                for (int k = 0; k < q; ++k) {
-                    T vals[MAXV];
-                    const int nv = q - k + 1; // z_k . z_l (l >= k), z_k . r
-                    for (int v = 0; v < nv; ++v) vals[v] = T(0);
-                    const T *zk = col(NCQ + k), *y = col(n);
-                    for (int i = n + tid; i < m; i += TB) {
-                        const T x = zk[i];
-                        for (int l = k; l < q; ++l) vals[l - k] = tfma(x, col(NCQ + l)[i], vals[l - k]);
-                        vals[nv - 1] = tfma(x, y[i], vals[nv - 1]);
+                for (int s = 0; s < NS; ++s) {
+                    evaluate<T>(a, sh, ws, b, false, b * NS + s);
+                    // Kaufman columns in Q-coordinates: z_k = -sum_{pairs p of parameter k} c_{basis(p)} (Q^T D_p), rows >= n
+                    for (int k = 0; k < q; ++k) {
+                        T *zk = col(NCQ + k);
+                        for (int i = n + tid; i < m; i += TB) {
+                            T acc = T(0);
+                            for (int p = 0; p < P; ++p)
+                                if (a.pp[p] == k) acc = tfma(-sh.c[a.pb[p]], col(n + 1 + p)[i], acc);
+                            zk[i] = acc;
+                        }
                     }
-                    multi_reduce(sh, vals, nv);
+                    __syncthreads();
+                    for (int k = 0; k < q; ++k) {
+                        T vals[MAXV];
+                        const int nv = q - k + 1; // z_k . z_l (l >= k), z_k . r
+                        for (int v = 0; v < nv; ++v) vals[v] = T(0);
+                        const T *zk = col(NCQ + k), *y = col(n);
+                        for (int i = n + tid; i < m; i += TB) {
+                            const T x = zk[i];
+                            for (int l = k; l < q; ++l) vals[l - k] = tfma(x, col(NCQ + l)[i], vals[l - k]);
+                            vals[nv - 1] = tfma(x, y[i], vals[nv - 1]);
+                        }
+                        multi_reduce(sh, vals, nv);
+                        if (tid == 0) {
+                            for (int l = k; l < q; ++l) s_acc[1 + k * q + l] += (double)sh.red[l - k];
+                            s_acc[1 + q * q + k] += (double)sh.red[nv - 1];
+                        }
+                        __syncthreads();
+                    }
                     if (tid == 0) {
-                        for (int l = k; l < q; ++l) s_acc[1 + k * q + l] += (double)sh.red[l - k];
-                        s_acc[1 + q * q + k] += (double)sh.red[nv - 1];
+                        s_acc[0] += (double)sh.fn2;
+                        if (!sh.ok) s_okall = 0;
                     }
                     __syncthreads();
                 }
+                if (phase == 2) { // hand the sums to the caller's collective
+                    if (tid == 0) {
+                        s_acc[1 + q * q + q] = s_okall ? 0.0 : 1.0;
+                        for (int i = 0; i < gen_nacc(q); ++i) a.acc[b * gen_nacc(q) + i] = s_acc[i];
+                    }
+                    __syncthreads();
+                    break;
+                }
+            } else { // ---- phase 3: the totals over all ranks ----
                 if (tid == 0) {
-                    s_acc[0] += (double)sh.fn2;
-                    if (!sh.ok) s_okall = 0;
+                    for (int i = 0; i < gen_nacc(q); ++i) s_acc[i] = a.acc[b * gen_nacc(q) + i];
+                    s_okall = s_acc[1 + q * q + q] == 0.0;
                 }
                 __syncthreads();
             }
             if (tid == 0) {
                 const T fnorm1 = tsqrt((T)s_acc[0]);
                 VP_GEN_DISPATCH(q, {
-                    const bool need = lm_after_eval<T, VP_MAX_BASIS, QQ, false>(S, a.lm, fnorm1, s_okall != 0 && is_finite(fnorm1),
-                                                                                 (long)m * (long)NS);
+                    if (phase == 3) s_trow = S.nfev; // (trace row of this evaluation)
+                    const bool need = lm_after_eval<T, VP_MAX_BASIS, QQ, false>(S, a.lm, fnorm1, s_okall != 0 && is_finite(fnorm1), mres);
                     if (a.trace && s_trow < a.trace_rows) {
                         double *tr = a.trace + ((size_t)b * a.trace_rows + s_trow) * (q + 4);
                         for (int k = 0; k < QQ; ++k) tr[k] = (double)S.xt[k];
@@ -690,8 +733,19 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_mrhs_fit_kernel(
                     s_term = S.term;
                     for (int k = 0; k < QQ; ++k) sh.alpha[k] = S.xt[k];
                 });
+                if (phase == 3) {
+                    gstate[b] = lm;
+                    if (s_term != 0) atomicAdd(a.nactive, -1);
+                }
             }
             __syncthreads();
+            if (phase == 3) break;
+        }
+        if (phase == 2 || phase == 3) {
+            if (phase == 2 && s_term != 0 && tid == 0) // finished earlier: contributes nothing (every rank agrees)
+                for (int i = 0; i < gen_nacc(q); ++i) a.acc[b * gen_nacc(q) + i] = 0.0;
+            __syncthreads();
+            continue;
         }
         // ---- results: parameters + report, then coefficients / cost / status of every column at the final point ----
         if (tid == 0) {
@@ -969,10 +1023,17 @@ template <typename T> int launch_fit(const LaunchParams &p) {
     hipLaunchKernelGGL((gen_fit_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
+template <typename T> size_t mrhs_lm_state_bytes() { return sizeof(LmAny<T>); }
 template <typename T> int launch_mrhs_fit(const LaunchParams &p) {
     GenArgs<T> a;
     if (!fill_args(p, a) || !p.gen_ws) return VP_ERR_UNSUPPORTED;
     if (a.B <= 0) return VP_ERR_OK;
+    a.phase = p.gen_phase;
+    a.lm_state = p.gen_lm_state;
+    a.acc = p.gen_acc;
+    a.nactive = p.gen_nactive;
+    a.S_global = p.mrhs_S_global;
+    if (a.phase != 0 && (!a.lm_state || !a.acc || !a.nactive)) return VP_ERR_INVALID;
     hipLaunchKernelGGL((gen_mrhs_fit_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }

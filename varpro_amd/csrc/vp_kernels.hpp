@@ -49,6 +49,10 @@ struct LaunchParams {
     double *gram_dbg;   // Gram fit kernel: evaluate-only diagnostics output (vp_debug_gram_evaluate) or null
     int num_cus;        // compute units of the device
     void *gen_ws;       // generic fallback kernels (vp_generic.hpp): workspace, gen_blocks slots
+    int gen_phase;      // generic global fit in phases (right-hand sides sharded over ranks): see GenArgs::phase
+    void *gen_lm_state; // [B] LM state between the phases
+    double *gen_acc;    // [B][2 + q*q + q] sums between `sums` and `step` (all-reduced by the caller's collective)
+    int32_t *gen_nactive;
     int gen_blocks;
     const void *mrhs_ws; // MRHS path: pointer to the handle's MrhsWs
     const void *mrhs_fws; // MRHS LM step + factorisation: the workspace the factorisation writes when it is not mrhs_ws (null: mrhs_ws)
