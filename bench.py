@@ -441,13 +441,14 @@ def main():
                 "trait_evaluation_ms": ev2_ms, "global_fit_ms": fit2_ms, "evaluations": int(r2["n_evals"][0]),
                 "termination": int(r2["termination"][0]),
                 "max_abs_tau_error": float(np.abs(a2.cpu().numpy()[0] - d2["tau_true"]).max()),
-                "roofline": {"kernel": "mrhs_stream_kernel<MODE 1> (+ mrhs_factor_kernel): y in, r and J out", "bound": "hbm",
+                "roofline": {"kernel": "mrhs_coop_out_kernel (workgroup-cooperative trait-level pass; + mrhs_factor_kernel): y in, r and J out", "bound": "hbm",
                              "achieved": bytes_ev2 / (ev2_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": bytes_ev2 / (ev2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bytes_ev2,
-                             "traffic": committed_traffic("mrhs_stream_kernel_mode1"),
-                             "traffic_source": traffic_source("mrhs_stream_kernel_mode1")},
+                             "traffic": committed_traffic("mrhs_coop_out_kernel"),
+                             "traffic_source": traffic_source("mrhs_coop_out_kernel")},
                 "roofline_fit": {"kernel": "mrhs_coop_dma_kernel (MODE 0: workgroup-cooperative, LDS-DMA prefetch): y re-read once per LM "
-                                           "evaluation; fraction over the WHOLE global fit incl. the factor / LM-step kernels between passes",
+                                           "evaluation; fraction over the WHOLE global fit (wall clock of vp_fit) incl. mrhs_step_kernel "
+                                           "(LM step + factorisation of the next trial point) between the passes; the fit is one captured graph",
                                  "bound": "hbm", "traffic": committed_traffic("mrhs_coop_dma_kernel"),
                                  "traffic_source": traffic_source("mrhs_coop_dma_kernel"),
                                  "achieved": T * m2 * S2 * int(r2["n_evals"][0]) / (fit2_ms * 1e-3) / 1e9,

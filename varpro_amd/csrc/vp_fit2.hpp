@@ -311,7 +311,7 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
         const T ifn = frcp(fnorm);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            const T an = dyn_get<Q>(acnorm, ipvt[j]);
+            const T an = dyn_get_o<Q, (Q > 3)>(acnorm, ipvt[j]);
             if (an != T(0)) {
                 T sum = T(0);
 #pragma unroll
@@ -350,7 +350,7 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
         for (int i = 0; i < Q; ++i)
 #pragma unroll
             for (int j = 0; j < Q; ++j) Rw[i][j] = Rj[i][j];
-        par = lmpar<T, Q, false>(Rw, ipvt, diag, qtf, delta, par, step, pnorm);
+        par = lmpar<T, Q, false, (Q > 3)>(Rw, ipvt, diag, qtf, delta, par, step, pnorm);
         if (!is_finite(pnorm)) {
             term = VP_TERM_NUMERICAL;
         } else {
@@ -359,7 +359,7 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
             for (int i = 0; i < Q; ++i) wa[i] = T(0);
 #pragma unroll
             for (int j = 0; j < Q; ++j) {
-                const T pj = dyn_get<Q>(step, ipvt[j]);
+                const T pj = dyn_get_o<Q, (Q > 3)>(step, ipvt[j]);
 #pragma unroll
                 for (int i = 0; i <= j; ++i) wa[i] = tfma(Rj[i][j], pj, wa[i]);
             }

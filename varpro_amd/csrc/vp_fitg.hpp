@@ -305,8 +305,9 @@ __device__ __forceinline__ void gram_load_chunk(GramChunk<UNIFORM, WEIGHTED> &c,
 // gram_out (LDS).  rec->xt holds the trial parameters; grid2 = {t_0, dt} of the slot's grid (UNIFORM).
 template <int NE, bool UNIFORM, bool WEIGHTED>
 __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRec<double, NE + 1, NE> *rec, VP_LDS const double *grid2,
-                                          VP_LDS double *gram_out, const int prob, const int lane, const int m, const int nchunk,
-                                          const bool vec) {
+                                          VP_LDS double *gram_out, const int prob, const int lane, const int m, const int ch0,
+                                          const int nchunk, const bool vec) {
+    // chunks [ch0, nchunk) of 256 rows (a whole pass: ch0 = 0, nchunk = all; a PART of a split pass: its chunk range)
     using GI = GramIdx<NE>;
     constexpr int NVR = WEIGHTED ? GI::NV : GI::NV - 1;
     double rt[NE];
@@ -319,7 +320,7 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
         dt = uni_d(grid2[1]);
         // anchor at the lane's first row, ratio per row, ratio per chunk: 3 NE exponentials per evaluation
         double ax[3 * NE], ex[3 * NE];
-        const double tl = tfma((double)(4 * lane), dt, t0);
+        const double tl = tfma((double)(ch0 * 256 + 4 * lane), dt, t0);
 #pragma unroll
         for (int kx = 0; kx < NE; ++kx) {
             ax[kx] = -tl * rt[kx];
@@ -341,9 +342,9 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
 #pragma unroll
     for (int i = 0; i < NVR; ++i) acc[i] = 0.0;
     GramChunk<UNIFORM, WEIGHTED> nxt;
-    gram_load_chunk(nxt, yp, tp, wp, 4 * lane, m, vec);
+    gram_load_chunk(nxt, yp, tp, wp, ch0 * 256 + 4 * lane, m, vec);
 #pragma nounroll
-    for (int ch = 0; ch < nchunk; ++ch) {
+    for (int ch = ch0; ch < nchunk; ++ch) {
         const GramChunk<UNIFORM, WEIGHTED> cur = nxt;
         const int row0 = ch * 256 + 4 * lane;
         if (ch + 1 < nchunk) gram_load_chunk(nxt, yp, tp, wp, row0 + 256, m, vec);
@@ -480,6 +481,12 @@ __device__ __forceinline__ void slotg_fill_lane(VP_LDS SlotRec<double, N, Q> *re
 #ifndef VP_FITG2_NWAVES
 #define VP_FITG2_NWAVES 8
 #endif
+#ifndef VP_FITG_PARTS
+#define VP_FITG_PARTS 4        // row ranges of a split moment pass
+#endif
+#ifndef VP_FITG_SPLIT_AFTER
+#define VP_FITG_SPLIT_AFTER 24 // a fit's passes are split from this evaluation on
+#endif
 constexpr int VP_FITG2_WAVES = VP_FITG2_NWAVES;
 
 template <class M, int NS, bool UNIFORM, bool WEIGHTED>
@@ -494,8 +501,11 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
     __shared__ __attribute__((aligned(16))) Rec s_recs[NS];
     __shared__ __attribute__((aligned(16))) KC s_kc;
     __shared__ double s_grid[NS][2];
-    __shared__ int s_state[NS]; // 0 empty | 1 needs a moment pass | 2 being streamed | 3 moments ready / bookkeeping
+    __shared__ int s_state[NS]; // 0 empty | 1 needs a moment pass | 2 being streamed | 3 moments ready / bookkeeping | 4 split pass, parts unclaimed
     __shared__ int s_live;      // slots that hold a fit
+    // split passes (the tail of a launch): the parts' moments, the next unclaimed part, the parts finished
+    __shared__ __attribute__((aligned(16))) double s_pgram[NS][VP_FITG_PARTS][GI::NV];
+    __shared__ int s_next[NS], s_done[NS];
     const int lane = lane_id();
     const int wv = (int)(threadIdx.x >> 6);
     const int m = a.m;
@@ -546,6 +556,8 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
             s_recs[lane].term = VP_TERM_NOT_RUN;
         }
         s_state[lane] = have ? 1 : 0;
+        s_next[lane] = VP_FITG_PARTS; // (nothing to claim)
+        s_done[lane] = 0;
     }
     __syncthreads();
     const int nchunk = (m + 255) / 256;
@@ -598,27 +610,81 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
             int sl = lane + start;
             sl = sl >= NS ? sl - NS : sl;
             const int st = (lane < NS) ? __hip_atomic_load(&s_state[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-            const unsigned long long ready = __builtin_amdgcn_ballot_w64(lane < NS && st == 1);
+            const unsigned long long ready = __builtin_amdgcn_ballot_w64(lane < NS && (st == 1 || st == 4));
             if (ready == 0ull) {
                 if (uni(__hip_atomic_load(&s_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= 0) break;
                 __builtin_amdgcn_s_sleep(4);
                 continue;
             }
-            int s = (int)__builtin_ctzll(ready) + start;
+            const int off = (int)__builtin_ctzll(ready);
+            int s = off + start;
             s = s >= NS ? s - NS : s;
-            int won = 0;
-            if (lane == 0) {
-                int expect = 1;
-                won = __hip_atomic_compare_exchange_strong(&s_state[s], &expect, 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+            const int sst = __builtin_amdgcn_readlane(st, off);
+            // A fit that has outlived VP_FITG_SPLIT_AFTER evaluations is (with the evaluation counts of this workload: mean
+            // 18) one of the few its workgroup still holds while most stream waves idle: its pass is SPLIT into
+            // VP_FITG_PARTS row ranges that as many waves stream at once, the last one to finish adds the parts' moments
+            // in a fixed order.  Whether a pass is split depends on the fit's own evaluation count only, never on timing:
+            // results stay independent of who processed a slot and when.
+            int part = -1; // -1: a whole pass
+            if (sst == 1) {
+                int won = 0;
+                if (lane == 0) {
+                    int expect = 1;
+                    won = __hip_atomic_compare_exchange_strong(&s_state[s], &expect, 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+                }
+                if (!uni(won)) continue; // another stream wave was faster
+                asm volatile("" ::: "memory");
+                if (VP_FITG_PARTS > 1 && !a.dbg && uni(s_recs[s].nfev) >= VP_FITG_SPLIT_AFTER) {
+                    part = 0;
+                    if (lane == 0) {
+                        s_done[s] = 0;
+                        s_next[s] = 1;
+                    }
+                    lds_release();
+                    if (lane == 0) __hip_atomic_store(&s_state[s], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else { // a split pass with unclaimed parts
+                int pp = 0;
+                if (lane == 0) pp = __hip_atomic_fetch_add(&s_next[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pp = uni(pp);
+                if (pp >= VP_FITG_PARTS) { // all taken (the state word was about to say so)
+                    start = s + 1 >= NS ? 0 : s + 1;
+                    continue;
+                }
+                if (pp == VP_FITG_PARTS - 1 && lane == 0) {
+                    int expect = 4; // (only while it still is THIS pass that is being split)
+                    (void)__hip_atomic_compare_exchange_strong(&s_state[s], &expect, 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                part = pp;
+                asm volatile("" ::: "memory");
             }
-            if (!uni(won)) continue; // another stream wave was faster
-            asm volatile("" ::: "memory");
             const int prob = uni(s_recs[s].prob);
-            gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0], gram + (size_t)s * GI::NV, prob, lane, m,
-                                             nchunk, vec);
-            lds_release(); // the moments are in LDS before the slot is handed to the scalar wave
-            if (lane == 0) __hip_atomic_store(&s_state[s], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (part < 0) {
+                gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0], gram + (size_t)s * GI::NV, prob, lane, m,
+                                                 0, nchunk, vec);
+                lds_release(); // the moments are in LDS before the slot is handed to the scalar wave
+                if (lane == 0) __hip_atomic_store(&s_state[s], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                const int c0 = (int)((long)part * nchunk / VP_FITG_PARTS), c1 = (int)((long)(part + 1) * nchunk / VP_FITG_PARTS);
+                gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0],
+                                                 (VP_LDS double *)&s_pgram[s][part][0], prob, lane, m, c0, c1, vec);
+                lds_release();
+                int d = 0;
+                if (lane == 0) d = __hip_atomic_fetch_add(&s_done[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (uni(d) == VP_FITG_PARTS - 1) { // the last part: total in the order of the parts
+                    asm volatile("" ::: "memory");
+                    for (int v = lane; v < GI::NV; v += 64) {
+                        double t = s_pgram[s][0][v];
+#pragma unroll
+                        for (int q2 = 1; q2 < VP_FITG_PARTS; ++q2) t += s_pgram[s][q2][v];
+                        s_gram[s][v] = t;
+                    }
+                    lds_release();
+                    if (lane == 0) __hip_atomic_store(&s_state[s], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
             start = s + 1 >= NS ? 0 : s + 1;
         }
     }
