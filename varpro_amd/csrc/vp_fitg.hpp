@@ -43,6 +43,16 @@
 #include "vp_fit2.hpp"
 #include "vp_lm_core.hpp"
 
+#ifndef VP_FITG_IDLE_PARTNER
+#define VP_FITG_IDLE_PARTNER 0
+#endif
+#ifndef VP_FITG_SCALAR_WAVES
+#define VP_FITG_SCALAR_WAVES 1 // bookkeeping waves per workgroup (each owns NS / this many slots)
+#endif
+#ifndef VP_FITG_CLOSED
+#define VP_FITG_CLOSED 1       // uniform grid + unit weights: the y-independent moments in closed form
+#endif
+
 namespace vp {
 
 template <int NE> struct GramIdx {
@@ -306,8 +316,9 @@ __device__ __forceinline__ void gram_load_chunk(GramChunk<UNIFORM, WEIGHTED> &c,
 template <int NE, bool UNIFORM, bool WEIGHTED>
 __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRec<double, NE + 1, NE> *rec, VP_LDS const double *grid2,
                                           VP_LDS double *gram_out, const int prob, const int lane, const int m, const int ch0,
-                                          const int nchunk, const bool vec) {
-    // chunks [ch0, nchunk) of 256 rows (a whole pass: ch0 = 0, nchunk = all; a PART of a split pass: its chunk range)
+                                          const int nchunk, const bool vec, const bool own_closed = true) {
+    // chunks [ch0, nchunk) of 256 rows (a whole pass: ch0 = 0, nchunk = all; a PART of a split pass: its chunk range;
+    // own_closed: this pass / part also delivers the moments that do not depend on y -- see below)
     using GI = GramIdx<NE>;
     constexpr int NVR = WEIGHTED ? GI::NV : GI::NV - 1;
     double rt[NE];
@@ -333,6 +344,57 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
             fa[kx] = ex[kx];
             q1[kx] = uni_d(ex[NE + kx]);
             qc[kx] = uni_d(ex[2 * NE + kx]);
+        }
+    }
+    // ---- uniform grid, unit weights: 55 of the 67 moments do not depend on y and have a closed form ----
+    // A0_ik = sum_r e^{-s t_r}, A1_ik = sum_r t_r e^{-s t_r}, A2_ik = sum_r t_r^2 e^{-s t_r} with s = 1/tau_i + 1/tau_k, and
+    // S0_k, S1_k the same with s = 1/tau_k: on the lattice t_r = t_0 + r dt these are e^{-s t_0} times polynomials in
+    // (t_0, dt) of H_j = sum_{r<m} r^j rho^r, rho = e^{-s dt}, j = 0, 1, 2.  The H_j follow from a DOUBLING recurrence
+    // over the bits of m (H(2n) = H(n) + rho^n * [H(n) shifted by n]; every term positive: no cancellation; rho^n from
+    // one exponential of n * (-s dt) per step, not by repeated squaring, which would double the relative error of rho^n
+    // at every step).  One lane per value of s (NE (NE + 1) / 2 + NE = 20 lanes for five exponentials), ~13 exponentials
+    // each: the row loop below then carries 12 accumulators instead of 67 (B0, B1, YY, SY) -- 28 instead of 86
+    // instructions per row.
+    constexpr bool CLOSED = UNIFORM && !WEIGHTED && (VP_FITG_CLOSED != 0);
+    constexpr int NPAIR = NE * (NE + 1) / 2;
+    double G0 = 0.0, G1 = 0.0, G2 = 0.0;
+    if constexpr (CLOSED) {
+        if (own_closed && lane < NPAIR + NE) {
+            // lane -> (i, k): pairs in the row-major upper-triangle order of GramIdx::tri, then the NE single columns
+            double sv = 0.0;
+            {
+                int idx = 0;
+#pragma unroll
+                for (int i = 0; i < NE; ++i)
+#pragma unroll
+                    for (int k2 = i; k2 < NE; ++k2) {
+                        sv = (lane == idx) ? rt[i] + rt[k2] : sv;
+                        ++idx;
+                    }
+#pragma unroll
+                for (int k2 = 0; k2 < NE; ++k2) sv = (lane == NPAIR + k2) ? rt[k2] : sv;
+            }
+            const double x1 = -sv * dt; // log rho
+            double H0 = 0.0, H1 = 0.0, H2 = 0.0;
+            int n = 0;
+            for (int bit = 31 - __builtin_clz((unsigned)m); bit >= 0; --bit) { // (m > 0; uniform over the wave)
+                const double Pn = texp(x1 * (double)n), dn = (double)n;        // rho^n
+                H2 = tfma(Pn, tfma(dn * dn, H0, tfma(2.0 * dn, H1, H2)), H2);
+                H1 = tfma(Pn, tfma(dn, H0, H1), H1);
+                H0 = tfma(Pn, H0, H0);
+                n *= 2;
+                if ((m >> bit) & 1) { // append the term r = n
+                    const double Pa = texp(x1 * (double)n), da = (double)n;
+                    H0 += Pa;
+                    H1 = tfma(da, Pa, H1);
+                    H2 = tfma(da * da, Pa, H2);
+                    n += 1;
+                }
+            }
+            const double e0 = texp(-sv * t0);
+            G0 = e0 * H0;
+            G1 = e0 * tfma(dt, H1, t0 * H0);
+            G2 = e0 * tfma(dt * dt, H2, tfma(2.0 * t0 * dt, H1, t0 * t0 * H0));
         }
     }
     const float *yp = a.yw + (int64_t)prob * m;
@@ -393,14 +455,16 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
             }
 #pragma unroll
             for (int kx = 0; kx < NE; ++kx) uh[kx] = td * eh[kx];
+            if constexpr (!CLOSED) {
 #pragma unroll
-            for (int i = 0; i < NE; ++i)
+                for (int i = 0; i < NE; ++i)
 #pragma unroll
-                for (int k2 = i; k2 < NE; ++k2) {
-                    acc[GI::A0(i, k2)] = tfma(eh[i], eh[k2], acc[GI::A0(i, k2)]);
-                    acc[GI::A1(i, k2)] = tfma(eh[i], uh[k2], acc[GI::A1(i, k2)]);
-                    acc[GI::A2(i, k2)] = tfma(uh[i], uh[k2], acc[GI::A2(i, k2)]);
-                }
+                    for (int k2 = i; k2 < NE; ++k2) {
+                        acc[GI::A0(i, k2)] = tfma(eh[i], eh[k2], acc[GI::A0(i, k2)]);
+                        acc[GI::A1(i, k2)] = tfma(eh[i], uh[k2], acc[GI::A1(i, k2)]);
+                        acc[GI::A2(i, k2)] = tfma(uh[i], uh[k2], acc[GI::A2(i, k2)]);
+                    }
+            }
 #pragma unroll
             for (int kx = 0; kx < NE; ++kx) {
                 acc[GI::B0(kx)] = tfma(eh[kx], yd, acc[GI::B0(kx)]);
@@ -416,10 +480,12 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
                 acc[GI::SY] = tfma(wd, yd, acc[GI::SY]);
                 acc[GI::SW] = tfma(wd, wd, acc[GI::SW]);
             } else {
+                if constexpr (!CLOSED) {
 #pragma unroll
-                for (int kx = 0; kx < NE; ++kx) {
-                    acc[GI::S0(kx)] += eh[kx];
-                    acc[GI::S1(kx)] += uh[kx];
+                    for (int kx = 0; kx < NE; ++kx) {
+                        acc[GI::S0(kx)] += eh[kx];
+                        acc[GI::S1(kx)] += uh[kx];
+                    }
                 }
                 acc[GI::SY] += yd;
             }
@@ -429,7 +495,31 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
             for (int kx = 0; kx < NE; ++kx) fa[kx] *= qc[kx];
         }
     }
-    wave_reduce_store<NVR>(acc, gram_out);
+    if constexpr (CLOSED) {
+        // the 12 y-dependent moments: B0, B1, YY are contiguous in the layout, SY travels as a 12th value (it lands on
+        // S0(0), is moved to its place, and S0(0) is then written with the rest of the closed-form moments)
+        constexpr int NY = 2 * NE + 2;
+        double ya[NY];
+#pragma unroll
+        for (int i = 0; i < 2 * NE + 1; ++i) ya[i] = acc[GI::B0(0) + i];
+        ya[NY - 1] = acc[GI::SY];
+        static_assert(GI::B1(0) == GI::B0(0) + NE && GI::YY == GI::B0(0) + 2 * NE && GI::S0(0) == GI::YY + 1, "layout");
+        wave_reduce_store<NY>(ya, gram_out + GI::B0(0));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) gram_out[GI::SY] = gram_out[GI::S0(0)];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (a part that does not own the closed-form moments contributes zeros: the parts are summed)
+        if (lane < NPAIR) {
+            gram_out[GI::NT * 0 + lane] = G0;
+            gram_out[GI::NT * 1 + lane] = G1;
+            gram_out[GI::NT * 2 + lane] = G2;
+        } else if (lane < NPAIR + NE) {
+            gram_out[GI::S0(lane - NPAIR)] = G0;
+            gram_out[GI::S1(lane - NPAIR)] = G1;
+        }
+    } else {
+        wave_reduce_store<NVR>(acc, gram_out);
+    }
 }
 
 // ---- role-specialised waves ------------------------------------------------------------------------------------------
@@ -565,10 +655,16 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
                                        reinterpret_cast<uintptr_t>(a.w)) & 15) == 0;
     auto lds_release = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
-    if (wv == 0) {
-        // ======================= the scalar wave: lane s <-> slot s =======================
+    constexpr int NSC = VP_FITG_SCALAR_WAVES, GSW = NS / NSC; // scalar waves, slots per scalar wave
+    static_assert(NS % NSC == 0 && NSC < VP_FITG2_WAVES, "the pool divides evenly over the scalar waves");
+    if (wv < NSC) {
+        // ======================= a scalar wave: lane s <-> slot base + s =======================
+        // (the bookkeeping costs its ~33 k cycles of issue per pass however few lanes are active: with the moment passes
+        // three times shorter -- closed-form moments -- one scalar wave per pool was what every fit's round waited for)
+        const int base = wv * GSW;
+        VP_LDS Rec *wrecs = recs + base;
         for (;;) {
-            const int st = (lane < NS) ? __hip_atomic_load(&s_state[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+            const int st = (lane < GSW) ? __hip_atomic_load(&s_state[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
             asm volatile("" ::: "memory");
             const bool act = st == 3;
             if (!uni(act)) {
@@ -576,33 +672,38 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
                 __builtin_amdgcn_s_sleep(8);
                 continue;
             }
-            gram_phase<NE, NS, WEIGHTED>(recs, gram, kc, a.dbg, act);
+            gram_phase<NE, GSW, WEIGHTED>(wrecs, gram + (size_t)base * GI::NV, kc, a.dbg, act);
             lds_release();
             if (!a.dbg) {
-                slot_scalar_phase<double, N, Q, NS, float>(recs, kc, act);
+                slot_scalar_phase<double, N, Q, GSW, float>(wrecs, kc, act);
                 lds_release();
             }
             if (act) {
                 int next_state = 1;
-                if (s_recs[lane].term != 0) { // the fit of this slot is finished (results written): next problem, or empty
+                if (s_recs[base + lane].term != 0) { // the fit of this slot is finished (results written): next problem, or empty
                     const int next = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((int64_t)next < a.B) {
-                        slotg_fill_lane<N, Q>(recs + lane, kc, next);
-                        grid_of(lane, next);
+                        slotg_fill_lane<N, Q>(wrecs + lane, kc, next);
+                        grid_of(base + lane, next);
                     } else {
-                        s_recs[lane].prob = -1;
-                        s_recs[lane].term = VP_TERM_NOT_RUN;
+                        s_recs[base + lane].prob = -1;
+                        s_recs[base + lane].term = VP_TERM_NOT_RUN;
                         next_state = 0;
                         __hip_atomic_fetch_add(&s_live, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
                 lds_release(); // the record is complete before the slot is handed to a stream wave
-                __hip_atomic_store(&s_state[lane], next_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&s_state[base + lane], next_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     } else {
+#if VP_FITG_IDLE_PARTNER
+        // the wave that shares its SIMD with a scalar wave (waves of a workgroup are dealt round-robin over the 4 SIMDs) stays
+        // idle: the lane-serial bookkeeping is the latency of every fit's round and runs at full issue rate alone
+        if (wv >= 4 && wv - 4 < NSC) return;
+#endif
         // ======================= stream waves: claim a slot with a trial point, stream its rows =======================
-        int start = (wv - 1) * (NS / (VP_FITG2_WAVES - 1)); // spread the first claims over the pool
+        int start = (wv - NSC) * (NS / (VP_FITG2_WAVES - NSC)); // spread the first claims over the pool
         for (;;) {
             // lanes look at one slot each; the first slot at or after `start` (cyclically) that has a trial point is claimed
             // (serving the OLDEST fit first instead was measured: no gain -- a fit's round is the pass + the bookkeeping, not
@@ -669,7 +770,7 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
             } else {
                 const int c0 = (int)((long)part * nchunk / VP_FITG_PARTS), c1 = (int)((long)(part + 1) * nchunk / VP_FITG_PARTS);
                 gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0],
-                                                 (VP_LDS double *)&s_pgram[s][part][0], prob, lane, m, c0, c1, vec);
+                                                 (VP_LDS double *)&s_pgram[s][part][0], prob, lane, m, c0, c1, vec, part == 0);
                 lds_release();
                 int d = 0;
                 if (lane == 0) d = __hip_atomic_fetch_add(&s_done[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
