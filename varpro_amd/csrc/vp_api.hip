@@ -214,6 +214,8 @@ struct vp_batch {
     int mrhs_graph_iters;   // ... and what the next capture should hold (evaluations of the previous fit + 1, >= 6)
     int32_t *h_nactive;     // pinned, device-mapped: the active count as the graph's last kernel leaves it
     int32_t *h_nactive_dev; // its device address
+    MrhsIo *h_io;           // pinned, device-mapped: the caller's arrays of the current vp_fit (whole-fit graph, device-pointer handles)
+    MrhsIo *h_io_dev;
     vp_lm_opts mrhs_graph_opts;
     hipStream_t cap_stream;
     bool mrhs_graph_failed;
@@ -481,7 +483,25 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
     else vp_lm_opts_default(&o, h->dtype);
     const size_t ts = tsize(h->dtype);
     const hipMemcpyKind kin = device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    VP_HIP(hipMemcpyAsync(h->d_alpha, alpha_inout, (size_t)h->B * h->q * ts, kin, h->stream));
+    // device-pointer handles with the MRHS kernel set: the kernels read the initial parameters from, and write the results
+    // into, the CALLER's arrays through a pinned record of their addresses (MrhsIo) -- no staging copies around the fit
+    const bool use_io = device_ptrs(h) && h->have_mrhs;
+    if (!h->h_nactive) {
+        VP_HIP(hipHostMalloc((void **)&h->h_nactive, 2 * sizeof(int32_t), hipHostMallocMapped));
+        VP_HIP(hipHostGetDevicePointer((void **)&h->h_nactive_dev, h->h_nactive, 0));
+        VP_HIP(hipHostMalloc((void **)&h->h_io, sizeof(MrhsIo), hipHostMallocMapped));
+        VP_HIP(hipHostGetDevicePointer((void **)&h->h_io_dev, h->h_io, 0));
+        std::memset(h->h_io, 0, sizeof(MrhsIo));
+    }
+    if (use_io) {
+        h->h_io->alpha_in = alpha_inout;
+        h->h_io->alpha_out = alpha_inout;
+        h->h_io->C_out = C_out;
+        h->h_io->rep_out = rep;
+    } else {
+        std::memset(h->h_io, 0, sizeof(MrhsIo));
+        VP_HIP(hipMemcpyAsync(h->d_alpha, alpha_inout, (size_t)h->B * h->q * ts, kin, h->stream));
+    }
     LaunchParams p;
     fill_params(h, p);
     p.mrhs_ws = &h->mrhs;
@@ -567,6 +587,7 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
     auto enqueue_init = [&](LaunchParams &lp) -> int {
         lp.mrhs_init = 1;
         lp.alpha = h->d_alpha;
+        lp.mrhs_io = h->h_io_dev;
         const int rc = h->kern->mrhs_lm(lp);
         lp.mrhs_init = 0;
         return rc ? fail(rc, "mrhs_step (init) launch failed") : 0;
@@ -609,13 +630,10 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         lp.cost_out = h->d_cost_bs;
         lp.status = h->d_status_bs;
         lp.mrhs_hflag = h->h_nactive_dev;
+        lp.mrhs_io = h->h_io_dev;
         if (int rc = h->kern->mrhs_finish(lp)) return fail(rc, "mrhs_finish launch failed");
         return reduce_rhs(h, lp.stream, true); // per-problem cost / status from the per-column ones
     };
-    if (!h->h_nactive) {
-        VP_HIP(hipHostMalloc((void **)&h->h_nactive, 2 * sizeof(int32_t), hipHostMallocMapped));
-        VP_HIP(hipHostGetDevicePointer((void **)&h->h_nactive_dev, h->h_nactive, 0));
-    }
     // The WHOLE fit as ONE captured HIP graph: init, `iters` iterations, finish (no trace, no all-reduce callback: both
     // put host state into the launch sequence).  Captured on a private stream -- the handle's stream may be the null
     // stream, which cannot be captured -- and replayed on the handle's stream.  The graph holds the LM options by
@@ -662,9 +680,9 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
     }
     // device-pointer handles: the copies into the caller's arrays are enqueued right behind the graph, BEFORE the host
     // waits for the active count (a fit that outlasts the graph repeats them after the tail graph)
-    bool outputs_done = false;
+    bool outputs_done = use_io; // (written by the finish / gather kernels themselves)
     auto early_outputs = [&]() -> int {
-        if (!device_ptrs(h) || tr.tmp) return 0;
+        if (outputs_done || !device_ptrs(h) || tr.tmp) return 0;
         if (int rc = copy_out(h, alpha_inout, h->d_alpha, (size_t)h->B * h->q * ts)) return rc;
         if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
         if (int rc = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc;
@@ -1033,6 +1051,7 @@ void vp_batch_destroy(vp_batch *h) {
     if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
     if (h->mrhs_graph_tail) (void)hipGraphExecDestroy(h->mrhs_graph_tail);
     if (h->h_nactive) (void)hipHostFree(h->h_nactive);
+    if (h->h_io) (void)hipHostFree(h->h_io);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -56,6 +56,7 @@ struct LaunchParams {
     int gen_blocks;
     const void *mrhs_ws; // MRHS path: pointer to the handle's MrhsWs
     const void *mrhs_fws; // MRHS LM step + factorisation: the workspace the factorisation writes when it is not mrhs_ws (null: mrhs_ws)
+    const void *mrhs_io; // MRHS whole-fit graph: device address of the pinned MrhsIo record (the caller's arrays of this call) or null
     int32_t *mrhs_hflag; // MRHS finish: pinned host words [active count, max evaluations] (device address) or null
     int mrhs_mode;      // MRHS stream: 0 = reduced quantities (fit), 1 = trait-level outputs
     int mrhs_init;      // MRHS LM step: 1 = initialise the state

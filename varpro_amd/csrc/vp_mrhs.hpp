@@ -52,6 +52,16 @@ struct MrhsWs {
     int32_t *widx, *bidx; // [B]
 };
 
+// where a captured whole-fit graph finds the CALLER's arrays of this call (device-pointer handles): a pinned, device-mapped
+// record the host fills before every replay -- the graph itself holds only its address.  Null members: not wanted /
+// host-pointer handle (the library's own staging copies are used instead).
+struct MrhsIo {
+    const void *alpha_in; // [B][q] initial parameters
+    void *alpha_out;      // [B][q]
+    void *C_out;          // [B][S][n]
+    void *rep_out;        // [B] vp_report
+};
+
 template <typename T, class M> struct MrhsFactorArgs {
     M mdl;
     const T *t;
@@ -1113,6 +1123,7 @@ template <typename T, int N, int Q, int P> struct MrhsLmArgs {
     MrhsWs ws;
     LmOpts<T> opts;
     const T *alpha0;   // init only
+    const MrhsIo *io;  // init only: != null and io->alpha_in != null: read the initial parameters from there instead
     int pb[P > 0 ? P : 1], pp[P > 0 ? P : 1];
     int m, S;
     int64_t S_global;  // right-hand sides of the whole problem (== S unless the columns are sharded over ranks)
@@ -1150,8 +1161,13 @@ __global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<
     Vars s;
     if (a.init) {
         T a0[Q];
+        const T *src0 = a.alpha0;
+        if (a.io) {
+            const T *user = (const T *)a.io->alpha_in;
+            if (user) src0 = user;
+        }
 #pragma unroll
-        for (int k = 0; k < Q; ++k) a0[k] = a.alpha0[b * Q + k];
+        for (int k = 0; k < Q; ++k) a0[k] = src0[b * Q + k];
         lm_init<T, N, Q>(s, a0);
         if (gl == 0) {
             *gs = s;
@@ -1459,6 +1475,7 @@ template <typename T, class M, int R> int launch_mrhs_lm(const LaunchParams &p) 
     a.opts.patience = p.opts->patience;
     a.opts.scale_diag = p.opts->scale_diag;
     a.alpha0 = (const T *)p.alpha;
+    a.io = (const MrhsIo *)p.mrhs_io;
     pair_maps<M>(*p.model, a.pb, a.pp);
     a.m = p.m;
     a.S = p.S;
@@ -1484,33 +1501,47 @@ template <typename T, class M> size_t mrhs_state_bytes() { return sizeof(LmVars<
 
 template <typename T, int N, int Q>
 __global__ void mrhs_finish_kernel(const LmVars<T, N, Q> *st, int64_t B, T *alpha_out, vp_report *rep, const int32_t *nactive,
-                                   int32_t *hflag) {
+                                   int32_t *hflag, const MrhsIo *io) {
     const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (b == 0 && hflag) { // pinned host memory: what the host looks at after the stream has drained
         hflag[0] = nactive[0];
         hflag[1] = nactive[1];
     }
     if (b >= B) return;
+    T *ua = nullptr;
+    vp_report *ur = nullptr;
+    if (io) {
+        ua = (T *)io->alpha_out;
+        ur = (vp_report *)io->rep_out;
+    }
     const LmVars<T, N, Q> s = st[b];
-    for (int k = 0; k < Q; ++k) alpha_out[b * Q + k] = s.x[k];
+    for (int k = 0; k < Q; ++k) {
+        alpha_out[b * Q + k] = s.x[k];
+        if (ua) ua[b * Q + k] = s.x[k];
+    }
     vp_report r;
     r.termination = s.term;
     r.n_evals = s.nfev;
     r.objective = (double)s.objective;
     rep[b] = r;
+    if (ur) ur[b] = r;
 }
 
 // (C, cost, status) of every column at the final parameters = the best point's buffer
 template <typename T>
 __global__ void mrhs_gather_kernel(const MrhsWs ws, int64_t B, int S, int n, T *C_out, double *cost_bs, int32_t *status_bs,
-                                   const int gx) {
+                                   const int gx, const MrhsIo *io) {
     const int64_t b = blockIdx.x / gx;
     const int wgi = (int)(blockIdx.x - b * gx), nwg = gx;
     if (b >= B) return;
     const int sel = ws.bidx[b] & 1;
     const T *cs = (const T *)ws.cbuf[sel] + b * (int64_t)S * n;
-    for (int64_t i = wgi * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)S * n; i += (int64_t)nwg * blockDim.x)
-        C_out[b * (int64_t)S * n + i] = cs[i];
+    T *uc = io ? (T *)io->C_out : nullptr; // the caller's array as well (device-pointer handles, whole-fit graph)
+    for (int64_t i = wgi * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)S * n; i += (int64_t)nwg * blockDim.x) {
+        const T v = cs[i];
+        C_out[b * (int64_t)S * n + i] = v;
+        if (uc) uc[b * (int64_t)S * n + i] = v;
+    }
     for (int64_t i = wgi * (int64_t)blockDim.x + threadIdx.x; i < S; i += (int64_t)nwg * blockDim.x) {
         cost_bs[b * S + i] = ws.costbuf[sel][b * S + i];
         status_bs[b * S + i] = ws.stbuf[sel][b * S + i];
@@ -1522,13 +1553,13 @@ template <typename T, class M, int R> int launch_mrhs_finish(const LaunchParams 
     const unsigned grid = (unsigned)((p.B + 63) / 64);
     hipLaunchKernelGGL((mrhs_finish_kernel<T, M::N, M::Q>), dim3(grid), dim3(64), 0, p.stream,
                        (const LmVars<T, M::N, M::Q> *)ws.lm_state, p.B, (T *)p.alpha_out, p.report, (const int32_t *)ws.nactive,
-                       p.mrhs_hflag);
+                       p.mrhs_hflag, (const MrhsIo *)p.mrhs_io);
     if (p.C_out && p.cost_out && p.status) {
         const int64_t per = (int64_t)p.S * M::N;
         unsigned gx = (unsigned)((per + 255) / 256);
         if (gx > 64) gx = 64;
         hipLaunchKernelGGL((mrhs_gather_kernel<T>), dim3((unsigned)((int64_t)gx * p.B)), dim3(256), 0, p.stream, ws, p.B, p.S, (int)M::N,
-                           (T *)p.C_out, p.cost_out, p.status, (int)gx);
+                           (T *)p.C_out, p.cost_out, p.status, (int)gx, (const MrhsIo *)p.mrhs_io);
     }
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
