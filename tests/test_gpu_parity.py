@@ -1,6 +1,11 @@
 """GPU parity tests proper: the HIP path (through the C ABI, libvarpro_hip.so) against the CPU oracle on
 the same seeded inputs.  fp64 tolerances follow BASELINE.json / SURVEY.md H3:
-    |dc| <= 1e-10 * max|c|,  |dr| <= 1e-10 * max|y_w|,  |dJ_k| <= 1e-10 * max|J_k|."""
+    |dc| <= 1e-10 * max|c|,  |dr| <= 1e-10 * max|y_w|,  |dJ_k| <= 1e-10 * max|J_k|.
+The contract on a FIT: identical success flags, the same minimum (alpha, c, objective to the tolerances in the tests) and
+the same LM trajectory up to the point where rounding decides -- NOT identical evaluation counts: the last iterations of a
+converged fit compare an actual reduction at rounding level with ftol, and the oracle itself changes its count by a few
+evaluations when it forms r under `long double`.  The tests therefore ask for |delta n_evals| <= 3
+on at least half of the fits, and for equal termination CLASSES everywhere."""
 import numpy as np
 import pytest
 
