@@ -78,3 +78,32 @@ def test_fit_reports_follow_the_reference_driver():
     ev = bp.evaluate(np.array([[1.0, 2.5, 6.0]]))
     assert abs(np.asarray(bp.best_fit()).ravel()[0] - 4.0) <= 1e-12
     bp.close()
+
+
+def test_device_pointer_handle_with_fewer_samples_than_basis_functions():
+    # the same through device pointers (torch tensors on cuda:0): padding happens inside vp_batch_create / vp_set_observations,
+    # outputs arrive with the caller's m in the caller's device arrays
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(7)
+    m, B = 2, 5
+    x = np.array([0.2, 1.1])
+    Y = rng.uniform(1.0, 5.0, (B, m))
+    alphas = np.array([1.0, 2.5, 6.0])[None] * rng.uniform(0.8, 1.2, (B, 3))
+    mdl = vp.multi_exponential_model(x, alphas[0], offset=True)
+    bp = vp.BatchProblem(mdl, torch.from_numpy(Y).to(dev), x=torch.from_numpy(x).to(dev))
+    ev = bp.evaluate(torch.from_numpy(alphas).to(dev))
+    C = ev["C"].cpu().numpy()
+    r = ev["r"].cpu().numpy()
+    assert r.shape == (B, m) and ev["J"].shape == (B, 3, m)
+    for b in range(B):
+        ref = O.Problem(mdl, x, Y[b][None])
+        ref.set_params(alphas[b])
+        assert np.abs(C[b] - ref.linear_coefficients()[0]).max() <= 1e-10 * np.abs(ref.linear_coefficients()).max()
+        assert np.abs(r[b]).max() <= 1e-10 * np.abs(Y[b]).max()
+    Y2 = rng.uniform(1.0, 5.0, (B, m))
+    bp.set_observations(torch.from_numpy(Y2).to(dev))
+    ev2 = bp.evaluate(torch.from_numpy(alphas).to(dev))
+    bf = bp.best_fit().cpu().numpy()
+    assert bf.shape == (B, m) and np.abs(bf - Y2).max() <= 1e-10 * np.abs(Y2).max()
+    bp.close()
