@@ -188,3 +188,33 @@ def test_debug_entry_refuses_other_handles():
     with pytest.raises(vp.VarproHipError):
         bp.debug_gram_evaluate(d["tau_guess"])
     bp.close()
+
+
+@pytest.mark.parametrize("m,t0,span", [(1000, 0.0, 12.5), (3000, 2.5, 9.0), (4096, 0.75, 30.0), (516, 0.0, 1.0)])
+def test_closed_form_moments_on_offset_grids_and_odd_lengths(m, t0, span):
+    # uniform grid + unit weights: 55 of the 67 moments come from the doubling recurrence over the bits of m (vp_fitg.hpp,
+    # gram_pass) -- lengths that are not powers of two (append steps), grids that do not start at 0 (the e^{-s t_0} factor
+    # and the (t_0, dt) polynomials), short and long spans (rho close to 1 / close to 0); same stated bound as above
+    B = 8
+    rng = np.random.default_rng(m)
+    x = (t0 + span * np.arange(m) / (m - 1)).astype(np.float32)
+    tau = np.array(TAUS)[None] * rng.uniform(0.9, 1.1, (B, 5))
+    c = rng.uniform(1.0, 10.0, (B, 6))
+    x64 = x.astype(np.float64)
+    Y = np.tile(c[:, 5:6], (1, m))
+    for j in range(5):
+        Y = Y + c[:, j:j + 1] * np.exp(-x64[None] / tau[:, j:j + 1])
+    Y = (Y + 1e-3 * np.abs(Y).max(1, keepdims=True) * rng.standard_normal(Y.shape)).astype(np.float32)
+    guess = (tau * rng.uniform(0.95, 1.05, (B, 5))).astype(np.float32)
+    mdl = vp.multi_exponential_model(x, guess[0], dtype=np.float32)
+    bp = vp.BatchProblem(mdl, Y, x=x)
+    dev = bp.debug_gram_evaluate(guess)
+    yw = np.asarray(bp.weighted_data()).astype(np.float64)
+    bp.close()
+    lat = _lattice(x)
+    assert np.abs(x.astype(np.float64) - lat).max() <= 4 * np.finfo(np.float32).eps * (abs(t0) + span)   # the handle takes the lattice
+    worst = np.zeros(4)
+    for b in range(B):
+        ref = _oracle_quantities(mdl, lat, yw[b], None, guess[b].astype(np.float64))
+        worst = np.maximum(worst, _check(dev, b, ref))
+    print("m", m, "t0", t0, "span", span, "worst error / (kappa^2 eps64): c %.2g cost %.2g Jtr %.2g JtJ %.2g" % tuple(worst))
