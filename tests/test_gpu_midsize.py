@@ -1,0 +1,73 @@
+"""The 12-rows-per-lane kernel set (double exponential + offset, fp64, 512 < m <= 768): evaluation, fit and the
+multiple-right-hand-side path against the oracle -- a length just above the 512-row set must not pay for 1024 rows, and the
+row-chunked MRHS streaming kernel must tile 12 rows (chunks of 4; its default chunk of 8 does not divide 12)."""
+import numpy as np
+import pytest
+
+import varpro_amd as vp
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _data(rng, B, m, noise=1e-3):
+    x = np.linspace(0.0, 12.5, m)
+    tau = np.stack([rng.uniform(0.8, 1.3, B), rng.uniform(2.5, 3.6, B)], 1)
+    c = rng.uniform(1, 50, (B, 3))
+    Y = c[:, 0:1] * np.exp(-x / tau[:, 0:1]) + c[:, 1:2] * np.exp(-x / tau[:, 1:2]) + c[:, 2:3]
+    return x, Y + noise * np.abs(Y).max(1, keepdims=True) * rng.standard_normal(Y.shape), tau
+
+
+@pytest.mark.parametrize("m,weighted", [(513, False), (520, True), (700, False), (767, True), (768, False)])
+def test_single_rhs_evaluation_and_fit(m, weighted):
+    rng = np.random.default_rng(m)
+    B = 40
+    x, Y, tau = _data(rng, B, m)
+    w = rng.uniform(0.3, 2.0, m) if weighted else None
+    guess = tau * rng.uniform(0.85, 1.2, (B, 2))
+    mdl = vp.multi_exponential_model(x, guess[0], offset=True)
+    bp = vp.BatchProblem(mdl, Y, x=x, weights=w)
+    ev = bp.evaluate(guess)
+    ref = O.evaluate_batch(mdl, x, Y, guess, w=w, n_threads=4)
+    yw = Y if w is None else Y * w
+    for b in range(B):
+        assert np.abs(ev["C"][b] - ref["C"][b]).max() <= TOL * np.abs(ref["C"][b]).max()
+        assert np.abs(ev["r"][b] - ref["r"][b]).max() <= TOL * np.abs(yw[b]).max()
+        for k in range(2):
+            assert np.abs(ev["J"][b, k] - ref["J"][b, k]).max() <= TOL * np.abs(ref["J"][b, k]).max()
+    a, C, rep = bp.fit(guess)
+    ar, Cr, repr_, _secs = O.fit_batch(mdl, x, Y, guess, w=w, n_threads=4)
+    ok = (rep["termination"] > 0) & (repr_["termination"] > 0)
+    assert ((rep["termination"] > 0) == (repr_["termination"] > 0)).all() and ok.mean() > 0.9
+    assert (np.abs(a[ok] - ar[ok]).max(1) <= 1e-6 * np.abs(ar[ok]).max(1)).all()   # (both stop on ftol: the minimum is flat to sqrt(eps))
+    assert (np.abs(rep["objective"][ok] - repr_["objective"][ok]) <= 1e-8 * repr_["objective"][ok]).all()
+    bp.close()
+
+
+@pytest.mark.parametrize("S,m,weighted", [(6, 710, True), (33, 520, False), (7, 768, False)])
+def test_multiple_right_hand_sides(S, m, weighted):
+    rng = np.random.default_rng(S * m)
+    x = np.linspace(0.0, 12.5, m)
+    Cm = rng.uniform(1, 50, (S, 3))
+    Y = Cm[:, 0:1] * np.exp(-x / 1.0) + Cm[:, 1:2] * np.exp(-x / 3.0) + Cm[:, 2:3]
+    Y = Y + 1e-3 * np.abs(Y).max() * rng.standard_normal(Y.shape)
+    w = rng.uniform(0.3, 2.0, m) if weighted else None
+    guess = np.array([1.3, 3.7])
+    mdl = vp.multi_exponential_model(x, guess, offset=True)
+    bp = vp.BatchProblem(mdl, Y[None], x=x, weights=w)
+    ev = bp.evaluate(guess[None])
+    ref = O.Problem(mdl, x, Y, w=w)
+    ref.set_params(guess)
+    yw = Y if w is None else Y * w
+    assert np.abs(ev["C"][0] - ref.linear_coefficients()).max() <= TOL * np.abs(ref.linear_coefficients()).max()
+    assert np.abs(ev["r"][0] - ref.residuals()).max() <= TOL * np.abs(yw).max()
+    Jr = ref.jacobian()
+    for k in range(2):
+        assert np.abs(ev["J"][0, k] - Jr[k]).max() <= 1e-9 * np.abs(Jr[k]).max()
+    a, C, rep = bp.fit(guess[None])
+    rr = ref.fit()
+    assert rep["termination"][0] > 0 and rr.termination > 0
+    assert np.abs(a[0] - ref.params()).max() <= 1e-6 * np.abs(ref.params()).max()
+    assert abs(rep["objective"][0] - rr.objective) <= 1e-8 * rr.objective
+    bp.close()

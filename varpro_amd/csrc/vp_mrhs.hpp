@@ -407,7 +407,9 @@ __global__ void __launch_bounds__(64 * VP_MRHS_WAVES) mrhs_stream_kernel(const M
         load_rows<T, R>(yp, m, lane, yvec, y);
         // All row loops are processed in chunks of CH rows separated by scheduling fences: without them the
         // scheduler hoists the LDS reads of every (column, row) ahead (7 columns x R rows) and spills.
-        constexpr int CH = (R > VP_MRHS_CH) ? VP_MRHS_CH : R;
+        // (the chunk must divide R: 12 rows per lane take chunks of 4)
+        constexpr int CH = (R > VP_MRHS_CH) ? ((R % VP_MRHS_CH == 0) ? VP_MRHS_CH : ((R % 4 == 0) ? 4 : 2)) : R;
+        static_assert(R % CH == 0, "row chunks tile the lane's rows");
         // T = Q^T y
         T tq[N];
 #pragma unroll
@@ -1379,7 +1381,7 @@ template <typename T, class M, int R> int launch_mrhs_factor(const LaunchParams 
     MrhsFactorArgs<T, M> a;
     if (!fill_factor_args<T, M>(p, a)) return VP_ERR_UNSUPPORTED;
     // few problems: the factorisation is pure latency -> 4 waves per problem (R/4 rows per lane)
-    if constexpr (R % 4 == 0 && R / 4 >= 2) {
+    if constexpr (R % 8 == 0) { // (R / 4 rows per lane, in pairs)
         if (a.B <= 1024) {
             hipLaunchKernelGGL((mrhs_factor_kernel<T, M, R / 4, 4>), dim3((unsigned)a.B), dim3(256), 0, p.stream, a);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
@@ -1486,7 +1488,7 @@ template <typename T, class M, int R> int launch_mrhs_lm(const LaunchParams &p) 
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
     // few problems: LM step and factorisation are pure latency -> 4 waves per problem (R/4 rows per lane)
-    if constexpr (R % 4 == 0 && R / 4 >= 2) {
+    if constexpr (R % 8 == 0) { // (R / 4 rows per lane, in pairs)
         if (a.B <= 1024) {
             hipLaunchKernelGGL((mrhs_step_kernel<T, M, R / 4, 4>), dim3((unsigned)a.B), dim3(256), 0, p.stream, fa, a);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
