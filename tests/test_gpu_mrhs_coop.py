@@ -146,3 +146,34 @@ def test_repeated_fits_on_one_handle_follow_the_graph_length_adaptation():
     a, C, rep = bp.fit(guess_hard, solver=slv)
     assert rep["n_evals"][0] <= 2 * 4 + 1
     bp.close()
+
+
+@pytest.mark.parametrize("m,S,B", [(1500, 40, 1), (600, 9, 3), (2048, 64, 2)])
+def test_device_pointer_global_fit_equals_the_host_pointer_fit(m, S, B):
+    # device-pointer handles: the whole-fit graph reads alpha_0 from, and writes alpha / C / reports into, the caller's device
+    # arrays through the pinned MrhsIo record; host-pointer handles stage through the library's buffers.  Same kernels, same
+    # numbers -- bit for bit -- and the handle's own state (params, coefficients) agrees with what was returned.
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(m + S)
+    tau = [1.0, 3.0, 7.0]
+    xs, Ys = zip(*[_data(rng, S, m, tau) for _ in range(B)])
+    x, Y = xs[0], np.stack(Ys)
+    guess = np.tile(np.array([[1.2, 3.4, 7.9]]), (B, 1)) * rng.uniform(0.95, 1.05, (B, 3))
+    mdl = vp.multi_exponential_model(x, guess[0], offset=True)
+    bh = vp.BatchProblem(mdl, Y, x=x)
+    ah, Ch, reph = bh.fit(guess)
+    bh.close()
+    bd = vp.BatchProblem(mdl, torch.from_numpy(Y).to(dev), x=torch.from_numpy(x).to(dev))
+    g = torch.from_numpy(guess).to(dev)
+    for _ in range(2):   # (the second fit replays the graph sized from the first)
+        ad, Cd, repd = bd.fit(g)
+        repd = bd.report_to_numpy(repd)
+        assert np.array_equal(ad.cpu().numpy(), ah) and np.array_equal(Cd.cpu().numpy(), Ch)
+        assert np.array_equal(repd["n_evals"], reph["n_evals"]) and np.array_equal(repd["objective"], reph["objective"])
+        assert np.array_equal(g.cpu().numpy(), guess)                 # the caller's initial parameters are left alone
+    assert np.array_equal(bd.params().cpu().numpy(), ah)
+    assert np.array_equal(bd.linear_coefficients().cpu().numpy(), Ch)
+    a2, C2, rep2 = bd.fit(g, want_coefficients=False)                 # no coefficient array from the caller
+    assert C2 is None and np.array_equal(a2.cpu().numpy(), ah)
+    bd.close()
