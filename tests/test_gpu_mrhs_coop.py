@@ -177,3 +177,35 @@ def test_device_pointer_global_fit_equals_the_host_pointer_fit(m, S, B):
     a2, C2, rep2 = bd.fit(g, want_coefficients=False)                 # no coefficient array from the caller
     assert C2 is None and np.array_equal(a2.cpu().numpy(), ah)
     bd.close()
+
+
+def test_device_pointer_fits_that_outlast_the_graph():
+    # a fit longer than the captured graph continues with the tail graph; on a device-pointer handle every replay writes the
+    # caller's arrays through the MrhsIo record -- easy / hard / easy data on one handle against host-pointer handles
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(21)
+    m, S = 1400, 10
+    x, Y_easy = _data(rng, S, m, [1.0, 3.0, 7.0], noise=1e-4)
+    _, Y_hard = _data(rng, S, m, [0.8, 1.1, 9.0], noise=5e-2)
+    g_easy, g_hard = np.array([[1.1, 3.2, 7.5]]), np.array([[0.3, 4.0, 20.0]])
+    mdl = vp.multi_exponential_model(x, g_easy[0], offset=True)
+
+    def host(Y, g):
+        bp = vp.BatchProblem(mdl, Y[None], x=x)
+        out = bp.fit(g)
+        bp.close()
+        return out
+
+    refs = {"easy": host(Y_easy, g_easy), "hard": host(Y_hard, g_hard)}
+    assert refs["hard"][2]["n_evals"][0] > 13          # longer than the first graph (12 iterations + the initial evaluation)
+    bd = vp.BatchProblem(mdl, torch.from_numpy(Y_easy[None]).to(dev), x=torch.from_numpy(x).to(dev))
+    for kind in ("hard", "easy", "hard", "easy"):
+        Y, g = (Y_hard, g_hard) if kind == "hard" else (Y_easy, g_easy)
+        bd.set_observations(torch.from_numpy(Y[None]).to(dev))
+        a, C, rep = bd.fit(torch.from_numpy(g).to(dev))
+        rep = bd.report_to_numpy(rep)
+        ra, rC, rrep = refs[kind]
+        assert np.array_equal(a.cpu().numpy(), ra) and np.array_equal(C.cpu().numpy(), rC)
+        assert rep["n_evals"][0] == rrep["n_evals"][0] and rep["termination"][0] == rrep["termination"][0]
+    bd.close()
