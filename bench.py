@@ -501,8 +501,9 @@ def main():
         # ---- generic fallback kernels (vp_generic.hpp): a model / size WITHOUT a specialised kernel set ----
         if world == 1 and not args.no_side_configs:
             # the O'Leary-Rust example model (shared_test_code/src/models.rs:397-425: exp(-a2 t) cos(a3 t), exp(-a1 t) cos(a2 t);
-            # n = 2, q = 3, 4 dependency pairs, a shared parameter) at m = 3000 -- beyond the 1024 rows of its specialised set
-            Bg, mg = 4096, 3000
+            # n = 2, q = 3, 4 dependency pairs, a shared parameter) at m = 5000 -- beyond the 4096 rows of its largest specialised
+            # set (round 3 added a 4-wave set for 1024 < m <= 4096: m = 3000, this leg's length until then, no longer falls back)
+            Bg, mg = 4096, 5000
             tg = np.linspace(0.0, 1.5, mg)
             rg = synth.SplitMix64(np.uint64(0x5EED3000) + np.arange(Bg, dtype=np.uint64))
             at = np.stack([1.0 * (1 + 0.1 * rg.uniform(-1, 1)), 2.5 * (1 + 0.1 * rg.uniform(-1, 1)), 4.0 * (1 + 0.1 * rg.uniform(-1, 1))], 1)
