@@ -20,8 +20,11 @@ def _data(rng, S, m, tau, noise=1e-3):
 
 
 @pytest.mark.parametrize("nexp", [2, 3])
+# (the cooperative kernels serve the 32-rows-per-lane set: 1792 < m <= 2048 for two exponentials, 1536 < m <= 2048 for three,
+# m even; the shorter and the odd lengths below run the one-wave-per-column kernel of the in-between sets)
 @pytest.mark.parametrize("S,m,weighted", [(2, 2048, False), (3, 1026, True), (33, 1500, False), (64, 2048, True),
-                                          (7, 1501, False), (129, 1030, False), (5, 2046, True)])
+                                          (7, 1501, False), (129, 1030, False), (5, 2046, True), (3, 1794, True),
+                                          (33, 1900, False), (7, 1801, False), (129, 1796, False)])
 def test_trait_outputs_match_oracle(nexp, S, m, weighted):
     rng = np.random.default_rng(1000 * nexp + S + m)
     tau = [1.0, 3.0, 7.0][:nexp]
@@ -50,7 +53,7 @@ def test_trait_outputs_match_oracle(nexp, S, m, weighted):
 
 def test_trait_outputs_several_problems_each_with_its_own_parameters():
     rng = np.random.default_rng(5)
-    B, S, m = 3, 19, 1400
+    B, S, m = 3, 19, 1900
     tau = [1.0, 3.0, 7.0]
     xs, Ys = zip(*[_data(rng, S, m, tau) for _ in range(B)])
     x = xs[0]
@@ -70,7 +73,7 @@ def test_trait_outputs_several_problems_each_with_its_own_parameters():
     bp.close()
 
 
-@pytest.mark.parametrize("S,m", [(9, 1500), (40, 2048)])
+@pytest.mark.parametrize("S,m", [(9, 1500), (9, 1850), (40, 2048)])
 def test_rank_deficient_basis_minimum_norm_solution_in_the_cooperative_kernel(S, m):
     # tau1 == tau2 (src/solvers/levmar/mod.rs:51-54: svd.solve(eps) -> minimum-norm coefficients for every column)
     rng = np.random.default_rng(S + m)
@@ -89,7 +92,7 @@ def test_rank_deficient_basis_minimum_norm_solution_in_the_cooperative_kernel(S,
     bp.close()
 
 
-@pytest.mark.parametrize("S,m,weighted", [(24, 1500, False), (70, 2048, True)])
+@pytest.mark.parametrize("S,m,weighted", [(24, 1500, False), (24, 1880, False), (70, 2048, True)])
 def test_global_fit_trajectory_matches_oracle(S, m, weighted):
     rng = np.random.default_rng(S * m)
     tau = [1.0, 3.0, 7.0]
@@ -117,7 +120,7 @@ def test_repeated_fits_on_one_handle_follow_the_graph_length_adaptation():
     # graph when a fit outlasts it: a sequence of fits of different lengths on ONE handle must give, fit by fit, exactly
     # what a fresh handle gives (same kernels, same order of operations: bit-identical reports and parameters)
     rng = np.random.default_rng(11)
-    m, S = 1500, 12
+    m, S = 1900, 12
     tau = [1.0, 3.0, 7.0]
     x, Y_easy = _data(rng, S, m, tau, noise=1e-4)
     _, Y_hard = _data(rng, S, m, [0.8, 1.1, 9.0], noise=5e-2)
@@ -148,7 +151,7 @@ def test_repeated_fits_on_one_handle_follow_the_graph_length_adaptation():
     bp.close()
 
 
-@pytest.mark.parametrize("m,S,B", [(1500, 40, 1), (600, 9, 3), (2048, 64, 2)])
+@pytest.mark.parametrize("m,S,B", [(1500, 40, 1), (600, 9, 3), (1900, 40, 1), (2048, 64, 2)])
 def test_device_pointer_global_fit_equals_the_host_pointer_fit(m, S, B):
     # device-pointer handles: the whole-fit graph reads alpha_0 from, and writes alpha / C / reports into, the caller's device
     # arrays through the pinned MrhsIo record; host-pointer handles stage through the library's buffers.  Same kernels, same
@@ -185,7 +188,7 @@ def test_device_pointer_fits_that_outlast_the_graph():
     import torch
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(21)
-    m, S = 1400, 10
+    m, S = 1840, 10
     x, Y_easy = _data(rng, S, m, [1.0, 3.0, 7.0], noise=1e-4)
     _, Y_hard = _data(rng, S, m, [0.8, 1.1, 9.0], noise=5e-2)
     g_easy, g_hard = np.array([[1.1, 3.2, 7.5]]), np.array([[0.3, 4.0, 20.0]])

@@ -5,7 +5,7 @@ import numpy as np, torch
 import varpro_amd as vp
 from varpro_amd import synth, _lib
 dev = torch.device("cuda", 0)
-for m in (1024, 2048):
+for m in [int(a) for a in sys.argv[1:]] or (1024, 2048):
     for B in (16384,):
         d = synth.multi_exp_batch(B, 3, m, [1.0, 3.0, 7.0], noise=1e-3, spread=0.1, guess_spread=0.1)
         mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0])

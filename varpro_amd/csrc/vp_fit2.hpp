@@ -48,10 +48,12 @@ template <typename T, int N, int Q> struct alignas(8) SlotRec {
 #ifndef VP_SLOT_CAP
 #define VP_SLOT_CAP 8
 #endif
-template <typename T, int R, int W, int NG, int BLOCKS_PER_CU> constexpr int fit2_slots() {
+// slots per group: what the LDS of a CU holds next to the shared grid -- per slot one data column and one LM record (REC
+// bytes: a wide model's records are not small change at 24 rows per lane), plus 3 KiB of constants / exchange area
+template <typename T, int R, int W, int NG, int BLOCKS_PER_CU, int REC = 0> constexpr int fit2_slots() {
     constexpr int col = 64 * R * W * (int)sizeof(T);
-    constexpr int budget = (160 * 1024) / BLOCKS_PER_CU - col - 3 * 1024; // grid + records/constants/exchange area
-    constexpr int gs = budget / (NG * col);
+    constexpr int budget = (160 * 1024) / BLOCKS_PER_CU - col - 3 * 1024;
+    constexpr int gs = budget / (NG * (col + REC));
     return gs < 1 ? 1 : (gs > VP_SLOT_CAP ? VP_SLOT_CAP : gs);
 }
 
@@ -993,7 +995,7 @@ template <typename T, class M, int R, int W = 1> int launch_fit2(const LaunchPar
         constexpr int NG = (W == 1) ? 4 : 1;                 // groups per workgroup
         constexpr int WPS = waves_for<T, R, M::N + M::P>();  // resident waves per SIMD
         constexpr int BPC = (4 * WPS) / (W * NG) > 0 ? (4 * WPS) / (W * NG) : 1; // workgroups per CU
-        constexpr int GS = fit2_slots<T, R, W, NG, BPC>();
+        constexpr int GS = fit2_slots<T, R, W, NG, BPC, (int)sizeof(SlotRec<T, M::N, M::Q>)>();
         // fit_group: 0 = automatic, 1 = one problem per wave(-group) (fit_kernel), 2 = slots regardless of B.
         // Automatic, W = 1: a launch costs (work / throughput) + the latency of its slowest fit (~0.5 ms at m = 1024:
         // >100 LM evaluations of one problem, nothing to overlap them with).  The slot kernel has the higher
@@ -1040,6 +1042,7 @@ template <typename T, class M, int R, int W = 1> int launch_fit2(const LaunchPar
         if (hipMemsetD32Async((hipDeviceptr_t)p.queue, (int)(blocks * NG * GS), 1, p.stream) != hipSuccess) return VP_ERR_HIP;
         const size_t lds = (size_t)64 * R * W * sizeof(T) * (1 + (size_t)NG * GS) + (size_t)NG * GS * sizeof(SlotRec<T, M::N, M::Q>) +
                            sizeof(SlotConsts<T>) + (size_t)((GS + 3) / 4) * 4 * sizeof(int) + (size_t)group_xch_bytes<W>() + 16;
+        if (lds > (size_t)(160 * 1024) / BPC) return launch_fit<T, M, R, W>(p); // (never with the slot count above; a guard)
 #define VP_F2(PADM_)                                                                                                   \
     hipLaunchKernelGGL((fit2_kernel<T, M, R, W, PADM_, GS, NG, WPS>), dim3((unsigned)blocks), dim3(64 * W * NG), lds,   \
                        p.stream, args)
