@@ -1,5 +1,6 @@
 """The in-between kernel sets of the double exponential + offset (fp64): 12 rows per lane (512 < m <= 768) and 20 / 24 / 28
-rows per lane (1024 < m <= 1280 / 1536 / 1792): evaluation, fit and the multiple-right-hand-side path against the oracle -- a
+rows per lane (1024 < m <= 1280 / 1536 / 1792), and the two-wave sets beyond 2048 rows (20 / 24 / 28 rows per lane on two
+waves: m <= 2560 / 3072 / 3584): evaluation, fit and the multiple-right-hand-side path against the oracle -- a
 length just above a set's capacity must not pay for twice the rows (or for the spilling 32-rows-per-lane set), and the
 row-chunked MRHS streaming kernel must tile any even number of rows per lane (chunks of 4 where 8 does not divide it)."""
 import numpy as np
@@ -21,7 +22,8 @@ def _data(rng, B, m, noise=1e-3):
 
 
 @pytest.mark.parametrize("m,weighted", [(513, False), (520, True), (700, False), (767, True), (768, False), (1026, False), (1100, True),
-                                        (1280, False), (1290, True), (1536, False), (1537, False), (1700, True), (1792, False)])
+                                        (1280, False), (1290, True), (1536, False), (1537, False), (1700, True), (1792, False),
+                                        (2100, False), (2560, True), (2562, False), (3000, True), (3584, False), (3600, False)])
 def test_single_rhs_evaluation_and_fit(m, weighted):
     rng = np.random.default_rng(m)
     B = 40
