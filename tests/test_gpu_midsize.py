@@ -80,3 +80,34 @@ def test_multiple_right_hand_sides(S, m, weighted):
     assert np.abs(a[0] - ref.params()).max() <= 1e-6 * np.abs(ref.params()).max()
     assert abs(rep["objective"][0] - rr.objective) <= 1e-8 * rr.objective
     bp.close()
+
+
+@pytest.mark.parametrize("m,weighted", [(1100, False), (1536, True), (1537, False), (2048, False), (2100, True), (3072, False),
+                                        (3500, False), (4096, True)])
+def test_single_exponential_beyond_1024_rows(m, weighted):
+    # one exponential + offset: 24 / 32 rows per lane up to 2048 rows, the same on two waves up to 4096 -- without these sets
+    # the model dropped to the generic kernels above 1024 rows
+    rng = np.random.default_rng(m + 1)
+    B = 24
+    x = np.linspace(0.0, 10.0, m)
+    tau = rng.uniform(1.5, 2.5, (B, 1))
+    c = rng.uniform(1, 50, (B, 2))
+    Y = c[:, 0:1] * np.exp(-x / tau) + c[:, 1:2]
+    Y = Y + 1e-3 * np.abs(Y).max(1, keepdims=True) * rng.standard_normal(Y.shape)
+    w = rng.uniform(0.3, 2.0, m) if weighted else None
+    guess = tau * rng.uniform(0.8, 1.25, (B, 1))
+    mdl = vp.multi_exponential_model(x, guess[0], offset=True)
+    bp = vp.BatchProblem(mdl, Y, x=x, weights=w)
+    ev = bp.evaluate(guess)
+    ref = O.evaluate_batch(mdl, x, Y, guess, w=w, n_threads=4)
+    yw = Y if w is None else Y * w
+    for b in range(B):
+        assert np.abs(ev["C"][b] - ref["C"][b]).max() <= TOL * np.abs(ref["C"][b]).max()
+        assert np.abs(ev["r"][b] - ref["r"][b]).max() <= TOL * np.abs(yw[b]).max()
+        assert np.abs(ev["J"][b, 0] - ref["J"][b, 0]).max() <= TOL * np.abs(ref["J"][b, 0]).max()
+    a, C, rep = bp.fit(guess)
+    ar, Cr, rr, _secs = O.fit_batch(mdl, x, Y, guess, w=w, n_threads=4)
+    assert (rep["termination"] > 0).all() and (rr["termination"] > 0).all()
+    assert (np.abs(a - ar).max(1) <= 1e-6 * np.abs(ar).max(1)).all()
+    assert (np.abs(rep["objective"] - rr["objective"]) <= 1e-8 * rr["objective"]).all()
+    bp.close()

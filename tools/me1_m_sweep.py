@@ -1,0 +1,18 @@
+"""single exponential + offset across problem lengths"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, varpro_amd as vp
+from varpro_amd import synth, _lib
+dev = torch.device("cuda", 0)
+B = 32768
+for m in (128, 512, 1024, 1100, 1536, 2048, 2100, 3072, 4096, 4100):
+    d = synth.multi_exp_batch(B, 1, m, [2.0], noise=1e-3, spread=0.2, guess_spread=0.2)
+    mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0])
+    bp = vp.BatchProblem(mdl, torch.from_numpy(d["Y"]).to(dev), x=torch.from_numpy(d["x"]).to(dev)); bp.set_timing(True)
+    g = torch.from_numpy(d["tau_guess"]).to(dev)
+    ts = []
+    for _ in range(4):
+        a, c, rep = bp.fit(g, want_coefficients=False); ts.append(bp.last_kernel_ms(_lib.VP_KERNEL_FIT))
+    r = bp.report_to_numpy(rep)
+    print("m %5d B %d fit %.3f ms %.2f Mfits/s evals/fit %.1f ok %.3f" % (m, B, min(ts), B / min(ts) / 1e3, r["n_evals"].mean(), (r["termination"] > 0).mean()), flush=True)
+    bp.close()
