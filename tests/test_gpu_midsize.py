@@ -111,3 +111,35 @@ def test_single_exponential_beyond_1024_rows(m, weighted):
     assert (np.abs(a - ar).max(1) <= 1e-6 * np.abs(ar).max(1)).all()
     assert (np.abs(rep["objective"] - rr["objective"]) <= 1e-8 * rr["objective"]).all()
     bp.close()
+
+
+@pytest.mark.parametrize("m,weighted", [(600, False), (1100, True), (1536, False), (2100, False), (3072, True), (4096, False)])
+def test_triple_exponential_at_the_in_between_and_four_wave_sets(m, weighted):
+    # three exponentials + offset: 12 / 20 / 24 rows per lane (m <= 768 / 1280 / 1536) and four waves beyond 2048 rows
+    # (12 / 16 rows per lane: m <= 3072 / 4096)
+    rng = np.random.default_rng(m + 3)
+    B = 16
+    x = np.linspace(0.0, 25.0, m)
+    tau = np.stack([rng.uniform(0.9, 1.1, B), rng.uniform(2.8, 3.3, B), rng.uniform(8.0, 10.0, B)], 1)
+    c = rng.uniform(5, 50, (B, 4))
+    Y = sum(c[:, j:j + 1] * np.exp(-x / tau[:, j:j + 1]) for j in range(3)) + c[:, 3:4]
+    Y = Y + 1e-4 * np.abs(Y).max(1, keepdims=True) * rng.standard_normal(Y.shape)
+    w = rng.uniform(0.5, 1.5, m) if weighted else None
+    guess = tau * rng.uniform(0.95, 1.05, (B, 3))
+    mdl = vp.multi_exponential_model(x, guess[0], offset=True)
+    bp = vp.BatchProblem(mdl, Y, x=x, weights=w)
+    ev = bp.evaluate(guess)
+    ref = O.evaluate_batch(mdl, x, Y, guess, w=w, n_threads=4)
+    yw = Y if w is None else Y * w
+    for b in range(B):
+        assert np.abs(ev["C"][b] - ref["C"][b]).max() <= 1e-9 * np.abs(ref["C"][b]).max()
+        assert np.abs(ev["r"][b] - ref["r"][b]).max() <= TOL * np.abs(yw[b]).max()
+        for k in range(3):
+            assert np.abs(ev["J"][b, k] - ref["J"][b, k]).max() <= 1e-9 * np.abs(ref["J"][b, k]).max()
+    a, C, rep = bp.fit(guess)
+    ar, Cr, rr, _secs = O.fit_batch(mdl, x, Y, guess, w=w, n_threads=4)
+    assert ((rep["termination"] > 0) == (rr["termination"] > 0)).all()
+    ok = (rep["termination"] > 0)
+    assert ok.mean() > 0.8
+    assert (np.abs(rep["objective"][ok] - rr["objective"][ok]) <= 1e-6 * rr["objective"][ok]).all()
+    bp.close()
