@@ -37,7 +37,7 @@ def test_fp64_four_waves_per_problem_matches_oracle(m):
     bp.close()
 
 
-@pytest.mark.parametrize("m", [100, 1024])
+@pytest.mark.parametrize("m", [100, 400, 512, 1024, 1100, 2048])   # (sets of 2 / 8 / 16 / 32 rows per lane)
 def test_fp32_double_exponential(m):
     # ScalarType = f32 (src/model/builder/mod.rs:66).  Tolerances: eps32 * cond(Phi) ~ 6e-8 * 1e2..1e3
     d = synth.double_exp_batch(16, m=m, noise=1e-3)
