@@ -23,7 +23,8 @@ def _data(rng, B, m, noise=1e-3):
 
 @pytest.mark.parametrize("m,weighted", [(513, False), (520, True), (700, False), (767, True), (768, False), (1026, False), (1100, True),
                                         (1280, False), (1290, True), (1536, False), (1537, False), (1700, True), (1792, False),
-                                        (2100, False), (2560, True), (2562, False), (3000, True), (3584, False), (3600, False)])
+                                        (2100, False), (2560, True), (2562, False), (3000, True), (3584, False), (3600, False),
+                                        (5000, False), (6144, True), (7000, False), (8192, False)])
 def test_single_rhs_evaluation_and_fit(m, weighted):
     rng = np.random.default_rng(m)
     B = 40
@@ -83,7 +84,7 @@ def test_multiple_right_hand_sides(S, m, weighted):
 
 
 @pytest.mark.parametrize("m,weighted", [(1100, False), (1536, True), (1537, False), (2048, False), (2100, True), (3072, False),
-                                        (3500, False), (4096, True)])
+                                        (3500, False), (4096, True), (5000, False), (8192, True)])
 def test_single_exponential_beyond_1024_rows(m, weighted):
     # one exponential + offset: 24 / 32 rows per lane up to 2048 rows, the same on two waves up to 4096 -- without these sets
     # the model dropped to the generic kernels above 1024 rows

@@ -856,6 +856,9 @@ static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dty
     // a specialised (register-resident) kernel set if one is instantiated for this (dtype, model, m), else the generic
     // fallback kernels (vp_generic.hpp): any descriptor, any m -- slower, but never a CPU path and never "unsupported"
     const KernelEntry *kern = find_kernels(dtype, *model, m, S);
+    // weighted problems on the largest multi-wave sets: grid + weights + data column of 64 R W rows each must fit the 160 KiB
+    // of LDS the one-problem-per-group fit kernel stages them in (32 rows per lane on four waves, fp64: 3 x 64 KiB does not)
+    if (kern && w && (size_t)3 * 64 * kern->R * kern->W * tsize(dtype) + 4096 > (size_t)160 * 1024) kern = nullptr;
     if (!kern) kern = generic_kernels(dtype);
     // a global fit (S > 1) on a specialised set WITHOUT multiple-right-hand-side kernels (the multi-wave sets: double
     // exponential at 2048 < m <= 4096, the fp32 Gram shape) runs on the generic kernels as well
