@@ -64,8 +64,11 @@ enum {
     VP_BASIS_EXP_RATE = 2,  /* exp(-p0*t)              d/dp0 = -t*exp(-p0*t)                                    */
     VP_BASIS_EXP_COS = 3,   /* exp(-p0*t)*cos(p1*t)    d/dp0 = -t*f ; d/dp1 = -t*exp(-p0*t)*sin(p1*t)
                                shared_test_code/src/models.rs:310-372 (O'Leary example)                         */
-    VP_BASIS_SIN_PHASE = 4  /* sin(p0*t+p1)            d/dp0 = t*cos(p0*t+p1) ; d/dp1 = cos(p0*t+p1)
+    VP_BASIS_SIN_PHASE = 4, /* sin(p0*t+p1)            d/dp0 = t*cos(p0*t+p1) ; d/dp1 = cos(p0*t+p1)
                                src/test_helpers/mod.rs:28-52                                                     */
+    VP_BASIS_EXTERNAL = 5   /* evaluated by the CALLER: any SeparableNonlinearModel (src/model/mod.rs:239-363), in
+                               particular the closure-based SeparableModel (:441-512).  Only produced by
+                               vp_batch_create_external; see "models outside the descriptor language" below          */
 };
 
 /*
@@ -251,6 +254,59 @@ int vp_evaluate(vp_batch *h, const void *alpha, void *r_out, void *J_out, void *
  */
 enum { VP_BASIS_SKIP_INVARIANT = 1 };
 int vp_basis(vp_batch *h, const void *alpha, void *Phi_out, void *dPhi_out, int flags);
+
+/* ---- models outside the descriptor language --------------------------------
+ *
+ * The reference's plugin boundary is a TRAIT: any `SeparableNonlinearModel` (src/model/mod.rs:239-363) works with its
+ * solver -- the closure-based `SeparableModel` (src/model/mod.rs:441-512, src/model/model_basis_function.rs:11-28) and
+ * every hand-written impl (shared_test_code/src/models.rs:40-150).  A model the closed descriptor language above cannot
+ * express (a Gaussian, a Lorentzian, a basis function of three parameters, a table look-up, ...) crosses this ABI as
+ * the VALUES the trait returns: the caller evaluates `eval()` -> Phi and `eval_partial_deriv(k)` -> its non-zero
+ * columns; the device does everything downstream of them -- weighting (src/solvers/levmar/mod.rs:47,141), the
+ * factorisation / truncated solve / residual (:51-59) and the Kaufman Jacobian (:101-201).
+ *
+ * vp_batch_create_external == SeparableProblemBuilder::{new|mrhs, observations, weights, epsilon, build}
+ * (src/problem/builder.rs:116-324) for a model that is known by its SHAPE only:
+ *   n_basis, n_params   base_function_count() / parameter_count()                   src/model/mod.rs:256-259
+ *   n_pairs, pair_basis[], pair_param[]
+ *                       the (basis j, parameter k) pairs with d phi_j / d alpha_k != 0, i.e. the columns
+ *                       eval_partial_deriv(k) does not leave zero (src/model/mod.rs:473-512; the "Ind" table of
+ *                       matlab/examples/adaex.m:33-34).  Any order, each pair once, n_pairs <= VP_MAX_PAIRS.  A basis
+ *                       function may depend on ANY number of parameters (no VP_MAX_BASIS_PARAMS limit here), and a
+ *                       caller that does not know the sparsity lists all n*q pairs.
+ * There is no grid: the independent variable is the caller's business (src/model/mod.rs:441-471 captures it in the
+ * closures).  Y, w, svd_epsilon, flags (VP_FLAG_DEVICE_PTRS, VP_FLAG_W_PER_PROBLEM, VP_FLAG_OWN_STREAM), device and
+ * hip_stream as for vp_batch_create.
+ *
+ * On such a handle:
+ *   vp_set_params_with_basis   == SeparableProblem::set_params (src/solvers/levmar/mod.rs:42-73) with the model call at
+ *                              :43-45 (`model.set_params(alpha); model.eval()`) replaced by its result:
+ *                                Phi   [B][n][m]         UNWEIGHTED basis matrix of every problem (column j = basis j)
+ *                                dPhi  [B][n_pairs][m]   UNWEIGHTED d phi_j / d alpha_k for the pairs in table order, or
+ *                                                        NULL (derivatives follow with vp_jacobian_with_derivatives --
+ *                                                        the LM driver asks for a Jacobian only at accepted points)
+ *                              alpha is stored (vp_params) but not interpreted.  Caches C, R, cost, status like
+ *                              vp_set_params.  Host-pointer handles copy Phi / dPhi; device-pointer handles keep the
+ *                              POINTERS: the arrays must stay valid and unchanged until the next vp_set_params_with_basis
+ *                              / vp_evaluate_with_basis / vp_batch_destroy (the model owns its matrices in the
+ *                              reference, too).
+ *   vp_jacobian_with_derivatives == SeparableProblem::jacobian (:101-201) with `model.eval_partial_deriv(k)` (:141)
+ *                              replaced by its non-zero columns dPhi [B][n_pairs][m] at the current parameters.
+ *   vp_evaluate_with_basis     the fused form (== vp_evaluate): Phi, dPhi in -> any subset of r, J, C, cost, status out in
+ *                              one pass over the columns.  dPhi may be NULL when J_out is.
+ *   vp_residuals, vp_jacobian (needs the dPhi of the last vp_set_params_with_basis), vp_linear_coeffs, vp_cost,
+ *   vp_params, vp_weighted_data, vp_set_observations, vp_best_fit, vp_statistics, vp_synchronize work as on any handle.
+ *   vp_set_params / vp_evaluate / vp_basis / vp_fit: VP_ERR_UNSUPPORTED -- the device cannot evaluate the model; the LM
+ *   loop is the caller's (the reference's own LevenbergMarquardt::minimize over the trait, src/solvers/levmar/mod.rs:247;
+ *   tests/c/test_external_model.c drives one).
+ */
+int vp_batch_create_external(vp_batch **h, int32_t n_basis, int32_t n_params, int32_t n_pairs, const int32_t *pair_basis,
+                             const int32_t *pair_param, int dtype, int64_t m, int64_t S, int64_t B, const void *Y,
+                             const void *w, double svd_epsilon, int flags, int device, void *hip_stream);
+int vp_set_params_with_basis(vp_batch *h, const void *alpha, const void *Phi, const void *dPhi);
+int vp_jacobian_with_derivatives(vp_batch *h, const void *dPhi, void *J_out, int32_t *status);
+int vp_evaluate_with_basis(vp_batch *h, const void *alpha, const void *Phi, const void *dPhi, void *r_out, void *J_out,
+                           void *C_out, double *cost_out, int32_t *status);
 
 /* ---- solver surface ------------------------------------------------------------------- */
 

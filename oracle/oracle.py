@@ -46,6 +46,11 @@ class Report(C.Structure):
 REPORT_DTYPE = np.dtype([("termination", np.int32), ("n_evals", np.int32), ("objective", np.float64)])
 
 
+# callbacks of a model outside the descriptor language (vpo_problem_set_external_model): eval() and eval_partial_deriv(k)
+EXT_EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
+EXT_DPHI_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double))
+
+
 def build():
     """(re)build liboracle with the committed Makefile"""
     subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -84,6 +89,8 @@ def _load():
                                        dp, dp, dp, C.POINTER(C.c_int32), C.c_int]
     lib.vpo_lm_opts_default.argtypes = [C.POINTER(LmOpts)]
     lib.vpo_max_threads.restype = C.c_int
+    lib.vpo_problem_set_external_model.argtypes = [C.c_void_p, EXT_EVAL_FN, EXT_DPHI_FN, C.c_void_p]
+    lib.vpo_problem_set_external_model.restype = None
     return lib
 
 
@@ -132,6 +139,12 @@ def default_opts(**kw):
     return o
 
 
+def make_shape_desc(n_basis, n_params):
+    """descriptor that only carries the shape of a caller-evaluated model (kinds unused)"""
+    d = make_desc([CONST] * n_basis, [()] * n_basis, n_params)
+    return d
+
+
 def multiexp_desc(n_exp, offset=True):
     kinds = [EXP_DECAY] * n_exp + ([CONST] if offset else [])
     params = [(i,) for i in range(n_exp)] + ([()] if offset else [])
@@ -141,9 +154,12 @@ def multiexp_desc(n_exp, offset=True):
 class Problem:
     """one SeparableProblem on the CPU oracle (Y: (m,) or (S, m) i.e. [s][i])"""
 
-    def __init__(self, model, t, Y, w=None, eps=-1.0):
+    def __init__(self, model, t, Y, w=None, eps=-1.0, external=None):
+        """external = (eval, dphi): a model outside the descriptor language, i.e. ANY SeparableNonlinearModel
+        (src/model/mod.rs:239-363) -- eval(alpha) -> Phi (n, m), dphi(alpha, k) -> D_k (n, m) with zero rows for
+        basis functions that do not depend on alpha_k; `model` then only carries the shape (make_shape_desc)."""
         self.desc = desc_of(model)
-        self.t = np.ascontiguousarray(t, dtype=np.float64)
+        self.t = np.ascontiguousarray(np.zeros(np.asarray(Y).shape[-1]) if t is None else t, dtype=np.float64)
         Y = np.ascontiguousarray(Y, dtype=np.float64)
         self.single = Y.ndim == 1
         Y2 = Y.reshape(1, -1) if self.single else Y
@@ -155,6 +171,20 @@ class Problem:
                                            float(eps), C.byref(err))
         if not self._h:
             raise ValueError("oracle problem build error %d" % err.value)
+        if external is not None:
+            ev, dv = external
+            n, m, q = self.n, self.m, self.q
+
+            def _eval(_user, a_ptr, out_ptr):
+                a = np.ctypeslib.as_array(a_ptr, shape=(max(q, 1),))[:q]
+                np.ctypeslib.as_array(out_ptr, shape=(n, m))[:] = np.asarray(ev(a.copy()), dtype=np.float64).reshape(n, m)
+
+            def _dphi(_user, a_ptr, k, out_ptr):
+                a = np.ctypeslib.as_array(a_ptr, shape=(max(q, 1),))[:q]
+                np.ctypeslib.as_array(out_ptr, shape=(n, m))[:] = np.asarray(dv(a.copy(), int(k)), dtype=np.float64).reshape(n, m)
+
+            self._ext = (EXT_EVAL_FN(_eval), EXT_DPHI_FN(_dphi))  # keep alive
+            lib().vpo_problem_set_external_model(self._h, self._ext[0], self._ext[1], None)
 
     def __del__(self):
         if getattr(self, "_h", None):

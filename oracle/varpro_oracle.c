@@ -272,8 +272,8 @@ vpo_problem *vpo_problem_create(const vp_model_desc *model, int m, int S, const 
     p->model = *model;
     p->m = m;
     p->S = S;
-    p->t = (double *)malloc(sizeof(double) * m);
-    memcpy(p->t, t, sizeof(double) * m);
+    p->t = (double *)calloc(m, sizeof(double));
+    if (t) memcpy(p->t, t, sizeof(double) * m); /* (NULL: a caller-evaluated model, vpo_problem_set_external_model) */
     p->w = NULL;
     if (w) {
         p->w = (double *)malloc(sizeof(double) * m);
@@ -300,6 +300,24 @@ vpo_problem *vpo_problem_create(const vp_model_desc *model, int m, int S, const 
     p->ws_fjac = (double *)malloc(sizeof(double) * (size_t)m * S * (q > 0 ? q : 1));
     p->cached = 0;
     return p;
+}
+
+void vpo_problem_set_external_model(vpo_problem *p, void (*eval)(void *, const double *, double *),
+                                    void (*dphi)(void *, const double *, int, double *), void *user) {
+    p->ext_eval = eval;
+    p->ext_dphi = dphi;
+    p->ext_user = user;
+    p->cached = 0;
+}
+
+/* the two model calls of the path: the descriptor formulas, or the user's trait impl (src/model/mod.rs:308, 359-362) */
+static void model_eval(const vpo_problem *p, double *Phi) {
+    if (p->ext_eval) p->ext_eval(p->ext_user, p->alpha, Phi);
+    else vpo_eval_phi(&p->model, p->m, p->t, p->alpha, Phi);
+}
+static void model_dphi(const vpo_problem *p, int k, double *Dk) {
+    if (p->ext_eval) p->ext_dphi(p->ext_user, p->alpha, k, Dk);
+    else vpo_eval_dphi(&p->model, p->m, p->t, p->alpha, k, Dk);
 }
 
 /* New observations for an existing problem (same model, grid and weights): == building another SeparableProblem
@@ -340,7 +358,7 @@ void vpo_set_params(vpo_problem *p, const double *alpha) {
     memcpy(p->alpha, alpha, sizeof(double) * q); /* :43 model.set_params(params.clone()) */
     double *Phi_w = p->ws_phi;
     /* :47  Phi_w = &self.weights * Phi */
-    vpo_eval_phi(&p->model, m, p->t, p->alpha, Phi_w);
+    model_eval(p, Phi_w);
     if (p->w)
         for (int j = 0; j < n; ++j)
             for (int i = 0; i < m; ++i) Phi_w[i + (size_t)j * m] *= p->w[i];
@@ -391,7 +409,7 @@ int vpo_jacobian(vpo_problem *p, double *J_out) {
     const double *U = p->U;
     for (int k = 0; k < q; ++k) {
         /* :141  Dk = &self.weights * model.eval_partial_deriv(k) */
-        vpo_eval_dphi(&p->model, m, p->t, p->alpha, k, Dk);
+        model_dphi(p, k, Dk);
         if (p->w)
             for (int j = 0; j < n; ++j)
                 for (int i = 0; i < m; ++i) Dk[i + (size_t)j * m] *= p->w[i];
@@ -448,7 +466,7 @@ int vpo_best_fit(const vpo_problem *p, double *fit_out) {
     if (!p->cached) return 0;
     const int m = p->m, S = p->S, n = p->model.n_basis;
     double *Phi = (double *)malloc(sizeof(double) * (size_t)m * n);
-    vpo_eval_phi(&p->model, m, p->t, p->alpha, Phi);
+    model_eval(p, Phi);
     for (int s = 0; s < S; ++s)
         for (int i = 0; i < m; ++i) {
             double acc = 0;
@@ -470,9 +488,9 @@ int vpo_statistics(vpo_problem *p, double *cov, double *reduced_chi2, double *co
     if (m <= k) return 0; /* Error::Underdetermined */
     double *J = (double *)malloc(sizeof(double) * (size_t)m * k); /* model_function_jacobian :481-511 */
     double *Dk = (double *)malloc(sizeof(double) * (size_t)m * n);
-    vpo_eval_phi(&p->model, m, p->t, p->alpha, J);
+    model_eval(p, J);
     for (int a = 0; a < q; ++a) {
-        vpo_eval_dphi(&p->model, m, p->t, p->alpha, a, Dk);
+        model_dphi(p, a, Dk);
         for (int i = 0; i < m; ++i) {
             double acc = 0;
             for (int j = 0; j < n; ++j) acc += Dk[i + (size_t)j * m] * p->C[j];

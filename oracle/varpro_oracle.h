@@ -59,7 +59,19 @@ typedef struct vpo_problem {
     long n_jacobians;
     /* workspace owned by the problem (no allocation per evaluation): Phi_w, QR scratch, D_k, LM vectors */
     double *ws_phi, *ws_qr, *ws_dk, *ws_fvec, *ws_fwork, *ws_fjac;
+    /* A model outside the descriptor language: the reference's solver works with ANY SeparableNonlinearModel
+     * (src/model/mod.rs:239-363), e.g. the closure-based SeparableModel (:441-512).  When ext_eval is set the two model
+     * calls of the path -- eval() at src/solvers/levmar/mod.rs:45 and eval_partial_deriv(k) at :141 -- go to these
+     * callbacks instead of the descriptor formulas; model.n_basis / n_params give the shape, the kinds are ignored. */
+    void (*ext_eval)(void *user, const double *alpha, double *Phi /* m x n, col-major */);
+    void (*ext_dphi)(void *user, const double *alpha, int k, double *Dk /* m x n, zero columns kept */);
+    void *ext_user;
 } vpo_problem;
+
+/* == SeparableProblemBuilder::new(model) with a user model (any impl of the trait): callbacks for eval() and
+ * eval_partial_deriv(k); `t` of vpo_problem_create may then be NULL */
+void vpo_problem_set_external_model(vpo_problem *p, void (*eval)(void *, const double *, double *),
+                                    void (*dphi)(void *, const double *, int, double *), void *user);
 
 /* == SeparableProblemBuilder::build (src/problem/builder.rs:278-324) WITHOUT the initial
  * set_params; returns NULL and sets *build_err (VP_BUILD_*) on validation failure. */

@@ -13,8 +13,8 @@ There is no CPU fallback: every compute call runs on the GPU through ``lib/libva
 from ._lib import VarproHipError, VarproHipUnavailable, device_count, load as load_library  # noqa: F401
 from .batch import BatchProblem, LevenbergMarquardt, REPORT_DTYPE  # noqa: F401
 from .pipeline import FitPipeline  # noqa: F401
-from .model import (ModelBuildError, ModelError, SeparableModel, SeparableModelBuilder, basis,  # noqa: F401
-                    multi_exponential_model)
+from .model import (ClosureModel, ExternalModel, ModelBuildError, ModelError, SeparableModel,  # noqa: F401
+                    SeparableModelBuilder, basis, multi_exponential_model)
 from .problem import SeparableProblem, SeparableProblemBuilder, SeparableProblemBuilderError  # noqa: F401
 from .solver import (FitError, FitResult, FitStatistics, LevMarSolver, MinimizationReport,  # noqa: F401
                      TerminationReason)  # noqa: F401

@@ -44,6 +44,7 @@ ABI_SYMBOLS = [
     "vp_linear_coeffs", "vp_weighted_data", "vp_set_observations", "vp_cost", "vp_evaluate", "vp_basis", "vp_lm_opts_default", "vp_fit", "vp_fit_trace",
     "vp_best_fit", "vp_debug_gram_evaluate", "vp_statistics", "vp_summary", "vp_summary_device", "vp_set_rhs_allreduce", "vp_set_fit_kernel", "vp_set_timing", "vp_last_kernel_ms", "vp_synchronize", "vp_last_error",
     "vp_last_error_detail", "vp_version", "vp_device_count",
+    "vp_batch_create_external", "vp_set_params_with_basis", "vp_jacobian_with_derivatives", "vp_evaluate_with_basis",
 ]
 
 
@@ -101,6 +102,11 @@ def load():
     vp, i32p, dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)
     lib.vp_batch_create.argtypes = [C.POINTER(vp), C.POINTER(ModelDesc), C.c_int, C.c_int64, C.c_int64, C.c_int64,
                                     vp, vp, vp, C.c_double, C.c_int, C.c_int, vp]
+    lib.vp_batch_create_external.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, i32p, i32p, C.c_int, C.c_int64,
+                                             C.c_int64, C.c_int64, vp, vp, C.c_double, C.c_int, C.c_int, vp]
+    lib.vp_set_params_with_basis.argtypes = [vp, vp, vp, vp]
+    lib.vp_jacobian_with_derivatives.argtypes = [vp, vp, vp, vp]
+    lib.vp_evaluate_with_basis.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.vp_batch_destroy.argtypes = [vp]
     lib.vp_batch_destroy.restype = None
     lib.vp_set_params.argtypes = [vp, vp]

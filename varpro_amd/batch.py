@@ -142,6 +142,7 @@ class BatchProblem:
             self._tdev = Y.device
         self.np_dtype = np.dtype(model.dtype)
         self.vp_dtype = _lib.VP_F64 if self.np_dtype == np.float64 else _lib.VP_F32
+        self.external = hasattr(model, "ext_pairs")  # model.ExternalModel: the caller evaluates Phi / dPhi
         x = model.x if x is None else x
         Y = self._as_array(Y)
         if Y.ndim == 2:
@@ -154,13 +155,18 @@ class BatchProblem:
         else:
             raise ValueError("Y must be (B, m) or (B, S, m)")
         self.B, self.S, self.m = int(B), int(S), int(m)
-        x = self._as_array(x)
+        if self.external:
+            x = None
+        else:
+            x = self._as_array(x)
         flags = 0 if grid_recurrence else _lib.VP_FLAG_NO_GRID_RECURRENCE
         if self.device_mode:
             flags |= _lib.VP_FLAG_DEVICE_PTRS  # work is enqueued on torch's current stream
         else:
             flags |= _lib.VP_FLAG_OWN_STREAM
-        if x.ndim == 2:
+        if x is None:
+            pass  # a caller-evaluated model has no grid
+        elif x.ndim == 2:
             flags |= _lib.VP_FLAG_T_PER_PROBLEM
             if tuple(x.shape) != (self.B, self.m):
                 raise ValueError("per-problem grid must be (B, m)")
@@ -184,10 +190,18 @@ class BatchProblem:
             stream = C.c_void_p(self._tstream.cuda_stream)
         self.device = int(device)
         h = C.c_void_p()
-        desc = model.desc()
         eps = -1.0 if epsilon is None else abs(float(epsilon))
-        check(self.lib.vp_batch_create(C.byref(h), C.byref(desc), self.vp_dtype, self.m, self.S, self.B,
-                                       self._ptr(x), self._ptr(Y), self._ptr(w), eps, flags, self.device, stream))
+        if self.external:
+            npairs = len(model.ext_pairs)
+            pb = (C.c_int32 * max(1, npairs))(*[j for j, _k in model.ext_pairs])
+            pp = (C.c_int32 * max(1, npairs))(*[k for _j, k in model.ext_pairs])
+            check(self.lib.vp_batch_create_external(C.byref(h), self.n, self.q, npairs, pb, pp, self.vp_dtype, self.m,
+                                                    self.S, self.B, self._ptr(Y), self._ptr(w), eps, flags, self.device,
+                                                    stream))
+        else:
+            desc = model.desc()
+            check(self.lib.vp_batch_create(C.byref(h), C.byref(desc), self.vp_dtype, self.m, self.S, self.B,
+                                           self._ptr(x), self._ptr(Y), self._ptr(w), eps, flags, self.device, stream))
         self._h = h
         self._have_params = False  # mirrors the handle: set_params / evaluate / fit has run on the current data
         self._keep = None  # the handle owns copies (Y_w = W*Y, t, w)
@@ -250,6 +264,50 @@ class BatchProblem:
         a = self._as_array(alpha).reshape(self.B, self.q)
         check(self.lib.vp_set_params(self._h, self._ptr(a)))
         self._have_params = True
+
+    # ---- caller-evaluated models (model.ExternalModel; vp_batch_create_external) ----
+    @_device_entry
+    def set_params_with_basis(self, alpha, Phi, dPhi=None):
+        """== SeparableProblem::set_params (src/solvers/levmar/mod.rs:42-73) with `model.eval()` replaced by its result:
+        Phi (B, n, m) and optionally the derivative columns dPhi (B, p, m), both UNWEIGHTED.  Device tensors are kept by
+        POINTER until the next call (keep them alive and unchanged); numpy arrays are copied."""
+        a = self._as_array(alpha).reshape(self.B, self.q)
+        Phi = self._as_array(Phi).reshape(self.B, self.n, self.m)
+        dPhi = None if dPhi is None else self._as_array(dPhi).reshape(self.B, self.p, self.m)
+        self._ext_keep = (Phi, dPhi)
+        check(self.lib.vp_set_params_with_basis(self._h, self._ptr(a), self._ptr(Phi), self._ptr(dPhi)))
+        self._have_params = True
+
+    @_device_entry
+    def jacobian_with_derivatives(self, dPhi, with_status=False):
+        """== jacobian() (src/solvers/levmar/mod.rs:101-201) with `model.eval_partial_deriv(k)` (:141) replaced by its
+        non-zero columns dPhi (B, p, m) at the current parameters"""
+        dPhi = self._as_array(dPhi).reshape(self.B, self.p, self.m)
+        self._ext_keep = (getattr(self, "_ext_keep", (None, None))[0], dPhi)
+        J = self._empty((self.B, self.q, self.S * self.m))
+        st = self._empty((self.B,), np.int32)
+        check(self.lib.vp_jacobian_with_derivatives(self._h, self._ptr(dPhi), self._ptr(J), self._ptr(st)))
+        if not self._have_params:
+            J = None
+        return (J, st) if with_status else J
+
+    @_device_entry
+    def evaluate_with_basis(self, alpha, Phi, dPhi=None, want_residuals=True, want_jacobian=True):
+        """fused form (vp_evaluate_with_basis): Phi, dPhi in -> r, J, C, cost, status out in one pass"""
+        a = self._as_array(alpha).reshape(self.B, self.q)
+        Phi = self._as_array(Phi).reshape(self.B, self.n, self.m)
+        dPhi = None if dPhi is None else self._as_array(dPhi).reshape(self.B, self.p, self.m)
+        self._ext_keep = (Phi, dPhi)
+        want_jacobian = want_jacobian and (dPhi is not None or self.p == 0)
+        r = self._empty((self.B, self.S * self.m)) if want_residuals else None
+        J = self._empty((self.B, self.q, self.S * self.m)) if want_jacobian else None
+        Cm = self._empty((self.B, self.S, self.n))
+        cost = self._empty((self.B,), np.float64)
+        st = self._empty((self.B,), np.int32)
+        check(self.lib.vp_evaluate_with_basis(self._h, self._ptr(a), self._ptr(Phi), self._ptr(dPhi), self._ptr(r),
+                                              self._ptr(J), self._ptr(Cm), self._ptr(cost), self._ptr(st)))
+        self._have_params = True
+        return dict(r=r, J=J, C=Cm.reshape(self.B, self.n) if self.single_rhs else Cm, cost=cost, status=st)
 
     @_device_entry
     def params(self):

@@ -210,6 +210,13 @@ struct vp_batch {
     int64_t m_user;  // != 0: the caller's row count m < n; the handle works on m = n rows, the extra ones with zero weight
     hipGraphExec_t mrhs_graph;
     hipGraphExec_t mrhs_graph_tail; // 12 further iterations + finish, for a fit that outlasts mrhs_graph
+    // caller-evaluated model (vp_batch_create_external): shape + dependency-pair table, and where the columns of the
+    // current parameters live (the caller's device arrays, or this handle's staged copies on host-pointer handles)
+    bool external;
+    int ext_np;
+    int32_t ext_pb[VP_MAX_PAIRS], ext_pp[VP_MAX_PAIRS];
+    const void *ext_phi, *ext_dphi;
+    void *ext_phi_own, *ext_dphi_own;
     int mrhs_graph_len;     // LM iterations mrhs_graph holds
     int mrhs_graph_iters;   // ... and what the next capture should hold (evaluations of the previous fit + 1, >= 6)
     int32_t *h_nactive;     // pinned, device-mapped: the active count as the graph's last kernel leaves it
@@ -392,6 +399,13 @@ void fill_params(vp_batch *h, LaunchParams &p) {
     p.gen_ws = h->d_gen_ws;
     p.gen_blocks = h->gen_blocks;
     p.fit_group = h->fit_kernel;
+    p.ext = h->external ? 1 : 0;
+    p.ext_np = h->ext_np;
+    p.ext_pb = h->ext_pb;
+    p.ext_pp = h->ext_pp;
+    p.ext_phi = h->ext_phi;
+    p.ext_dphi = h->ext_dphi;
+    p.ext_rows = (int)(h->m_user ? h->m_user : h->m);
 }
 
 struct Timer {
@@ -759,9 +773,14 @@ void vp_lm_opts_default(vp_lm_opts *o, int dtype) {
     o->scale_diag = 1;
 }
 
+// a caller-evaluated model: dependency pairs (basis, parameter) in the caller's order
+struct ExtSpec {
+    int np;
+    const int32_t *pb, *pp;
+};
 static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dtype, int64_t m, int64_t S, int64_t B,
                              const void *t, const void *Y, const void *w, double svd_epsilon, int flags, int device,
-                             void *hip_stream, bool data_on_device);
+                             void *hip_stream, bool data_on_device, const ExtSpec *ext = nullptr);
 
 // pad the row dimension of `blocks` blocks from m to mp rows with `fill` (host arrays of 4- or 8-byte elements)
 static void pad_rows_host(const void *src, void *dst, size_t blocks, int64_t m, int64_t mp, size_t ts, double fill) {
@@ -825,22 +844,86 @@ int vp_batch_create(vp_batch **out, const vp_model_desc *model, int dtype, int64
     return rc;
 }
 
+// == SeparableProblemBuilder::build (src/problem/builder.rs:278-324) for a model the caller evaluates: any
+// SeparableNonlinearModel (src/model/mod.rs:239-363), known here by its shape and dependency-pair table only
+int vp_batch_create_external(vp_batch **out, int32_t n_basis, int32_t n_params, int32_t n_pairs, const int32_t *pair_basis,
+                             const int32_t *pair_param, int dtype, int64_t m, int64_t S, int64_t B, const void *Y,
+                             const void *w, double svd_epsilon, int flags, int device, void *hip_stream) {
+    if (!out) return fail(VP_ERR_INVALID, "null output handle");
+    *out = nullptr;
+    if (n_basis <= 0 || n_basis > VP_MAX_BASIS || n_params < 0 || n_params > VP_MAX_PARAMS)
+        return fail(VP_ERR_INVALID, "model sizes out of range");
+    if (n_pairs < 0 || n_pairs > VP_MAX_PAIRS || (n_pairs > 0 && (!pair_basis || !pair_param)))
+        return fail(VP_ERR_INVALID, "too many dependency pairs (or a null pair table)");
+    for (int i = 0; i < n_pairs; ++i) {
+        if (pair_basis[i] < 0 || pair_basis[i] >= n_basis || pair_param[i] < 0 || pair_param[i] >= n_params)
+            return fail(VP_ERR_INVALID, "dependency pair out of range");
+        for (int k = 0; k < i; ++k)
+            if (pair_basis[k] == pair_basis[i] && pair_param[k] == pair_param[i])
+                return fail(VP_ERR_INVALID, "dependency pair listed twice");
+    }
+    if (flags & VP_FLAG_T_PER_PROBLEM) return fail(VP_ERR_INVALID, "a caller-evaluated model has no grid");
+    vp_model_desc md;
+    std::memset(&md, 0, sizeof(md));
+    md.n_basis = n_basis;
+    md.n_params = n_params;
+    for (int j = 0; j < VP_MAX_BASIS; ++j) {
+        md.kind[j] = j < n_basis ? VP_BASIS_EXTERNAL : 0;
+        for (int a = 0; a < VP_MAX_BASIS_PARAMS; ++a) md.param[j][a] = -1;
+    }
+    const ExtSpec ext{n_pairs, pair_basis, pair_param};
+    const bool dev_data = (flags & VP_FLAG_DEVICE_PTRS) != 0;
+    if (!Y || m <= 0 || S <= 0 || B <= 0 || (dtype != VP_F64 && dtype != VP_F32) || m >= n_basis)
+        return batch_create_impl(out, &md, dtype, m, S, B, nullptr, Y, w, svd_epsilon, flags, device, hip_stream, dev_data, &ext);
+    // m < n: as vp_batch_create -- n - m extra rows of zero weight; the caller's Phi / dPhi keep THEIR m rows
+    // (LaunchParams::ext_rows), the kernels read the missing rows as zeros
+    const size_t ts = dtype == VP_F64 ? 8 : 4;
+    const int64_t mp = n_basis;
+    const size_t wb = (flags & VP_FLAG_W_PER_PROBLEM) ? (size_t)B : 1;
+    std::vector<char> yh((size_t)B * S * m * ts), wh(wb * m * ts);
+    if (dev_data) {
+        if (vp_device_count() <= 0) return fail(VP_ERR_NO_DEVICE, "no HIP device visible");
+        DeviceGuard g__;
+        if (int rc = g__.enter(device)) return rc;
+        hipStream_t st = (flags & VP_FLAG_OWN_STREAM) ? nullptr : (hipStream_t)hip_stream;
+        VP_HIP(hipMemcpyAsync(yh.data(), Y, yh.size(), hipMemcpyDeviceToHost, st));
+        if (w) VP_HIP(hipMemcpyAsync(wh.data(), w, wh.size(), hipMemcpyDeviceToHost, st));
+        VP_HIP(hipStreamSynchronize(st));
+    } else {
+        std::memcpy(yh.data(), Y, yh.size());
+        if (w) std::memcpy(wh.data(), w, wh.size());
+    }
+    if (!w)
+        for (size_t i = 0; i < wb * (size_t)m; ++i) {
+            if (ts == 8) ((double *)wh.data())[i] = 1.0;
+            else ((float *)wh.data())[i] = 1.0f;
+        }
+    std::vector<char> yp((size_t)B * S * mp * ts), wp(wb * mp * ts);
+    pad_rows_host(yh.data(), yp.data(), (size_t)B * S, m, mp, ts, 0.0);
+    pad_rows_host(wh.data(), wp.data(), wb, m, mp, ts, 0.0);
+    const int rc = batch_create_impl(out, &md, dtype, mp, S, B, nullptr, yp.data(), wp.data(), svd_epsilon, flags, device,
+                                     hip_stream, false, &ext);
+    if (rc == VP_ERR_OK) (*out)->m_user = m;
+    return rc;
+}
+
 static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dtype, int64_t m, int64_t S, int64_t B,
                              const void *t, const void *Y, const void *w, double svd_epsilon, int flags, int device,
-                             void *hip_stream, const bool data_on_device) {
+                             void *hip_stream, const bool data_on_device, const ExtSpec *ext) {
     if (!out) return fail(VP_ERR_INVALID, "null output handle");
     *out = nullptr;
     if (!model) return fail(VP_ERR_INVALID, "null model");
     if (dtype != VP_F64 && dtype != VP_F32) return fail(VP_ERR_INVALID, "bad dtype");
     // builder validation (src/problem/builder.rs:278-302)
     if (!Y) return fail(VP_ERR_INVALID, "Right hand side(s) not provided", VP_BUILD_Y_DATA_MISSING);
-    if (m <= 0 || S <= 0 || B <= 0 || !t)
+    if (m <= 0 || S <= 0 || B <= 0 || (!t && !ext))
         return fail(VP_ERR_INVALID, "x or y must have nonzero number of elements.", VP_BUILD_ZERO_LENGTH_VECTOR);
     if (model->n_basis <= 0 || model->n_basis > VP_MAX_BASIS || model->n_params < 0 ||
         model->n_params > VP_MAX_PARAMS)
         return fail(VP_ERR_INVALID, "model sizes out of range");
     int fa, fb, fc, npairs;
-    if (classify_model(*model, fa, fb, fc, npairs) < 0) return fail(VP_ERR_INVALID, "malformed model descriptor");
+    if (ext) npairs = ext->np; // caller-evaluated model: shape and pair table only, nothing to classify
+    else if (classify_model(*model, fa, fb, fc, npairs) < 0) return fail(VP_ERR_INVALID, "malformed model descriptor");
     if (npairs > VP_MAX_PAIRS) return fail(VP_ERR_INVALID, "too many dependency pairs");
 
     int ndev = vp_device_count();
@@ -855,7 +938,7 @@ static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dty
 
     // a specialised (register-resident) kernel set if one is instantiated for this (dtype, model, m), else the generic
     // fallback kernels (vp_generic.hpp): any descriptor, any m -- slower, but never a CPU path and never "unsupported"
-    const KernelEntry *kern = find_kernels(dtype, *model, m, S);
+    const KernelEntry *kern = ext ? external_kernels(dtype, model->n_basis, model->n_params, ext->np, m, S) : find_kernels(dtype, *model, m, S);
     // weighted problems on the largest multi-wave sets: grid + weights + data column of 64 R W rows each must fit the 160 KiB
     // of LDS the one-problem-per-group fit kernel stages them in (32 rows per lane on four waves, fp64: 3 x 64 KiB does not)
     if (kern && w && (size_t)3 * 64 * kern->R * kern->W * tsize(dtype) + 4096 > (size_t)160 * 1024) kern = nullptr;
@@ -881,6 +964,14 @@ static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dty
     const double meps = dtype == VP_F32 ? (double)FLT_EPSILON : DBL_EPSILON;
     h->eps = svd_epsilon < 0 ? meps : std::fabs(svd_epsilon); // src/problem/builder.rs:246-251, 282
     h->kern = kern;
+    if (ext) {
+        h->external = true;
+        h->ext_np = ext->np;
+        for (int i = 0; i < ext->np; ++i) {
+            h->ext_pb[i] = ext->pb[i];
+            h->ext_pp[i] = ext->pp[i];
+        }
+    }
     if (!(flags & VP_FLAG_OWN_STREAM)) {
         h->stream = (hipStream_t)hip_stream; // NULL == the null stream (PyTorch's default stream)
         h->own_stream = false;
@@ -906,15 +997,17 @@ static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dty
         }                                                                                                             \
     } while (0)
     const hipMemcpyKind kin = data_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    VP_TRY(hipMalloc(&h->d_t, t_elems * ts));
-    VP_TRY(hipMemcpyAsync(h->d_t, t, t_elems * ts, kin, h->stream));
+    if (t) { // (a caller-evaluated model has no grid)
+        VP_TRY(hipMalloc(&h->d_t, t_elems * ts));
+        VP_TRY(hipMemcpyAsync(h->d_t, t, t_elems * ts, kin, h->stream));
+    }
     if (w) {
         VP_TRY(hipMalloc(&h->d_w, w_elems * ts));
         VP_TRY(hipMemcpyAsync(h->d_w, w, w_elems * ts, kin, h->stream));
     }
     int *&d_gflag = reinterpret_cast<int *&>(h->tmp_a);
     // (fp32 handles: only the Gram fit kernel, vp_fitg.hpp, uses the flag -- the other fp32 kernels have no recurrence)
-    const bool try_uniform = m >= 3 && !(flags & VP_FLAG_NO_GRID_RECURRENCE);
+    const bool try_uniform = t && m >= 3 && !(flags & VP_FLAG_NO_GRID_RECURRENCE);
     if (try_uniform) {
         const int one = 1;
         VP_TRY(hipMalloc((void **)&d_gflag, sizeof(int)));
@@ -1034,6 +1127,8 @@ void vp_batch_destroy(vp_batch *h) {
     (void)hipFree(h->d_gen_ws);
     (void)hipFree(h->tmp_a);
     (void)hipFree(h->tmp_b);
+    (void)hipFree(h->ext_phi_own);
+    (void)hipFree(h->ext_dphi_own);
     // (the struct is zero-initialised: freeing unconditionally also covers a create that failed half way)
     (void)hipFree(h->mrhs.qthin);
     (void)hipFree(h->mrhs.g);
@@ -1062,8 +1157,85 @@ void vp_batch_destroy(vp_batch *h) {
     delete h;
 }
 
+// ---- caller-evaluated models (vp_batch_create_external) -----------------------------------------------------------
+#define VP_NOT_EXTERNAL(h, what)                                                                                       \
+    if ((h)->external)                                                                                                 \
+    return fail(VP_ERR_UNSUPPORTED, what ": the handle's model is evaluated by the caller (vp_set_params_with_basis / "   \
+                                         "vp_evaluate_with_basis)")
+
+// where the kernels find the columns of the current parameters: the caller's device arrays, or staged copies of host arrays
+static int ext_stage(vp_batch *h, const void *user, int64_t cols, const void *&dev, void *&own) {
+    if (!user) {
+        dev = nullptr;
+        return 0;
+    }
+    if (device_ptrs(h)) {
+        dev = user;
+        return 0;
+    }
+    const size_t bytes = (size_t)h->B * (size_t)cols * (size_t)(h->m_user ? h->m_user : h->m) * tsize(h->dtype);
+    if (!own) VP_HIP(hipMalloc(&own, bytes ? bytes : 1));
+    VP_HIP(hipMemcpyAsync(own, user, bytes, hipMemcpyHostToDevice, h->stream));
+    dev = own;
+    return 0;
+}
+
+int vp_set_params_with_basis(vp_batch *h, const void *alpha, const void *Phi, const void *dPhi) {
+    VP_ENTER(h);
+    if (!h->external) return fail(VP_ERR_UNSUPPORTED, "vp_set_params_with_basis needs a handle made by vp_batch_create_external");
+    if (!alpha || !Phi) return fail(VP_ERR_INVALID, "null alpha / Phi");
+    VP_HIP(hipMemcpyAsync(h->d_alpha, alpha, (size_t)h->B * h->q * tsize(h->dtype),
+                          device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (int rc = ext_stage(h, Phi, h->n, h->ext_phi, h->ext_phi_own)) return rc;
+    if (int rc = ext_stage(h, dPhi, h->ext_np, h->ext_dphi, h->ext_dphi_own)) return rc;
+    if (int rc = ensure_R(h)) return rc;
+    if (int rc = run_evaluate(h, h->d_R, nullptr, h->d_C)) return rc;
+    h->have_params = true;
+    h->r_valid = true;
+    if (!device_ptrs(h)) VP_HIP(hipStreamSynchronize(h->stream)); // the caller may reuse its host arrays
+    return VP_ERR_OK;
+}
+
+static int copy_status(vp_batch *h, int32_t *status);
+
+int vp_jacobian_with_derivatives(vp_batch *h, const void *dPhi, void *J_out, int32_t *status) {
+    VP_ENTER(h);
+    if (!h->external) return fail(VP_ERR_UNSUPPORTED, "vp_jacobian_with_derivatives needs a handle made by vp_batch_create_external");
+    if (!h->have_params) return copy_status(h, status) ? VP_ERR_HIP : VP_ERR_OK; // jacobian() before set_params(): None
+    if (!dPhi && h->ext_np > 0) return fail(VP_ERR_INVALID, "null dPhi");
+    if (int rc = ext_stage(h, dPhi, h->ext_np, h->ext_dphi, h->ext_dphi_own)) return rc;
+    return vp_jacobian(h, J_out, status);
+}
+
+int vp_evaluate_with_basis(vp_batch *h, const void *alpha, const void *Phi, const void *dPhi, void *r_out, void *J_out,
+                           void *C_out, double *cost_out, int32_t *status) {
+    VP_ENTER(h);
+    if (!h->external) return fail(VP_ERR_UNSUPPORTED, "vp_evaluate_with_basis needs a handle made by vp_batch_create_external");
+    if (!alpha || !Phi) return fail(VP_ERR_INVALID, "null alpha / Phi");
+    if (J_out && !dPhi && h->ext_np > 0) return fail(VP_ERR_INVALID, "a Jacobian needs the derivative columns dPhi");
+    const size_t ts = tsize(h->dtype);
+    VP_HIP(hipMemcpyAsync(h->d_alpha, alpha, (size_t)h->B * h->q * ts,
+                          device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (int rc = ext_stage(h, Phi, h->n, h->ext_phi, h->ext_phi_own)) return rc;
+    if (int rc = ext_stage(h, dPhi, h->ext_np, h->ext_dphi, h->ext_dphi_own)) return rc;
+    RowOut r, J;
+    if (int rc = r.init(h, r_out, (size_t)h->B * h->S)) return rc;
+    if (int rc = J.init(h, J_out, (size_t)h->B * h->q * h->S)) return rc;
+    if (int rc = run_evaluate(h, r.dptr, J.dptr, h->d_C)) return rc;
+    h->have_params = true;
+    h->r_valid = false;
+    if (int rc = r.finish(h)) return rc;
+    if (int rc = J.finish(h)) return rc;
+    if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
+    if (int rc = copy_out(h, cost_out, h->d_cost, (size_t)h->B * sizeof(double))) return rc;
+    if (int rc = copy_status(h, status)) return rc;
+    if (!device_ptrs(h)) VP_HIP(hipStreamSynchronize(h->stream));
+    return VP_ERR_OK;
+}
+
 int vp_set_params(vp_batch *h, const void *alpha) {
     VP_ENTER(h);
+    VP_NOT_EXTERNAL(h, "vp_set_params");
     if (!alpha) return fail(VP_ERR_INVALID, "null alpha");
     const size_t bytes = (size_t)h->B * h->q * tsize(h->dtype);
     VP_HIP(hipMemcpyAsync(h->d_alpha, alpha, bytes, device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
@@ -1114,6 +1286,9 @@ int vp_jacobian(vp_batch *h, void *J_out, int32_t *status) {
     VP_ENTER(h);
     if (!h->have_params) return copy_status(h, status) ? VP_ERR_HIP : VP_ERR_OK;
     if (!J_out) return fail(VP_ERR_INVALID, "null J_out");
+    if (h->external && h->ext_np > 0 && !h->ext_dphi)
+        return fail(VP_ERR_INVALID, "no derivative columns at the current parameters: pass dPhi to vp_set_params_with_basis "
+                                    "or call vp_jacobian_with_derivatives");
     RowOut J;
     if (int rc = J.init(h, J_out, (size_t)h->B * h->q * h->S)) return rc;
     if (int rc = run_evaluate(h, nullptr, J.dptr, nullptr)) return rc;
@@ -1188,6 +1363,7 @@ int vp_cost(vp_batch *h, double *cost_out) {
 int vp_evaluate(vp_batch *h, const void *alpha, void *r_out, void *J_out, void *C_out, double *cost_out,
                 int32_t *status) {
     VP_ENTER(h);
+    VP_NOT_EXTERNAL(h, "vp_evaluate");
     if (!alpha) return fail(VP_ERR_INVALID, "null alpha");
     const size_t ts = tsize(h->dtype);
     VP_HIP(hipMemcpyAsync(h->d_alpha, alpha, (size_t)h->B * h->q * ts,
@@ -1207,6 +1383,7 @@ int vp_evaluate(vp_batch *h, const void *alpha, void *r_out, void *J_out, void *
 
 int vp_basis(vp_batch *h, const void *alpha, void *Phi_out, void *dPhi_out, int flags) {
     VP_ENTER(h);
+    VP_NOT_EXTERNAL(h, "vp_basis");
     if (!alpha) return fail(VP_ERR_INVALID, "null alpha");
     const size_t ts = tsize(h->dtype);
     int ncols = 0;
@@ -1240,6 +1417,7 @@ int vp_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, 
 int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep,
                  double *trace_out, int trace_rows) {
     VP_ENTER(h);
+    VP_NOT_EXTERNAL(h, "vp_fit");
     if (!alpha_inout) return fail(VP_ERR_INVALID, "null alpha");
     if (h->m_user && (int64_t)h->q > h->m_user * h->S) {
         // m < n AND fewer residuals than nonlinear parameters (the padded handle would count its own n rows): the reference's
@@ -1302,7 +1480,7 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
 int vp_debug_gram_evaluate(vp_batch *h, const void *alpha, double *out) {
     VP_ENTER(h);
     if (!alpha || !out) return fail(VP_ERR_INVALID, "null argument");
-    if (h->S != 1 || !h->kern->gram_fit || !h->kern->fit)
+    if (h->external || h->S != 1 || !h->kern->gram_fit || !h->kern->fit)
         return fail(VP_ERR_UNSUPPORTED, "the handle's fit does not run on the Gram kernel (fp32, exponentials + offset beyond one wavefront)");
     const size_t ts = tsize(h->dtype);
     const int per = 1 + h->n + h->q + h->q * h->q;
@@ -1355,6 +1533,8 @@ int vp_statistics(vp_batch *h, void *cov_out, double *reduced_chi2_out, void *co
     if (h->S != 1) // src/solvers/levmar/mod.rs:271-273: statistics are single-RHS only
         return fail(VP_ERR_UNSUPPORTED, "fit statistics are only supported for a single right-hand side");
     if (!h->kern->stats) return fail(VP_ERR_UNSUPPORTED, "no statistics kernel for this model");
+    if (h->external && h->ext_np > 0 && !h->ext_dphi)
+        return fail(VP_ERR_INVALID, "fit statistics need the derivative columns at the current parameters (vp_set_params_with_basis with dPhi)");
     if (!cov_out || !reduced_chi2_out) return fail(VP_ERR_INVALID, "null output");
     const size_t ts = tsize(h->dtype);
     const int k = h->n + h->q;
@@ -1458,7 +1638,7 @@ static int kind_arity(int kind) {
     case VP_BASIS_EXP_RATE: return 1;
     case VP_BASIS_EXP_COS:
     case VP_BASIS_SIN_PHASE: return 2;
-    default: return -1;
+    default: return -1; // (VP_BASIS_EXTERNAL never reaches a descriptor: vp_batch_create_external only)
     }
 }
 
@@ -1495,6 +1675,16 @@ int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out) {
     b = d.n_params;
     c = pairs;
     return FAMILY_RT;
+}
+
+// caller-evaluated models: the generic kernels read the columns from the caller's arrays (any shape, any m, any S)
+const KernelEntry *external_kernels(int dtype, int n, int q, int np, int64_t m, int64_t S) {
+    (void)n;
+    (void)q;
+    (void)np;
+    (void)m;
+    (void)S;
+    return generic_kernels(dtype);
 }
 
 const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m, int64_t S) {

@@ -58,6 +58,11 @@ template <typename T> struct GenArgs {
     double *acc;        // [B][gen_nacc(q)]: sum ||r||^2 | J^T J | J^T r | columns whose evaluation failed
     int32_t *nactive;   // [1]
     int64_t S_global;   // right-hand sides of the WHOLE problem (0: S)
+    // caller-evaluated model (vp_batch_create_external; the reference's trait boundary, src/model/mod.rs:239-363): the
+    // columns are READ -- Phi [B][n][ext_rows], dPhi [B][P][ext_rows] (UNWEIGHTED, pair-table order) -- not evaluated
+    int ext;
+    const T *ext_phi, *ext_dphi;
+    int ext_rows;       // rows per column in the caller's arrays (< m only when the handle padded m < n: zero rows)
 };
 __host__ __device__ constexpr int gen_nacc(int q) { return 2 + q * q + q; }
 
@@ -201,6 +206,20 @@ __device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b
     const T *yp = a.yw + (prob >= 0 ? prob : b) * (int64_t)m; // prob = b*S + s for multiple right-hand sides
     auto col = [&](int c) { return ws + (int64_t)c * m; };
     // ---- columns ----
+    if (a.ext) {
+        // == `&self.weights * self.model.eval()` (src/solvers/levmar/mod.rs:45-47) and `&self.weights *
+        // model.eval_partial_deriv(k)` (:141) with the model calls replaced by the caller's arrays
+        const int er = a.ext_rows;
+        const T *ph = a.ext_phi + b * (int64_t)n * er;
+        const T *dp = a.ext_dphi ? a.ext_dphi + b * (int64_t)P * er : nullptr;
+        for (int i = tid; i < m; i += TB) {
+            const bool in = i < er;
+            const T sc = wp ? wp[i] : T(1);
+            for (int j = 0; j < n; ++j) col(j)[i] = in ? ph[(int64_t)j * er + i] * sc : T(0);
+            for (int p = 0; p < P; ++p) col(n + 1 + p)[i] = (in && dp) ? dp[(int64_t)p * er + i] * sc : T(0);
+            col(n)[i] = yp[i];
+        }
+    } else
     for (int i = tid; i < m; i += TB) {
         const T t = tp[i], sc = wp ? wp[i] : T(1);
         for (int j = 0; j < n; ++j) {
@@ -811,6 +830,17 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_best_fit_kernel(
     for (int64_t prob = blockIdx.x; prob < a.B * S; prob += gridDim.x) {
         const int64_t b = prob / S;
         const T *tp = a.t + b * a.t_stride;
+        if (a.ext) { // the caller's (unweighted) Phi of the last vp_set_params_with_basis times the coefficients
+            const int er = a.ext_rows;
+            const T *ph = a.ext_phi + b * (int64_t)n * er;
+            for (int i = (int)threadIdx.x; i < m; i += TB) {
+                T acc = T(0);
+                if (i < er)
+                    for (int j = 0; j < n; ++j) acc = tfma(ph[(int64_t)j * er + i], a.C_in[prob * n + j], acc);
+                a.r_out[prob * (int64_t)m + i] = acc;
+            }
+            continue;
+        }
         for (int i = (int)threadIdx.x; i < m; i += TB) {
             const T t = tp[i];
             T acc = T(0);
@@ -858,9 +888,18 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_stats_kernel(con
         // J rows (optionally weighted) into columns 0..K-1
         auto build = [&](bool weighted) {
             for (int i = tid; i < m; i += TB) {
-                const T t = tp[i], sc = (weighted && wp) ? wp[i] : T(1);
+                const T t = a.ext ? T(0) : tp[i], sc = (weighted && wp) ? wp[i] : T(1);
                 T jr[MAXK];
                 for (int k = 0; k < q; ++k) jr[n + k] = T(0);
+                if (a.ext) {
+                    const int er = a.ext_rows;
+                    const bool in = i < er;
+                    const T *ph = a.ext_phi + b * (int64_t)n * er;
+                    const T *dp = a.ext_dphi + b * (int64_t)a.P * er;
+                    for (int j = 0; j < n; ++j) jr[j] = in ? ph[(int64_t)j * er + i] : T(0);
+                    for (int p = 0; p < a.P; ++p)
+                        jr[n + a.pp[p]] = tfma(cc[a.pb[p]], in ? dp[(int64_t)p * er + i] : T(0), jr[n + a.pp[p]]);
+                } else
                 for (int j = 0; j < n; ++j) {
                     const int i0 = a.mdl.param[j][0], i1 = a.mdl.param[j][1];
                     T f, d0, d1;
@@ -965,6 +1004,18 @@ template <typename T> inline bool fill_args(const LaunchParams &p, GenArgs<T> &a
     std::memset(&a, 0, sizeof(a));
     a.mdl = *p.model;
     int np = 0;
+    if (p.ext) { // caller-evaluated model: the pair table comes with the handle, there is no argument slot
+        if (p.ext_np > VP_MAX_PAIRS || !p.ext_phi) return false;
+        for (; np < p.ext_np; ++np) {
+            a.pb[np] = p.ext_pb[np];
+            a.pa[np] = 0;
+            a.pp[np] = p.ext_pp[np];
+        }
+        a.ext = 1;
+        a.ext_phi = (const T *)p.ext_phi;
+        a.ext_dphi = (const T *)p.ext_dphi;
+        a.ext_rows = p.ext_rows > 0 ? p.ext_rows : p.m;
+    } else
     for (int j = 0; j < p.model->n_basis; ++j)
         for (int k = 0; k < VP_MAX_BASIS_PARAMS; ++k)
             if (p.model->param[j][k] >= 0) {

@@ -70,6 +70,14 @@ struct LaunchParams {
     int64_t w_stride; // 0 (shared) or m
     double eps;
     int grid_uniform;   // every grid of the handle passed grid_check_kernel: kernels may use the exp recurrence
+    // caller-evaluated models (vp_batch_create_external): the columns come from these arrays instead of the descriptor
+    const void *ext_phi;     // [B][n][ext_rows] UNWEIGHTED basis matrices, or null (descriptor model)
+    const void *ext_dphi;    // [B][ext_np][ext_rows] UNWEIGHTED derivative columns in pair-table order, or null
+    const int32_t *ext_pb;   // [ext_np] pair -> basis   (host pointers: copied into the kernel arguments)
+    const int32_t *ext_pp;   // [ext_np] pair -> parameter
+    int ext;                 // 1: external model (the fields above are meaningful)
+    int ext_np;              // dependency pairs of the external model
+    int ext_rows;            // rows per column in the caller's arrays (== m unless the handle padded m < n)
     hipStream_t stream;
 };
 

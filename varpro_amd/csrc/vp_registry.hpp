@@ -42,6 +42,8 @@ int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out);
 // S: right-hand sides of the handle -- among sets of equal capacity a single-RHS handle prefers the one whose columns fit
 // the registers (R <= 16: more waves per problem), a multiple-RHS handle the one that has MRHS kernels
 const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m, int64_t S = 1);
+// kernel set of a caller-evaluated model (vp_batch_create_external) of shape (n, q, np pairs)
+const KernelEntry *external_kernels(int dtype, int n, int q, int np, int64_t m, int64_t S);
 // the generic fallback set (vp_generic.hpp): any descriptor, any m, single right-hand side fits
 const KernelEntry *generic_kernels(int dtype);
 

@@ -118,6 +118,94 @@ class SeparableModel:
         return out
 
 
+class ExternalModel:
+    """Shape of a model the CALLER evaluates: any ``SeparableNonlinearModel`` (src/model/mod.rs:239-363), e.g. the
+    reference's closure-based ``SeparableModel`` (src/model/mod.rs:441-512), whose basis functions the closed descriptor
+    language above cannot express.  Only what the device needs: n basis functions, q parameters and the
+    (basis j, parameter k) pairs with a non-zero derivative -- the columns ``eval_partial_deriv(k)`` fills
+    (src/model/mod.rs:473-512).  ``BatchProblem(ExternalModel(...), Y)`` makes a handle with
+    ``vp_batch_create_external``; Phi / dPhi then enter through ``set_params_with_basis`` /
+    ``jacobian_with_derivatives`` / ``evaluate_with_basis``.  ``ClosureModel`` builds one from Python callables."""
+
+    def __init__(self, n_basis, n_params, pairs, dtype=np.float64):
+        self.n_basis, self.n_params = int(n_basis), int(n_params)
+        self.ext_pairs = [(int(j), int(k)) for j, k in pairs]
+        self.pairs = self.ext_pairs  # len() == number of derivative columns
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise TypeError("ScalarType must be float64 or float32")
+        self.x = None
+
+    def parameter_count(self):
+        return self.n_params
+
+    def base_function_count(self):
+        return self.n_basis
+
+
+class ClosureModel:
+    """== the reference's closure-based ``SeparableModel`` (src/model/mod.rs:367-517, built by
+    ``SeparableModelBuilder::function(params, f).partial_deriv(param, df)``, src/model/builder/mod.rs:338-525) with REAL
+    Python callables: ``f(x, *params) -> (m,)`` evaluated on the host with numpy for a whole batch of parameter sets.
+    ``eval_batch(alpha (B, q)) -> Phi (B, n, m)`` and ``derivs_batch(alpha) -> dPhi (B, p, m)`` produce exactly what
+    ``BatchProblem.set_params_with_basis`` takes; ``shape()`` is the matching ``ExternalModel``."""
+
+    def __init__(self, parameter_names, x, dtype=np.float64):
+        self.names = list(parameter_names)
+        self.x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        self.dtype = np.dtype(dtype)
+        self._functions = []  # (param indices, f, {param index: df})
+
+    def invariant_function(self, f):
+        self._functions.append(((), f, {}))
+        return self
+
+    def function(self, function_params, f):
+        idx = tuple(self.names.index(p) for p in function_params)  # FunctionParameterNotInModel -> ValueError
+        self._functions.append((idx, f, {}))
+        return self
+
+    def partial_deriv(self, parameter, df):
+        idx, _f, derivs = self._functions[-1]
+        k = self.names.index(parameter)
+        if k not in idx:
+            raise ModelBuildError("InvalidDerivative", "Parameter '%s' is not in the function's parameter list" % parameter)
+        if k in derivs:
+            raise ModelBuildError("DuplicateDerivative", "Derivative for parameter '%s' was already provided!" % parameter)
+        derivs[k] = df
+        return self
+
+    def pairs(self):
+        return [(j, k) for j, (idx, _f, _d) in enumerate(self._functions) for k in idx]
+
+    def shape(self):
+        for idx, _f, derivs in self._functions:
+            for k in idx:
+                if k not in derivs:
+                    raise ModelBuildError("MissingDerivative", "missing derivative for parameter '%s'" % self.names[k])
+        return ExternalModel(len(self._functions), len(self.names), self.pairs(), dtype=self.dtype)
+
+    def eval_batch(self, alpha):
+        """== eval() (src/model/mod.rs:441-471) for every parameter set of the batch: (B, n, m), UNWEIGHTED"""
+        a = np.asarray(alpha, dtype=np.float64).reshape(-1, len(self.names))
+        out = np.empty((a.shape[0], len(self._functions), self.x.size), dtype=self.dtype)
+        for b in range(a.shape[0]):
+            for j, (idx, f, _d) in enumerate(self._functions):
+                out[b, j] = f(self.x, *[a[b, k] for k in idx])
+        return out
+
+    def derivs_batch(self, alpha):
+        """== the non-zero columns of eval_partial_deriv(k) (src/model/mod.rs:473-512) in pair order: (B, p, m)"""
+        a = np.asarray(alpha, dtype=np.float64).reshape(-1, len(self.names))
+        prs = self.pairs()
+        out = np.empty((a.shape[0], len(prs), self.x.size), dtype=self.dtype)
+        for b in range(a.shape[0]):
+            for p, (j, k) in enumerate(prs):
+                idx, _f, derivs = self._functions[j]
+                out[b, p] = derivs[k](self.x, *[a[b, kk] for kk in idx])
+        return out
+
+
 class SeparableModelBuilder:
     """mirrors ``SeparableModelBuilder`` (src/model/builder/mod.rs:338-525)"""
 
