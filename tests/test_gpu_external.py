@@ -312,3 +312,44 @@ def test_nonfinite_basis_is_latched_as_status():
     got = bp.evaluate_with_basis(a, Phi, cm.derivs_batch(a))
     assert list(np.asarray(got["status"])) == [0, 1, 0]
     bp.close()
+
+
+@pytest.mark.parametrize("n,q,npairs", [(1, 1, 1), (2, 5, 7), (5, 2, 6), (6, 3, 5), (7, 3, 12), (8, 8, 16), (4, 6, 6)])
+@pytest.mark.parametrize("m", [100, 700])
+def test_any_shape_the_header_admits(n, q, npairs, m):
+    """shapes inside and outside the table of resident kernels (vp_ext.hpp; the rest runs on the generic kernels reading
+    the caller's columns): fixed smooth columns handed over as Phi / dPhi, the oracle gets them through its callbacks"""
+    rng = np.random.default_rng(1000 * n + 10 * q + npairs + m)
+    B = 3
+    x = np.linspace(0.0, 1.0, m)
+    allp = [(j, k) for j in range(n) for k in range(q)]
+    rng.shuffle(allp)
+    pairs = sorted(allp[:npairs], key=lambda jk: rng.random())  # any order
+    # every parameter needs a pair for the reference's builder; not for the ABI (a column of J is then zero)
+    Phi = np.stack([[np.cos((j + 1) * np.pi * (1.0 + 0.05 * b) * x) + 0.2 * np.sin(3 * (j + 1) * x) for j in range(n)]
+                    for b in range(B)])  # nearly orthogonal columns: cond(Phi_w) < 1e2, parity at the plain 1e-10
+    dPhi = np.stack([[np.sin((p + 2) * (1.0 + 0.2 * b) * x) * (1 + 0.1 * p) for p in range(npairs)] for b in range(B)])
+    Y = rng.standard_normal((B, m)) + Phi.sum(1)
+    w = 0.5 + rng.random(m)
+    alpha = rng.random((B, q))
+    bp = vp.BatchProblem(vp.ExternalModel(n, q, pairs), Y, weights=w)
+    got = bp.evaluate_with_basis(alpha, Phi, dPhi)
+    assert (np.asarray(got["status"]) == 0).all()
+    for b in range(B):
+        def dv(a, k, b=b):
+            out = np.zeros((n, m))
+            for pi, (j, kk) in enumerate(pairs):
+                if kk == k:
+                    out[j] += dPhi[b, pi]
+            return out
+        p = O.Problem(O.make_shape_desc(n, q), None, Y[b], w=w, external=(lambda a, b=b: Phi[b], dv))
+        p.set_params(alpha[b])
+        c_ref, r_ref, J_ref = p.linear_coefficients(), p.residuals(), p.jacobian()
+        assert np.linalg.cond(Phi[b].T * w[:, None]) < 1e2
+        tol = TOL
+        assert np.abs(got["C"][b] - c_ref).max() <= tol * np.abs(c_ref).max()
+        assert np.abs(got["r"][b] - r_ref).max() <= TOL * np.abs(Y[b] * w).max()
+        for k in range(q):
+            unproj = np.abs(dv(None, k) * np.asarray(c_ref)[:, None]).sum(0).max()
+            assert np.abs(got["J"][b, k] - J_ref[k]).max() <= tol * np.abs(J_ref[k]).max() + 1e-13 * unproj
+    bp.close()

@@ -433,6 +433,18 @@ int reduce_rhs(vp_batch *h, hipStream_t stream_override = nullptr, bool use_over
     return 0;
 }
 
+// workspace of the generic kernels (vp_generic.hpp): one slot of (n + 1 + p + q) columns per persistent workgroup; at most
+// 1024 workgroups and 4 GiB
+int ensure_gen_ws(vp_batch *h) {
+    if (h->d_gen_ws || h->kern->family != FAMILY_GENERIC) return 0;
+    const size_t slot = (size_t)(h->n + 1 + h->p + h->q) * (size_t)h->m * tsize(h->dtype);
+    int64_t blocks = std::min<int64_t>(h->B * h->S, 1024);
+    while (blocks > 1 && (size_t)blocks * slot > ((size_t)4 << 30)) blocks /= 2;
+    h->gen_blocks = (int)blocks;
+    VP_HIP(hipMalloc(&h->d_gen_ws, (size_t)blocks * slot));
+    return 0;
+}
+
 int ensure_R(vp_batch *h) {
     if (!h->d_R) VP_HIP(hipMalloc(&h->d_R, (size_t)h->B * h->S * h->m * tsize(h->dtype)));
     return 0;
@@ -440,6 +452,9 @@ int ensure_R(vp_batch *h) {
 
 // run the evaluate kernel at h->d_alpha; any output may be null
 int run_evaluate(vp_batch *h, void *r_dev, void *J_dev, void *C_dev) {
+    if (h->external && !h->d_gen_ws &&
+        !external_resident(h->dtype, h->n, h->ext_np, h->m, h->m_user ? h->m_user : h->m, J_dev != nullptr))
+        if (int rc = ensure_gen_ws(h)) return rc;
     LaunchParams p;
     fill_params(h, p);
     p.r_out = r_dev;
@@ -945,7 +960,7 @@ static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dty
     if (!kern) kern = generic_kernels(dtype);
     // a global fit (S > 1) on a specialised set WITHOUT multiple-right-hand-side kernels (the multi-wave sets: double
     // exponential at 2048 < m <= 4096, the fp32 Gram shape) runs on the generic kernels as well
-    if (S > 1 && !(kern->mrhs_factor && kern->mrhs_stream && kern->mrhs_lm && kern->mrhs_finish) && !kern->mrhs_fit_whole)
+    if (!ext && S > 1 && !(kern->mrhs_factor && kern->mrhs_stream && kern->mrhs_lm && kern->mrhs_finish) && !kern->mrhs_fit_whole)
         kern = generic_kernels(dtype);
 
     vp_batch *h = new vp_batch();
@@ -1064,13 +1079,12 @@ static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dty
     VP_TRY(hipMalloc((void **)&h->d_report, (size_t)B * sizeof(vp_report)));
     VP_TRY(hipMalloc((void **)&h->d_sum4, 4 * sizeof(double)));
     VP_TRY(hipMalloc((void **)&h->d_queue, sizeof(int)));
-    if (kern->family == FAMILY_GENERIC) {
-        // one workspace slot per persistent workgroup; at most 1024 workgroups and 4 GiB
-        const size_t slot = (size_t)(h->n + 1 + h->p + h->q) * (size_t)m * ts;
-        int64_t blocks = std::min<int64_t>(B * S, 1024);
-        while (blocks > 1 && (size_t)blocks * slot > ((size_t)4 << 30)) blocks /= 2;
-        h->gen_blocks = (int)blocks;
-        VP_TRY(hipMalloc(&h->d_gen_ws, (size_t)blocks * slot));
+    if (kern->family == FAMILY_GENERIC && !ext) {
+        // (caller-evaluated models allocate it on first use: their resident kernels -- vp_ext.hpp -- need none)
+        if (int rc = ensure_gen_ws(h)) {
+            vp_batch_destroy(h);
+            return rc;
+        }
     }
     VP_TRY(hipEventCreate(&h->ev0));
     VP_TRY(hipEventCreate(&h->ev1));
@@ -1535,6 +1549,7 @@ int vp_statistics(vp_batch *h, void *cov_out, double *reduced_chi2_out, void *co
     if (!h->kern->stats) return fail(VP_ERR_UNSUPPORTED, "no statistics kernel for this model");
     if (h->external && h->ext_np > 0 && !h->ext_dphi)
         return fail(VP_ERR_INVALID, "fit statistics need the derivative columns at the current parameters (vp_set_params_with_basis with dPhi)");
+    if (int rc = ensure_gen_ws(h)) return rc;
     if (!cov_out || !reduced_chi2_out) return fail(VP_ERR_INVALID, "null output");
     const size_t ts = tsize(h->dtype);
     const int k = h->n + h->q;
@@ -1675,16 +1690,6 @@ int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out) {
     b = d.n_params;
     c = pairs;
     return FAMILY_RT;
-}
-
-// caller-evaluated models: the generic kernels read the columns from the caller's arrays (any shape, any m, any S)
-const KernelEntry *external_kernels(int dtype, int n, int q, int np, int64_t m, int64_t S) {
-    (void)n;
-    (void)q;
-    (void)np;
-    (void)m;
-    (void)S;
-    return generic_kernels(dtype);
 }
 
 const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m, int64_t S) {

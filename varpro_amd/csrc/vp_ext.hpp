@@ -1,0 +1,241 @@
+// vp_ext.hpp -- register-resident evaluation for CALLER-EVALUATED models (vp_batch_create_external).
+//
+// The reference's plugin boundary is a trait: any `SeparableNonlinearModel` (src/model/mod.rs:239-363) -- the closure-based
+// `SeparableModel` (:441-512) in particular -- works with its solver.  A model the descriptor language cannot express
+// crosses the C ABI as the VALUES the trait returns: Phi = eval() and the non-zero columns of eval_partial_deriv(k).
+// This kernel is `evaluate_kernel` (vp_kernels.hpp) with the column BUILD replaced by column LOADS:
+//     Phi_w = W Phi, D_w = W dPhi     src/solvers/levmar/mod.rs:47, 141
+//     Householder QR of Phi_w applied to [y_w | D_w], truncated solve, ||r||^2          :51-59  (house_qr, solve_coeffs)
+//     r = Q [e; (Q^T y)_{>=n}],  J_k = -Q [0; sum_{pairs p of k} c_j(p) (Q^T D_p)_{>=n}]  :91-95, 101-201 (apply_q_cols)
+// One wavefront per (problem, right-hand side); the columns live in registers (R rows per lane), every global access is
+// 16 bytes per lane when the arrays allow it.  It streams T*m*(n + p + 1) bytes in and T*m*(1 + q) out per
+// problem-evaluation and is HBM-bound.
+//
+// Shapes: compile-time (N, P, R); the parameter count q and the pair table are run-time (J_k is assembled from the P
+// back-transformed derivative columns when it is stored), and a model with fewer pairs than P runs with zero columns that
+// are never loaded.  Shapes / lengths outside the table (and fp32) run on the generic kernels (vp_generic.hpp).
+#pragma once
+#include <vector>
+
+#include "vp_kernels.hpp"
+
+namespace vp {
+namespace ext {
+
+template <typename T> struct ExtArgs {
+    const T *phi;   // [B][N][m]  UNWEIGHTED
+    const T *dphi;  // [B][np][m] UNWEIGHTED, pair-table order (null: no derivative columns)
+    const T *w;     // null, [m] or [B][m]
+    const T *yw;    // [B][S][m] weighted data
+    T *r_out, *J_out, *C_out;
+    double *cost_out;
+    int32_t *status;
+    int32_t pb[VP_MAX_PAIRS], pp[VP_MAX_PAIRS];
+    int np; // pairs of the model (<= P of the instantiation)
+    int q;
+    int m, S;
+    int64_t nprob; // B*S
+    int64_t w_stride;
+    T eps;
+    int vec; // every array 16-byte aligned and m even: 2-element accesses
+};
+
+// waves per SIMD the register allocator must leave room for: the NC resident columns plus the wave-uniform state of the
+// factorisation (R, R^-1, Q^T y, c, e, the reflector's dot products: ~2N^2 + 6N values -- gfx950 has no scalar fp64 registers, they sit in VGPRs)
+template <typename T, int R, int N, int NC> constexpr int ext_waves() {
+    return ((NC * R + 2 * N * N + 6 * N) * (int)(sizeof(T) / 4) <= 200) ? 2 : 1;
+}
+
+template <typename T, int N, int P, int R, bool WITH_D>
+__global__ void __launch_bounds__(64, (ext_waves<T, R, N, N + 1 + (WITH_D ? P : 0)>())) ext_evaluate_kernel(const ExtArgs<T> a) {
+    constexpr int NC = N + 1 + (WITH_D ? P : 0);
+    using G = Grp<1>;
+    using L = Layout<R, 1>;
+    G grp = G::make(nullptr);
+    const int lane = grp.gl;
+    const int64_t prob = blockIdx.x; // problem * S + rhs
+    if (prob >= a.nprob) return;
+    const int64_t b = prob / a.S;
+    const int s = (int)(prob - b * a.S);
+    const int m = a.m;
+    const bool vec = a.vec != 0;
+
+    T C[NC][R];
+    {
+        const T *ph = a.phi + b * (int64_t)N * m;
+#pragma unroll
+        for (int j = 0; j < N; ++j) load_rows<T, R, 1>(ph + (int64_t)j * m, m, lane, vec, C[j]);
+        load_rows<T, R, 1>(a.yw + prob * (int64_t)m, m, lane, vec, C[N]);
+        if constexpr (WITH_D) {
+            const T *dp = a.dphi + b * (int64_t)a.np * m;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (p < a.np) { // (uniform)
+                    load_rows<T, R, 1>(dp + (int64_t)p * m, m, lane, vec, C[N + 1 + p]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) C[N + 1 + p][r] = T(0);
+                }
+            }
+        }
+        if (a.w) { // `&self.weights * ...` (src/util/weights.rs:82-99): row i of every model column times w_i
+            T wt[R];
+            load_rows<T, R, 1>(a.w + b * a.w_stride, m, lane, vec, wt);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                if (j == N) continue; // y_w was weighted when the handle was made (src/problem/builder.rs:307)
+#pragma unroll
+                for (int r = 0; r < R; ++r) C[j][r] *= wt[r];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    T g[N], Rm[N][N], qty[N], c[N], e[N];
+    house_qr<T, R, N, NC, 0, true, G>(C, g, Rm, qty, grp);
+    bool truncated;
+    solve_coeffs<T, N>(Rm, qty, a.eps, c, e, truncated);
+    // ||r||^2 = ||e||^2 + sum_{rows >= N} (Q^T y)^2
+    T sq = T(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const T v = (r >= L::VW || L::row_of(r, lane) >= N) ? C[N][r] : T(0);
+        sq = tfma(v, v, sq);
+    }
+    T fn2 = group_sum(grp, sq);
+#pragma unroll
+    for (int k = 0; k < N; ++k) fn2 = tfma(e[k], e[k], fn2);
+    bool ok = is_finite(fn2);
+#pragma unroll
+    for (int k = 0; k < N; ++k) ok = ok && is_finite(c[k]) && is_finite(Rm[k][k]);
+    ok = uni(ok);
+
+    if (lane == 0) {
+        if (a.status) a.status[prob] = ok ? VP_ST_OK : VP_ST_NONFINITE;
+        if (a.cost_out) a.cost_out[prob] = 0.5 * (double)fn2;
+    }
+    if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(c, lane);
+
+    const bool want_j = WITH_D && a.J_out != nullptr;
+    if (!a.r_out && !want_j) return;
+    residual_qcoords<T, R, N>(C[N], e, grp);
+    if constexpr (!WITH_D) {
+        apply_q_cols<T, R, N, NC, N, N + 1>(C, g, grp);
+        store_rows<T, R, 1>(a.r_out + prob * (int64_t)m, m, lane, vec, C[N]);
+    } else {
+        // P_perp: the rows < N of the derivative columns in Q-coordinates do not enter the Kaufman columns
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int r = 0; r < L::VW && r < R; ++r)
+                if (L::row_of(r, lane) < N) C[N + 1 + p][r] = T(0);
+        apply_q_cols<T, R, N, NC, N, NC>(C, g, grp); // [r~ | D~_1 .. D~_P] <- Q (.)  in ONE back-sweep
+        if (a.r_out) store_rows<T, R, 1>(a.r_out + prob * (int64_t)m, m, lane, vec, C[N]);
+        if (a.J_out) {
+            for (int k = 0; k < a.q; ++k) { // J[b][k][s][m] = -sum over the pairs p of parameter k of c_{basis(p)} Q D~_p
+                T cj[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) cj[p] = (p < a.np && a.pp[p] == k) ? -dyn_get<N>(c, a.pb[p]) : T(0);
+                T *jp = a.J_out + ((b * a.q + k) * (int64_t)a.S + s) * (int64_t)m;
+                // assembled and stored row pair by row pair: no R-register accumulator column next to the resident ones
+#pragma unroll
+                for (int r0 = 0; r0 < R; r0 += L::VW) {
+                    T v[2] = {T(0), T(0)};
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+#pragma unroll
+                        for (int x = 0; x < L::VW; ++x) v[x] = tfma(cj[p], C[N + 1 + p][r0 + x], v[x]);
+                    const int i = L::row_of(r0, lane);
+                    if (L::VW == 2 && vec) {
+                        if (i < m) {
+                            using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+                            V2 o;
+                            o.x = v[0];
+                            o.y = v[1];
+                            *reinterpret_cast<V2 *>(jp + i) = o;
+                        }
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < L::VW; ++x)
+                            if (i + x < m) jp[i + x] = v[x];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int N, int P, int R, bool WITH_D> int launch_one(const ExtArgs<T> &a, hipStream_t stream) {
+    hipLaunchKernelGGL((ext_evaluate_kernel<T, N, P, R, WITH_D>), dim3((unsigned)a.nprob), dim3(64), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+// one row of the table of compiled shapes (vp_inst_ext*.hip)
+template <typename T> struct ExtEntry {
+    int N, P, R;   // P == 0: the kernel without derivative columns (set_params / residuals only)
+    int (*launch)(const ExtArgs<T> &, hipStream_t);
+};
+template <typename T> std::vector<ExtEntry<T>> &ext_table() {
+    static std::vector<ExtEntry<T>> t;
+    return t;
+}
+template <typename T> struct ExtRegistrar {
+    explicit ExtRegistrar(const ExtEntry<T> &e) { ext_table<T>().push_back(e); }
+};
+
+// the resident kernel that covers (n, np pairs, m) with / without derivative columns, or null
+template <typename T> const ExtEntry<T> *find_ext(int n, int np, int m, bool with_d) {
+    const ExtEntry<T> *best = nullptr;
+    for (const ExtEntry<T> &e : ext_table<T>()) {
+        if (e.N != n || 64 * e.R < m) continue;
+        if (with_d ? (e.P == 0 || e.P < np) : e.P != 0) continue;
+        if (!best || e.R < best->R || (e.R == best->R && e.P < best->P)) best = &e;
+    }
+    return best;
+}
+
+// evaluate entry of the external kernel set: the resident kernel when the shape is in the table, else the generic one
+template <typename T> int launch_evaluate(const LaunchParams &p, int (*fallback)(const LaunchParams &)) {
+    const int n = p.model->n_basis, q = p.model->n_params;
+    const bool with_d = p.J_out != nullptr && p.ext_np > 0;
+    const ExtEntry<T> *e = (p.ext_rows == p.m && p.m >= n && (!with_d || p.ext_dphi)) ? find_ext<T>(n, p.ext_np, p.m, with_d) : nullptr;
+    if (!e || !p.ext_phi) return fallback(p);
+    ExtArgs<T> a;
+    a.phi = (const T *)p.ext_phi;
+    a.dphi = (const T *)p.ext_dphi;
+    a.w = (const T *)p.w;
+    a.yw = (const T *)p.yw;
+    a.r_out = (T *)p.r_out;
+    a.J_out = (T *)p.J_out;
+    a.C_out = (T *)p.C_out;
+    a.cost_out = p.cost_out;
+    a.status = p.status;
+    for (int i = 0; i < VP_MAX_PAIRS; ++i) {
+        a.pb[i] = i < p.ext_np ? p.ext_pb[i] : 0;
+        a.pp[i] = i < p.ext_np ? p.ext_pp[i] : -1;
+    }
+    a.np = p.ext_np;
+    a.q = q;
+    a.m = p.m;
+    a.S = p.S;
+    a.nprob = p.B * p.S;
+    a.w_stride = p.w_stride;
+    a.eps = (T)p.eps;
+    a.vec = host_aligned<T>(p.m, {p.ext_phi, p.ext_dphi, p.w, p.yw, p.r_out, p.J_out}) ? 1 : 0;
+    if (a.nprob <= 0) return VP_ERR_OK;
+    return e->launch(a, p.stream);
+}
+
+} // namespace ext
+} // namespace vp
+
+#define VP_EXT_CAT_(a, b) a##b
+#define VP_EXT_CAT(a, b) VP_EXT_CAT_(a, b)
+// one shape with derivative columns (P >= 1) ...
+#define VP_REGISTER_EXT(T, NN, PP, RR)                                                                                 \
+    static ::vp::ext::ExtRegistrar<T> VP_EXT_CAT(vp_ext_reg_, __COUNTER__)(                                           \
+        ::vp::ext::ExtEntry<T>{NN, PP, RR, &::vp::ext::launch_one<T, NN, PP, RR, true>});
+// ... and the kernel without them
+#define VP_REGISTER_EXT0(T, NN, RR)                                                                                    \
+    static ::vp::ext::ExtRegistrar<T> VP_EXT_CAT(vp_ext_reg_, __COUNTER__)(                                           \
+        ::vp::ext::ExtEntry<T>{NN, 0, RR, &::vp::ext::launch_one<T, NN, 1, RR, false>});

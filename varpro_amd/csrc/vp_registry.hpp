@@ -44,6 +44,8 @@ int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out);
 const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m, int64_t S = 1);
 // kernel set of a caller-evaluated model (vp_batch_create_external) of shape (n, q, np pairs)
 const KernelEntry *external_kernels(int dtype, int n, int q, int np, int64_t m, int64_t S);
+// true: an evaluation of this shape runs on a register-resident kernel (vp_ext.hpp) and needs no generic workspace
+bool external_resident(int dtype, int n, int np, int64_t m, int64_t ext_rows, bool with_d);
 // the generic fallback set (vp_generic.hpp): any descriptor, any m, single right-hand side fits
 const KernelEntry *generic_kernels(int dtype);
 
