@@ -176,12 +176,20 @@ def main():
     torch.cuda.synchronize()
     bp = handles[0]
 
-    def step(k, nslots):
+    fit_events = []  # (start, end) HIP events around the fit of every TIMED step (recorded on the launch stream, no host sync)
+
+    def step(k, nslots, events=None):
         # everything is enqueued asynchronously: the fit kernel, the 4-double batch summary (device side) and
         # the RCCL-over-xGMI all-reduce of those 32 bytes (the scalar LM cost reduction); no host sync per step
         i = k % nslots
         with torch.cuda.stream(streams[i]):
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             handles[i].fit(guess, want_coefficients=False)
+            if events is not None:
+                e1.record()
+                events.append((e0, e1))
             handles[i].summary_device(reds[i])
             if use_dist:
                 allreduce(reds[i])
@@ -194,7 +202,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for k in range(args.steps):
-            last_ = step(k, nslots)
+            last_ = step(k, nslots, fit_events if nslots == 1 else None)
         torch.cuda.synchronize()
         barrier()
         dt_ = time.perf_counter() - t0
@@ -246,7 +254,7 @@ def main():
             torch.cuda.synchronize()
             return sum(a_.elapsed_time(b_) for a_, b_ in ev) / reps
 
-        TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")
+        TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
         def committed_traffic(key, field="hbm_bytes_per_launch_corrected"):
             """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r0x_pmc_traffic.json; separate
@@ -270,7 +278,7 @@ def main():
 
         def committed_valu_issue(key):
             """VALU issue fraction over the launch from the committed SQ PMC pass (profiles/r0x_fit_kernels_valu_pmc.json)"""
-            for fn in ("r03_fit_kernels_valu_pmc.json", "r02_fit_kernels_valu_pmc.json"):
+            for fn in ("r04_fit_kernels_valu_pmc.json", "r03_fit_kernels_valu_pmc.json", "r02_fit_kernels_valu_pmc.json"):
                 try:
                     e = json.load(open(os.path.join(ROOT, "profiles", fn)))[key]
                     # wave-level VALU instructions x 4 issue cycles / (1024 SIMDs x launch duration x 2.4 GHz)
@@ -281,7 +289,9 @@ def main():
             return None, None
 
         # ---- per-kernel durations with HIP events on the launch stream ----
-        fit_ms = event_ms(lambda: bp.fit(guess, want_coefficients=False), args.steps)
+        # the fit kernel: the event pairs recorded around vp_fit INSIDE the timed region above (same loop as ms_per_step, so
+        # avg_launch_ms <= ms_per_step by construction; the difference is the summary kernel + the all-reduce)
+        fit_ms = sum(a_.elapsed_time(b_) for a_, b_ in fit_events) / max(1, len(fit_events))
         n_alpha, p = 2, 2
         phi = torch.empty((B, n_alpha, m), dtype=torch.float64, device=dev)
         dphi = torch.empty((B, p, m), dtype=torch.float64, device=dev)
@@ -310,9 +320,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "B=%d fits/GPU, m=%d, fp64, n=3, q=2 (double-exp+offset), full LM fit per step = BASELINE "
-                            "configs[3] per-GPU shard = north_star 1-GPU headline; noise %.0e, one batch at a time on one "
-                            "HIP stream" % (B, m, args.noise),
+                "workload": "B=%d fits/GPU, m=%d, fp64, double-exp+offset (n=3, q=2), one full LM fit per step" % (B, m),
+                "workload_detail": "BASELINE configs[3] per-GPU shard = north_star 1-GPU headline; noise %.0e; one batch at a "
+                                   "time on one HIP stream; every step starts from the initial guesses" % args.noise,
                 "batch_per_gpu": B, "m": m, "parallelism": "batch-sharded x%d" % world,
                 "world_size": dist.get_world_size() if use_dist else 1,
                 "collective_backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if use_dist else None,
@@ -488,15 +498,91 @@ def main():
                 "roofline": {"kernel": "fitg2_kernel<5 exp + offset> (fp32 data, fp64 moment/Gram pass with closed-form y-independent "
                                        "moments + Cholesky-based LM; per CU one 8-wave workgroup = 7 streaming waves + 1 bookkeeping "
                                        "wave over a pool of 32 problem slots; passes of long fits split over 4 waves)",
-                             "bound": "fp64_valu",
-                             "achieved": tf4, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf4 / FP64_VALU_PEAK_TFLOPS, "flops_per_evaluation": flops4,
-                             "flops_executed_per_evaluation": flops4_exec, "frac_executed": tf4 * flops4_exec / flops4 / FP64_VALU_PEAK_TFLOPS,
+                             "bound": "latency (the longest fit's chain of rounds: evaluations x {moment pass + LM bookkeeping})",
+                             "achieved": tf4 * flops4_exec / flops4, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf4 * flops4_exec / flops4 / FP64_VALU_PEAK_TFLOPS,
+                             "flops_executed_per_evaluation": flops4_exec,
+                             "note": "frac = fp64 flops the kernel EXECUTES (33 per row: closed-form y-independent moments) over the "
+                                     "fp64 VALU peak; against the 158 flop/row Gram model of round 2 it would read %.2f" % (tf4 / FP64_VALU_PEAK_TFLOPS),
                              "hbm_bytes_per_evaluation": 4 * m4, "y_reread_bytes_per_launch": 4.0 * m4 * float(r4["n_evals"].sum()),
                              "traffic": committed_traffic("fitg2_kernel"), "traffic_source": traffic_source("fitg2_kernel")},
             }
             bp4.close()
             del Y4
+
+        if world == 1 and not args.no_side_configs:
+            # ---- the S = 1 evaluation boundary: what a trait-level caller of a BATCH pays per LM
+            # evaluation -- vp_evaluate with r and J out; B_eval = T [m S (2 + q) + n S + q] = 32808 B per problem ----
+            r_ev = torch.empty((B, m), dtype=torch.float64, device=dev)
+            J_ev = torch.empty((B, 2, m), dtype=torch.float64, device=dev)
+            C_ev = torch.empty((B, 3), dtype=torch.float64, device=dev)
+            cost_ev = torch.empty((B,), dtype=torch.float64, device=dev)
+            st_ev = torch.empty((B,), dtype=torch.int32, device=dev)
+            import ctypes as C_
+
+            def vptr(t):
+                return C_.c_void_p(t.data_ptr()) if t is not None else None
+
+            def ev_call():
+                _lib.check(bp.lib.vp_evaluate(bp._h, vptr(guess), vptr(r_ev), vptr(J_ev), vptr(C_ev), vptr(cost_ev), vptr(st_ev)))
+
+            ev_ms = event_ms_each(ev_call, 20, 3)
+            bytes_ev = B * T * (m * (2 + 2) + 3 + 2)
+            out["evaluate_boundary"] = {
+                "workload": "vp_evaluate, B=%d, m=%d, fp64: alpha in; y read; r, J, c, cost out (the trait-level set_params + "
+                            "residuals + jacobian of a batch in one launch)" % (B, m),
+                "ms": ev_ms, "bytes_per_problem": T * (m * 4 + 5),
+                "roofline": {"kernel": "evaluate_kernel<MODE 2>", "bound": "hbm", "achieved": bytes_ev / (ev_ms * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_ev / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "bytes_per_launch": bytes_ev, "traffic": committed_traffic("evaluate_kernel"),
+                             "traffic_source": traffic_source("evaluate_kernel")},
+            }
+
+            # ---- a model OUTSIDE the descriptor language (vp_batch_create_external): the caller hands over Phi and dPhi, the
+            # device does weighting / QR / solve / residual / Kaufman J.  Columns here: the double-exponential model's own
+            # (written once by vp_basis -- a stand-in for the caller's closures, so the result can be compared with vp_evaluate)
+            phi_x = torch.empty((B, 3, m), dtype=torch.float64, device=dev)
+            dphi_x = torch.empty((B, 2, m), dtype=torch.float64, device=dev)
+            bp.basis(guess, skip_invariant=False, out_phi=phi_x, out_dphi=dphi_x)
+            bpx = vp.BatchProblem(vp.ExternalModel(3, 2, [(0, 0), (1, 1)]), Y)
+            r_x, J_x = torch.empty_like(r_ev), torch.empty_like(J_ev)
+            C_x, cost_x, st_x = torch.empty_like(C_ev), torch.empty_like(cost_ev), torch.empty_like(st_ev)
+
+            def x_full():
+                _lib.check(bpx.lib.vp_evaluate_with_basis(bpx._h, vptr(guess), vptr(phi_x), vptr(dphi_x), vptr(r_x), vptr(J_x),
+                                                          vptr(C_x), vptr(cost_x), vptr(st_x)))
+
+            def x_in():
+                _lib.check(bpx.lib.vp_evaluate_with_basis(bpx._h, vptr(guess), vptr(phi_x), None, None, None, vptr(C_x),
+                                                          vptr(cost_x), vptr(st_x)))
+
+            xf_ms = event_ms_each(x_full, 20, 3)
+            xi_ms = event_ms_each(x_in, 20, 3)
+            ev_call()
+            x_full()
+            torch.cuda.synchronize()
+            okx = (st_ev == 0) & (st_x == 0)
+            dJ = float(((J_x - J_ev).abs().amax(dim=(1, 2)) / J_ev.abs().amax(dim=(1, 2)))[okx].max())
+            dr = float(((r_x - r_ev).abs().amax(dim=1) / Y.abs().amax(dim=1))[okx].max())
+            dC = float(((C_x - C_ev).abs().amax(dim=1) / C_ev.abs().amax(dim=1))[okx].max())
+            bytes_xin = B * T * m * (3 + 1)            # Phi (n) + y
+            bytes_xfull = B * T * m * (3 + 2 + 1 + 1 + 2)  # Phi (n) + dPhi (p) + y in, r + J (q) out
+            out["external_model"] = {
+                "workload": "vp_evaluate_with_basis, B=%d, m=%d, fp64, n=3, q=2, p=2: caller-evaluated Phi / dPhi in (device "
+                            "pointers), device weighting + QR / solve + residual + Kaufman J" % (B, m),
+                "ms_phi_dphi_in_r_J_out": xf_ms, "ms_phi_in_c_cost_out": xi_ms,
+                "max_rel_diff_vs_vp_evaluate": {"c": dC, "r": dr, "J": dJ},
+                "roofline": {"kernel": "ext_evaluate_kernel<double, 3, 2, 16, true> (columns loaded, not built)", "bound": "hbm",
+                             "achieved": bytes_xfull / (xf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": bytes_xfull / (xf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bytes_xfull,
+                             "input_stream_GBps": B * T * m * (3 + 2 + 1) / (xf_ms * 1e-3) / 1e9,
+                             "traffic": committed_traffic("ext_evaluate_kernel"), "traffic_source": traffic_source("ext_evaluate_kernel")},
+                "roofline_set_params": {"kernel": "ext_evaluate_kernel<double, 3, 1, 16, false> (Phi and y in; c, cost out)", "bound": "hbm",
+                                        "achieved": bytes_xin / (xi_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": bytes_xin / (xi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bytes_xin},
+            }
+            bpx.close()
+            del phi_x, dphi_x, r_x, J_x, r_ev, J_ev
 
         # ---- generic fallback kernels (vp_generic.hpp): a model / size WITHOUT a specialised kernel set ----
         if world == 1 and not args.no_side_configs:
@@ -564,8 +650,17 @@ def main():
         n_cpu = int(min(max(pilot_n, args.cpu_seconds * pilot_n / max(pilot, 1e-6)), 262144))
         dd = d if n_cpu <= B else synth.double_exp_batch(n_cpu, m=m, noise=args.noise)
         t1 = time.perf_counter()
-        _a, _c, rep_cpu, secs_fit = O.fit_batch(mdl, dd["x"], dd["Y"][:n_cpu], dd["tau_guess"][:n_cpu], n_threads=threads)
+        a_cpu, _c, rep_cpu, secs_fit = O.fit_batch(mdl, dd["x"], dd["Y"][:n_cpu], dd["tau_guess"][:n_cpu], n_threads=threads)
         wall = time.perf_counter() - t1
+        # parity census: the oracle's fits of this sample against the device's fits of the SAME problems, problem by
+        # problem (oracle/census.py; tests/test_gpu_census.py asserts the contract on the whole 65536-problem shard)
+        from oracle import census as CS
+        n_cen = min(n_cpu, B)
+        a_dev, _cd, rep_dev = bp.fit(guess, want_coefficients=False)
+        torch.cuda.synchronize()
+        cen = CS.census(bp.report_to_numpy(rep_dev)[:n_cen], a_dev.cpu().numpy()[:n_cen], rep_cpu[:n_cen], a_cpu[:n_cen], max_listed=10)
+        out["parity_census"] = dict(cen, what="vp_fit vs the oracle on the first %d problems of the timed workload: success class, "
+                                              "termination codes, objective, evaluation counts per problem" % n_cen)
         out["cpu_baseline"] = {
             "value": n_cpu / wall, "unit": "fits/s", "cores": threads, "kind": "port",
             "cpu_model": cpu_model, "sockets": sockets, "physical_cores": phys_cores, "logical_cpus_usable": usable,
@@ -591,6 +686,11 @@ def main():
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         out["gpu_over_cpu_single_socket_extrapolated"] = value / out["cpu_baseline"]["extrapolated_single_socket_fits_per_s"]
     if rank == 0:
+        try:
+            out["build"] = {"library_bytes": os.path.getsize(_lib.LIB_PATH)}
+            out["build"].update(json.load(open(os.path.join(ROOT, "varpro_amd", "lib", "build_info.json"))))
+        except Exception:
+            pass
         print(json.dumps(out))
     for h_ in handles:
         h_.close()

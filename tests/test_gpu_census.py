@@ -1,0 +1,93 @@
+"""Parity census at BATCH scale ("next" item 2): the oracle fits the WHOLE batch the device fits -- every
+one of BASELINE configs[1]'s 4 096 problems, every one of the 65 536 problems of a configs[3] per-GPU shard (the headline
+workload of bench.py), and a 2 048-problem sample of configs[4] -- and the two are compared problem by problem: what
+`LevMarSolver::fit` returns for each (/root/reference/src/solvers/levmar/mod.rs:238-254: Ok / Err by
+`termination.was_successful()`; /root/reference/src/fit.rs:113-122).  The slot kernel's refill / queue path, the lone tail
+and the long fits (50-114 evaluations) are all inside these batches.
+
+Contract asserted for the fp64 double exponential: the SAME success class for every problem (a disagreement would be
+listed with both termination codes, evaluation counts and objectives), the same failures by termination code, objective of
+the common successes to 1e-12 (median) / 1e-6 (max), |delta n_evals| <= 3 on >= 95 %, equal maximum evaluation counts.
+For fp32 configs[4] the oracle runs in fp64 on the converted inputs with the handle's fp32 tolerances (30 eps_32): five
+exponentials are conditioned 1e6+, a trial point that steps a decay time through zero ends the fit as `User` (non-finite
+evaluation) on whichever side takes that step -- the census states the rates, and asserts that EVERY disagreement is of that
+kind."""
+import json
+
+import numpy as np
+import pytest
+
+import varpro_amd as vp
+from oracle import census as CS
+from oracle import oracle as O
+from varpro_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _double_exp_census(B, first=0):
+    d = synth.double_exp_batch(B, m=1024, first_problem=first, noise=1e-3)
+    mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0])
+    bp = vp.BatchProblem(mdl, d["Y"], x=d["x"])
+    a, _c, rep = bp.fit(d["tau_guess"])
+    bp.close()
+    ao, _co, ro, _s = O.fit_batch(mdl, d["x"], d["Y"], d["tau_guess"], n_threads=min(16, O.max_threads()))
+    res = CS.census(rep, a, ro, ao, max_listed=200)
+    print(json.dumps({k: v for k, v in res.items() if k != "disagreements"}))
+    for dis in res["disagreements"]:
+        print("DISAGREEMENT", dis)
+    return res
+
+
+def _assert_fp64_contract(res):
+    assert res["success_class_disagreements"] == 0, res["disagreements"]
+    assert res["failures_by_code_device"] == res["failures_by_code_oracle"]
+    assert res["failed_on_both"] == res["failed_device"] == res["failed_oracle"]
+    assert res["objective_rel_diff_median_common_successes"] <= 1e-12
+    assert res["objective_rel_diff_max_common_successes"] <= 1e-6
+    assert res["share_evals_within_3"] >= 0.95
+    assert res["max_evals_device"] == res["max_evals_oracle"]
+    assert abs(res["sum_evals_device"] - res["sum_evals_oracle"]) <= 0.02 * res["sum_evals_oracle"]
+
+
+def test_census_configs1_all_4096_problems():
+    _assert_fp64_contract(_double_exp_census(4096))
+
+
+def test_census_configs3_shard_all_65536_problems():
+    res = _double_exp_census(65536)
+    _assert_fp64_contract(res)
+    # the failures of the headline set (bench.py reports them as fits_failed): non-finite evaluations on BOTH sides
+    assert set(res["failures_by_code_device"]) <= {"User", "LostPatience", "NoImprovementPossible", "Numerical"}
+
+
+def test_census_second_shard_of_configs3():
+    # shard 7 of the 8-GPU problem set (problems 458752 ..): the one that holds a 300-evaluation LostPatience fit
+    res = _double_exp_census(65536, first=7 * 65536)
+    _assert_fp64_contract(res)
+
+
+def test_census_configs4_sample_of_2048():
+    B = 2048
+    d = synth.multi_exp_batch(B, 5, 4096, [0.5, 1.5, 3.0, 6.0, 12.0], noise=1e-3, spread=0.1, guess_spread=0.05, dtype=np.float32)
+    mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0], dtype=np.float32)
+    bp = vp.BatchProblem(mdl, d["Y"], x=d["x"])
+    a, _c, rep = bp.fit(d["tau_guess"])
+    bp.close()
+    x64, Y64, g64 = d["x"].astype(np.float64), d["Y"].astype(np.float64), d["tau_guess"].astype(np.float64)
+    mdl64 = vp.multi_exponential_model(x64, g64[0])
+    e32 = float(np.finfo(np.float32).eps)
+    ao, _co, ro, _s = O.fit_batch(mdl64, x64, Y64, g64, n_threads=min(16, O.max_threads()),
+                                  opts=O.default_opts(ftol=30 * e32, xtol=30 * e32, gtol=30 * e32))
+    res = CS.census(rep, a, ro, ao, max_listed=B)
+    print(json.dumps({k: v for k, v in res.items() if k != "disagreements"}))
+    # every disagreement: one side ended `User` (a trial point with a non-positive / overflowing decay time), the other converged
+    for dis in res["disagreements"]:
+        assert "User" in (dis["device"], dis["oracle"]), dis
+    assert res["same_success_class"] >= 0.93
+    assert set(res["failures_by_code_device"]) <= {"User"} and set(res["failures_by_code_oracle"]) <= {"User", "LostPatience"}
+    assert res["failed_device"] <= 0.04 * B and res["failed_oracle"] <= 0.05 * B
+    # the common successes sit in the same valley of a very flat objective (cond(Phi) >= 1e6: parameters are NOT comparable)
+    assert res["objective_rel_diff_median_common_successes"] <= 1e-4
+    assert res["share_objective_within_1e-3"] >= 0.9
+    assert abs(res["sum_evals_device"] - res["sum_evals_oracle"]) <= 0.1 * res["sum_evals_oracle"]
