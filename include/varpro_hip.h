@@ -96,7 +96,12 @@ enum {
      * |t_i - (t_0 + i dt)| <= 4 eps |t_i - t_0|) by a per-lane recurrence instead of one exponential per row;
      * results then agree with the per-row form to ~1e-15 relative instead of 1 ulp.  This flag keeps the per-row
      * exponential (== the reference's evaluation, shared_test_code/src/lib.rs:101-114) regardless of the grid. */
-    VP_FLAG_NO_GRID_RECURRENCE = 1 << 4
+    VP_FLAG_NO_GRID_RECURRENCE = 1 << 4,
+    /* Single-RHS fits of this handle run on the LENGTH-AGNOSTIC kernels (rows streamed in blocks through a TSQR-style
+     * update of an (n+1+p)^2 triangle; any m) even where a register-resident kernel set covers m.  The library selects them
+     * by itself beyond the largest resident set; the flag exists for memory-lean handles and for the parity tests.  Ignored
+     * for models without such a set (they run on the generic kernels, as before). */
+    VP_FLAG_STREAM_ROWS = 1 << 5
 };
 
 /* per-problem status word (0 == the reference's `cached = Some(..)`) */
@@ -370,6 +375,17 @@ int vp_summary(vp_batch *h, double out[4]);
 /* same aggregates written to 4 DEVICE doubles, enqueued on the handle's stream without any host
  * synchronisation: the buffer can be handed straight to ncclAllReduce (RCCL) */
 int vp_summary_device(vp_batch *h, double *dev_out4);
+
+/*
+ * The scalar LM cost reduction of SURVEY.md 8(b) / 8(e) for hosts WITHOUT a collective layer of their own (plain C / C++ /
+ * Rust; Python callers use torch.distributed on vp_summary_device): the handle's aggregates
+ * { sum 1/2||r||^2, #successful, #failed, sum n_evals } summed over all ranks of `rccl_comm` (an ncclComm_t) by ONE
+ * ncclAllReduce of 4 doubles on the handle's stream -- 32 bytes over xGMI -- and returned in HOST doubles.  The library
+ * does not link RCCL: ncclAllReduce is resolved at the first call from the process (a host that links librccl) or, failing
+ * that, from librccl.so.1 (dlopen); VP_ERR_UNSUPPORTED if neither is there.  rccl_comm == NULL: the local aggregates
+ * (== vp_summary).  Every rank of the communicator must make the call (it is a collective).
+ */
+int vp_reduce_cost(vp_batch *h, void *rccl_comm, double out[4]);
 
 /*
  * One global fit whose right-hand sides are SHARDED over ranks (second row).  The reference fits

@@ -22,6 +22,7 @@ VP_MAX_PAIRS = 16
 VP_F64, VP_F32 = 0, 1
 VP_FLAG_DEVICE_PTRS, VP_FLAG_T_PER_PROBLEM, VP_FLAG_W_PER_PROBLEM, VP_FLAG_OWN_STREAM = 1, 2, 4, 8
 VP_FLAG_NO_GRID_RECURRENCE = 16
+VP_FLAG_STREAM_ROWS = 32
 VP_BASIS_SKIP_INVARIANT = 1
 VP_KERNEL_EVALUATE, VP_KERNEL_BASIS, VP_KERNEL_FIT = 0, 1, 2
 VP_ST_OK, VP_ST_NONFINITE, VP_ST_NOT_EVALUATED = 0, 1, 2
@@ -45,6 +46,7 @@ ABI_SYMBOLS = [
     "vp_best_fit", "vp_debug_gram_evaluate", "vp_statistics", "vp_summary", "vp_summary_device", "vp_set_rhs_allreduce", "vp_set_fit_kernel", "vp_set_timing", "vp_last_kernel_ms", "vp_synchronize", "vp_last_error",
     "vp_last_error_detail", "vp_version", "vp_device_count",
     "vp_batch_create_external", "vp_set_params_with_basis", "vp_jacobian_with_derivatives", "vp_evaluate_with_basis",
+    "vp_reduce_cost",
 ]
 
 
@@ -128,6 +130,7 @@ def load():
     lib.vp_statistics.argtypes = [vp, vp, vp, vp, vp]
     lib.vp_summary.argtypes = [vp, dp]
     lib.vp_summary_device.argtypes = [vp, vp]
+    lib.vp_reduce_cost.argtypes = [vp, vp, dp]
     lib.vp_set_rhs_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, C.c_int64]
     lib.vp_set_fit_kernel.argtypes = [vp, C.c_int]
     lib.vp_set_timing.argtypes = [vp, C.c_int]

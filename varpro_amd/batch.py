@@ -128,7 +128,7 @@ def _device_entry(fn):
 
 
 class BatchProblem:
-    def __init__(self, model, Y, x=None, weights=None, epsilon=None, device=0, grid_recurrence=True):
+    def __init__(self, model, Y, x=None, weights=None, epsilon=None, device=0, grid_recurrence=True, stream_rows=False):
         """model: varpro_amd.SeparableModel; Y: (B, m) or (B, S, m); x: (m,) shared grid or (B, m)
         per-problem grids (default: model.x); weights: None (unit), (m,) or (B, m).
         grid_recurrence=False sets VP_FLAG_NO_GRID_RECURRENCE (per-row exponentials even on uniform grids)."""
@@ -160,6 +160,8 @@ class BatchProblem:
         else:
             x = self._as_array(x)
         flags = 0 if grid_recurrence else _lib.VP_FLAG_NO_GRID_RECURRENCE
+        if stream_rows:  # VP_FLAG_STREAM_ROWS: the length-agnostic fit kernels even where a resident set covers m
+            flags |= _lib.VP_FLAG_STREAM_ROWS
         if self.device_mode:
             flags |= _lib.VP_FLAG_DEVICE_PTRS  # work is enqueued on torch's current stream
         else:
@@ -396,10 +398,10 @@ class BatchProblem:
         a = self._as_array(alpha0).reshape(self.B, self.q)
         a = a.clone() if _is_torch(a) else a.copy()
         Cm = self._empty((self.B, self.S, self.n)) if want_coefficients else None
-        self._have_params = True
         if self.device_mode:
             rep_t = torch.empty((self.B, 16), dtype=torch.uint8, device=self._torch_device())
             check(self.lib.vp_fit(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), self._ptr(rep_t)))
+            self._have_params = True  # (only once the call has succeeded: a failed fit leaves the handle without parameters)
             rep = rep_t  # raw bytes on device; use report_to_numpy() to decode
             if Cm is not None and self.single_rhs:
                 Cm = Cm.reshape(self.B, self.n)
@@ -407,6 +409,7 @@ class BatchProblem:
         else:
             rep = np.zeros(self.B, dtype=REPORT_DTYPE)
             check(self.lib.vp_fit(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), C.c_void_p(rep.ctypes.data)))
+            self._have_params = True
         if Cm is not None and self.single_rhs:
             Cm = Cm.reshape(self.B, self.n)
         return a, Cm, rep
@@ -421,9 +424,9 @@ class BatchProblem:
         Cm = self._empty((self.B, self.S, self.n))
         rep = np.zeros(self.B, dtype=REPORT_DTYPE)
         tr = np.zeros((self.B, max_rows, self.q + 4))
-        self._have_params = True
         check(self.lib.vp_fit_trace(self._h, C.byref(opts), self._ptr(a), self._ptr(Cm), C.c_void_p(rep.ctypes.data),
                                     C.c_void_p(tr.ctypes.data), int(max_rows)))
+        self._have_params = True
         if self.single_rhs:
             Cm = Cm.reshape(self.B, self.n)
         return a, Cm, rep, tr

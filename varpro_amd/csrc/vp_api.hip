@@ -3,6 +3,8 @@
 // entry point runs HIP kernels on a gfx950 device or returns an error.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -304,7 +306,8 @@ __global__ void strip_rows_kernel(const unsigned *__restrict__ src, unsigned *__
 // the LM crate's answer when there are fewer residuals than nonlinear parameters: one evaluation at the initial point,
 // then TerminationReason::WrongDimensions (vp_lm_core.hpp lm_after_eval, first evaluation)
 __global__ void wrong_dimensions_report_kernel(const double *__restrict__ cost, const int32_t *__restrict__ status, int64_t B,
-                                               vp_report *__restrict__ rep) {
+                                               vp_report *__restrict__ rep, double *__restrict__ trace, int trace_rows, int q,
+                                               int dtype, const void *__restrict__ alpha) {
     const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (b >= B) return;
     vp_report r;
@@ -313,6 +316,15 @@ __global__ void wrong_dimensions_report_kernel(const double *__restrict__ cost, 
     r.n_evals = 1;
     r.objective = ok ? cost[b] : 0.0 / 0.0;
     rep[b] = r;
+    if (trace && trace_rows > 0) { // vp_fit_trace: row 0 = [alpha_0, ||r||, ratio = NaN, delta, par] of the one evaluation
+        double *tr = trace + (size_t)b * trace_rows * (q + 4);
+        for (int k = 0; k < q; ++k)
+            tr[k] = dtype == VP_F64 ? ((const double *)alpha)[b * q + k] : (double)((const float *)alpha)[b * q + k];
+        tr[q] = ok ? sqrt(2.0 * cost[b]) : 0.0 / 0.0;
+        tr[q + 1] = 0.0 / 0.0;
+        tr[q + 2] = 0.0;
+        tr[q + 3] = 0.0;
+    }
 }
 
 // `blocks` blocks of the handle's m rows in device memory -> the caller's array of `blocks` blocks of ITS m rows
@@ -331,8 +343,8 @@ int copy_out_rows(vp_batch *h, void *user, const void *dev, size_t blocks) {
     if (e == hipSuccess && !device_ptrs(h)) {
         e = hipMemcpyAsync(user, packed, bytes, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        (void)hipFree(packed);
     }
+    if (!device_ptrs(h)) (void)hipFree(packed); // the temporary of host-pointer handles, on every path
     if (e != hipSuccess) return fail(VP_ERR_HIP, std::string("copy_out_rows: ") + hipGetErrorString(e));
     return 0;
 }
@@ -436,7 +448,7 @@ int reduce_rhs(vp_batch *h, hipStream_t stream_override = nullptr, bool use_over
 // workspace of the generic kernels (vp_generic.hpp): one slot of (n + 1 + p + q) columns per persistent workgroup; at most
 // 1024 workgroups and 4 GiB
 int ensure_gen_ws(vp_batch *h) {
-    if (h->d_gen_ws || h->kern->family != FAMILY_GENERIC) return 0;
+    if (h->d_gen_ws || !h->kern->uses_gen_ws) return 0;
     const size_t slot = (size_t)(h->n + 1 + h->p + h->q) * (size_t)h->m * tsize(h->dtype);
     int64_t blocks = std::min<int64_t>(h->B * h->S, 1024);
     while (blocks > 1 && (size_t)blocks * slot > ((size_t)4 << 30)) blocks /= 2;
@@ -694,16 +706,28 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         }
         return ok;
     };
-    if (want_graph && (!h->mrhs_graph || h->mrhs_graph_len != want_iters || std::memcmp(&h->mrhs_graph_opts, &o, sizeof(o)) != 0)) {
+    // Re-capture with hysteresis: on streaming data the longest fit moves by +-1 evaluation from one call to the next, and a
+    // capture + instantiation costs as much as the fit it speeds up.  The head is re-captured when the options changed, when
+    // the wanted length EXCEEDS the captured one (every further iteration would cost a replay of the tail graph) or falls
+    // short of it by 4 or more (each idle iteration is two empty launches, ~10 us); the 12-iteration tail graph does not
+    // depend on the length and is only re-captured with the options.
+    const bool opts_changed = !h->mrhs_graph || std::memcmp(&h->mrhs_graph_opts, &o, sizeof(o)) != 0;
+    if (want_graph && (opts_changed || want_iters > h->mrhs_graph_len || want_iters + 4 <= h->mrhs_graph_len)) {
         if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
-        if (h->mrhs_graph_tail) (void)hipGraphExecDestroy(h->mrhs_graph_tail);
-        h->mrhs_graph = h->mrhs_graph_tail = nullptr;
-        if (capture(h->mrhs_graph, true, want_iters) && capture(h->mrhs_graph_tail, false, 12)) {
+        h->mrhs_graph = nullptr;
+        bool ok = capture(h->mrhs_graph, true, want_iters);
+        if (ok && (opts_changed || !h->mrhs_graph_tail)) {
+            if (h->mrhs_graph_tail) (void)hipGraphExecDestroy(h->mrhs_graph_tail);
+            h->mrhs_graph_tail = nullptr;
+            ok = capture(h->mrhs_graph_tail, false, 12);
+        }
+        if (ok) {
             h->mrhs_graph_opts = o;
             h->mrhs_graph_len = want_iters;
         } else {
             if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
-            h->mrhs_graph = nullptr;
+            if (h->mrhs_graph_tail) (void)hipGraphExecDestroy(h->mrhs_graph_tail);
+            h->mrhs_graph = h->mrhs_graph_tail = nullptr;
             h->mrhs_graph_failed = true; // fall back to plain launches for the rest of this handle's life
         }
     }
@@ -746,6 +770,10 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
             if (nact <= 0) break;
         }
         if (int rc = enqueue_finish(p)) return rc;
+        // device-pointer handles: the finish / gather kernels read the caller's array addresses from the pinned MrhsIo record
+        // at EXECUTION time and nothing below waits for them on this path (no copies: they write the results themselves) --
+        // a following vp_fit would overwrite the record under them
+        if (use_io) VP_HIP(hipStreamSynchronize(h->stream));
     }
     tm.stop();
     h->have_params = true;
@@ -953,10 +981,12 @@ static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dty
 
     // a specialised (register-resident) kernel set if one is instantiated for this (dtype, model, m), else the generic
     // fallback kernels (vp_generic.hpp): any descriptor, any m -- slower, but never a CPU path and never "unsupported"
-    const KernelEntry *kern = ext ? external_kernels(dtype, model->n_basis, model->n_params, ext->np, m, S) : find_kernels(dtype, *model, m, S);
-    // weighted problems on the largest multi-wave sets: grid + weights + data column of 64 R W rows each must fit the 160 KiB
-    // of LDS the one-problem-per-group fit kernel stages them in (32 rows per lane on four waves, fp64: 3 x 64 KiB does not)
-    if (kern && w && (size_t)3 * 64 * kern->R * kern->W * tsize(dtype) + 4096 > (size_t)160 * 1024) kern = nullptr;
+    const KernelEntry *kern = ext ? external_kernels(dtype, model->n_basis, model->n_params, ext->np, m, S)
+                                  : find_kernels(dtype, *model, m, S, w != nullptr);
+    if (!ext && (flags & VP_FLAG_STREAM_ROWS)) { // only the length-agnostic sets (capacity 2^26 rows) pass this length
+        const KernelEntry *ks = find_kernels(dtype, *model, (int64_t)1 << 24, S, w != nullptr);
+        if (ks) kern = ks;
+    }
     if (!kern) kern = generic_kernels(dtype);
     // a global fit (S > 1) on a specialised set WITHOUT multiple-right-hand-side kernels (the multi-wave sets: double
     // exponential at 2048 < m <= 4096, the fp32 Gram shape) runs on the generic kernels as well
@@ -1079,7 +1109,7 @@ static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dty
     VP_TRY(hipMalloc((void **)&h->d_report, (size_t)B * sizeof(vp_report)));
     VP_TRY(hipMalloc((void **)&h->d_sum4, 4 * sizeof(double)));
     VP_TRY(hipMalloc((void **)&h->d_queue, sizeof(int)));
-    if (kern->family == FAMILY_GENERIC && !ext) {
+    if (kern->uses_gen_ws && !ext) {
         // (caller-evaluated models allocate it on first use: their resident kernels -- vp_ext.hpp -- need none)
         if (int rc = ensure_gen_ws(h)) {
             vp_batch_destroy(h);
@@ -1094,7 +1124,14 @@ static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dty
         VP_TRY(hipMalloc(&h->mrhs.g, (size_t)B * std::max(1, p_) * m * ts));
         VP_TRY(hipMalloc((void **)&h->mrhs.small, (size_t)B * mrhs_small_stride_rt(n_, p_) * sizeof(double)));
         VP_TRY(hipMalloc((void **)&h->mrhs.statusA, (size_t)B * sizeof(int32_t)));
-        VP_TRY(hipMalloc((void **)&h->mrhs.acc, (size_t)B * VP_MRHS_GX_MAX * (1 + n_ * n_ + p_) * sizeof(double)));
+        // partial-sum slots of the MODE 0 pass (the only writer): gx is fixed per handle -- min(ceil(S/8), the kernel set's
+        // cap) -- not the upper bound VP_MRHS_GX_MAX (B = 70000, S = 2 needs 1 slot per problem, not 512)
+        const int gx_acc = mrhs_gx(S, kern->mrhs_gx_cap > 0 ? kern->mrhs_gx_cap : 256);
+        if (gx_acc > VP_MRHS_GX_MAX) {
+            vp_batch_destroy(h);
+            return fail(VP_ERR_INVALID, "internal: partial-sum slots per problem exceed VP_MRHS_GX_MAX");
+        }
+        VP_TRY(hipMalloc((void **)&h->mrhs.acc, (size_t)B * gx_acc * (1 + n_ * n_ + p_) * sizeof(double)));
         VP_TRY(hipMalloc(&h->mrhs.lm_state, (size_t)B * kern->mrhs_state_bytes));
         VP_TRY(hipMalloc((void **)&h->mrhs.nactive, 2 * sizeof(int32_t)));
         VP_TRY(hipMalloc((void **)&h->mrhs.done, (size_t)B * sizeof(int32_t)));
@@ -1440,14 +1477,22 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
         VP_HIP(hipMemcpyAsync(h->d_alpha, alpha_inout, (size_t)h->B * h->q * ts,
                               device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
         if (int rc = run_evaluate(h, nullptr, nullptr, h->d_C)) return rc;
+        OutBuf trw;
+        if (trace_out && trace_rows > 0) { // rows never written read as NaN; row 0 = the initial point (ratio = NaN)
+            const size_t trb = (size_t)h->B * (size_t)trace_rows * (h->q + 4) * sizeof(double);
+            if (int rc = trw.init(h, trace_out, trb)) return rc;
+            VP_HIP(hipMemsetAsync(trw.dptr, 0xFF, trb, h->stream));
+        }
         hipLaunchKernelGGL(wrong_dimensions_report_kernel, dim3((unsigned)((h->B + 255) / 256)), dim3(256), 0, h->stream,
-                           (const double *)h->d_cost, (const int32_t *)h->d_status, h->B, h->d_report);
+                           (const double *)h->d_cost, (const int32_t *)h->d_status, h->B, h->d_report,
+                           trw.dptr ? (double *)trw.dptr : nullptr, trace_rows, h->q, h->dtype, (const void *)h->d_alpha);
         VP_HIP(hipGetLastError());
         h->have_params = true;
         h->r_valid = false;
         h->have_report = true;
         if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
-        return copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report));
+        if (int rc = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc;
+        return trw.finish(h);
     }
     if (h->S != 1) return mrhs_fit(h, opts, alpha_inout, C_out, rep, trace_out, trace_rows);
     if (!h->kern->fit && !h->kern->fit_single) return fail(VP_ERR_UNSUPPORTED, "no fit kernel for this model");
@@ -1610,6 +1655,44 @@ int vp_summary_device(vp_batch *h, double *dev_out4) {
     return VP_ERR_OK;
 }
 
+// == the vp_reduce_cost of SURVEY.md 8(b): local aggregates + ONE RCCL all-reduce of 4 doubles on the handle's stream.
+// RCCL is resolved at run time (the library itself does not link it).
+typedef int (*vp_nccl_allreduce_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
+static vp_nccl_allreduce_t resolve_nccl_allreduce() {
+    static vp_nccl_allreduce_t fn = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void *sym = dlsym(RTLD_DEFAULT, "ncclAllReduce"); // the host process links / has loaded RCCL
+        if (!sym) {
+            void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (lib) sym = dlsym(lib, "ncclAllReduce");
+        }
+        fn = reinterpret_cast<vp_nccl_allreduce_t>(sym);
+    }
+    return fn;
+}
+
+int vp_reduce_cost(vp_batch *h, void *rccl_comm, double out[4]) {
+    VP_ENTER(h);
+    if (!out) return fail(VP_ERR_INVALID, "null output");
+    if (!h->have_report) return fail(VP_ERR_INVALID, "vp_reduce_cost requires a completed vp_fit");
+    VP_HIP(hipMemsetAsync(h->d_sum4, 0, 4 * sizeof(double), h->stream));
+    const unsigned grid = (unsigned)std::min<int64_t>((h->B + 255) / 256, 1024);
+    hipLaunchKernelGGL(summary_kernel, dim3(grid), dim3(256), 0, h->stream, h->d_report, h->B, h->d_sum4);
+    VP_HIP(hipGetLastError());
+    if (rccl_comm) {
+        vp_nccl_allreduce_t ar = resolve_nccl_allreduce();
+        if (!ar) return fail(VP_ERR_UNSUPPORTED, "ncclAllReduce not found: link librccl or make librccl.so.1 loadable");
+        const int rc = ar(h->d_sum4, h->d_sum4, 4, /*ncclDouble*/ 8, /*ncclSum*/ 0, rccl_comm, h->stream);
+        if (rc != 0) return fail(VP_ERR_HIP, "ncclAllReduce failed with code " + std::to_string(rc));
+    }
+    VP_HIP(hipMemcpyAsync(out, h->d_sum4, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    VP_HIP(hipStreamSynchronize(h->stream));
+    return VP_ERR_OK;
+}
+
 int vp_set_fit_kernel(vp_batch *h, int which) {
     if (!h) return fail(VP_ERR_INVALID, "null handle");
     if (which != VP_FIT_KERNEL_AUTO && which != VP_FIT_KERNEL_WAVE && which != VP_FIT_KERNEL_SLOTS)
@@ -1692,7 +1775,7 @@ int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out) {
     return FAMILY_RT;
 }
 
-const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m, int64_t S) {
+const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m, int64_t S, bool weighted) {
     int a, b, c, p;
     const int fam = classify_model(d, a, b, c, p);
     if (fam < 0) return nullptr;
@@ -1710,6 +1793,10 @@ const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m, in
         for (const KernelEntry &e : registry()) {
             if (e.dtype != dtype || e.family != f || e.a != ka || e.b != kb || e.c != kc) continue;
             if ((int64_t)64 * e.R * e.W < m) continue;
+            if (S == 1 && !e.evaluate) continue; // (a set that only carries multiple-right-hand-side kernels)
+            // weighted problems: grid + weights + data column of 64 R W rows each must fit the 160 KiB of LDS the
+            // one-problem-per-group fit kernel stages them in (KernelEntry::fit_lds_w: launch_fit's own expression)
+            if (weighted && e.fit_lds_w > (size_t)160 * 1024) continue;
             // smallest capacity first.  Among equal capacities: a multiple-RHS handle takes the set that has MRHS kernels;
             // a single-RHS handle the one whose columns fit the registers (R <= 16 rows per lane -- the R = 32 sets spill
             // hundreds of VGPRs: triple exponential at m = 2048, 0.71 vs 0.10 ms per 16384 evaluations at m = 1024), else

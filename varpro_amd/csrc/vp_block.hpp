@@ -1,0 +1,725 @@
+// vp_block.hpp -- LENGTH-AGNOSTIC single-RHS fit: the rows of a problem are streamed in blocks through a TSQR-style update.
+//
+// The reference takes any `output_len()` (src/model/mod.rs:263).  The register-resident kernels (vp_fit.hpp, vp_fit2.hpp)
+// keep all m rows of every column in VGPRs and therefore exist per (model, rows-per-lane, waves) SET; one row past the
+// largest set a problem used to fall to the generic kernels at a 60-100x step.  Here m is a run-time number:
+//
+//   One wavefront owns one problem.  Its columns  A = [W Phi | y_w | W dPhi_1 .. W dPhi_P]  (NC = N + 1 + P) are never
+//   resident: per evaluation the wave walks the rows in blocks of 64*RB, builds the block's columns in registers
+//   (build_columns on an offset row source -- the same code, incl. the uniform-grid exp recurrence, re-seeded per block) and
+//   folds it into an NC x NC upper-triangular CARRY  T  by Householder reflectors on the stacked matrix [T; block]
+//   (stacked_qr: reflector k touches row k of T and the block rows only, because T is triangular).  That is a
+//   sequential TSQR: T^T T = A^T A with the conditioning of A, not of A^T A -- nothing is squared.
+//
+//   After the last block  A = Q_A T  with orthonormal Q_A, so the compressed problem (T_Phi, T_y, T_D) has the same
+//   coefficients c, the same ||r|| and -- the Kaufman Jacobian being  J = -P_perp D c  -- J = Q_A J_T, r = Q_A r_T: the
+//   LM loop, which only sees quantities invariant under an orthogonal change of basis of the residual space (vp_fit.hpp),
+//   runs UNCHANGED on the NC-row problem held in the carry: solve_coeffs on T's leading N x N block
+//   (src/solvers/levmar/mod.rs:51-59), MINPACK qrfac on the (P + 1) x Q compressed Jacobian (jac_qrfac at two rows per
+//   lane), lm_after_eval / lm_next_step (vp_lm_core.hpp) -- LevenbergMarquardt::minimize (:247) as everywhere else.
+//
+// The carry sits in the first register PAIR of every column (lane l holds carry rows 2l, 2l+1, i.e. row i of T lives in
+// lane i/2): NC * 2 VGPR pairs, whatever m is.  y (and the grid / weights) are re-read per evaluation, 16 bytes per lane:
+// T*m bytes per evaluation from L2 / HBM, the price of not holding m rows on chip.
+#pragma once
+#include "vp_lm_core.hpp"
+
+namespace vp {
+namespace blk {
+
+// Householder reflectors k = 0 .. NREF-1 on the stacked matrix [K; Cb]:
+//   K  [NC][2]   the carry: upper triangular in its first NC rows (row i in lane i/2, register i%2), zero below
+//   Cb [NC][RB]  the block's rows
+// On return K holds the updated triangle (rows < NREF), Cb the rows of Q^T(block) that later reflectors of THIS call still
+// acted on -- for columns >= NREF they are the block's contribution to the part of the column orthogonal to the first NREF
+// columns (final: later blocks never touch them again); the reflector vectors themselves are not kept.
+template <typename T, int NC, int NREF, int RB, class G>
+__device__ __forceinline__ void stacked_qr(T (&K)[NC][2], T (&Cb)[NC][RB], G &grp) {
+    const int lane = grp.gl;
+    static_for<0, NREF>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int NREM = NC - k;
+        constexpr int own = k / 2, reg = k % 2; // carry row k lives in lane `own`, register `reg`
+        // block part of the raw dot products a_k^T a_j (j = k .. NC-1) and the carry row's entries T[k][j]
+        T d[NREM], top[NREM];
+#pragma unroll
+        for (int j = k; j < NC; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc = tfma(Cb[k][r], Cb[j][r], acc);
+            d[j - k] = acc;
+            top[j - k] = K[j][reg];
+        }
+        group_allreduce(grp, d);
+        group_bcast<NREM>(grp, top, own);
+        // (T is upper triangular: column k has no carry entries below row k, so the carry contributes top_k * top_j)
+#pragma unroll
+        for (int j = 0; j < NREM; ++j) d[j] = tfma(top[0], top[j], d[j]);
+        const T alpha = top[0], nrm2 = d[0];
+        const bool live = nrm2 > T(0) && is_finite(nrm2);
+        const T y = live ? frsqrt(nrm2) : T(0);
+        const T s0 = nrm2 * y;
+        const T sigma = tfma(tfma(-s0, s0, nrm2), T(0.5) * y, s0);
+        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+        const T u = live ? alpha - beta : T(0);
+        const T gk = live ? -y * frcp(tabs(alpha) + sigma) : T(0);
+        K[k][reg] = (lane == own) ? beta : K[k][reg];
+#pragma unroll
+        for (int j = k + 1; j < NC; ++j) {
+            const T f = gk * tfma(-beta, top[j - k], d[j - k]); // g * v^T a_j,  v = [u; block part of a_k]
+#pragma unroll
+            for (int r = 0; r < RB; ++r) Cb[j][r] = tfma(f, Cb[k][r], Cb[j][r]);
+            const T tj = tfma(f, u, top[j - k]); // row k of the updated column: the new T[k][j]
+            K[j][reg] = (lane == own) ? tj : K[j][reg];
+        }
+    });
+}
+
+// ---- lane-private compression of the TRAILING columns --------------------------------------------------------------------
+// After the N wave-wide reflectors of a block the rows of the trailing columns [y | D_1 .. D_P] (PT = P + 1) are final: no
+// later block touches them.  Their R factor is all the LM loop needs of them, and a tall-skinny QR does not care how the
+// rows are grouped (TSQR): every LANE folds its own RB rows into a PRIVATE PT x PT triangle by Householder reflectors on
+// the stacked [Tl; rows] -- per-lane arithmetic only, no reduction, no broadcast -- and the 64 triangles are merged ONCE per
+// evaluation by an ordinary wave-wide QR of the 64*PT rows.  A block then costs N reduction rounds instead of N + 1 + P.
+template <typename T, int NC, int N, int PT, int RB>
+__device__ __forceinline__ void lane_trail_update(T (&Tl)[PT][PT], T (&Cb)[NC][RB]) {
+    static_for<0, PT>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        T d[PT - k];
+#pragma unroll
+        for (int j = k; j < PT; ++j) {
+            T acc = Tl[k][k] * Tl[k][j];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc = tfma(Cb[N + k][r], Cb[N + j][r], acc);
+            d[j - k] = acc;
+        }
+        const T alpha = Tl[k][k], nrm2 = d[0];
+        const bool live = nrm2 > T(0) && is_finite(nrm2);
+        const T y = live ? frsqrt(nrm2) : T(0);
+        const T s0 = nrm2 * y;
+        const T sigma = tfma(tfma(-s0, s0, nrm2), T(0.5) * y, s0);
+        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+        const T u = live ? alpha - beta : T(0);
+        const T gk = live ? -y * frcp(tabs(alpha) + sigma) : T(0);
+        Tl[k][k] = beta;
+#pragma unroll
+        for (int j = k + 1; j < PT; ++j) {
+            const T f = gk * tfma(-beta, Tl[k][j], d[j - k]);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) Cb[N + j][r] = tfma(f, Cb[N + k][r], Cb[N + j][r]);
+            Tl[k][j] = tfma(f, u, Tl[k][j]);
+        }
+    });
+}
+// merge the 64 private triangles and write the PT x PT result into the carry rows N .. N + PT - 1
+template <typename T, int NC, int N, int PT, class G>
+__device__ __forceinline__ void lane_trail_merge(const T (&Tl)[PT][PT], T (&K)[NC][2], G &grp) {
+    constexpr int RZ = (PT + 1) / 2 * 2;
+    T Z[PT][RZ];
+#pragma unroll
+    for (int j = 0; j < PT; ++j)
+#pragma unroll
+        for (int i = 0; i < RZ; ++i) Z[j][i] = (i <= j && i < PT) ? Tl[i < PT ? i : 0][j] : T(0);
+    T gq[PT], Rz[PT][PT], qd[PT];
+    house_qr<T, RZ, PT, PT, 0, false, G>(Z, gq, Rz, qd, grp);
+    const int lane = grp.gl;
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+#pragma unroll
+        for (int j = i; j < PT; ++j) K[N + j][(N + i) % 2] = (lane == (N + i) / 2) ? Rz[i][j] : K[N + j][(N + i) % 2];
+}
+
+// rows per lane and block: the NC x (RB + 2) register columns + the wave-uniform LM state must fit two waves per SIMD
+// The wave's LDS ring of row blocks: 2 slots x {grid, data[, weights]} x 64*RB rows in natural row order.  Block i's rows
+// are staged by ASYNCHRONOUS global -> LDS DMA (global_load_lds_dwordx4: no VGPRs; lane l of instruction k delivers the
+// 16-byte group k*64 + l) issued ONE BLOCK AHEAD of their use: without it every block started with a dependent global round
+// trip for its grid values that two resident waves per SIMD cannot hide (measured at m = 10^5: 2.9x).  vmcnt is hand-counted
+// as in vp_mrhs.hpp: between begin() and the last stage() of a pass the wave must issue nothing else that counts in vmcnt
+// except what the caller declares (`extra` stores per block).  Arrays that do not allow whole 16-byte groups (m not a
+// multiple of 16/sizeof(T), unaligned bases) are staged element-wise through registers, without prefetch.
+template <typename T, int RB, bool WEIGHTED> struct RowRing {
+    static constexpr int ROWS = 64 * RB;
+    static constexpr int NARR = WEIGHTED ? 3 : 2;
+    static constexpr int EL = 16 / (int)sizeof(T); // elements per lane and DMA instruction
+    static constexpr int KA = RB / EL;             // DMA instructions per array and block
+    static constexpr int KD = NARR * KA;           // ... per block
+    static_assert(RB % EL == 0 && KD <= 40, "block rows must be whole DMA instructions; vmcnt is a 6-bit counter");
+    T *ring;
+    unsigned ring_lds;
+    const T *tp, *yp, *wp;
+    int m, lane, it;
+    bool dma;
+    __device__ __forceinline__ void init(T *ring_, const T *tp_, const T *yp_, const T *wp_, int m_, int lane_) {
+        ring = ring_;
+        ring_lds = (unsigned)(uintptr_t)(VP_LDS unsigned char *)ring_;
+        tp = tp_;
+        yp = yp_;
+        wp = wp_;
+        m = m_;
+        lane = lane_;
+        it = 0;
+        dma = (m % EL) == 0 && ((reinterpret_cast<uintptr_t>(tp) | reinterpret_cast<uintptr_t>(yp) |
+                                 (WEIGHTED ? reinterpret_cast<uintptr_t>(wp) : 0)) & 15) == 0;
+    }
+    __device__ __forceinline__ void issue(const int off, const int slot) {
+        const int mrem = m - off;
+#pragma unroll
+        for (int arr = 0; arr < NARR; ++arr) {
+            // (the base must sit in an SGPR pair: made explicitly wave-uniform, or under register pressure the "s" operand
+            // below is handed over in VGPRs and the instruction does not assemble)
+            const uint64_t sv = reinterpret_cast<uint64_t>((arr == 0 ? tp : (arr == 1 ? yp : wp)) + off);
+            const uint64_t src = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(sv >> 32)) << 32) |
+                                 (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(sv & 0xffffffffu));
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                const int row = (k * 64 + lane) * EL; // groups past the end re-read the block's first group (zeroed afterwards)
+                const unsigned roff = (unsigned)(row < mrem ? row : 0) * (unsigned)sizeof(T);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((slot * NARR + arr) * ROWS * (int)sizeof(T)) + (unsigned)k * 1024u);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(roff), "s"(src), "s"(dst)
+                             : "memory");
+            }
+        }
+    }
+    // start of a pass over the blocks whose first block begins at row `off0`
+    __device__ __forceinline__ void begin(const int off0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        it = 0;
+        if (dma) issue(off0, 0);
+    }
+    // the block at row `off` alone, no prefetch: for passes that issue stores (loads and stores share vmcnt and do not
+    // complete in order with respect to each other, so a prefetch in flight cannot be counted past them)
+    __device__ __forceinline__ void stage_sync(const int off, T *&s_t, T *&s_y, T *&s_w) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        it = 0;
+        if (dma) issue(off, 0);
+        stage(off, -1, s_t, s_y, s_w);
+    }
+    // Make the block at row `off` readable and request the one at `next_off` (< 0: none).
+    __device__ __forceinline__ void stage(const int off, const int next_off, T *&s_t, T *&s_y, T *&s_w) {
+        const int slot = it & 1;
+        ++it;
+        const int mrem = m - off;
+        s_t = ring + (size_t)slot * NARR * ROWS;
+        s_y = s_t + ROWS;
+        s_w = s_y + ROWS;
+        if (dma) {
+            if (next_off >= 0) {
+                issue(next_off, slot ^ 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KD) : "memory"); // this block has landed, the next one is in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (mrem < ROWS) { // the last block: groups past the end were clamped for the DMA -> zero data, zero weight
+#pragma unroll
+                for (int k = 0; k < KA; ++k) {
+                    const int row = (k * 64 + lane) * EL;
+                    if (row >= mrem) {
+#pragma unroll
+                        for (int x = 0; x < EL; ++x) {
+                            s_y[row + x] = T(0);
+                            if constexpr (WEIGHTED) s_w[row + x] = T(0);
+                        }
+                    }
+                }
+            }
+        } else {
+            T tmp[RB];
+            load_rows<T, RB, 1>(tp + off, mrem, lane, false, tmp);
+            store_rows<T, RB, 1>(s_t, ROWS, lane, true, tmp);
+            load_rows<T, RB, 1>(yp + off, mrem, lane, false, tmp);
+            store_rows<T, RB, 1>(s_y, ROWS, lane, true, tmp);
+            if constexpr (WEIGHTED) {
+                load_rows<T, RB, 1>(wp + off, mrem, lane, false, tmp);
+                store_rows<T, RB, 1>(s_w, ROWS, lane, true, tmp);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+};
+
+#ifndef VP_BLK_WAVES
+#define VP_BLK_WAVES 2
+#endif
+// (run-time-descriptor models evaluate every basis kind per element -- their column build alone needs the registers of a
+// multi-exponential block twice as long: half the rows)
+template <typename T, int NC, bool STATIC = true> constexpr int block_rows() {
+#ifdef VP_BLK_RB
+    return VP_BLK_RB;
+#else
+    constexpr int words = NC * (int)(sizeof(T) / 4);
+    if constexpr (STATIC) return words <= 14 ? 8 : ((words <= 28 || sizeof(T) == 4) ? 4 : 2);
+    else return words <= 6 ? 8 : ((words <= 10 || sizeof(T) == 4) ? 4 : 2);
+#endif
+}
+
+template <typename T, class M, int RB, bool WEIGHTED>
+__global__ void __launch_bounds__(64, VP_BLK_WAVES) blk_fit_kernel(const FitArgs<T, M> a) {
+    constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
+    constexpr int ROWS = 64 * RB;
+    using G = Grp<1>;
+    G grp = G::make(nullptr);
+    const int lane = grp.gl;
+    const int64_t b = blockIdx.x;
+    if (b >= a.B) return;
+    const int m = a.m;
+    const T *tp = a.t + b * a.t_stride;
+    const T *wp = WEIGHTED ? a.w + b * a.w_stride : nullptr;
+    const T *yp = a.yw + b * (int64_t)m;
+
+    LmVars<T, N, Q> S;
+    LmOpts<T> opt;
+    opt.ftol = a.ftol;
+    opt.xtol = a.xtol;
+    opt.gtol = a.gtol;
+    opt.stepbound = a.stepbound;
+    opt.patience = a.patience;
+    opt.scale_diag = a.scale_diag;
+    {
+        T a0[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) a0[k] = a.alpha[b * Q + k];
+        lm_init<T, N, Q>(S, a0);
+    }
+    T cbest[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) cbest[k] = T(0);
+    int trow = 0;
+
+    using Ring = RowRing<T, RB, WEIGHTED>;
+    __shared__ __attribute__((aligned(16))) T ring_mem[2 * Ring::NARR * ROWS];
+    Ring ring;
+    ring.init(ring_mem, tp, yp, wp, m, lane);
+    // distance between a lane's consecutive row pairs on a uniform grid (RowSource::set_uniform, from the WHOLE grid)
+    const T dpair = (m >= 3) ? (tp[m - 1] - tp[0]) / T(m - 1) * T(128) : T(0);
+
+    while (S.term == 0) {
+        // ================= compress the problem at xt: stream the rows, fold every block into the carry =================
+        T K[NC][2];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) K[j][0] = K[j][1] = T(0);
+        constexpr int PT = P + 1;
+        constexpr bool kLaneTrail = PT <= 6; // (the private triangle: PT (PT + 1) / 2 values per lane)
+        T Tl[kLaneTrail ? PT : 1][kLaneTrail ? PT : 1];
+        if constexpr (kLaneTrail) {
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) Tl[i][j] = T(0);
+        }
+        ring.begin(0);
+        for (int off = 0; off < m; off += ROWS) {
+            T *s_t, *s_y, *s_w;
+            ring.stage(off, off + ROWS < m ? off + ROWS : -1, s_t, s_y, s_w);
+            using Src = RowSource<T, RB, true, WEIGHTED ? 1 : 0, 1, 1, true, 0>;
+            Src src;
+            src.t = s_t;
+            src.w = WEIGHTED ? s_w : nullptr;
+            src.m = m - off;
+            src.lane = lane;
+            src.vec = true;
+            src.uniform = Src::kRecur && a.grid_uniform != 0 && m >= 3;
+            src.delta = dpair;
+            T Cb[NC][RB];
+            load_rows_lds<T, RB, 1>(s_y, lane, Cb[N]);
+            build_columns<T, M, RB, NC, Src>(a.mdl, S.xt, src, Cb);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kLaneTrail) {
+                stacked_qr<T, NC, N, RB, G>(K, Cb, grp);
+                lane_trail_update<T, NC, N, PT, RB>(Tl, Cb);
+            } else {
+                stacked_qr<T, NC, NC, RB, G>(K, Cb, grp);
+            }
+            asm volatile("" ::: "memory");
+        }
+        if constexpr (kLaneTrail) lane_trail_merge<T, NC, N, PT, G>(Tl, K, grp);
+        // ================= the compressed problem: T's leading N x N block, (T_y)[0:N], the rows >= N =================
+        T Rm[N][N], qty[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) Rm[i][j] = (j >= i) ? readlane(K[j][i % 2], i / 2) : T(0);
+            qty[i] = readlane(K[N][i % 2], i / 2);
+        }
+        T c[N], e[N];
+        bool truncated;
+        solve_coeffs<T, N>(Rm, qty, a.eps, c, e, truncated);
+        // ||r||^2 = ||e||^2 + sum over the carry rows >= N of (T_y)^2   (only row N is non-zero)
+        T sq = T(0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const T v = (2 * lane + r >= N) ? K[N][r] : T(0);
+            sq = tfma(v, v, sq);
+        }
+        T fn2 = group_sum(grp, sq);
+#pragma unroll
+        for (int k = 0; k < N; ++k) fn2 = tfma(e[k], e[k], fn2);
+        bool ok = is_finite(fn2);
+#pragma unroll
+        for (int k = 0; k < N; ++k) ok = ok && is_finite(c[k]) && is_finite(Rm[k][k]);
+        ok = uni(ok);
+
+        const T fnorm1 = usqrt(fn2);
+        const bool need = lm_after_eval<T, N, Q, true>(S, opt, fnorm1, ok, (long)m);
+        if (S.accepted) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) cbest[k] = c[k];
+        }
+        if (a.trace && trow < a.trace_rows && lane == 0) {
+            double *tr = a.trace + ((size_t)b * a.trace_rows + trow) * (Q + 4);
+#pragma unroll
+            for (int k = 0; k < Q; ++k) tr[k] = (double)S.xt[k];
+            tr[Q] = (double)fnorm1;
+            tr[Q + 1] = 0.0 / 0.0;
+            tr[Q + 2] = (double)S.delta;
+            tr[Q + 3] = (double)S.par;
+        }
+        ++trow;
+        if (S.term != 0) break;
+        if (need) {
+            // Jacobian of the compressed problem in Q-coordinates: z_k = -sum_{pairs p of k} c_{basis(p)} (T_D)_p, rows >= N;
+            // residual column: rows < N <- e (zero at full rank), rows >= N keep T_y.  Then MINPACK's pivoted QR.
+            residual_qcoords<T, 2, N>(K[N], e, grp);
+            T Zs[Q][2];
+            if constexpr (M::kDiagonalPairs) {
+                T Zd[1][2];
+                jacobian_qcoords<T, M, 2, NC, G, N + 1>(a.mdl, K, c, Zd, grp); // in place: z_k = K[N + 1 + k]
+#pragma unroll
+                for (int k = 0; k < Q; ++k) Zs[k][0] = K[N + 1 + k][0], Zs[k][1] = K[N + 1 + k][1];
+            } else {
+                jacobian_qcoords<T, M, 2, NC, G, N + 1>(a.mdl, K, c, Zs, grp);
+            }
+            jac_qrfac<T, 2, Q, N>(Zs, K[N], S.Rj, S.acnorm, S.ipvt, S.qtf, grp);
+        }
+        lm_next_step<T, N, Q, true>(S, opt, need);
+    }
+
+    if (lane == 0) {
+        vp_report rep;
+        rep.termination = S.term;
+        rep.n_evals = S.nfev;
+        rep.objective = (double)S.objective;
+        a.report[b] = rep;
+        if (a.cost_out) a.cost_out[b] = (double)S.objective;
+        if (a.status) a.status[b] = S.status;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) a.alpha[b * Q + k] = S.x[k];
+        if (a.C_out) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) a.C_out[b * N + k] = cbest[k];
+        }
+    }
+}
+
+// ---- trait-level evaluation at any m: set_params (+ residuals + Jacobian), src/solvers/levmar/mod.rs:42-73, 91-95, 101-201 ----
+// Pass 1 streams the blocks forward with the N reflectors of Phi only (stacked_qr<NREF = N>): R, Q^T y and Q^T D in the
+// carry's first N rows, ||r||^2 from the rows of the data column the reflectors leave behind -- c, cost, status.  With
+// r / J wanted it also records, per block, the carry rows it STARTED from (N x NC values in LDS).  Pass 2 walks the blocks
+// BACKWARDS: block i is rebuilt, its reflectors are recomputed from the recorded carry (identical arithmetic, identical
+// reflectors), which also yields the block's rows of Q^T y and Q^T D; r~ = [e; (Q^T y)_>=N], J~_k = -[0; sum_p c_j(p) (Q^T D_p)_>=N]
+// are then carried back through the block's reflectors in reverse order -- Q = Q_1 ... Q_nb applied exactly as the resident
+// kernels' apply_q does, block by block -- and the block's rows of r and J are stored.  Exact Householder arithmetic on both
+// passes: no normal equations, no R^-1 Phi products.
+
+// stacked_qr with NREF = N that keeps what the back-application needs: u_k (carry entry of v_k), g_k; Cb[k] keeps the block
+// part of v_k, Cb[j >= N] the block's rows of Q^T (.)
+template <typename T, int NC, int N, int RB, class G>
+__device__ __forceinline__ void stacked_qr_keep(T (&K)[NC][2], T (&Cb)[NC][RB], T (&uo)[N], T (&go)[N], G &grp) {
+    const int lane = grp.gl;
+    static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int NREM = NC - k;
+        constexpr int own = k / 2, reg = k % 2;
+        T d[NREM], top[NREM];
+#pragma unroll
+        for (int j = k; j < NC; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc = tfma(Cb[k][r], Cb[j][r], acc);
+            d[j - k] = acc;
+            top[j - k] = K[j][reg];
+        }
+        group_allreduce(grp, d);
+        group_bcast<NREM>(grp, top, own);
+#pragma unroll
+        for (int j = 0; j < NREM; ++j) d[j] = tfma(top[0], top[j], d[j]);
+        const T alpha = top[0], nrm2 = d[0];
+        const bool live = nrm2 > T(0) && is_finite(nrm2);
+        const T y = live ? frsqrt(nrm2) : T(0);
+        const T s0 = nrm2 * y;
+        const T sigma = tfma(tfma(-s0, s0, nrm2), T(0.5) * y, s0);
+        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+        const T u = live ? alpha - beta : T(0);
+        const T gk = live ? -y * frcp(tabs(alpha) + sigma) : T(0);
+        uo[k] = u;
+        go[k] = gk;
+        K[k][reg] = (lane == own) ? beta : K[k][reg];
+#pragma unroll
+        for (int j = k + 1; j < NC; ++j) {
+            const T f = gk * tfma(-beta, top[j - k], d[j - k]);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) Cb[j][r] = tfma(f, Cb[k][r], Cb[j][r]);
+            const T tj = tfma(f, u, top[j - k]);
+            K[j][reg] = (lane == own) ? tj : K[j][reg];
+        }
+    });
+}
+
+// [Wc; Wb] <- Q_block [Wc; Wb] for NW columns: the block's reflectors k = N-1 .. 0, v_k = [u_k at carry row k; Cb[k]]
+template <typename T, int NC, int N, int NW, int RB, class G>
+__device__ __forceinline__ void stacked_apply_q(const T (&Cb)[NC][RB], const T (&u)[N], const T (&g)[N], T (&Wc)[NW][2],
+                                                T (&Wb)[NW][RB], G &grp) {
+    const int lane = grp.gl;
+    static_for<0, N>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = N - 1 - decltype(kc)::value;
+        constexpr int own = k / 2, reg = k % 2;
+        T w[NW], top[NW];
+#pragma unroll
+        for (int z = 0; z < NW; ++z) {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc = tfma(Cb[k][r], Wb[z][r], acc);
+            w[z] = acc;
+            top[z] = Wc[z][reg];
+        }
+        group_allreduce(grp, w);
+        group_bcast<NW>(grp, top, own);
+#pragma unroll
+        for (int z = 0; z < NW; ++z) {
+            const T f = g[k] * tfma(u[k], top[z], w[z]); // g v^T [Wc; Wb]
+#pragma unroll
+            for (int r = 0; r < RB; ++r) Wb[z][r] = tfma(f, Cb[k][r], Wb[z][r]);
+            const T tz = tfma(f, u[k], top[z]);
+            Wc[z][reg] = (lane == own) ? tz : Wc[z][reg];
+        }
+    });
+}
+
+// LDS the evaluate kernel needs for the per-block carry records of a problem of m rows (0 when r / J are not wanted)
+template <typename T, class M, int RB> constexpr size_t eval_snap_bytes(int64_t m) {
+    return (size_t)((m + 64 * RB - 1) / (64 * RB)) * M::N * (M::N + 1 + M::P) * sizeof(T);
+}
+constexpr size_t kEvalSnapMax = 40 * 1024; // beyond: the generic kernels (vp_generic.hpp)
+
+template <typename T, class M, int RB, bool WEIGHTED>
+__global__ void __launch_bounds__(64, VP_BLK_WAVES) blk_evaluate_kernel(const EvalArgs<T, M> a) {
+    constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P, NW = 1 + Q;
+    constexpr int ROWS = 64 * RB;
+    using G = Grp<1>;
+    using LB = Layout<RB, 1>;
+    G grp = G::make(nullptr);
+    const int lane = grp.gl;
+    const int64_t prob = blockIdx.x; // problem * S + rhs
+    if (prob >= a.nprob) return;
+    const int64_t b = prob / a.S;
+    const int s = (int)(prob - b * a.S);
+    const int m = a.m;
+    const T *tp = a.t + b * a.t_stride;
+    const T *wp = WEIGHTED ? a.w + b * a.w_stride : nullptr;
+    const T *yp = a.yw + prob * (int64_t)m;
+    const bool want_rj = a.r_out != nullptr || a.J_out != nullptr;
+    T alpha[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
+
+    using Ring = RowRing<T, RB, WEIGHTED>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *ring_mem = reinterpret_cast<T *>(smem_raw);
+    T *snap = ring_mem + 2 * Ring::NARR * ROWS; // [block][N][NC]: the carry rows block i started from
+    Ring ring;
+    ring.init(ring_mem, tp, yp, wp, m, lane);
+    const T dpair = (m >= 3) ? (tp[m - 1] - tp[0]) / T(m - 1) * T(128) : T(0);
+    using Src = RowSource<T, RB, true, WEIGHTED ? 1 : 0, 1, 1, true, 0>;
+    auto make_src = [&](T *s_t, T *s_w, const int off) __attribute__((always_inline)) {
+        Src src;
+        src.t = s_t;
+        src.w = WEIGHTED ? s_w : nullptr;
+        src.m = m - off;
+        src.lane = lane;
+        src.vec = true;
+        src.uniform = Src::kRecur && a.grid_uniform != 0 && m >= 3;
+        src.delta = dpair;
+        return src;
+    };
+
+    // ================= pass 1: forward, N reflectors per block =================
+    T K[NC][2];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) K[j][0] = K[j][1] = T(0);
+    T sq = T(0); // this lane's share of sum_{rows >= N} (Q^T y)^2
+    ring.begin(0);
+    for (int off = 0, ib = 0; off < m; off += ROWS, ++ib) {
+        T *s_t, *s_y, *s_w;
+        ring.stage(off, off + ROWS < m ? off + ROWS : -1, s_t, s_y, s_w);
+        if (want_rj) { // record the carry rows < N this block starts from (row i: lane i/2, register i%2)
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (lane == i / 2) {
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) snap[((size_t)ib * N + i) * NC + j] = K[j][i % 2];
+                }
+        }
+        const Src src = make_src(s_t, s_w, off);
+        T Cb[NC][RB];
+        load_rows_lds<T, RB, 1>(s_y, lane, Cb[N]);
+        build_columns<T, M, RB, NC, Src>(a.mdl, alpha, src, Cb);
+        __builtin_amdgcn_sched_barrier(0);
+        stacked_qr<T, NC, N, RB, G>(K, Cb, grp);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) sq = tfma(Cb[N][r], Cb[N][r], sq);
+        asm volatile("" ::: "memory");
+    }
+    T Rm[N][N], qty[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) Rm[i][j] = (j >= i) ? readlane(K[j][i % 2], i / 2) : T(0);
+        qty[i] = readlane(K[N][i % 2], i / 2);
+    }
+    T c[N], e[N];
+    bool truncated;
+    solve_coeffs<T, N>(Rm, qty, a.eps, c, e, truncated);
+    T fn2 = group_sum(grp, sq);
+#pragma unroll
+    for (int k = 0; k < N; ++k) fn2 = tfma(e[k], e[k], fn2);
+    bool ok = is_finite(fn2);
+#pragma unroll
+    for (int k = 0; k < N; ++k) ok = ok && is_finite(c[k]) && is_finite(Rm[k][k]);
+    ok = uni(ok);
+    if (lane == 0) {
+        if (a.status) a.status[prob] = ok ? VP_ST_OK : VP_ST_NONFINITE;
+        if (a.cost_out) a.cost_out[prob] = 0.5 * (double)fn2;
+    }
+    if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(c, lane);
+    if (!want_rj) return;
+
+    // ================= pass 2: backward, r and J block by block =================
+    const bool vec = ring.dma; // (whole 16-byte groups: m even, aligned bases) -> 2-element stores where the outputs allow it
+    const bool vec_r = vec && a.r_out && ((reinterpret_cast<uintptr_t>(a.r_out + prob * (int64_t)m) & (2 * sizeof(T) - 1)) == 0);
+    const bool vec_j = vec && a.J_out && ((reinterpret_cast<uintptr_t>(a.J_out) & (2 * sizeof(T) - 1)) == 0);
+    T Wc[NW][2]; // carry part of [r~ | J~_1 .. J~_Q]: rows < N hold e (residual) and 0 (Kaufman columns)
+#pragma unroll
+    for (int z = 0; z < NW; ++z) Wc[z][0] = Wc[z][1] = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) Wc[0][i % 2] = (lane == i / 2) ? e[i] : Wc[0][i % 2];
+    const int nb = (m + ROWS - 1) / ROWS;
+    for (int ib = nb - 1; ib >= 0; --ib) {
+        const int off = ib * ROWS;
+        T *s_t, *s_y, *s_w;
+        ring.stage_sync(off, s_t, s_y, s_w);
+        T Kb[NC][2];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) Kb[j][0] = Kb[j][1] = T(0);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (lane == i / 2) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) Kb[j][i % 2] = snap[((size_t)ib * N + i) * NC + j];
+            }
+        const Src src = make_src(s_t, s_w, off);
+        T Cb[NC][RB];
+        load_rows_lds<T, RB, 1>(s_y, lane, Cb[N]);
+        build_columns<T, M, RB, NC, Src>(a.mdl, alpha, src, Cb);
+        __builtin_amdgcn_sched_barrier(0);
+        T u[N], g[N];
+        stacked_qr_keep<T, NC, N, RB, G>(Kb, Cb, u, g, grp);
+        // the block's rows of r~ and J~_k (Q-coordinates)
+        T Wb[NW][RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) Wb[0][r] = Cb[N][r];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) Wb[1 + k][r] = T(0);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (a.mdl.pair_param(p) == k) {
+                    const T cj = -dyn_get<N>(c, a.mdl.pair_basis(p));
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) Wb[1 + k][r] = tfma(cj, Cb[N + 1 + p][r], Wb[1 + k][r]);
+                }
+            }
+        }
+        stacked_apply_q<T, NC, N, NW, RB, G>(Cb, u, g, Wc, Wb, grp);
+        if (a.r_out) store_rows<T, RB, 1>(a.r_out + prob * (int64_t)m + off, m - off, lane, vec_r, Wb[0]);
+        if (a.J_out) {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) { // J[b][k][s][m]
+                T *jp = a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m + off;
+                store_rows<T, RB, 1>(jp, m - off, lane, vec_j && ((m & 1) == 0), Wb[1 + k]);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    (void)sizeof(LB);
+}
+
+template <typename T, class M> int launch_evaluate(const LaunchParams &p, int (*fallback)(const LaunchParams &)) {
+    constexpr int RB = block_rows<T, M::N + 1 + M::P, M::kStatic>();
+    using Ring = RowRing<T, RB, false>;
+    const bool want_rj = p.r_out || p.J_out;
+    const size_t snap = want_rj ? eval_snap_bytes<T, M, RB>(p.m) : 0;
+    if (snap > kEvalSnapMax || p.m < M::N) return fallback(p); // (m < N: the padded handles of vp_batch_create stay generic)
+    EvalArgs<T, M> a;
+    if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+    a.t = (const T *)p.t;
+    a.w = (const T *)p.w;
+    a.yw = (const T *)p.yw;
+    a.alpha = (const T *)p.alpha;
+    a.r_out = (T *)p.r_out;
+    a.J_out = (T *)p.J_out;
+    a.C_out = (T *)p.C_out;
+    a.cost_out = p.cost_out;
+    a.status = p.status;
+    a.m = p.m;
+    a.S = p.S;
+    a.nprob = p.B * p.S;
+    a.t_stride = p.t_stride;
+    a.w_stride = p.w_stride;
+    a.eps = (T)p.eps;
+    a.grid_uniform = p.grid_uniform;
+    if (a.nprob <= 0) return VP_ERR_OK;
+    const size_t lds = (size_t)2 * (p.w ? 3 : 2) * 64 * RB * sizeof(T) + snap;
+    (void)sizeof(Ring);
+    if (p.w) hipLaunchKernelGGL((blk_evaluate_kernel<T, M, RB, true>), dim3((unsigned)a.nprob), dim3(64), lds, p.stream, a);
+    else hipLaunchKernelGGL((blk_evaluate_kernel<T, M, RB, false>), dim3((unsigned)a.nprob), dim3(64), lds, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+template <typename T, class M> int launch_fit(const LaunchParams &p) {
+    FitArgs<T, M> a;
+    if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+    a.t = (const T *)p.t;
+    a.w = (const T *)p.w;
+    a.yw = (const T *)p.yw;
+    a.alpha = (T *)p.alpha_out;
+    a.C_out = (T *)p.C_out;
+    a.cost_out = p.cost_out;
+    a.status = p.status;
+    a.report = p.report;
+    a.m = p.m;
+    a.B = p.B;
+    a.t_stride = p.t_stride;
+    a.w_stride = p.w_stride;
+    a.eps = (T)p.eps;
+    a.ftol = (T)p.opts->ftol;
+    a.xtol = (T)p.opts->xtol;
+    a.gtol = (T)p.opts->gtol;
+    a.stepbound = (T)p.opts->stepbound;
+    a.patience = p.opts->patience;
+    a.scale_diag = p.opts->scale_diag;
+    a.trace = p.trace;
+    a.trace_rows = p.trace_rows;
+    a.grid_uniform = p.grid_uniform;
+    if (a.B <= 0) return VP_ERR_OK;
+    constexpr int RB = block_rows<T, M::N + 1 + M::P, M::kStatic>();
+    if (p.w) hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, true>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+    else hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, false>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+} // namespace blk
+} // namespace vp

@@ -679,7 +679,7 @@ template <typename T, int N, int Q> struct LmState {
 // can hold padding rows -- the row-validity masks (32 SGPRs of hoisted lane masks, two selects per element) disappear
 // from the column build entirely or from all pairs but the last
 template <typename T, class M, int R, int W, bool WEIGHTED, int PADM = 0>
-__global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
+__global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
     static_assert(!(WEIGHTED && PADM != 0), "PADM is a unit-weight specialisation");
     constexpr int N = M::N, P = M::P, Q = M::Q;
     // CF: the constant column leads the factorisation and is never materialised (evaluate_core_const_first)
@@ -1065,6 +1065,12 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P>())) 
     }
 }
 
+// dynamic LDS of fit_kernel: zero-padded copies of the grid, the data column and (weighted problems) the weights, the group
+// exchange area, one parked LM state per wave.  vp_batch_create checks it against the CU's 160 KiB (KernelEntry::fit_lds_w)
+template <typename T, class M, int R, int W> constexpr size_t fit_lds_bytes(bool weighted) {
+    return (size_t)(weighted ? 3 : 2) * 64 * R * W * sizeof(T) + ((group_xch_bytes<W>() + 15) / 16) * 16 +
+           (size_t)W * sizeof(LmState<T, M::N, M::Q>);
+}
 template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchParams &p) {
     FitArgs<T, M> a;
     if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
@@ -1091,8 +1097,7 @@ template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchPara
     a.trace_rows = p.trace_rows;
     a.grid_uniform = p.grid_uniform;
     if (a.B <= 0) return VP_ERR_OK;
-    const size_t lds = (size_t)(p.w ? 3 : 2) * 64 * R * W * sizeof(T) + ((group_xch_bytes<W>() + 15) / 16) * 16 +
-                       (size_t)W * sizeof(LmState<T, M::N, M::Q>);
+    const size_t lds = fit_lds_bytes<T, M, R, W>(p.w != nullptr);
     if (p.w) hipLaunchKernelGGL((fit_kernel<T, M, R, W, true>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     else if (p.m == 64 * R * W)
         hipLaunchKernelGGL((fit_kernel<T, M, R, W, false, 1>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);

@@ -1,0 +1,7 @@
+// length-agnostic fit kernels (vp_block.hpp), run-time-descriptor models, f64 (second file: parallel build)
+#include "vp_inst_blk.hpp"
+
+VP_REGISTER_BLOCKED_RT(double, VP_F64, 1, 2, 2)
+VP_REGISTER_BLOCKED_RT(double, VP_F64, 2, 4, 4)
+VP_REGISTER_BLOCKED_RT(double, VP_F64, 2, 1, 1)
+VP_REGISTER_BLOCKED_RT(double, VP_F64, 3, 3, 3)

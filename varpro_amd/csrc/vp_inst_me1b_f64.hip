@@ -4,6 +4,4 @@
 #include "vp_inst.hpp"
 VP_REGISTER_MULTIEXP(double, VP_F64, 1, 1, 24)
 VP_REGISTER_MULTIEXP(double, VP_F64, 1, 1, 32)
-// ... and on two waves up to 4096 rows (single-RHS kernel set)
-VP_REGISTER_MULTIEXP_W(double, VP_F64, 1, 1, 24, 2)
-VP_REGISTER_MULTIEXP_W(double, VP_F64, 1, 1, 32, 2)
+// (beyond 2048 rows: the length-agnostic set, vp_inst_blk_me13_f64.hip)

@@ -20,6 +20,15 @@ namespace vp {
 template <typename T, int R, int NC> constexpr int waves_for() {
     return (NC * R * (int)(sizeof(T) / 4) <= VP_TWO_WAVE_VGPRS) ? 2 : 1;
 }
+// run-time-descriptor models (kinds and dependency table read at run time: every basis kind is evaluated per element, and
+// the general Jacobian keeps q extra columns): their kernels at 12 and more rows per lane run ONE wave per SIMD (512
+// VGPRs) -- at two they spilled 300-600 VGPRs
+#ifndef VP_RT_ONE_WAVE
+#define VP_RT_ONE_WAVE 1
+#endif
+template <typename T, class M, int R, int NC> constexpr int model_waves_for() {
+    return (VP_RT_ONE_WAVE && !M::kStatic && R >= 12) ? 1 : waves_for<T, R, NC>();
+}
 // launch bound (2nd argument = waves per SIMD) for a kernel whose workgroup is one group of W waves
 template <typename T, int R, int NC, int W> constexpr int group_waves_per_eu() {
     return W >= 4 ? ((waves_for<T, R, NC>() * W) / 4 > 0 ? (waves_for<T, R, NC>() * W) / 4 : 1) : waves_for<T, R, NC>();
@@ -167,6 +176,9 @@ __device__ __forceinline__ RowSource<T, R> make_row_source(const T *t, const T *
     return s;
 }
 
+#ifndef VP_EVAL2_ONE_WAVE
+#define VP_EVAL2_ONE_WAVE 0
+#endif
 template <typename T, class M> struct EvalArgs {
     M mdl;
     const T *t;
@@ -190,7 +202,7 @@ template <typename T, class M> struct EvalArgs {
 // ALIGNED: m even and every array 16-byte aligned (checked on the host) -> 2-element accesses only
 // WEIGHTED: weights present (decided on the host)
 template <typename T, class M, int R, int W, int MODE, bool ALIGNED, bool WEIGHTED>
-__global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>()))
+__global__ void __launch_bounds__(64 * W, ((MODE == 2 && VP_EVAL2_ONE_WAVE) ? 1 : model_waves_for<T, M, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>()))
     evaluate_kernel(const EvalArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     __shared__ __attribute__((aligned(16))) unsigned char s_xch[group_xch_bytes<W>() > 0 ? group_xch_bytes<W>() : 16];
@@ -202,13 +214,24 @@ __global__ void __launch_bounds__(64 * W, (waves_for<T, R, M::N + 1 + M::P + ((M
     const int64_t b = prob / a.S;
     const int s = (int)(prob - b * a.S);
     const int m = a.m;
+#ifdef VP_EVAL2_STAGGER
+    if constexpr (MODE == 2 && W == 1) {
+        if (blockIdx.x < 2048u && (blockIdx.x & 1u)) {
+#pragma unroll
+            for (int i = 0; i < VP_EVAL2_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#endif
 
     T alpha[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
 
     // MODE 2 (residual + Jacobian output) is store-bound and register-tight: per-row exponentials there
-    using Src = RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0, W, MODE != 2>;
+#ifndef VP_EVAL2_RECUR
+#define VP_EVAL2_RECUR 0
+#endif
+    using Src = RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0, W, (MODE != 2) || VP_EVAL2_RECUR>;
     Src src;
     src.t = a.t + b * a.t_stride;
     src.w = WEIGHTED ? a.w + b * a.w_stride : nullptr;
@@ -302,10 +325,15 @@ template <typename T, class M> struct BasisArgs {
 #ifndef VP_BASIS_ROWPAIR
 #define VP_BASIS_ROWPAIR 1 /* multi-exponential fp64: the thread-per-row-pair kernel below */
 #endif
+// problems (waves) per workgroup of basis_kernel: run-time-descriptor models at 12 and more rows per lane need the 512
+// VGPRs of one wave per SIMD (4 waves per workgroup), see model_waves_for
+template <class M, int R, int W> constexpr int basis_ppb() {
+    return (W == 1) ? ((!M::kStatic && R >= 12 && VP_RT_ONE_WAVE) ? 4 : VP_BASIS_WPB) : 1;
+}
 template <typename T, class M, int R, int W, bool ALIGNED>
-__global__ void __launch_bounds__(64 * W * (W == 1 ? VP_BASIS_WPB : 1)) basis_kernel(const BasisArgs<T, M> a) {
+__global__ void __launch_bounds__((64 * W * basis_ppb<M, R, W>())) basis_kernel(const BasisArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
-    constexpr int PPB = (W == 1) ? VP_BASIS_WPB : 1;
+    constexpr int PPB = basis_ppb<M, R, W>();
     const int lane = (W == 1) ? (int)(threadIdx.x & 63u) : (int)threadIdx.x; // group lane
     const int64_t b = (int64_t)blockIdx.x * PPB + ((W == 1) ? (int)(threadIdx.x >> 6) : 0);
     if (b >= a.B) return;
@@ -460,7 +488,7 @@ template <typename T, class M, int R, int W = 1> int launch_basis(const LaunchPa
         }
     }
 #endif
-    constexpr int PPB = (W == 1) ? VP_BASIS_WPB : 1;
+    constexpr int PPB = basis_ppb<M, R, W>();
     const dim3 grid((unsigned)((a.B + PPB - 1) / PPB)), block(64 * W * PPB);
     if (host_aligned<T>(p.m, {p.t, p.Phi_out, p.dPhi_out}))
         hipLaunchKernelGGL((basis_kernel<T, M, R, W, true>), grid, block, 0, p.stream, a);

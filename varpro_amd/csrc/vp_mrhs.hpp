@@ -1377,17 +1377,25 @@ template <typename T, class M> inline bool fill_factor_args(const LaunchParams &
     return true;
 }
 
+// the N + 1 + P columns of R rows per lane do not fit the 512 VGPRs of a wave running alone on its SIMD
+template <typename T, class M, int R> constexpr bool mrhs_one_wave_spills() {
+    return (M::N + 1 + M::P) * R * (int)(sizeof(T) / 4) > 400;
+}
+
 template <typename T, class M, int R> int launch_mrhs_factor(const LaunchParams &p) {
     MrhsFactorArgs<T, M> a;
     if (!fill_factor_args<T, M>(p, a)) return VP_ERR_UNSUPPORTED;
-    // few problems: the factorisation is pure latency -> 4 waves per problem (R/4 rows per lane)
+    // few problems: the factorisation is pure latency -> 4 waves per problem (R/4 rows per lane); ALWAYS four waves where
+    // the columns of a problem do not fit the registers of one (the one-wave form of the triple exponential at 32 rows per
+    // lane spilled 596 VGPRs)
     if constexpr (R % 8 == 0) { // (R / 4 rows per lane, in pairs)
-        if (a.B <= 1024) {
+        if (a.B <= 1024 || mrhs_one_wave_spills<T, M, R>()) {
             hipLaunchKernelGGL((mrhs_factor_kernel<T, M, R / 4, 4>), dim3((unsigned)a.B), dim3(256), 0, p.stream, a);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL((mrhs_factor_kernel<T, M, R, 1>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+    if constexpr (!(R % 8 == 0 && mrhs_one_wave_spills<T, M, R>()))
+        hipLaunchKernelGGL((mrhs_factor_kernel<T, M, R, 1>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
@@ -1489,12 +1497,13 @@ template <typename T, class M, int R> int launch_mrhs_lm(const LaunchParams &p) 
     a.trace_rows = p.trace_rows;
     // few problems: LM step and factorisation are pure latency -> 4 waves per problem (R/4 rows per lane)
     if constexpr (R % 8 == 0) { // (R / 4 rows per lane, in pairs)
-        if (a.B <= 1024) {
+        if (a.B <= 1024 || mrhs_one_wave_spills<T, M, R>()) {
             hipLaunchKernelGGL((mrhs_step_kernel<T, M, R / 4, 4>), dim3((unsigned)a.B), dim3(256), 0, p.stream, fa, a);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL((mrhs_step_kernel<T, M, R, 1>), dim3((unsigned)p.B), dim3(64), 0, p.stream, fa, a);
+    if constexpr (!(R % 8 == 0 && mrhs_one_wave_spills<T, M, R>()))
+        hipLaunchKernelGGL((mrhs_step_kernel<T, M, R, 1>), dim3((unsigned)p.B), dim3(64), 0, p.stream, fa, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 

@@ -28,6 +28,9 @@ struct KernelEntry {
     launch_fn mrhs_fit_whole; // S > 1 fit as ONE launch (generic fallback kernels only; null elsewhere)
     int gram_fit;       // 1: `fit` is the fp64-Gram kernel (vp_fitg.hpp), which also serves vp_debug_gram_evaluate
     int mrhs_gx_cap;    // MRHS streaming kernel: max workgroups (partial-sum slots) per problem; 0 = 256
+    size_t fit_lds_w;   // dynamic LDS the single-RHS fit kernel needs for a WEIGHTED problem (0: not recorded, fits)
+    int uses_gen_ws;    // 1: evaluate / stats / global fits of this set run on the generic kernels (vp_generic.hpp) and need
+                        // their global-memory workspace (the generic set itself; the length-agnostic sets of vp_block.hpp)
 };
 
 std::vector<KernelEntry> &registry();
@@ -41,7 +44,8 @@ int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out);
 
 // S: right-hand sides of the handle -- among sets of equal capacity a single-RHS handle prefers the one whose columns fit
 // the registers (R <= 16: more waves per problem), a multiple-RHS handle the one that has MRHS kernels
-const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m, int64_t S = 1);
+// weighted: sets whose fit kernel cannot stage grid + weights + data of a weighted problem in the CU's LDS are skipped
+const KernelEntry *find_kernels(int dtype, const vp_model_desc &d, int64_t m, int64_t S = 1, bool weighted = false);
 // kernel set of a caller-evaluated model (vp_batch_create_external) of shape (n, q, np pairs)
 const KernelEntry *external_kernels(int dtype, int n, int q, int np, int64_t m, int64_t S);
 // true: an evaluation of this shape runs on a register-resident kernel (vp_ext.hpp) and needs no generic workspace
