@@ -584,6 +584,34 @@ def main():
             bpx.close()
             del phi_x, dphi_x, r_x, J_x, r_ev, J_ev
 
+        if world == 1 and not args.no_side_configs:
+            # ---- the LENGTH-AGNOSTIC kernels (vp_block.hpp): rows streamed in blocks through a TSQR update of an
+            # (n+1+p)^2 triangle -- what a problem lands on beyond the largest register-resident set (2048 rows) ----
+            legs = {}
+            for ms, Bs in ((10000, 16384), (100000, 2048)):
+                ds = synth.double_exp_batch(Bs, m=ms, noise=args.noise)
+                mdls = vp.multi_exponential_model(ds["x"], ds["tau_guess"][0])
+                bps = vp.BatchProblem(mdls, torch.from_numpy(ds["Y"]).to(dev), x=torch.from_numpy(ds["x"]).to(dev))
+                gs = torch.from_numpy(ds["tau_guess"]).to(dev)
+                mss = event_ms(lambda: bps.fit(gs, want_coefficients=False), 3, 1)
+                _as, _cs, reps = bps.fit(gs, want_coefficients=False)
+                rs = bps.report_to_numpy(reps)
+                evs = float(rs["n_evals"].sum())
+                fl = ms * 2 * 28 + 2 * ms * 9 + 4 * ms * 3 + (4 * 3 + 2) * ms * 2   # SURVEY 8(d) at this m
+                legs["m%d" % ms] = {
+                    "workload": "B=%d double-exp+offset fits, m=%d, fp64 (no resident kernel set is this long)" % (Bs, ms),
+                    "fits_per_s": Bs / (mss * 1e-3), "ms_per_step": mss, "mean_evaluations_per_fit": evs / Bs,
+                    "fraction_failed": float((rs["termination"] <= 0).mean()),
+                    "roofline": {"kernel": "blk_fit_kernel<double, MultiExpModel<2, true>, 8>", "bound": "fp64_valu",
+                                 "achieved": evs * fl / (mss * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": evs * fl / (mss * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                 "y_stream_GBps": evs * ms * T / (mss * 1e-3) / 1e9,
+                                 "note": "y (8 m bytes) is re-read per evaluation through the LDS ring; the grid comes from L2"},
+                }
+                bps.close()
+                del ds, gs
+            out["streamed_rows"] = legs
+
         # ---- generic fallback kernels (vp_generic.hpp): a model / size WITHOUT a specialised kernel set ----
         if world == 1 and not args.no_side_configs:
             # the O'Leary-Rust example model (shared_test_code/src/models.rs:397-425: exp(-a2 t) cos(a3 t), exp(-a1 t) cos(a2 t);
@@ -607,19 +635,19 @@ def main():
             _ag, _cg2, repg = bpg.fit(ggd, want_coefficients=False)
             rgp = bpg.report_to_numpy(repg)
             evg = float(rgp["n_evals"].sum())
-            # workspace traffic of one evaluation: the n + 1 + p + q columns of m doubles are written and re-read a handful of
-            # times from the L2-resident slot (Householder sweep n passes, Jacobian QR q passes): ~ (n + q + 2) x (n+1+p+q) x m x 8 B
-            ws_bytes = (2 + 3 + 2) * (2 + 1 + 4 + 3) * mg * 8.0
             out["generic_fallback"] = {
-                "workload": "O'Leary exp*cos model (n=2, q=3, p=4, shared parameter), B=%d, m=%d, fp64: no specialised kernel set "
-                            "at this m -> gen_fit_kernel (one 256-thread workgroup per problem, columns in a global-memory workspace)" % (Bg, mg),
+                "workload": "O'Leary exp*cos model (n=2, q=3, p=4, shared parameter), B=%d, m=%d, fp64: no register-resident kernel "
+                            "set at this m -> round 4: the length-agnostic blk_fit_kernel<RtModel<2,3,4>> (round 3: gen_fit_kernel, "
+                            "one workgroup per problem with its columns in a global-memory workspace, 0.042 M fits/s)" % (Bg, mg),
                 "fits_per_s": Bg / (msg * 1e-3), "ms_per_step": msg, "mean_evaluations_per_fit": evg / Bg,
                 "fraction_failed": float((rgp["termination"] <= 0).mean()),
-                "us_per_evaluation_per_workgroup": msg * 1e3 / (evg / min(Bg, 1024)),
-                "roofline": {"kernel": "gen_fit_kernel", "bound": "latency (workgroup barriers + L2 round trips per reflector)",
-                             "l2_workspace_GBps": evg * ws_bytes / (msg * 1e-3) / 1e9,
-                             "note": "columns live in an L2-resident workspace slot, ~2(n+q) workgroup barriers per evaluation; "
-                                     "neither HBM nor the fp64 pipe is the bound"},
+                "roofline": {"kernel": "blk_fit_kernel<double, RtModel<2, 3, 4>, 8>", "bound": "fp64_valu (column build: exp, cos, sin per element "
+                                                                                          "of two basis functions and four derivative columns)",
+                             "y_stream_GBps": evg * mg * 8.0 / (msg * 1e-3) / 1e9,
+                             "traffic": committed_traffic("blk_fit_kernel"), "traffic_source": traffic_source("blk_fit_kernel"),
+                             "algorithmic_bytes_per_launch": evg * mg * 8.0,
+                             "note": "one wavefront per problem, one wave per SIMD (the run-time-descriptor column build needs the registers); "
+                                     "y re-read per evaluation"},
             }
             bpg.close()
 

@@ -244,20 +244,21 @@ template <typename T, int RB, bool WEIGHTED> struct RowRing {
 #ifndef VP_BLK_WAVES
 #define VP_BLK_WAVES 2
 #endif
-// (run-time-descriptor models evaluate every basis kind per element -- their column build alone needs the registers of a
-// multi-exponential block twice as long: half the rows)
+// (run-time-descriptor models evaluate every basis kind per element and their column build needs about as many registers
+// again as the block itself: their kernels run ONE wave per SIMD -- 512 VGPRs -- like the resident ones, model_waves_for)
+template <class M> constexpr int blk_waves() { return M::kStatic ? VP_BLK_WAVES : 1; }
 template <typename T, int NC, bool STATIC = true> constexpr int block_rows() {
 #ifdef VP_BLK_RB
     return VP_BLK_RB;
 #else
     constexpr int words = NC * (int)(sizeof(T) / 4);
     if constexpr (STATIC) return words <= 14 ? 8 : ((words <= 28 || sizeof(T) == 4) ? 4 : 2);
-    else return words <= 6 ? 8 : ((words <= 10 || sizeof(T) == 4) ? 4 : 2);
+    else return words <= 14 ? 8 : ((words <= 24 || sizeof(T) == 4) ? 4 : 2); // (one wave per SIMD: blk_waves)
 #endif
 }
 
 template <typename T, class M, int RB, bool WEIGHTED>
-__global__ void __launch_bounds__(64, VP_BLK_WAVES) blk_fit_kernel(const FitArgs<T, M> a) {
+__global__ void __launch_bounds__(64, (blk_waves<M>())) blk_fit_kernel(const FitArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     constexpr int ROWS = 64 * RB;
     using G = Grp<1>;
@@ -505,7 +506,7 @@ template <typename T, class M, int RB> constexpr size_t eval_snap_bytes(int64_t 
 constexpr size_t kEvalSnapMax = 40 * 1024; // beyond: the generic kernels (vp_generic.hpp)
 
 template <typename T, class M, int RB, bool WEIGHTED>
-__global__ void __launch_bounds__(64, VP_BLK_WAVES) blk_evaluate_kernel(const EvalArgs<T, M> a) {
+__global__ void __launch_bounds__(64, (blk_waves<M>())) blk_evaluate_kernel(const EvalArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P, NW = 1 + Q;
     constexpr int ROWS = 64 * RB;
     using G = Grp<1>;

@@ -2,4 +2,3 @@
 #include "vp_inst.hpp"
 VP_REGISTER_RT(double, VP_F64, 2, 1, 1, 16)
 VP_REGISTER_RT(double, VP_F64, 3, 3, 3, 16)
-VP_REGISTER_RT(double, VP_F64, 4, 3, 3, 16)
