@@ -267,6 +267,16 @@ def main():
                     continue
             return None
 
+        def committed_traffic_grid(kernel, grid):
+            """the same for ONE launch shape of a kernel (per_kernel_and_grid entry)"""
+            for fn in TRAFFIC_FILES:
+                try:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    return pj["per_kernel_and_grid"]["%s@grid%d" % (kernel, grid)]["hbm_bytes_per_launch_corrected"]
+                except Exception:
+                    continue
+            return None
+
         def traffic_source(key):
             for fn in TRAFFIC_FILES:
                 try:
@@ -605,7 +615,8 @@ def main():
                     "roofline": {"kernel": "blk_fit_kernel<double, MultiExpModel<2, true>, 8>", "bound": "fp64_valu",
                                  "achieved": evs * fl / (mss * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": evs * fl / (mss * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                 "y_stream_GBps": evs * ms * T / (mss * 1e-3) / 1e9,
+                                 "y_stream_GBps": evs * ms * T / (mss * 1e-3) / 1e9, "algorithmic_bytes_per_launch": evs * ms * T,
+                                 "traffic": committed_traffic_grid("blk_fit_kernel", Bs * 64), "traffic_source": traffic_source("blk_fit_kernel"),
                                  "note": "y (8 m bytes) is re-read per evaluation through the LDS ring; the grid comes from L2"},
                 }
                 bps.close()
@@ -644,7 +655,7 @@ def main():
                 "roofline": {"kernel": "blk_fit_kernel<double, RtModel<2, 3, 4>, 8>", "bound": "fp64_valu (column build: exp, cos, sin per element "
                                                                                           "of two basis functions and four derivative columns)",
                              "y_stream_GBps": evg * mg * 8.0 / (msg * 1e-3) / 1e9,
-                             "traffic": committed_traffic("blk_fit_kernel"), "traffic_source": traffic_source("blk_fit_kernel"),
+                             "traffic": committed_traffic("blk_fit_kernel_rt"), "traffic_source": traffic_source("blk_fit_kernel_rt"),
                              "algorithmic_bytes_per_launch": evg * mg * 8.0,
                              "note": "one wavefront per problem, one wave per SIMD (the run-time-descriptor column build needs the registers); "
                                      "y re-read per evaluation"},

@@ -17,9 +17,11 @@ python - <<PY
 import csv, glob, json, collections, re
 out = "$OUT"; tag = "$TAG"
 def short(name):
-    m = re.match(r"(?:void )?(?:vp::)?([A-Za-z0-9_]+)<(.*)>\(", name)
+    m = re.match(r"(?:void )?(?:vp::)?(?:(?:blk|ext|gen)::)?([A-Za-z0-9_]+)<(.*)>\(", name)
     if not m: return name.split("(")[0][:50]
     k, targs = m.group(1), m.group(2)
+    if k in ("blk_fit_kernel", "blk_evaluate_kernel") and "RtModel" in targs: return k + "_rt"
+    if k == "ext_evaluate_kernel": return k + ("" if targs.rstrip().endswith("true") else "_no_derivatives")
     if k == "mrhs_stream_kernel": return "%s_mode%s" % (k, targs.split(",")[-1].strip())
     if k in ("fit_kernel", "fit2_kernel", "evaluate_kernel", "basis_kernel"):
         return k + ("_f32" if targs.startswith("float") else "")
