@@ -195,6 +195,8 @@ def main():
                 allreduce(reds[i])
         return reds[i]
 
+    per_rank_s = {}
+
     def timed(nslots):
         for k in range(args.warmup):
             step(k, nslots)
@@ -207,6 +209,12 @@ def main():
         barrier()
         dt_ = time.perf_counter() - t0
         if world > 1:
+            # every rank's own time for the K steps (rank 0 prints them: the weak-scaling loss of this design is the spread of
+            # the ranks' step times)
+            mine = torch.tensor([dt_], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank_s[nslots] = [float(t_.item()) for t_ in every]
             tmax = torch.tensor([dt_], dtype=torch.float64, device=dev)
             if backend == "gloo":
                 h = tmax.cpu()
@@ -340,6 +348,7 @@ def main():
                     "fits_per_s": total_fits / dt_pipe, "ms_per_step": dt_pipe / args.steps * 1e3,
                     "note": "same K steps, step k on handle/stream k mod 2: the straggler tail of a launch overlaps the "
                             "bulk of the next step (kernel trace: profiles/r02_pipelined_overlap.json)"},
+                "per_rank_ms_per_step": [t_ / args.steps * 1e3 for t_ in per_rank_s.get(1, [dt])],
                 "mean_evaluations_per_fit": evals_per_fit, "fits_successful": n_ok, "fits_failed": n_bad,
                 "sum_cost": sum_cost,
             },
