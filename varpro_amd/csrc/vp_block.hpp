@@ -257,13 +257,21 @@ template <typename T, int NC, bool STATIC = true> constexpr int block_rows() {
 #endif
 }
 
-template <typename T, class M, int RB, bool WEIGHTED>
-__global__ void __launch_bounds__(64, (blk_waves<M>())) blk_fit_kernel(const FitArgs<T, M> a) {
+// W waves per problem (W = 1, or 4 for launches smaller than the device, where the launch is its LONGEST fit's chain of
+// evaluations -- 100+ evaluations x blocks x ~4 us -- and not its work): wave w streams the blocks w, w + W, ... into its own
+// carry and private trailing triangles; the W carries are then stacked through LDS and every wave reduces the stack by the
+// same stacked_qr (TSQR merges carries as easily as blocks), so all waves hold the bit-identical compressed problem and
+// run the LM bookkeeping redundantly -- no LM state is ever exchanged (as in the resident multi-wave groups, Grp<W>).
+template <typename T, class M, int RB, bool WEIGHTED, int W = 1>
+__global__ void __launch_bounds__(64 * W, (blk_waves<M>())) blk_fit_kernel(const FitArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     constexpr int ROWS = 64 * RB;
-    using G = Grp<1>;
+    constexpr int NTRI = NC * (NC + 1) / 2;
+    static_assert(W * NC <= 128, "the stacked carries must fit two rows per lane");
+    using G = Grp<1>; // (reductions are per wave: each wave owns its blocks and, after the merge, a full copy of the problem)
     G grp = G::make(nullptr);
     const int lane = grp.gl;
+    const int wave = (W > 1) ? (int)(threadIdx.x >> 6) : 0;
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
     const int m = a.m;
@@ -291,9 +299,11 @@ __global__ void __launch_bounds__(64, (blk_waves<M>())) blk_fit_kernel(const Fit
     int trow = 0;
 
     using Ring = RowRing<T, RB, WEIGHTED>;
-    __shared__ __attribute__((aligned(16))) T ring_mem[2 * Ring::NARR * ROWS];
+    __shared__ __attribute__((aligned(16))) T ring_mem[W * 2 * Ring::NARR * ROWS];
+    __shared__ T s_merge[W > 1 ? 2 * W * NTRI : 1]; // the waves' carries, double-buffered by the evaluation's parity
     Ring ring;
-    ring.init(ring_mem, tp, yp, wp, m, lane);
+    ring.init(ring_mem + (size_t)wave * 2 * Ring::NARR * ROWS, tp, yp, wp, m, lane);
+    int parity = 0;
     // distance between a lane's consecutive row pairs on a uniform grid (RowSource::set_uniform, from the WHOLE grid)
     const T dpair = (m >= 3) ? (tp[m - 1] - tp[0]) / T(m - 1) * T(128) : T(0);
 
@@ -311,10 +321,10 @@ __global__ void __launch_bounds__(64, (blk_waves<M>())) blk_fit_kernel(const Fit
 #pragma unroll
                 for (int j = 0; j < PT; ++j) Tl[i][j] = T(0);
         }
-        ring.begin(0);
-        for (int off = 0; off < m; off += ROWS) {
+        if (wave * ROWS < m) ring.begin(wave * ROWS);
+        for (int off = wave * ROWS; off < m; off += W * ROWS) {
             T *s_t, *s_y, *s_w;
-            ring.stage(off, off + ROWS < m ? off + ROWS : -1, s_t, s_y, s_w);
+            ring.stage(off, off + W * ROWS < m ? off + W * ROWS : -1, s_t, s_y, s_w);
             using Src = RowSource<T, RB, true, WEIGHTED ? 1 : 0, 1, 1, true, 0>;
             Src src;
             src.t = s_t;
@@ -337,6 +347,31 @@ __global__ void __launch_bounds__(64, (blk_waves<M>())) blk_fit_kernel(const Fit
             asm volatile("" ::: "memory");
         }
         if constexpr (kLaneTrail) lane_trail_merge<T, NC, N, PT, G>(Tl, K, grp);
+        if constexpr (W > 1) {
+            // ---- merge the W carries: stack them through LDS, every wave reduces the same stack ----
+            T *mg = s_merge + (size_t)parity * W * NTRI;
+            parity ^= 1;
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                if (lane == i / 2) {
+#pragma unroll
+                    for (int j = i; j < NC; ++j) mg[wave * NTRI + i * NC - i * (i - 1) / 2 + (j - i)] = K[j][i % 2];
+                }
+            __syncthreads();
+            T Cm[NC][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int rho = 2 * lane + r; // row of the stack [K_0; K_1; ...; K_{W-1}]
+                const int w = rho / NC, i = rho - w * NC;
+                const bool in = rho < W * NC;
+#pragma unroll
+                for (int j = 0; j < NC; ++j)
+                    Cm[j][r] = (in && i <= j) ? mg[w * NTRI + i * NC - i * (i - 1) / 2 + (j - i)] : T(0);
+            }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) K[j][0] = K[j][1] = T(0);
+            stacked_qr<T, NC, NC, 2, G>(K, Cm, grp);
+        }
         // ================= the compressed problem: T's leading N x N block, (T_y)[0:N], the rows >= N =================
         T Rm[N][N], qty[N];
 #pragma unroll
@@ -369,7 +404,7 @@ __global__ void __launch_bounds__(64, (blk_waves<M>())) blk_fit_kernel(const Fit
 #pragma unroll
             for (int k = 0; k < N; ++k) cbest[k] = c[k];
         }
-        if (a.trace && trow < a.trace_rows && lane == 0) {
+        if (a.trace && trow < a.trace_rows && lane == 0 && wave == 0) {
             double *tr = a.trace + ((size_t)b * a.trace_rows + trow) * (Q + 4);
 #pragma unroll
             for (int k = 0; k < Q; ++k) tr[k] = (double)S.xt[k];
@@ -398,7 +433,7 @@ __global__ void __launch_bounds__(64, (blk_waves<M>())) blk_fit_kernel(const Fit
         lm_next_step<T, N, Q, true>(S, opt, need);
     }
 
-    if (lane == 0) {
+    if (lane == 0 && wave == 0) {
         vp_report rep;
         rep.termination = S.term;
         rep.n_evals = S.nfev;
@@ -717,8 +752,18 @@ template <typename T, class M> int launch_fit(const LaunchParams &p) {
     a.grid_uniform = p.grid_uniform;
     if (a.B <= 0) return VP_ERR_OK;
     constexpr int RB = block_rows<T, M::N + 1 + M::P, M::kStatic>();
-    if (p.w) hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, true>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
-    else hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, false>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+    // A launch that does not fill the device several times over ends when its LONGEST fit does (evaluation counts are
+    // heavy-tailed: mean ~8, max 100+): four waves per problem then shorten every chain ~3.5x at no cost in throughput that
+    // matters there.  Results do not depend on the choice beyond rounding (a different but equally valid TSQR tree).
+    constexpr int WM = 4;
+    const bool multi = p.B <= (int64_t)16 * (p.num_cus > 0 ? p.num_cus : 256) && p.m >= 2 * WM * 64 * RB && WM * (M::N + 1 + M::P) <= 128;
+    if (multi) {
+        if (p.w) hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, true, WM>), dim3((unsigned)a.B), dim3(64 * WM), 0, p.stream, a);
+        else hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, false, WM>), dim3((unsigned)a.B), dim3(64 * WM), 0, p.stream, a);
+    } else {
+        if (p.w) hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, true>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+        else hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, false>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+    }
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 

@@ -88,14 +88,16 @@ __device__ __forceinline__ void basis_eval(int kind, T t, T p0, T p1, T &f, T &d
         break;
     case VP_BASIS_EXP_COS: {
         const T ex = g_exp(-p0 * t);
-        f = ex * tcos(p1 * t);
+        T sn_, cs_;
+        tsincos(p1 * t, sn_, cs_);
+        f = ex * cs_;
         d0 = f * (-t);
-        d1 = -t * ex * tsin(p1 * t);
+        d1 = -t * ex * sn_;
     } break;
     default: { // VP_BASIS_SIN_PHASE
         const T ph = p0 * t + p1;
-        const T cs = tcos(ph);
-        f = tsin(ph);
+        T cs;
+        tsincos(ph, f, cs);
         d0 = t * cs;
         d1 = cs;
     } break;

@@ -108,12 +108,65 @@ template <int NX> __device__ __forceinline__ void texp_n(const float (&x)[NX], f
 #pragma unroll
     for (int i = 0; i < NX; ++i) out[i] = texp(x[i]);
 }
-// sin / cos only occur in run-time-descriptor models, whose column build is unrolled over rows x columns x kinds:
-// kept out of line (one copy per kernel instead of R*N inlined Payne-Hanek expansions, which made MBs of code)
+// sin / cos only occur in run-time-descriptor models, whose column build is unrolled over rows x columns x kinds.
+// The library routines stay out of line (one copy per kernel instead of R*N inlined Payne-Hanek expansions, which made MBs
+// of code) and are only reached for huge arguments:
 __device__ __noinline__ double tsin(double x) { return __ocml_sin_f64(x); }
 __device__ __noinline__ float tsin(float x) { return __ocml_sin_f32(x); }
 __device__ __noinline__ double tcos(double x) { return __ocml_cos_f64(x); }
 __device__ __noinline__ float tcos(float x) { return __ocml_cos_f32(x); }
+// sin AND cos of one fp64 argument, inline (round 4): k = rint(x 2/pi), three-term Cody-Waite reduction with FMAs
+// (pi/2 = HI + MID + LO to ~160 bits: exact to rounding for |x| <= 2^20), the fdlibm kernel polynomials on |r| <= pi/4
+// (< 1 ulp each), quadrant by k mod 4: ~45 instructions for both values.  Every element of an exp*cos / sin-phase
+// column needed two out-of-line library calls before, and a CALL in the middle of the unrolled column build is what costs
+// (the live columns around it): inlined, the O'Leary model fits 46 % faster (3.2 -> 4.7 M fits/s at m = 1024) -- and every
+// run-time-descriptor kernel grows by N x R copies of it (library + 12 MB).  Inlined therefore only in the translation
+// units that define VP_INLINE_SINCOS (the length-agnostic run-time-descriptor sets, where the blocks are short and the
+// generic_fallback leg of bench.py lives); one out-of-line copy per kernel elsewhere.  |x| > 2^20 (never on a sane grid)
+// takes the library routines.
+#ifdef VP_INLINE_SINCOS
+#define VP_SINCOS_ATTR __forceinline__
+#else
+#define VP_SINCOS_ATTR __noinline__
+#endif
+__device__ VP_SINCOS_ATTR void tsincos(double x, double &sn, double &cs) {
+    if (__builtin_expect(!(__builtin_fabs(x) <= 1048576.0), 0)) { // (also NaN / inf)
+        sn = tsin(x);
+        cs = tcos(x);
+        return;
+    }
+    const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+    r = __builtin_fma(-k, -1.49738490485916983294e-33, r);
+    const double z = r * r;
+    // __kernel_sin: r + r^3 (S1 + z (S2 + ... ))
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double s0 = __builtin_fma(r * z, ps, r);
+    // __kernel_cos: 1 - z/2 + z^2 (C1 + z (C2 + ...))
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w1 = 1.0 - hz;
+    const double c0 = w1 + (((1.0 - w1) - hz) + z * z * pc);
+    const int q = (int)k;
+    const double a = (q & 1) ? c0 : s0, b = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
+__device__ __forceinline__ void tsincos(float x, float &sn, float &cs) {
+    sn = tsin(x);
+    cs = tcos(x);
+}
 
 // ---- row sources: where the grid value t_i and the row scale of a lane's rows come from -----------
 // scale_i = w_i for rows i < m (1 for unit weights) and 0 for padding rows i >= m, so that padding
@@ -349,13 +402,17 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                     } else if (kind[j] == VP_BASIS_EXP_COS) {
                         // exp(-a t) cos(b t)   (shared_test_code/src/models.rs:313-314, 349-372)
                         const T ex = texp(-p0[j] * t) * scl;
-                        f = ex * tcos(p1[j] * t);
+                        T sn_, cs_;
+                        tsincos(p1[j] * t, sn_, cs_);
+                        f = ex * cs_;
                         d0 = f * (-t);
-                        d1 = -t * ex * tsin(p1[j] * t);
+                        d1 = -t * ex * sn_;
                     } else { // VP_BASIS_SIN_PHASE   (src/test_helpers/mod.rs:28-52)
                         const T ph = p0[j] * t + p1[j];
-                        const T cs = tcos(ph) * scl;
-                        f = tsin(ph) * scl;
+                        T sn_, cs_;
+                        tsincos(ph, sn_, cs_);
+                        const T cs = cs_ * scl;
+                        f = sn_ * scl;
                         d0 = t * cs;
                         d1 = cs;
                     }
