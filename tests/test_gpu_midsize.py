@@ -74,7 +74,7 @@ def test_multiple_right_hand_sides(S, m, weighted):
     assert np.abs(ev["r"][0] - ref.residuals()).max() <= TOL * np.abs(yw).max()
     Jr = ref.jacobian()
     for k in range(2):
-        assert np.abs(ev["J"][0, k] - Jr[k]).max() <= 1e-9 * np.abs(Jr[k]).max()
+        assert np.abs(ev["J"][0, k] - Jr[k]).max() <= 1e-10 * np.abs(Jr[k]).max()
     a, C, rep = bp.fit(guess[None])
     rr = ref.fit()
     assert rep["termination"][0] > 0 and rr.termination > 0

@@ -43,7 +43,7 @@ def test_trait_outputs_match_oracle(nexp, S, m, weighted):
     assert np.abs(ev["r"][0] - ref.residuals()).max() <= TOL * np.abs(yw).max()
     Jr = ref.jacobian()
     for k in range(nexp):
-        assert np.abs(ev["J"][0, k] - Jr[k]).max() <= 1e-9 * np.abs(Jr[k]).max()
+        assert np.abs(ev["J"][0, k] - Jr[k]).max() <= 1e-10 * np.abs(Jr[k]).max()
     assert abs(ev["cost"][0] - 0.5 * (ref.residuals() ** 2).sum()) <= 1e-10 * ev["cost"][0]
     # residuals alone and the Jacobian alone (each output pointer may be absent)
     e2 = bp.evaluate(guess[None], want_jacobian=False)
@@ -69,7 +69,7 @@ def test_trait_outputs_several_problems_each_with_its_own_parameters():
         assert np.abs(ev["r"][b] - ref.residuals()).max() <= TOL * np.abs(Y[b]).max()
         Jr = ref.jacobian()
         for k in range(3):
-            assert np.abs(ev["J"][b, k] - Jr[k]).max() <= 1e-9 * np.abs(Jr[k]).max()
+            assert np.abs(ev["J"][b, k] - Jr[k]).max() <= 1e-10 * np.abs(Jr[k]).max()
     bp.close()
 
 
