@@ -241,6 +241,9 @@ template <typename T, int RB, bool WEIGHTED> struct RowRing {
     }
 };
 
+#ifndef VP_BLK_MULTI_MIN_BLOCKS
+#define VP_BLK_MULTI_MIN_BLOCKS 2 /* blocks per wave from which four waves per problem pay */
+#endif
 #ifndef VP_BLK_WAVES
 #define VP_BLK_WAVES 2
 #endif
@@ -756,7 +759,7 @@ template <typename T, class M> int launch_fit(const LaunchParams &p) {
     // heavy-tailed: mean ~8, max 100+): four waves per problem then shorten every chain ~3.5x at no cost in throughput that
     // matters there.  Results do not depend on the choice beyond rounding (a different but equally valid TSQR tree).
     constexpr int WM = 4;
-    const bool multi = p.B <= (int64_t)16 * (p.num_cus > 0 ? p.num_cus : 256) && p.m >= 2 * WM * 64 * RB && WM * (M::N + 1 + M::P) <= 128;
+    const bool multi = p.B <= (int64_t)16 * (p.num_cus > 0 ? p.num_cus : 256) && p.m >= VP_BLK_MULTI_MIN_BLOCKS * WM * 64 * RB && WM * (M::N + 1 + M::P) <= 128;
     if (multi) {
         if (p.w) hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, true, WM>), dim3((unsigned)a.B), dim3(64 * WM), 0, p.stream, a);
         else hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, false, WM>), dim3((unsigned)a.B), dim3(64 * WM), 0, p.stream, a);
