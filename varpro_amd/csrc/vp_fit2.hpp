@@ -57,6 +57,9 @@ template <typename T, int R, int W, int NG, int BLOCKS_PER_CU, int REC = 0> cons
     return gs < 1 ? 1 : (gs > VP_SLOT_CAP ? VP_SLOT_CAP : gs);
 }
 
+#ifndef VP_FITG_TIMELINE
+#define VP_FITG_TIMELINE 0 // (vp_fitg.hpp, debug builds)
+#endif
 template <typename T, class M> struct Fit2Args {
     FitArgs<T, M> f;
     int *queue;        // next problem index to hand out (pre-set to the number of statically assigned problems)
@@ -420,7 +423,7 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
         int32_t *status_out = k->status;
         TO *alpha_out = k->alpha, *C_out = k->C_out;
         if (cost_out) cost_out[prob] = (double)objective;
-        if (status_out) status_out[prob] = status;
+        if (status_out && !VP_FITG_TIMELINE) status_out[prob] = status;
 #pragma unroll
         for (int i = 0; i < Q; ++i) alpha_out[prob * Q + i] = (TO)x[i];
         if (C_out) {

@@ -563,6 +563,9 @@ __device__ __forceinline__ void slotg_fill_lane(VP_LDS SlotRec<double, N, Q> *re
     rec->status = VP_ST_NOT_EVALUATED;
     rec->prob = prob;
     rec->trow = 0;
+#if VP_FITG_TIMELINE
+    if (k->status) k->status[prob] = (int32_t)(wall_clock64() & 0x7fffffffull);
+#endif
 }
 
 #ifndef VP_FITG_NS
@@ -577,10 +580,19 @@ __device__ __forceinline__ void slotg_fill_lane(VP_LDS SlotRec<double, N, Q> *re
 #ifndef VP_FITG_SPLIT_AFTER
 #define VP_FITG_SPLIT_AFTER 24 // a fit's passes are split from this evaluation on
 #endif
+#ifndef VP_FITG_TIMELINE
+#define VP_FITG_TIMELINE 0     // debug builds: start / finish clock of every fit in status / cost (100 MHz ticks)
+#endif
+#ifndef VP_FITG_OLD_FIRST
+#define VP_FITG_OLD_FIRST 1    // fits past VP_FITG_SPLIT_AFTER evaluations: claimed first, bookkeeping by the wave that streamed them
+#endif
+#ifndef VP_FITG_TAIL_LIVE
+#define VP_FITG_TAIL_LIVE 7    // live fits per workgroup from which a stream wave keeps the slot for the bookkeeping
+#endif
 constexpr int VP_FITG2_WAVES = VP_FITG2_NWAVES;
 
 template <class M, int NS, bool UNIFORM, bool WEIGHTED>
-__global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 : 1) fitg2_kernel(const FitgArgs a) {
+__global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES == 8 ? 2 : 1) fitg2_kernel(const FitgArgs a) {
     constexpr int N = M::N, Q = M::Q, NE = M::N - 1;
     static_assert(M::kStatic && M::kConstLast && M::kDiagonalPairs && M::Q == NE, "exponentials + offset");
     static_assert(NS <= 64, "one lane of the scalar wave per slot");
@@ -613,7 +625,7 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
         k->cost_out = a.cost_out;
         k->status = a.status;
         k->report = a.report;
-        k->trace = a.trace;
+        k->trace = VP_FITG_TIMELINE ? nullptr : a.trace;
         k->yw = a.yw;
         k->queue = a.queue;
         k->B = a.B;
@@ -657,12 +669,70 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
 
     constexpr int NSC = VP_FITG_SCALAR_WAVES, GSW = NS / NSC; // scalar waves, slots per scalar wave
     static_assert(NS % NSC == 0 && NSC < VP_FITG2_WAVES, "the pool divides evenly over the scalar waves");
+    // after the bookkeeping of slot `slot` (executed by ONE lane, `on`): a finished fit's slot takes the next problem of the
+    // device-side queue or becomes empty; then the slot is handed back to the stream waves
+    auto slot_advance = [&](const int slot, const bool on) __attribute__((always_inline)) {
+        if (on) {
+            int next_state = 1;
+            if (s_recs[slot].term != 0) { // the fit of this slot is finished (results written): next problem, or empty
+#if VP_FITG_TIMELINE
+                if (a.cost_out) a.cost_out[s_recs[slot].prob] = (double)(wall_clock64() & 0x7fffffffull); // (tools/cfg4_timeline.py)
+#endif
+                const int next = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int64_t)next < a.B) {
+                    slotg_fill_lane<N, Q>(recs + slot, kc, next);
+                    grid_of(slot, next);
+                } else {
+                    s_recs[slot].prob = -1;
+                    s_recs[slot].term = VP_TERM_NOT_RUN;
+                    next_state = 0;
+                    __hip_atomic_fetch_add(&s_live, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            lds_release(); // the record is complete before the slot is handed to a stream wave
+            __hip_atomic_store(&s_state[slot], next_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    // The moments of slot s are in LDS.  While the workgroup holds many fits the slot goes to the scalar wave (state 3), whose
+    // one bookkeeping pass serves every slot that is ready; a slot that becomes ready just after that pass began waits for the
+    // whole of it, though, and at the END of a launch -- a handful of long fits per workgroup, out of phase with each other --
+    // that wait was half of every round (31 us per round of the longest fit against 3 + 14 us of pass + bookkeeping).  With at
+    // most VP_FITG_TAIL_LIVE fits left there is a stream wave per fit: the wave that delivered the moments keeps the slot
+    // (state 2) and runs the same two functions itself on its lane 0 -- the same arithmetic on the same record, so the result
+    // is the same whoever served the slot.
+#if VP_FITG_TIMELINE
+    unsigned long long tl_own_clocks = 0;
+#endif
+    auto moments_ready = [&](const int s) __attribute__((always_inline)) {
+        const bool own = VP_FITG_TAIL_LIVE > 0 && !a.dbg &&
+                         (uni(__hip_atomic_load(&s_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= VP_FITG_TAIL_LIVE ||
+                          (VP_FITG_OLD_FIRST && uni(s_recs[s].nfev) >= VP_FITG_SPLIT_AFTER));
+        if (!own) {
+            if (lane == 0) __hip_atomic_store(&s_state[s], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+#if VP_FITG_TIMELINE
+        const unsigned long long tl_b = wall_clock64();
+#endif
+        gram_phase<NE, GSW, WEIGHTED>(recs + s, gram + (size_t)s * GI::NV, kc, nullptr, lane == 0);
+        lds_release();
+        slot_scalar_phase<double, N, Q, GSW, float>(recs + s, kc, lane == 0);
+        lds_release();
+        slot_advance(s, lane == 0);
+#if VP_FITG_TIMELINE
+        tl_own_clocks += wall_clock64() - tl_b;
+#endif
+    };
     if (wv < NSC) {
         // ======================= a scalar wave: lane s <-> slot base + s =======================
         // (the bookkeeping costs its ~33 k cycles of issue per pass however few lanes are active: with the moment passes
         // three times shorter -- closed-form moments -- one scalar wave per pool was what every fit's round waited for)
         const int base = wv * GSW;
         VP_LDS Rec *wrecs = recs + base;
+#if VP_FITG_TIMELINE
+        const unsigned long long tl_t0 = wall_clock64();
+        unsigned long long tl_busy = 0, tl_trips = 0, tl_served = 0;
+#endif
         for (;;) {
             const int st = (lane < GSW) ? __hip_atomic_load(&s_state[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
             asm volatile("" ::: "memory");
@@ -672,30 +742,28 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
                 __builtin_amdgcn_s_sleep(8);
                 continue;
             }
+#if VP_FITG_TIMELINE
+            const unsigned long long tl_a = wall_clock64();
+            tl_trips += 1;
+            tl_served += __builtin_popcountll(__builtin_amdgcn_ballot_w64(act));
+#endif
             gram_phase<NE, GSW, WEIGHTED>(wrecs, gram + (size_t)base * GI::NV, kc, a.dbg, act);
             lds_release();
             if (!a.dbg) {
                 slot_scalar_phase<double, N, Q, GSW, float>(wrecs, kc, act);
                 lds_release();
             }
-            if (act) {
-                int next_state = 1;
-                if (s_recs[base + lane].term != 0) { // the fit of this slot is finished (results written): next problem, or empty
-                    const int next = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((int64_t)next < a.B) {
-                        slotg_fill_lane<N, Q>(wrecs + lane, kc, next);
-                        grid_of(base + lane, next);
-                    } else {
-                        s_recs[base + lane].prob = -1;
-                        s_recs[base + lane].term = VP_TERM_NOT_RUN;
-                        next_state = 0;
-                        __hip_atomic_fetch_add(&s_live, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-                lds_release(); // the record is complete before the slot is handed to a stream wave
-                __hip_atomic_store(&s_state[base + lane], next_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            slot_advance(base + lane, act);
+#if VP_FITG_TIMELINE
+            tl_busy += wall_clock64() - tl_a;
+#endif
         }
+#if VP_FITG_TIMELINE
+        if (a.trace && lane == 0) {
+            double *o = a.trace + ((size_t)blockIdx.x * VP_FITG2_WAVES + wv) * 8;
+            o[0] = 0.0; o[1] = (double)(wall_clock64() - tl_t0); o[2] = (double)tl_busy; o[3] = (double)tl_trips; o[4] = (double)tl_served; o[5] = 0.0;
+        }
+#endif
     } else {
 #if VP_FITG_IDLE_PARTNER
         // the wave that shares its SIMD with a scalar wave (waves of a workgroup are dealt round-robin over the 4 SIMDs) stays
@@ -704,6 +772,18 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
 #endif
         // ======================= stream waves: claim a slot with a trial point, stream its rows =======================
         int start = (wv - NSC) * (NS / (VP_FITG2_WAVES - NSC)); // spread the first claims over the pool
+#if VP_FITG_TIMELINE
+        const unsigned long long tl_t0 = wall_clock64();
+        unsigned long long tl_busy = 0, tl_pass = 0, tl_parts = 0, tl_a = 0;
+#define VP_TL_END()                                                                                                     \
+    if (a.trace && lane == 0) {                                                                                         \
+        double *o = a.trace + ((size_t)blockIdx.x * VP_FITG2_WAVES + wv) * 8;                                           \
+        o[0] = 1.0; o[1] = (double)(wall_clock64() - tl_t0); o[2] = (double)tl_busy; o[3] = (double)tl_pass;            \
+        o[4] = (double)tl_parts; o[5] = (double)tl_own_clocks;                                                                 \
+    }
+#else
+#define VP_TL_END()
+#endif
         for (;;) {
             // lanes look at one slot each; the first slot at or after `start` (cyclically) that has a trial point is claimed
             // (serving the OLDEST fit first instead was measured: no gain -- a fit's round is the pass + the bookkeeping, not
@@ -711,12 +791,21 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
             int sl = lane + start;
             sl = sl >= NS ? sl - NS : sl;
             const int st = (lane < NS) ? __hip_atomic_load(&s_state[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-            const unsigned long long ready = __builtin_amdgcn_ballot_w64(lane < NS && (st == 1 || st == 4));
+            unsigned long long ready = __builtin_amdgcn_ballot_w64(lane < NS && (st == 1 || st == 4));
+            if (VP_FITG_OLD_FIRST && ready != 0ull) {
+                // the fits that have outlived VP_FITG_SPLIT_AFTER evaluations decide when the launch ends: they are served first
+                const bool old_fit = lane < NS && (st == 4 || (st == 1 && s_recs[sl].nfev >= VP_FITG_SPLIT_AFTER));
+                const unsigned long long older = __builtin_amdgcn_ballot_w64(old_fit);
+                if (older != 0ull) ready = older;
+            }
             if (ready == 0ull) {
                 if (uni(__hip_atomic_load(&s_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= 0) break;
                 __builtin_amdgcn_s_sleep(4);
                 continue;
             }
+#if VP_FITG_TIMELINE
+            tl_a = wall_clock64();
+#endif
             const int off = (int)__builtin_ctzll(ready);
             int s = off + start;
             s = s >= NS ? s - NS : s;
@@ -765,8 +854,8 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
             if (part < 0) {
                 gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0], gram + (size_t)s * GI::NV, prob, lane, m,
                                                  0, nchunk, vec);
-                lds_release(); // the moments are in LDS before the slot is handed to the scalar wave
-                if (lane == 0) __hip_atomic_store(&s_state[s], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_release(); // the moments are in LDS before the slot is handed on
+                moments_ready(s);
             } else {
                 const int c0 = (int)((long)part * nchunk / VP_FITG_PARTS), c1 = (int)((long)(part + 1) * nchunk / VP_FITG_PARTS);
                 gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0],
@@ -783,11 +872,16 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES >= 8 ? 2 :
                         s_gram[s][v] = t;
                     }
                     lds_release();
-                    if (lane == 0) __hip_atomic_store(&s_state[s], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    moments_ready(s);
                 }
             }
             start = s + 1 >= NS ? 0 : s + 1;
+#if VP_FITG_TIMELINE
+            tl_busy += wall_clock64() - tl_a;
+            if (part < 0) tl_pass += 1; else tl_parts += 1;
+#endif
         }
+        VP_TL_END();
     }
 }
 
