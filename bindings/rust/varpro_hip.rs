@@ -209,3 +209,80 @@ pub fn fit_batch(h: *mut vp_batch, opts: &vp_lm_opts, alpha: &mut [f64], c_out: 
     unsafe { vp_fit(h, opts, alpha.as_mut_ptr() as *mut c_void, c_out.as_mut_ptr() as *mut c_void, rep.as_mut_ptr()); }
     rep
 }
+
+// ---- round 4: models outside the descriptor language (caller-evaluated Phi / dPhi) and the cost reduction ---------------
+extern "C" {
+    pub fn vp_batch_create_external(h: *mut *mut vp_batch, n_basis: i32, n_params: i32, n_pairs: i32, pair_basis: *const i32,
+                                    pair_param: *const i32, dtype: i32, m: i64, s: i64, b: i64, y: *const c_void,
+                                    w: *const c_void, svd_epsilon: f64, flags: i32, device: i32, hip_stream: *mut c_void) -> i32;
+    pub fn vp_set_params_with_basis(h: *mut vp_batch, alpha: *const c_void, phi: *const c_void, dphi: *const c_void) -> i32;
+    pub fn vp_jacobian_with_derivatives(h: *mut vp_batch, dphi: *const c_void, j_out: *mut c_void, status: *mut i32) -> i32;
+    pub fn vp_evaluate_with_basis(h: *mut vp_batch, alpha: *const c_void, phi: *const c_void, dphi: *const c_void,
+                                  r: *mut c_void, j: *mut c_void, c: *mut c_void, cost: *mut f64, status: *mut i32) -> i32;
+    pub fn vp_reduce_cost(h: *mut vp_batch, rccl_comm: *mut c_void, out4: *mut f64) -> i32;
+}
+
+/// `SeparableProblem<M, Rhs>` for ANY model `M` (src/problem.rs:57-83): the model is evaluated where it lives (host
+/// closures, `src/model/mod.rs:441-512`), everything downstream of `eval()` / `eval_partial_deriv(k)` runs on the device
+/// (weighting src/solvers/levmar/mod.rs:47,141; solve + residual :51-59; Kaufman Jacobian :101-201).
+pub struct GpuProblemAnyModel<M: SeparableNonlinearModel<ScalarType = f64>> {
+    model: M,
+    h: *mut vp_batch,
+    pairs: Vec<(usize, usize)>, // (basis j, parameter k) whose derivative is not identically zero, fixed at build()
+    m: usize,
+    s: usize,
+}
+
+impl<M: SeparableNonlinearModel<ScalarType = f64>> GpuProblemAnyModel<M> {
+    /// == SeparableProblemBuilder::build (src/problem/builder.rs:278-324)
+    pub fn build(model: M, y: &DMatrix<f64>, w: Option<&DVector<f64>>, eps: f64, pairs: Vec<(usize, usize)>) -> Result<Self, String> {
+        let (pb, pp): (Vec<i32>, Vec<i32>) = pairs.iter().map(|&(j, k)| (j as i32, k as i32)).unzip();
+        let mut h: *mut vp_batch = null_mut();
+        let rc = unsafe {
+            vp_batch_create_external(&mut h, model.base_function_count() as i32, model.parameter_count() as i32, pairs.len() as i32,
+                                     pb.as_ptr(), pp.as_ptr(), 0 /* VP_F64 */, y.nrows() as i64, y.ncols() as i64, 1,
+                                     y.as_ptr() as *const c_void, w.map_or(std::ptr::null(), |w| w.as_ptr() as *const c_void), eps,
+                                     0, 0, null_mut())
+        };
+        if rc != 0 { return Err(last_error()); }
+        let mut p = Self { model, h, pairs, m: y.nrows(), s: y.ncols() };
+        let a0 = p.model.params();
+        p.set_params(&a0); // the builder's initial evaluation (src/problem/builder.rs:321)
+        Ok(p)
+    }
+}
+
+impl<M: SeparableNonlinearModel<ScalarType = f64>> Drop for GpuProblemAnyModel<M> {
+    fn drop(&mut self) { unsafe { vp_batch_destroy(self.h) } }
+}
+
+impl<M: SeparableNonlinearModel<ScalarType = f64>> LeastSquaresProblem<f64, Dyn, Dyn> for GpuProblemAnyModel<M> {
+    type ResidualStorage = Owned<f64, Dyn>;
+    type JacobianStorage = Owned<f64, Dyn, Dyn>;
+    type ParameterStorage = Owned<f64, Dyn>;
+
+    fn set_params(&mut self, x: &DVector<f64>) { // src/solvers/levmar/mod.rs:42-73
+        let phi = if self.model.set_params(x.clone()).is_ok() { self.model.eval().ok() } else { None };
+        // a model error is handed over as a NaN basis: status != 0  <=>  cached = None (:61-72)
+        let phi = phi.unwrap_or_else(|| DMatrix::from_element(self.m, self.model.base_function_count(), f64::NAN));
+        unsafe { vp_set_params_with_basis(self.h, x.as_ptr() as *const c_void, phi.as_ptr() as *const c_void, std::ptr::null()); }
+    }
+    fn params(&self) -> DVector<f64> { self.model.params() }
+    fn residuals(&self) -> Option<DVector<f64>> { // :91-95
+        let (mut r, mut st) = (DVector::<f64>::zeros(self.m * self.s), 0i32);
+        let rc = unsafe { vp_residuals(self.h, r.as_mut_ptr() as *mut c_void, &mut st) };
+        (rc == 0 && st == 0).then_some(r)
+    }
+    fn jacobian(&self) -> Option<DMatrix<f64>> { // :101-201; eval_partial_deriv(k) is only needed HERE (:141)
+        let q = self.model.parameter_count();
+        let mut dphi = vec![0f64; self.pairs.len() * self.m]; // the non-zero columns, in pair order
+        let mut cache: Vec<Option<DMatrix<f64>>> = vec![None; q];
+        for (p, &(j, k)) in self.pairs.iter().enumerate() {
+            if cache[k].is_none() { cache[k] = Some(self.model.eval_partial_deriv(k).ok()?); }
+            dphi[p * self.m..(p + 1) * self.m].copy_from_slice(cache[k].as_ref().unwrap().column(j).as_slice());
+        }
+        let (mut jac, mut st) = (DMatrix::<f64>::zeros(self.m * self.s, q), 0i32);
+        let rc = unsafe { vp_jacobian_with_derivatives(self.h, dphi.as_ptr() as *const c_void, jac.as_mut_ptr() as *mut c_void, &mut st) };
+        (rc == 0 && st == 0).then_some(jac)
+    }
+}
