@@ -457,17 +457,20 @@ def main():
                 ts.append(bp2.last_kernel_ms(_lib.VP_KERNEL_EVALUATE))
             ev2_ms = min(ts[1:])
             bytes_ev2 = T * m2 * S2 * (2 + 3)                      # T*m*S*(2+q) = 1.34 GB
-            tf = []
+            tf, tfe = [], []
             for _ in range(5):
                 t0 = time.perf_counter()
                 a2, _C2, rep2 = bp2.fit(g2, want_coefficients=False)
                 torch.cuda.synchronize()
                 tf.append((time.perf_counter() - t0) * 1e3)
+                tfe.append(bp2.last_kernel_ms(_lib.VP_KERNEL_FIT))  # the library's own HIP events around the captured graph
             r2 = bp2.report_to_numpy(rep2)
             fit2_ms = min(tf[1:])
+            fit2_event_ms = min(tfe[1:])
             out["configs2"] = {
                 "workload": "BASELINE configs[2]: global fit, 1 alpha shared by %d right-hand sides, m=%d, triple-exp+offset" % (S2, m2),
-                "trait_evaluation_ms": ev2_ms, "global_fit_ms": fit2_ms, "evaluations": int(r2["n_evals"][0]),
+                "trait_evaluation_ms": ev2_ms, "global_fit_ms": fit2_ms, "global_fit_event_ms": fit2_event_ms,
+                "evaluations": int(r2["n_evals"][0]),
                 "termination": int(r2["termination"][0]),
                 "max_abs_tau_error": float(np.abs(a2.cpu().numpy()[0] - d2["tau_true"]).max()),
                 "roofline": {"kernel": "mrhs_coop_out_kernel (workgroup-cooperative trait-level pass; + mrhs_factor_kernel): y in, r and J out", "bound": "hbm",
@@ -518,6 +521,11 @@ def main():
                                        "moments + Cholesky-based LM; per CU one 8-wave workgroup = 7 streaming waves + 1 bookkeeping "
                                        "wave over a pool of 32 problem slots; passes of long fits split over 4 waves)",
                              "bound": "latency (the longest fit's chain of rounds: evaluations x {moment pass + LM bookkeeping})",
+                             "timeline": "tools/cfg4_timeline.py on a -DVP_FITG_TIMELINE=1 build: the first ~1.25 ms every workgroup holds "
+                                         "32..8 live fits and both roles are busy (bookkeeping wave 100 %, 9.4 slots per 21 us trip; stream "
+                                         "waves 10.4 us per pass at 2 waves per SIMD) -- a round costs 55-60 us there; the rest is the fits "
+                                         "past ~24 evaluations at the 21 us of a lone round (5.5 us pass, 15 us of dependent fp64 "
+                                         "bookkeeping: Cholesky of the 6x6 Gram, pivoted Cholesky of J^T J, lmpar's Givens sweeps)",
                              "achieved": tf4 * flops4_exec / flops4, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf4 * flops4_exec / flops4 / FP64_VALU_PEAK_TFLOPS,
                              "flops_executed_per_evaluation": flops4_exec,
