@@ -65,6 +65,42 @@ def test_streamed_fit_multiexponential(nexp, offset, m, weighted):
     _check_fit(mdl, x, Y, guess, w, min_ok=0.8 if nexp == 3 else 0.9)
 
 
+@pytest.mark.parametrize("nexp,m", [(1, 4100), (2, 6000), (3, 5000)])
+def test_streamed_fit_four_waves_per_problem_weighted(nexp, m):
+    """launches smaller than the device with >= 2 blocks per wave run FOUR waves per problem (vp_block.hpp, blk_fit_kernel W = 4:
+    per-wave rings and carries, merged through LDS by the same stacked QR) -- here with weights (the ring carries three streams)"""
+    rng = np.random.default_rng(7 * nexp + m)
+    B = 40
+    x, Y, guess = _multiexp(rng, B, m, nexp, True)
+    w = rng.uniform(0.5, 1.5, m)
+    mdl = vp.multi_exponential_model(x, guess[0], offset=True)
+    _check_fit(mdl, x, Y, guess, w, min_ok=0.8 if nexp == 3 else 0.9)
+
+
+def test_streamed_fit_one_and_four_waves_per_problem_agree():
+    """the same 40 problems alone (four waves each) and as the head of a batch larger than 16 x the CU count (one wave each):
+    different TSQR orders, same fits"""
+    rng = np.random.default_rng(21)
+    m, B0 = 4608, 40
+    x, Y, guess = _multiexp(rng, B0, m, 2, True)
+    mdl = vp.multi_exponential_model(x, guess[0])
+    bp = vp.BatchProblem(mdl, Y, x=x, stream_rows=True)
+    a4, C4, r4 = bp.fit(guess)
+    bp.close()
+    reps = 16 * 304 // B0 + 2  # (> 16 workgroups' worth per CU on any current part)
+    Yb, gb = np.tile(Y, (reps, 1)), np.tile(guess, (reps, 1))
+    bp = vp.BatchProblem(mdl, Yb, x=x, stream_rows=True)
+    a1, C1, r1 = bp.fit(gb)
+    bp.close()
+    assert ((r4["termination"] > 0) == (r1["termination"][:B0] > 0)).all() and (r4["termination"] > 0).mean() >= 0.9
+    ok = r4["termination"] > 0
+    assert (np.abs(r4["objective"][ok] - r1["objective"][:B0][ok]) <= 1e-10 * r4["objective"][ok]).all()
+    assert (np.abs(a4[ok] - a1[:B0][ok]).max(1) <= 1e-6 * np.abs(a4[ok]).max(1)).all()
+    assert np.abs(r4["n_evals"].astype(int) - r1["n_evals"][:B0].astype(int)).max() <= 8
+    # every copy of a problem inside the big batch gets the same answer bit for bit (one wave each, same arithmetic)
+    assert (a1.reshape(reps, B0, -1) == a1[:B0][None]).all()
+
+
 def test_streamed_fit_nonuniform_and_per_problem_grids():
     rng = np.random.default_rng(5)
     B, m = 24, 2500
