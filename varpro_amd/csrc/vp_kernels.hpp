@@ -176,9 +176,6 @@ __device__ __forceinline__ RowSource<T, R> make_row_source(const T *t, const T *
     return s;
 }
 
-#ifndef VP_EVAL2_ONE_WAVE
-#define VP_EVAL2_ONE_WAVE 0
-#endif
 template <typename T, class M> struct EvalArgs {
     M mdl;
     const T *t;
@@ -201,8 +198,12 @@ template <typename T, class M> struct EvalArgs {
 // MODE 0: coefficients/cost/status only; 1: + residuals; 2: + residuals + Jacobian
 // ALIGNED: m even and every array 16-byte aligned (checked on the host) -> 2-element accesses only
 // WEIGHTED: weights present (decided on the host)
-template <typename T, class M, int R, int W, int MODE, bool ALIGNED, bool WEIGHTED>
-__global__ void __launch_bounds__(64 * W, ((MODE == 2 && VP_EVAL2_ONE_WAVE) ? 1 : model_waves_for<T, M, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>()))
+// UNIFORM (MODE 2 only): the handle's grid check found a uniform grid -- the exponentials by recurrence, and ONLY that path
+// compiled.  MODE 2 is register-tight (six 32-register columns at 16 rows per lane): with both the per-row-exponential and
+// the recurrence path in the kernel it spilled 65 VGPRs and was slower than per-row exponentials alone (0.59 vs 0.50 ms per
+// 65 536 problems); with the recurrence alone 38 and 0.45-0.48 ms (600 of ~2 000 instructions per problem less).
+template <typename T, class M, int R, int W, int MODE, bool ALIGNED, bool WEIGHTED, bool UNIFORM = false>
+__global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>()))
     evaluate_kernel(const EvalArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     __shared__ __attribute__((aligned(16))) unsigned char s_xch[group_xch_bytes<W>() > 0 ? group_xch_bytes<W>() : 16];
@@ -214,24 +215,13 @@ __global__ void __launch_bounds__(64 * W, ((MODE == 2 && VP_EVAL2_ONE_WAVE) ? 1 
     const int64_t b = prob / a.S;
     const int s = (int)(prob - b * a.S);
     const int m = a.m;
-#ifdef VP_EVAL2_STAGGER
-    if constexpr (MODE == 2 && W == 1) {
-        if (blockIdx.x < 2048u && (blockIdx.x & 1u)) {
-#pragma unroll
-            for (int i = 0; i < VP_EVAL2_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-#endif
-
     T alpha[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
 
-    // MODE 2 (residual + Jacobian output) is store-bound and register-tight: per-row exponentials there
-#ifndef VP_EVAL2_RECUR
-#define VP_EVAL2_RECUR 0
-#endif
-    using Src = RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0, W, (MODE != 2) || VP_EVAL2_RECUR>;
+    // MODE 2 (residual + Jacobian output) is register-tight: per-row exponentials unless the grid is known to be uniform
+    static_assert(!UNIFORM || MODE == 2, "UNIFORM specialises MODE 2");
+    using Src = RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0, W, (MODE != 2) || UNIFORM, 0, UNIFORM>;
     Src src;
     src.t = a.t + b * a.t_stride;
     src.w = WEIGHTED ? a.w + b * a.w_stride : nullptr;
@@ -447,6 +437,13 @@ template <typename T, class M, int R, int W = 1> int launch_evaluate(const Launc
     // path that is not throughput-critical
     const bool aligned = M::kStatic && host_aligned<T>(p.m, {p.t, p.w, p.yw, p.r_out, p.J_out});
     const int mode = p.J_out ? 2 : (p.r_out ? 1 : 0);
+    if constexpr (M::kStatic && sizeof(T) == 8 && (R > 2)) {
+        if (mode == 2 && aligned && p.grid_uniform != 0 && p.m >= 3) { // (RowSource::set_uniform's own conditions)
+            if (p.w) hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, true, true>), grid, block, 0, p.stream, a);
+            else hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, false, true>), grid, block, 0, p.stream, a);
+            return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+        }
+    }
     const int variant = mode * 4 + (aligned ? 2 : 0) + (p.w ? 1 : 0);
 #define VP_EV(MODE_, AL_, W_)                                                                                          \
     case (MODE_) * 4 + (AL_) * 2 + (W_):                                                                               \

@@ -182,8 +182,10 @@ __device__ __forceinline__ void tsincos(float x, float &sn, float &cs) {
 //   PADM   : (PADDED, unit weights) which register pairs can hold padding rows, i.e. need the validity select on
 //            the scale:  0 = any pair (general m);  1 = none (m == 64*R*W);  2 = only the LAST pair
 //            (64*(R-2)*W < m < 64*R*W, e.g. m = 1000 in the 1024-row kernel)
+//   UNI    : (with RECUR) the grid IS uniform -- the caller dispatched on the handle's grid check -- so only the recurrence
+//            path of build_columns is compiled: a kernel that carries both paths is register-allocated for the wider one
 template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2, int W = 1, bool RECUR = false,
-          int PADM = 0>
+          int PADM = 0, bool UNI = false>
 struct RowSource {
     const T *t;  // grid, indexed by row (LDS or global)
     const T *w;  // weights indexed by row, or nullptr for unit weights
@@ -197,6 +199,7 @@ struct RowSource {
     using L = Layout<R, W>;
     static constexpr int kGroupWaves = W;
     static constexpr bool kRecur = RECUR && sizeof(T) == 8 && (R > L::VW);
+    static constexpr bool kAlwaysUniform = kRecur && UNI;
     // every row is valid and unweighted: the scale is the literal 1 and the recurrence needs no inf * 0 guard
     static constexpr bool kScaleOne = PADDED && WMODE == 0 && PADM == 1;
     __device__ __forceinline__ void set_uniform(bool flag) {
@@ -427,7 +430,8 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
         }
     };
     if constexpr (kRecur) {
-        if (uni(fast)) rows(std::true_type{});
+        if constexpr (Src::kAlwaysUniform) rows(std::true_type{}); // (the caller dispatched on the handle's grid check)
+        else if (uni(fast)) rows(std::true_type{});
         else rows(std::false_type{});
     } else {
         rows(std::false_type{});
