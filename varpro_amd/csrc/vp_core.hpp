@@ -421,21 +421,84 @@ __device__ __forceinline__ ConstReflector<T> make_const_reflector(const Src &src
     return h;
 }
 
+// Z <- H_0 Z for the implicit reflector of the scale column (H_0 is symmetric: the same call serves the forward sweep and
+// the back-application).  One reduction round.
+template <typename T, int R, int NZ, class Src, class G>
+__device__ __forceinline__ void apply_const_reflector(T (&Z)[NZ][R], const ConstReflector<T> &h0, const Src &src, G &grp) {
+    using L = Layout<R, G::W>;
+    constexpr int VW = L::VW;
+    const int lane = grp.gl;
+    T d[NZ], top[NZ];
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) d[j] = T(0);
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += VW) {
+        T tt[2], sc[2];
+        src.get(r0, tt, sc);
+#pragma unroll
+        for (int j = 0; j < NZ; ++j)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) d[j] = tfma(sc[e], Z[j][r0 + e], d[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) top[j] = Z[j][L::reg_of_row(0)];
+    group_allreduce(grp, d);
+    group_bcast<NZ>(grp, top, L::lane_of_row(0));
+    T tau[NZ];
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) tau[j] = h0.g * tfma(-h0.beta, top[j], d[j]);
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += VW) {
+        T tt[2], sc[2];
+        src.get(r0, tt, sc);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            const T v = (r0 + e < VW && L::row_of(r0 + e, lane) == 0) ? h0.u : sc[e];
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) Z[j][r0 + e] = tfma(tau[j], v, Z[j][r0 + e]);
+        }
+    }
+}
+
+// z <- Q^T z for NZ columns: the reflectors of apply_q in ascending order (V = the first N columns left by house_qr)
+template <typename T, int R, int N, int NC, int NZ, class G>
+__device__ __forceinline__ void apply_qt(const T (&V)[NC][R], const T (&g)[N], T (&Z)[NZ][R], G &grp) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        T w[NZ];
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) {
+            T acc = T(0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc = tfma(V[k][r], Z[z][r], acc);
+            w[z] = acc;
+        }
+        group_allreduce(grp, w);
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) {
+            const T f = g[k] * w[z];
+#pragma unroll
+            for (int r = 0; r < R; ++r) Z[z][r] = tfma(f, V[k][r], Z[z][r]);
+        }
+    }
+}
+
 // C: [0, NEXP) exponential columns, [NEXP] data column (already loaded with y_w), [NEXP+1, 2 NEXP+1) derivative
 // columns.  On return: columns in Q-coordinates (rows >= N of the data / derivative columns are what the LM uses).
 //   YPRE: the data column arrives as H_0 y_w (the slot kernel applies the alpha-independent reflector once per fit,
 //         vp_fit2.hpp) and skips reflector 0 here; qty0 = (H_0 y_w)[0]
-template <typename T, class M, int R, int NCX, class Src, class G, bool YPRE = false>
+//   NOD:  no derivative columns (NCX = N: exponentials + data) -- phase 1 of the split evaluate kernel
+template <typename T, class M, int R, int NCX, class Src, class G, bool YPRE = false, bool NOD = false>
 __device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T (&alpha)[M::Q], const Src &src, T eps,
                                                           G &grp, const ConstReflector<T> &h0, T (&C)[NCX][R],
                                                           EvalUniform<T, M::N> &u, SectionClock *clk = nullptr,
                                                           const T qty0 = T(0)) {
     constexpr int N = M::N, NE = M::N - 1;
-    static_assert(M::kConstLast && NCX == M::N + M::P, "const-first sweep: N-1 exponentials + data + P derivatives");
+    static_assert(M::kConstLast && NCX == M::N + (NOD ? 0 : M::P), "const-first sweep: N-1 exponentials + data + P derivatives");
     using L = Layout<R, G::W>;
     constexpr int VW = L::VW;
     const int lane = grp.gl;
-    build_columns<T, M, R, NCX, Src, NE + 1, true>(mdl, alpha, src, C);
+    build_columns<T, M, R, NCX, Src, NE + 1, true, true, !NOD>(mdl, alpha, src, C);
     VP_TICK(clk, 1);
     __builtin_amdgcn_sched_barrier(0);
     // ---- reflector 0: the implicit scale column ----

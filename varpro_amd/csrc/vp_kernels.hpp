@@ -202,8 +202,34 @@ template <typename T, class M> struct EvalArgs {
 // compiled.  MODE 2 is register-tight (six 32-register columns at 16 rows per lane): with both the per-row-exponential and
 // the recurrence path in the kernel it spilled 65 VGPRs and was slower than per-row exponentials alone (0.59 vs 0.50 ms per
 // 65 536 problems); with the recurrence alone 38 and 0.45-0.48 ms (600 of ~2 000 instructions per problem less).
-template <typename T, class M, int R, int W, int MODE, bool ALIGNED, bool WEIGHTED, bool UNIFORM = false>
-__global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>()))
+// SPLIT form of MODE 2 (uniform grid, constant column last, one derivative column per parameter): the columns are never all
+// in registers at once.  Phase 1: [exp_1 .. exp_NE | y] with the constant column implicit (evaluate_core_const_first) -> c,
+// cost, r written.  Phase 2: the derivative columns are REBUILT (the exponentials were overwritten by the reflectors; on a
+// uniform grid a rebuild is 2 exponentials per lane and column), carried through Q^T, scaled to the Kaufman columns and
+// carried back through Q.  Peak: 2 NE register columns instead of 2 NE + 2 -- VP_EVAL2_SPLIT_WAVES waves per SIMD.
+#ifndef VP_EVAL2_SPLIT
+#define VP_EVAL2_SPLIT 1
+#endif
+#ifndef VP_EVAL2_TCALC
+#define VP_EVAL2_TCALC 1
+#endif
+#ifndef VP_EVAL2_SPLIT_WAVES
+#define VP_EVAL2_SPLIT_WAVES 2
+#endif
+// FULL: m == 64 R W and unit weights (host dispatch): every row is valid, so the row scale is the literal 1 and there is no
+// validity mask anywhere -- with masks the 16 scale values of a lane (0.0 / 1.0 selects) are common subexpressions of every
+// loop that asks the row source and end up as a seventh register column.
+template <typename T, class M, int R, int W, int MODE, bool UNIFORM, bool FULL> constexpr bool eval2_split() {
+    return VP_EVAL2_SPLIT && FULL && MODE == 2 && UNIFORM && W == 1 && R == 16 && M::kStatic && M::kConstLast &&
+           M::kDiagonalPairs && sizeof(T) == 8;
+}
+template <typename T, class M, int R, int W, int MODE, bool UNIFORM, bool FULL> constexpr int eval_waves() {
+    return eval2_split<T, M, R, W, MODE, UNIFORM, FULL>()
+               ? VP_EVAL2_SPLIT_WAVES
+               : model_waves_for<T, M, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>();
+}
+template <typename T, class M, int R, int W, int MODE, bool ALIGNED, bool WEIGHTED, bool UNIFORM = false, bool FULL = false>
+__global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM, FULL>()))
     evaluate_kernel(const EvalArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     __shared__ __attribute__((aligned(16))) unsigned char s_xch[group_xch_bytes<W>() > 0 ? group_xch_bytes<W>() : 16];
@@ -214,14 +240,17 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
     if (prob >= a.nprob) return;
     const int64_t b = prob / a.S;
     const int s = (int)(prob - b * a.S);
-    const int m = a.m;
+    constexpr bool SPLIT = eval2_split<T, M, R, W, MODE, UNIFORM, FULL>();
+    static_assert(!FULL || (SPLIT && !WEIGHTED && ALIGNED), "FULL exists for the split kernel only");
+    const int m = SPLIT ? 64 * R * W : a.m;
     T alpha[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
 
     // MODE 2 (residual + Jacobian output) is register-tight: per-row exponentials unless the grid is known to be uniform
     static_assert(!UNIFORM || MODE == 2, "UNIFORM specialises MODE 2");
-    using Src = RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0, W, (MODE != 2) || UNIFORM, 0, UNIFORM>;
+    using Src = typename std::conditional<SPLIT, RowSource<T, R, true, 0, 1, W, true, 1, true, VP_EVAL2_TCALC != 0>,
+                                          RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0, W, (MODE != 2) || UNIFORM, 0, UNIFORM>>::type;
     Src src;
     src.t = a.t + b * a.t_stride;
     src.w = WEIGHTED ? a.w + b * a.w_stride : nullptr;
@@ -229,9 +258,90 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
     src.lane = lane;
     src.vec = ALIGNED;
     src.set_uniform(a.grid_uniform != 0);
-    T C[NC][R];
     const T *yp = a.yw + prob * (int64_t)m;
     constexpr bool yvec = ALIGNED;
+    if constexpr (SPLIT) {
+        constexpr int NE = N - 1, NCX = NE + 1;
+        using L = Layout<R, G::W>;
+        T C[NCX][R];
+        load_rows<T, R, W>(yp, m, lane, yvec, C[NE]);
+        // every row valid, unit scale: ||s||^2 = 64 R W, s_0 = 1 -- the reflector of the scale column is a constant
+        ConstReflector<T> h0;
+        {
+            const T sigma = tsqrt(T(64 * R * W));
+            h0.live = true;
+            h0.beta = -sigma;
+            h0.u = T(1) + sigma;
+            h0.g = T(1) / (h0.beta * h0.u);
+        }
+        EvalUniform<T, N> u;
+        evaluate_core_const_first<T, M, R, NCX, Src, G, false, true>(a.mdl, alpha, src, a.eps, grp, h0, C, u);
+        if (lane == 0) {
+            if (a.status) a.status[prob] = u.ok ? VP_ST_OK : VP_ST_NONFINITE;
+            if (a.cost_out) a.cost_out[prob] = 0.5 * (double)u.fn2;
+        }
+        if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(u.c, lane);
+        T g1[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) g1[j] = u.g[1 + j];
+        // r = Q r~ = H_0 H_1 .. H_NE r~
+        residual_qcoords<T, R, N>(C[NE], u.e, grp);
+        apply_q_cols<T, R, NE, NCX, NE, NCX>(C, g1, grp);
+        {
+            T Y1[1][R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) Y1[0][r] = C[NE][r];
+            apply_const_reflector<T, R, 1, Src, G>(Y1, h0, src, grp);
+            if (a.r_out) store_rows<T, R, W>(a.r_out + prob * (int64_t)m, m, lane, yvec, Y1[0]);
+        }
+        asm volatile("" ::: "memory"); // (the grid loads of phase 2 must not be hoisted into phase 1)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2: D_p rebuilt, Z_k = -c_k P_perp D_k = -c_k Q [0; (Q^T D_k)(rows >= N)]
+        if constexpr (NE >= 3) {
+        // one derivative column at a time: NE + 1 register columns at the peak
+        static_for<0, Q>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            T D[1][R];
+            build_columns<T, M, R, 1, Src, -k, true, false, true, k>(a.mdl, alpha, src, D);
+            apply_const_reflector<T, R, 1, Src, G>(D, h0, src, grp);
+            apply_qt<T, R, NE, NCX, 1, G>(C, g1, D, grp);
+            const T ck = -u.c[k];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool top = (r < L::VW) && (L::row_of(r, lane) < N);
+                D[0][r] = top ? T(0) : ck * D[0][r];
+            }
+            apply_q<T, R, NE, NCX, 1, G>(C, g1, D, grp);
+            apply_const_reflector<T, R, 1, Src, G>(D, h0, src, grp);
+            if (a.J_out) store_rows<T, R, W>(a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m, m, lane, ALIGNED, D[0]);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        } else {
+        T D[P][R];
+        build_columns<T, M, R, P, Src, 0, true, false, true>(a.mdl, alpha, src, D);
+        apply_const_reflector<T, R, P, Src, G>(D, h0, src, grp);
+        apply_qt<T, R, NE, NCX, P, G>(C, g1, D, grp);
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            const T ck = -u.c[k];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool top = (r < L::VW) && (L::row_of(r, lane) < N);
+                D[k][r] = top ? T(0) : ck * D[k][r];
+            }
+        }
+        apply_q<T, R, NE, NCX, P, G>(C, g1, D, grp);
+        apply_const_reflector<T, R, P, Src, G>(D, h0, src, grp);
+        if (a.J_out) {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) // J[b][k][s][m]
+                store_rows<T, R, W>(a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m, m, lane, ALIGNED, D[k]);
+        }
+        }
+        return;
+    }
+    T C[NC][R];
     load_rows<T, R, W>(yp, m, lane, yvec, C[N]);
 
     EvalUniform<T, N> u;
@@ -439,7 +549,15 @@ template <typename T, class M, int R, int W = 1> int launch_evaluate(const Launc
     const int mode = p.J_out ? 2 : (p.r_out ? 1 : 0);
     if constexpr (M::kStatic && sizeof(T) == 8 && (R > 2)) {
         if (mode == 2 && aligned && p.grid_uniform != 0 && p.m >= 3) { // (RowSource::set_uniform's own conditions)
-            if (p.w) hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, true, true>), grid, block, 0, p.stream, a);
+            bool launched = false;
+            if constexpr (eval2_split<T, M, R, W, 2, true, true>()) {
+                if (!p.w && p.m == 64 * R * W) { // a full-length, unweighted problem: the split kernel
+                    hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, false, true, true>), grid, block, 0, p.stream, a);
+                    launched = true;
+                }
+            }
+            if (launched) {
+            } else if (p.w) hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, true, true>), grid, block, 0, p.stream, a);
             else hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, false, true>), grid, block, 0, p.stream, a);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
         }

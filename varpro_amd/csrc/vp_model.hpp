@@ -184,8 +184,11 @@ __device__ __forceinline__ void tsincos(float x, float &sn, float &cs) {
 //            (64*(R-2)*W < m < 64*R*W, e.g. m = 1000 in the 1024-row kernel)
 //   UNI    : (with RECUR) the grid IS uniform -- the caller dispatched on the handle's grid check -- so only the recurrence
 //            path of build_columns is compiled: a kernel that carries both paths is register-allocated for the wider one
+//   TCALC  : (UNI, PADDED, unit weights, PADM == 1) the grid values are COMPUTED, t = t(lane's first row pair) + k * delta,
+//            instead of loaded: 16 loads that the scheduler issues together are 32 live registers; the lattice is within
+//            4 ulp of the stored grid (grid_check_kernel)
 template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2, int W = 1, bool RECUR = false,
-          int PADM = 0, bool UNI = false>
+          int PADM = 0, bool UNI = false, bool TCALC = false>
 struct RowSource {
     const T *t;  // grid, indexed by row (LDS or global)
     const T *w;  // weights indexed by row, or nullptr for unit weights
@@ -196,6 +199,7 @@ struct RowSource {
     // grid_check_kernel) and `delta` = 64*W*VW*dt is the grid distance between a lane's consecutive row pairs
     bool uniform = false;
     T delta = T(0);
+    T tl[2] = {T(0), T(0)}; // (TCALC) grid values of the lane's first row pair
     using L = Layout<R, W>;
     static constexpr int kGroupWaves = W;
     static constexpr bool kRecur = RECUR && sizeof(T) == 8 && (R > L::VW);
@@ -206,6 +210,13 @@ struct RowSource {
         if constexpr (kRecur) {
             uniform = flag && m >= 3;
             if (uniform) delta = (t[m - 1] - t[0]) / T(m - 1) * T(64 * W * L::VW);
+            if constexpr (TCALC) {
+                static_assert(PADDED && UNI && WMODE == 0 && PADM == 1 && L::VW == 2, "computed grid: full, unweighted, uniform");
+                using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+                const V2 v = (reinterpret_cast<const V2 *>(t) + lane)[0];
+                tl[0] = v.x;
+                tl[1] = v.y;
+            }
         } else {
             uniform = false;
         }
@@ -220,6 +231,14 @@ struct RowSource {
     __device__ __forceinline__ void get(int r0, T (&tt)[2], T (&sc)[2]) const {
         // r0 even (or R == 1): registers r0, r0+1 hold rows i, i+1
         const int i = L::row_of(r0, lane);
+        if constexpr (TCALC) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                tt[e] = (r0 == 0) ? tl[e] : tfma(T(r0 / 2), delta, tl[e]);
+                sc[e] = T(1);
+            }
+            return;
+        }
         if constexpr (L::VW == 2) {
             using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
             if constexpr (PADDED) {
@@ -280,11 +299,15 @@ struct RowSource {
 // array C:  C[j] = W phi_j  (j < N),  C[N] is left alone (data column),  C[N+1+p] = W dphi_pair_p.
 //   DOFF: index of the first derivative column (N + 1 with a data column at N; N without one)
 //   SKIP_CONST: constant basis columns are not written (the caller treats them implicitly)
-template <typename T, class M, int R, int NC, class Src, int DOFF = M::N + 1, bool SKIP_CONST = false>
+//   WF / WD: write the basis columns / the derivative columns (the split evaluate kernel builds them in two phases; the
+//            arithmetic of the phase that is not written is dead code)
+//   JSEL:    >= 0: only basis JSEL is processed (with WF = false, WD = true and DOFF = -pair: ONE derivative column into C[0])
+template <typename T, class M, int R, int NC, class Src, int DOFF = M::N + 1, bool SKIP_CONST = false, bool WF = true,
+          bool WD = true, int JSEL = -1>
 __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::Q], const Src &src, T (&C)[NC][R]) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
     constexpr int VW = Layout<R>::VW;
-    static_assert(NC >= DOFF + P, "column array too small");
+    static_assert(!WD || JSEL >= 0 || NC >= DOFF + P, "column array too small");
     // per-column invariants (wave-uniform)
     int kind[N], s0[N], s1[N];
     T p0[N], p1[N], rt[N], rt2[N];
@@ -368,6 +391,9 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
             src.get(r0, tt, sc);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
+                if constexpr (JSEL >= 0) {
+                    if (j != JSEL) continue;
+                }
 #pragma unroll
                 for (int e = 0; e < VW; ++e) {
                     const int r = r0 + e;
@@ -419,11 +445,13 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                         d0 = t * cs;
                         d1 = cs;
                     }
-                    C[j][r] = f;
+                    if constexpr (WF) C[j][r] = f;
+                    if constexpr (WD) {
 #pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        if (p == s0[j]) C[DOFF + p][r] = d0;
-                        if (p == s1[j]) C[DOFF + p][r] = d1;
+                        for (int p = 0; p < P; ++p) {
+                            if (p == s0[j]) C[DOFF + p][r] = d0;
+                            if (p == s1[j]) C[DOFF + p][r] = d1;
+                        }
                     }
                 }
             }
