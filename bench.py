@@ -617,13 +617,23 @@ def main():
             def ev_call():
                 _lib.check(bp.lib.vp_evaluate(bp._h, vptr(guess), vptr(r_ev), vptr(J_ev), vptr(C_ev), vptr(cost_ev), vptr(st_ev)))
 
+            def ev_call_r():  # set_params + residuals: what the LM driver asks for at every inner trial point
+                _lib.check(bp.lib.vp_evaluate(bp._h, vptr(guess), vptr(r_ev), None, vptr(C_ev), vptr(cost_ev), vptr(st_ev)))
+
             ev_ms = event_ms_each(ev_call, 20, 3)
+            ev_r_ms = event_ms_each(ev_call_r, 20, 3)
             bytes_ev = B * T * (m * (2 + 2) + 3 + 2)
+            bytes_ev_r = B * T * (m * 2 + 3 + 2)
             out["evaluate_boundary"] = {
                 "workload": "vp_evaluate, B=%d, m=%d, fp64: alpha in; y read; r, J, c, cost out (the trait-level set_params + "
                             "residuals + jacobian of a batch in one launch)" % (B, m),
                 "ms": ev_ms, "bytes_per_problem": T * (m * 4 + 5),
-                "roofline": {"kernel": "evaluate_kernel<MODE 2>", "bound": "hbm", "achieved": bytes_ev / (ev_ms * 1e-3) / 1e9,
+                "residuals_only": {"ms": ev_r_ms, "bytes_per_problem": T * (m * 2 + 5),
+                                   "achieved_GBps": bytes_ev_r / (ev_r_ms * 1e-3) / 1e9,
+                                   "frac": bytes_ev_r / (ev_r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "what": "y in; r, c, cost out (set_params + residuals: the LM driver's inner trial point)"},
+                "roofline": {"kernel": "evaluate_kernel<MODE 2, FULL> (split: [exp | y] factored and r written, then the derivative "
+                                       "columns rebuilt, projected and written)", "bound": "hbm", "achieved": bytes_ev / (ev_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_ev / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "bytes_per_launch": bytes_ev, "traffic": committed_traffic("evaluate_kernel"),
                              "traffic_source": traffic_source("evaluate_kernel")},

@@ -23,7 +23,11 @@ def short(name):
     if k in ("blk_fit_kernel", "blk_evaluate_kernel") and "RtModel" in targs: return k + "_rt"
     if k == "ext_evaluate_kernel": return k + ("" if targs.rstrip().endswith("true") else "_no_derivatives")
     if k == "mrhs_stream_kernel": return "%s_mode%s" % (k, targs.split(",")[-1].strip())
-    if k in ("fit_kernel", "fit2_kernel", "evaluate_kernel", "basis_kernel"):
+    if k == "evaluate_kernel":  # MODE (0: c / cost, 1: + r, 2: + r + J) is the 5th template argument
+        flat = re.sub(r"<[^<>]*>", "", targs).split(",")
+        mode = flat[4].strip() if len(flat) > 4 else "2"
+        return k + ("_f32" if targs.startswith("float") else "") + ("" if mode == "2" else "_mode" + mode)
+    if k in ("fit_kernel", "fit2_kernel", "basis_kernel"):
         return k + ("_f32" if targs.startswith("float") else "")
     return k
 # ---- 1. kernel stats + trace ----

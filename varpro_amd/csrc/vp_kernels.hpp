@@ -213,6 +213,9 @@ template <typename T, class M> struct EvalArgs {
 #ifndef VP_EVAL2_TCALC
 #define VP_EVAL2_TCALC 1
 #endif
+#ifndef VP_EVAL2_PHASE1_WAVES
+#define VP_EVAL2_PHASE1_WAVES 2
+#endif
 #ifndef VP_EVAL2_SPLIT_WAVES
 #define VP_EVAL2_SPLIT_WAVES 2
 #endif
@@ -220,12 +223,12 @@ template <typename T, class M> struct EvalArgs {
 // validity mask anywhere -- with masks the 16 scale values of a lane (0.0 / 1.0 selects) are common subexpressions of every
 // loop that asks the row source and end up as a seventh register column.
 template <typename T, class M, int R, int W, int MODE, bool UNIFORM, bool FULL> constexpr bool eval2_split() {
-    return VP_EVAL2_SPLIT && FULL && MODE == 2 && UNIFORM && W == 1 && R == 16 && M::kStatic && M::kConstLast &&
-           M::kDiagonalPairs && sizeof(T) == 8;
+    return VP_EVAL2_SPLIT && FULL && UNIFORM && W == 1 && R == 16 && M::kStatic && M::kConstLast && M::kDiagonalPairs &&
+           sizeof(T) == 8;
 }
 template <typename T, class M, int R, int W, int MODE, bool UNIFORM, bool FULL> constexpr int eval_waves() {
     return eval2_split<T, M, R, W, MODE, UNIFORM, FULL>()
-               ? VP_EVAL2_SPLIT_WAVES
+               ? (MODE == 2 ? VP_EVAL2_SPLIT_WAVES : VP_EVAL2_PHASE1_WAVES)
                : model_waves_for<T, M, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>();
 }
 template <typename T, class M, int R, int W, int MODE, bool ALIGNED, bool WEIGHTED, bool UNIFORM = false, bool FULL = false>
@@ -248,7 +251,7 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
     for (int k = 0; k < Q; ++k) alpha[k] = a.alpha[b * Q + k];
 
     // MODE 2 (residual + Jacobian output) is register-tight: per-row exponentials unless the grid is known to be uniform
-    static_assert(!UNIFORM || MODE == 2, "UNIFORM specialises MODE 2");
+    static_assert(!UNIFORM || MODE == 2 || FULL, "UNIFORM specialises MODE 2 (and every mode of the split kernel)");
     using Src = typename std::conditional<SPLIT, RowSource<T, R, true, 0, 1, W, true, 1, true, VP_EVAL2_TCALC != 0>,
                                           RowSource<T, R, false, WEIGHTED ? 1 : 0, ALIGNED ? 1 : 0, W, (MODE != 2) || UNIFORM, 0, UNIFORM>>::type;
     Src src;
@@ -284,6 +287,7 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
         T g1[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) g1[j] = u.g[1 + j];
+        if constexpr (MODE == 0) return; // (phase 1 alone is the set_params of a full-length problem: 3 register columns)
         // r = Q r~ = H_0 H_1 .. H_NE r~
         residual_qcoords<T, R, N>(C[NE], u.e, grp);
         apply_q_cols<T, R, NE, NCX, NE, NCX>(C, g1, grp);
@@ -294,6 +298,7 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
             apply_const_reflector<T, R, 1, Src, G>(Y1, h0, src, grp);
             if (a.r_out) store_rows<T, R, W>(a.r_out + prob * (int64_t)m, m, lane, yvec, Y1[0]);
         }
+        if constexpr (MODE == 1) return;
         asm volatile("" ::: "memory"); // (the grid loads of phase 2 must not be hoisted into phase 1)
         __builtin_amdgcn_sched_barrier(0);
         // phase 2: D_p rebuilt, Z_k = -c_k P_perp D_k = -c_k Q [0; (Q^T D_k)(rows >= N)]
@@ -559,6 +564,14 @@ template <typename T, class M, int R, int W = 1> int launch_evaluate(const Launc
             if (launched) {
             } else if (p.w) hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, true, true>), grid, block, 0, p.stream, a);
             else hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, false, true>), grid, block, 0, p.stream, a);
+            return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+        }
+    }
+    if constexpr (eval2_split<T, M, R, W, 1, true, true>()) {
+        // set_params (+ residuals) of a full-length, unweighted problem on a uniform grid: phase 1 of the split kernel
+        if (mode < 2 && aligned && p.grid_uniform != 0 && !p.w && p.m == 64 * R * W) {
+            if (mode == 1) hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 1, true, false, true, true>), grid, block, 0, p.stream, a);
+            else hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 0, true, false, true, true>), grid, block, 0, p.stream, a);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
         }
     }
