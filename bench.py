@@ -400,10 +400,11 @@ def main():
                 "sum_cost": sum_cost,
             },
             "roofline": {
-                "kernel": "basis_rowpair_kernel (vp_basis: stand-alone Phi/dPhi evaluation; one thread per row pair of a problem)",
+                "kernel": "basis_flat_kernel (vp_basis: stand-alone Phi/dPhi evaluation; one thread per row pair of one column: "
+                          "Phi and dPhi are each written as one linear sweep)",
                 "bound": "hbm", "achieved": gbs_phi, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs_phi / HBM_PEAK_GBS, "traffic": committed_traffic("basis_rowpair_kernel") or committed_traffic("basis_kernel"),
-                "traffic_source": traffic_source("basis_rowpair_kernel") or traffic_source("basis_kernel"),
+                "frac": gbs_phi / HBM_PEAK_GBS, "traffic": committed_traffic("basis_flat_kernel") or committed_traffic("basis_rowpair_kernel"),
+                "traffic_source": traffic_source("basis_flat_kernel") or traffic_source("basis_rowpair_kernel"),
                 "bytes_per_launch": bytes_phi, "avg_launch_ms": basis_ms, "back_to_back_ms_per_launch": basis_ms_back_to_back,
             },
             "roofline_fit": {

@@ -507,6 +507,34 @@ template <class M> __global__ void __launch_bounds__(256) basis_rowpair_kernel(c
     if (M::kConstLast && !a.skip_invariant && phi) *reinterpret_cast<double2 *>(phi + (int64_t)NE * m) = make_double2(1.0, 1.0);
 }
 
+// The same with a thread owning one row pair of ONE column: when Phi is written without its constant column, Phi [B][NE][m]
+// and dPhi [B][NE][m] have the same shape and thread e writes 16 bytes at the same flat offset of both -- workgroups in
+// dispatch order sweep each array linearly from end to end (two memset-like streams instead of 2 NE interleaved ones).
+#ifndef VP_BASIS_FLAT
+#define VP_BASIS_FLAT 1
+#endif
+template <class M> __global__ void __launch_bounds__(256) basis_flat_kernel(const BasisArgs<double, M> a, const int blocks_per_col) {
+    constexpr int NE = M::kConstLast ? M::N - 1 : M::N, Q = M::Q;
+    const unsigned col = blockIdx.x / (unsigned)blocks_per_col; // b * NE + k
+    const int piece = (int)(blockIdx.x - col * (unsigned)blocks_per_col);
+    const int i = 2 * (piece * 256 + (int)threadIdx.x);
+    const int m = a.m;
+    if (i >= m) return;
+    const unsigned b = col / (unsigned)NE;
+    const int k = (int)(col - b * (unsigned)NE);
+    const double2 tv = *reinterpret_cast<const double2 *>(a.t + (int64_t)b * a.t_stride + i);
+    const double tau = a.alpha[(int64_t)b * Q + k];
+    const double rt = frcp(tau), rt2 = rt * rt;
+    double2 f, d;
+    f.x = texp(-div_refined(tv.x, tau, rt));
+    f.y = texp(-div_refined(tv.y, tau, rt));
+    d.x = (f.x * tv.x) * rt2;
+    d.y = (f.y * tv.y) * rt2;
+    const int64_t off = (int64_t)col * m + i;
+    if (a.Phi_out) *reinterpret_cast<double2 *>(a.Phi_out + off) = f;
+    if (a.dPhi_out) *reinterpret_cast<double2 *>(a.dPhi_out + off) = d;
+}
+
 // ---- host-side launch templates ------------------------------------------------------------------
 // every per-problem / per-column slice starts at a multiple of m elements from its base: with m even and
 // 16-byte aligned bases all 2-element accesses are aligned
@@ -610,6 +638,16 @@ template <typename T, class M, int R, int W = 1> int launch_basis(const LaunchPa
 #if VP_BASIS_ROWPAIR
     if constexpr (M::kStatic && M::kDiagonalPairs && sizeof(T) == 8) {
         const int bpp = (p.m / 2 + 255) / 256;
+#if VP_BASIS_FLAT
+        {
+            constexpr int NE = M::kConstLast ? M::N - 1 : M::N;
+            if (host_aligned<T>(p.m, {p.t, p.Phi_out, p.dPhi_out}) && a.n_phi_cols == NE && M::P == NE &&
+                a.B * NE * bpp < ((int64_t)1 << 31)) {
+                hipLaunchKernelGGL((basis_flat_kernel<M>), dim3((unsigned)(a.B * NE * bpp)), dim3(256), 0, p.stream, a, bpp);
+                return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+            }
+        }
+#endif
         if (host_aligned<T>(p.m, {p.t, p.Phi_out, p.dPhi_out}) && a.B * bpp < ((int64_t)1 << 31)) {
             hipLaunchKernelGGL((basis_rowpair_kernel<M>), dim3((unsigned)(a.B * bpp)), dim3(256), 0, p.stream, a, bpp);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
