@@ -344,13 +344,15 @@ template <typename T, int N> struct EvalUniform {
 
 // One full evaluation at `alpha`: builds the columns (the data column C[N] must already hold y_w),
 // runs the fused sweep, solves for c and forms ||r||^2.
-template <typename T, class M, int R, int NC, class Src, class G>
+//   NOD: no derivative columns (NC = N + 1: basis + data) -- phase 1 of the split evaluate kernels
+template <typename T, class M, int R, int NC, class Src, class G, bool NOD = false>
 __device__ __forceinline__ void evaluate_core(const M &mdl, const T (&alpha)[M::Q], const Src &src, T eps, G &grp,
                                               T (&C)[NC][R], EvalUniform<T, M::N> &u, SectionClock *clk = nullptr) {
     constexpr int N = M::N;
     using L = Layout<R, G::W>;
     const int lane = grp.gl;
-    build_columns<T, M, R, NC, Src>(mdl, alpha, src, C);
+    static_assert(!NOD || NC == N + 1, "phase 1: basis + data");
+    build_columns<T, M, R, NC, Src, N + 1, false, true, !NOD>(mdl, alpha, src, C);
     VP_TICK(clk, 1);
 #ifndef VP_NO_SWEEP_FENCE
     // keep the scheduler from interleaving the tail of the column build with the first dot products: the

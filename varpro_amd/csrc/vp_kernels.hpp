@@ -226,7 +226,22 @@ template <typename T, class M, int R, int W, int MODE, bool UNIFORM, bool FULL> 
     return VP_EVAL2_SPLIT && FULL && UNIFORM && W == 1 && R == 16 && M::kStatic && M::kConstLast && M::kDiagonalPairs &&
            sizeof(T) == 8;
 }
+// The GENERAL split form (any grid, weights, any length; static models with one derivative column per parameter, r and J
+// out): phase 1 = evaluate_core on [Phi | y]; phase 2 = one derivative column at a time, rebuilt, carried through Q^T, scaled,
+// carried back through Q, stored.  N + 2 register columns at the peak instead of N + 1 + P.  Used where the one-sweep
+// kernel's N + 1 + P columns take 168 and more register pairs per lane (double exponential + offset from 28 rows per lane
+// on, triple from 24), i.e. where it spills 80-190 VGPRs at one wave per SIMD: double exponential, m = 2048, B = 32 768:
+// 1.00 -> 0.70 ms, weighted 1.24 -> 0.89.  At 16 rows per lane it has no spills either but loses to the one-sweep kernel's
+// ~40 (0.27 -> 0.31 ms: twice the reduction rounds and a rebuild per column); double exponential at 24: even.
+#ifndef VP_EVAL2_SPLITG
+#define VP_EVAL2_SPLITG 1
+#endif
+template <typename T, class M, int R, int W, int MODE, bool FULL> constexpr bool eval2_split_general() {
+    return VP_EVAL2_SPLITG && !FULL && MODE == 2 && W == 1 && (M::N + 1 + M::P) * R >= 168 && M::kStatic && M::kDiagonalPairs &&
+           sizeof(T) == 8;
+}
 template <typename T, class M, int R, int W, int MODE, bool UNIFORM, bool FULL> constexpr int eval_waves() {
+    if (eval2_split_general<T, M, R, W, MODE, FULL>()) return model_waves_for<T, M, R, M::N + 2>();
     return eval2_split<T, M, R, W, MODE, UNIFORM, FULL>()
                ? (MODE == 2 ? VP_EVAL2_SPLIT_WAVES : VP_EVAL2_PHASE1_WAVES)
                : model_waves_for<T, M, R, M::N + 1 + M::P + ((MODE == 2 && !M::kDiagonalPairs) ? 1 + M::Q : 0)>();
@@ -344,6 +359,45 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
                 store_rows<T, R, W>(a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m, m, lane, ALIGNED, D[k]);
         }
         }
+        return;
+    }
+    if constexpr (eval2_split_general<T, M, R, W, MODE, FULL>()) {
+        using L = Layout<R, G::W>;
+        T C[N + 1][R];
+        load_rows<T, R, W>(yp, m, lane, yvec, C[N]);
+        EvalUniform<T, N> u;
+        evaluate_core<T, M, R, N + 1, Src, G, true>(a.mdl, alpha, src, a.eps, grp, C, u);
+        if (lane == 0) {
+            if (a.status) a.status[prob] = u.ok ? VP_ST_OK : VP_ST_NONFINITE;
+            if (a.cost_out) a.cost_out[prob] = 0.5 * (double)u.fn2;
+        }
+        if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(u.c, lane);
+        residual_qcoords<T, R, N>(C[N], u.e, grp);
+        apply_q_cols<T, R, N, N + 1, N, N + 1>(C, u.g, grp);
+        if (a.r_out) store_rows<T, R, W>(a.r_out + prob * (int64_t)m, m, lane, yvec, C[N]);
+        if (!a.J_out) return;
+        static_for<0, Q>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;
+            asm volatile("" ::: "memory"); // (the grid / weight loads of this column stay here)
+            __builtin_amdgcn_sched_barrier(0);
+            // the row count through an empty asm: the validity masks / 0-1 scales of this column are recomputed here instead
+            // of being kept (spilled) from phase 1 as common subexpressions
+            Src src2 = src;
+            int m2 = m;
+            asm volatile("" : "+s"(m2));
+            src2.m = m2;
+            T D[1][R];
+            build_columns<T, M, R, 1, Src, -k, false, false, true, k>(a.mdl, alpha, src2, D);
+            apply_qt<T, R, N, N + 1, 1, G>(C, u.g, D, grp);
+            const T ck = -u.c[k];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool top = (r < L::VW) && (L::row_of(r, lane) < N);
+                D[0][r] = top ? T(0) : ck * D[0][r];
+            }
+            apply_q<T, R, N, N + 1, 1, G>(C, u.g, D, grp);
+            store_rows<T, R, W>(a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m, m2, lane, ALIGNED, D[0]);
+        });
         return;
     }
     T C[NC][R];
