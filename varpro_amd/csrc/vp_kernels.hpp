@@ -636,15 +636,13 @@ template <typename T, class M, int R, int W = 1> int launch_evaluate(const Launc
     const int mode = p.J_out ? 2 : (p.r_out ? 1 : 0);
     if constexpr (M::kStatic && sizeof(T) == 8 && (R > 2)) {
         if (mode == 2 && aligned && p.grid_uniform != 0 && p.m >= 3) { // (RowSource::set_uniform's own conditions)
-            bool launched = false;
             if constexpr (eval2_split<T, M, R, W, 2, true, true>()) {
                 if (!p.w && p.m == 64 * R * W) { // a full-length, unweighted problem: the split kernel
                     hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, false, true, true>), grid, block, 0, p.stream, a);
-                    launched = true;
+                    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
                 }
             }
-            if (launched) {
-            } else if (p.w) hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, true, true>), grid, block, 0, p.stream, a);
+            if (p.w) hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, true, true>), grid, block, 0, p.stream, a);
             else hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 2, true, false, true>), grid, block, 0, p.stream, a);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
         }
