@@ -1,4 +1,5 @@
-"""The one success-class disagreement of the configs[3] census (shard 3, problem 29433): device and oracle traces side by side.\nusage: PYTHONPATH=. python tools/census_disagreement_probe.py"""
+"""The one success-class disagreement of the configs[3] census (shard 3, problem 29433): device and oracle traces side by side.
+usage: PYTHONPATH=. python tools/census_disagreement_probe.py"""
 import numpy as np
 import varpro_amd as vp
 from oracle import oracle as O
