@@ -223,6 +223,157 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
     return par;
 }
 
+// lmpar for callers whose R is itself the Cholesky factor of a Gram matrix J^T J (vp_fitg.hpp: J is never materialised).
+// Same trust-region sub-problem, same Newton iteration on par, same exits as lmpar above; what differs is how the
+// regularised factor S  (S^T S = R^T R + par D_p^2, what qrsolv's Q(Q+1)/2 Givens rotations produce) is obtained: as the
+// Cholesky factor of  G + par D_p^2  with  G = R^T R  formed once per call.  Each rotation of qrsolv needs the row the
+// previous one left (a chain of Q(Q+1)/2 reciprocal square roots with their selects and branches: ~2 500 instructions per
+// lmpar iteration at Q = 5 on one lane); the Cholesky form is Q dependent pivots and ~Q^3/3 multiply-adds (~250).  R came
+// from the Gram matrix in the first place, so nothing is lost against the data: G is what the caller measured, R its
+// factor.  A pivot is clamped from below by  par d_j^2  -- its exact lower bound (the Schur complement of a positive
+// semi-definite matrix plus par D^2) -- so that rounding in an ill-conditioned G cannot drive it through zero.
+// The step and the norms are formed in pivoted order (a permutation does not change a Euclidean norm).
+template <typename T, int Q, bool U = true, bool O = false>
+__device__ __forceinline__ T lmpar_chol(const T (&r)[Q][Q], const int (&ipvt)[Q], const T (&diag)[Q], const T (&qtb)[Q],
+                                        const T delta, T par, T (&x)[Q], T &dxnorm_out) {
+    const T p1 = T(0.1), p001 = T(0.001), dwarf = num<T>::tiny;
+    T wa1[Q], wa2[Q], rinv[Q], dperm[Q];
+    int nsing = Q;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        wa1[j] = qtb[j];
+        if (r[j][j] == T(0) && nsing == Q) nsing = j;
+        if (nsing < Q) wa1[j] = T(0);
+        rinv[j] = (r[j][j] != T(0)) ? frcp(r[j][j]) : T(0);
+        dperm[j] = dyn_get_o<Q, O>(diag, ipvt[j]);
+    }
+    nsing = pol<U>(nsing);
+    // Gauss-Newton direction (pivoted order): R_11 p = (Q^T f)_1, zero beyond the numerical rank
+#pragma unroll
+    for (int k = 1; k <= Q; ++k) {
+        const int j = Q - k;
+        if (j < nsing) {
+            wa1[j] = wa1[j] * rinv[j];
+            const T temp = wa1[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) wa1[i] = tfma(-r[i][j], temp, wa1[i]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) wa2[j] = dperm[j] * wa1[j];
+    T dxnorm = enorm_small<T, Q, U>(wa2);
+    T fp = dxnorm - delta;
+    if (pol<U>(fp <= p1 * delta)) {
+#pragma unroll
+        for (int j = 0; j < Q; ++j) dyn_set_o<Q, O>(x, ipvt[j], wa1[j]);
+        dxnorm_out = dxnorm;
+        return T(0);
+    }
+    const T idelta = frcp(delta);
+    T parl = T(0);
+    if (nsing >= Q) {
+        const T idx = frcp(dxnorm);
+        T z[Q];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) z[j] = dperm[j] * (wa2[j] * idx);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            T sum = T(0);
+#pragma unroll
+            for (int i = 0; i < j; ++i) sum = tfma(r[i][j], z[i], sum);
+            z[j] = (z[j] - sum) * rinv[j];
+        }
+        T t2 = T(0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) t2 = tfma(z[j], z[j], t2);
+        parl = (fp * idelta) * frcp(t2);
+    }
+    // G = R^T R (upper triangle) and b = R^T (Q^T f) = P^T J^T f
+    T G[Q][Q], bp[Q], dp2[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+#pragma unroll
+        for (int i = 0; i <= j; ++i) {
+            T sum = T(0);
+#pragma unroll
+            for (int k = 0; k <= i; ++k) sum = tfma(r[k][i], r[k][j], sum);
+            G[i][j] = sum;
+        }
+        T sum = T(0);
+#pragma unroll
+        for (int i = 0; i <= j; ++i) sum = tfma(r[i][j], qtb[i], sum);
+        bp[j] = sum;
+        wa1[j] = sum * frcp(dperm[j]);
+        dp2[j] = dperm[j] * dperm[j];
+    }
+    const T gnorm = enorm_small<T, Q, U>(wa1);
+    T paru = gnorm * idelta;
+    if (paru == T(0)) paru = dwarf / tmin(delta, p1);
+    par = tmax(par, parl);
+    par = tmin(par, paru);
+    if (par == T(0)) par = gnorm * frcp(dxnorm);
+    T xp[Q];
+    for (int iter = 1;; ++iter) {
+        if (par == T(0)) par = tmax(dwarf, p001 * paru);
+        // S^T S = G + par D_p^2  (S upper triangular, is[j] = 1 / S_jj)
+        T S[Q][Q], is[Q], w[Q];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const T floor_j = par * dp2[j];
+            T d = G[j][j] + floor_j;
+#pragma unroll
+            for (int k = 0; k < j; ++k) d = tfma(-S[k][j], S[k][j], d);
+            d = tmax(d, floor_j);
+            is[j] = (d > T(0)) ? frsqrt(d) : T(0);
+#pragma unroll
+            for (int l = j + 1; l < Q; ++l) {
+                T a = G[j][l];
+#pragma unroll
+                for (int k = 0; k < j; ++k) a = tfma(-S[k][j], S[k][l], a);
+                S[j][l] = a * is[j];
+            }
+            // S^T w = b alongside
+            T a = bp[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) a = tfma(-S[k][j], w[k], a);
+            w[j] = a * is[j];
+        }
+        // S p = w
+#pragma unroll
+        for (int k = 1; k <= Q; ++k) {
+            const int j = Q - k;
+            T a = w[j];
+#pragma unroll
+            for (int i = j + 1; i < Q; ++i) a = tfma(-S[j][i], xp[i], a);
+            xp[j] = a * is[j];
+        }
+#pragma unroll
+        for (int j = 0; j < Q; ++j) wa2[j] = dperm[j] * xp[j];
+        dxnorm = enorm_small<T, Q, U>(wa2);
+        const T temp = fp;
+        fp = dxnorm - delta;
+        if (pol<U>(tabs(fp) <= p1 * delta || (parl == T(0) && fp <= temp && temp < T(0)) || iter == 10)) break;
+        const T idx = frcp(dxnorm);
+        T t2 = T(0);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { // S^T z = D_p^2 p / ||D p||
+            T a = dperm[j] * (wa2[j] * idx);
+#pragma unroll
+            for (int k = 0; k < j; ++k) a = tfma(-S[k][j], wa1[k], a);
+            wa1[j] = a * is[j];
+            t2 = tfma(wa1[j], wa1[j], t2);
+        }
+        const T parc = (fp * idelta) * frcp(t2);
+        if (fp > T(0)) parl = tmax(parl, par);
+        if (fp < T(0)) paru = tmin(paru, par);
+        par = tmax(parl, par + parc);
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) dyn_set_o<Q, O>(x, ipvt[j], xp[j]);
+    dxnorm_out = dxnorm;
+    return par;
+}
+
 // MINPACK qrfac (column pivoting, partial-norm downdating) of the Q Jacobian columns Z living in
 // rows >= ROW0 (rows < ROW0 of Z are zero), applied simultaneously to the residual column rv (-> qtf), as lmder
 // does.  MINPACK's reflector  v = a/ajnorm + e_p,  H = I - v v^T / v_p  is applied in the equivalent

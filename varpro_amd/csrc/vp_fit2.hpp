@@ -192,7 +192,8 @@ __device__ __noinline__ void slot_fill(VP_LDS SlotRec<T, N, Q> *rec, VP_LDS T *s
 // SCALAR phase: lane s runs the LM bookkeeping of slot s on its LDS record (trust-region update, accept / reject,
 // termination tests, gradient test, lmpar, predicted reduction, next trial point) and writes the results of a fit that
 // terminated.  == the body of LevenbergMarquardt::minimize between two evaluations.  Out of line (see slot_fill).
-template <typename T, int N, int Q, int GS, typename TO = T>
+// GRAM: the Jacobian factor in the record is the Cholesky factor of a Gram matrix (vp_fitg.hpp) -> lmpar_chol.
+template <typename T, int N, int Q, int GS, typename TO = T, bool GRAM = false>
 __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP_LDS const SlotConsts<T, TO> *k, const bool act = true) {
     const int lane = lane_id();
     if (!(act && lane < GS && recs[lane].prob >= 0)) return;
@@ -355,7 +356,8 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
         for (int i = 0; i < Q; ++i)
 #pragma unroll
             for (int j = 0; j < Q; ++j) Rw[i][j] = Rj[i][j];
-        par = lmpar<T, Q, false, (Q > 3)>(Rw, ipvt, diag, qtf, delta, par, step, pnorm);
+        if constexpr (GRAM) par = lmpar_chol<T, Q, false, (Q > 3)>(Rj, ipvt, diag, qtf, delta, par, step, pnorm);
+        else par = lmpar<T, Q, false, (Q > 3)>(Rw, ipvt, diag, qtf, delta, par, step, pnorm);
         if (!is_finite(pnorm)) {
             term = VP_TERM_NUMERICAL;
         } else {

@@ -49,6 +49,9 @@
 #ifndef VP_FITG_SCALAR_WAVES
 #define VP_FITG_SCALAR_WAVES 1 // bookkeeping waves per workgroup (each owns NS / this many slots)
 #endif
+#ifndef VP_FITG_CHOL_LMPAR
+#define VP_FITG_CHOL_LMPAR 1   // trust-region sub-problem on the Cholesky factor of J^T J + par D^2 (lmpar_chol) instead of qrsolv
+#endif
 #ifndef VP_FITG_CLOSED
 #define VP_FITG_CLOSED 1       // uniform grid + unit weights: the y-independent moments in closed form
 #endif
@@ -716,7 +719,7 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES == 8 ? 2 :
 #endif
         gram_phase<NE, GSW, WEIGHTED>(recs + s, gram + (size_t)s * GI::NV, kc, nullptr, lane == 0);
         lds_release();
-        slot_scalar_phase<double, N, Q, GSW, float>(recs + s, kc, lane == 0);
+        slot_scalar_phase<double, N, Q, GSW, float, VP_FITG_CHOL_LMPAR != 0>(recs + s, kc, lane == 0);
         lds_release();
         slot_advance(s, lane == 0);
 #if VP_FITG_TIMELINE
@@ -750,7 +753,7 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES == 8 ? 2 :
             gram_phase<NE, GSW, WEIGHTED>(wrecs, gram + (size_t)base * GI::NV, kc, a.dbg, act);
             lds_release();
             if (!a.dbg) {
-                slot_scalar_phase<double, N, Q, GSW, float>(wrecs, kc, act);
+                slot_scalar_phase<double, N, Q, GSW, float, VP_FITG_CHOL_LMPAR != 0>(wrecs, kc, act);
                 lds_release();
             }
             slot_advance(base + lane, act);
