@@ -577,7 +577,7 @@ def main():
                 "workload": "BASELINE configs[4]: %d fp32 fits, five exponentials + offset (n=6, q=5), m=%d" % (B4, m4),
                 "fits_per_s": B4 / (ms4 * 1e-3), "ms_per_step": ms4, "mean_evaluations_per_fit": float(r4["n_evals"].mean()),
                 "two_batches_in_flight": {"ms_per_batch": ms4_two, "fits_per_s": B4 / (ms4_two * 1e-3),
-                                          "note": "two handles on two HIP streams: the ~1.1 ms in which a launch runs only its fits "
+                                          "note": "two handles on two HIP streams: the ~1 ms in which a launch runs only its fits "
                                                   "past ~24 evaluations overlaps the next batch's bulk"},
                 "fraction_failed": float((r4["termination"] <= 0).mean()),
                 "longest_fit_evaluations": int(r4["n_evals"].max()),
@@ -587,10 +587,11 @@ def main():
                                        "wave over a pool of 32 problem slots; passes of long fits split over 4 waves)",
                              "bound": "latency (the longest fit's chain of rounds: evaluations x {moment pass + LM bookkeeping})",
                              "timeline": "tools/cfg4_timeline.py on a -DVP_FITG_TIMELINE=1 build: the first ~1.25 ms every workgroup holds "
-                                         "32..8 live fits and both roles are busy (bookkeeping wave 100 %, 9.4 slots per 21 us trip; stream "
+                                         "32..8 live fits and both roles are busy (bookkeeping wave 100 %, 9.4 slots per trip; stream "
                                          "waves 10.4 us per pass at 2 waves per SIMD) -- a round costs 55-60 us there; the rest is the fits "
-                                         "past ~24 evaluations at the 21 us of a lone round (5.5 us pass, 15 us of dependent fp64 "
-                                         "bookkeeping: Cholesky of the 6x6 Gram, pivoted Cholesky of J^T J, lmpar's Givens sweeps)",
+                                         "past ~24 evaluations at the 17 us of a lone round (3 us split pass, 12 us of dependent fp64 "
+                                         "bookkeeping: Cholesky of the 6x6 Gram, pivoted Cholesky of J^T J, lmpar on the Cholesky factor "
+                                         "of R^T R + par D^2 -- lmpar_chol; with qrsolv's Givens sweeps a lone round took 21 us)",
                              "achieved": tf4 * flops4_exec / flops4, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf4 * flops4_exec / flops4 / FP64_VALU_PEAK_TFLOPS,
                              "flops_executed_per_evaluation": flops4_exec,
