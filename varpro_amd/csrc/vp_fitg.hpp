@@ -52,6 +52,9 @@
 #ifndef VP_FITG_CHOL_LMPAR
 #define VP_FITG_CHOL_LMPAR 1   // trust-region sub-problem on the Cholesky factor of J^T J + par D^2 (lmpar_chol) instead of qrsolv
 #endif
+#ifndef VP_FITG_RESOLUTION_GUARD
+#define VP_FITG_RESOLUTION_GUARD 1 // a trial point whose ||r||^2 cancelled to <= 0 is rejected, not read as a zero residual
+#endif
 #ifndef VP_FITG_CLOSED
 #define VP_FITG_CLOSED 1       // uniform grid + unit weights: the y-independent moments in closed form
 #endif
@@ -194,10 +197,19 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
         ok = ok && is_finite(c[i]);
     }
     ok = ok && is_finite(fn2);
-    const double fnorm1 = usqrt(tmax(fn2, 0.0));
-
     const int fl_in = rec->flags;
     const bool first = (fl_in & 1) != 0;
+    // ||r||^2 = y^T y - z^T z is a difference of two numbers of the size of ||y||^2: at a trial point where kappa(Phi)^2 eps64
+    // exceeds the noise level of the data it can come out <= 0 -- a value no residual has.  Read as 0 it would be the best
+    // point ever seen and end the fit `ResidualsZero` with objective 0 (0.4 % of configs[4]'s fits did).  Such a trial point
+    // carries no information: it is REJECTED like any step that does not reduce the residual (the trust region shrinks by
+    // the factor 10 MINPACK applies to a step that fails badly), never accepted.  The first evaluation keeps its value.
+#if VP_FITG_RESOLUTION_GUARD
+    const bool lost = ok && !first && !(fn2 > 0.0);
+#else
+    const bool lost = false;
+#endif
+    const double fnorm1 = lost ? 1.0e150 : usqrt(tmax(fn2, 0.0));
     const double fnorm = rec->fnorm, prered = rec->prered;
     double actred = 0.0, ratio = 0.0;
     bool good = false;
