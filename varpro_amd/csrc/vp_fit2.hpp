@@ -193,8 +193,10 @@ __device__ __noinline__ void slot_fill(VP_LDS SlotRec<T, N, Q> *rec, VP_LDS T *s
 // termination tests, gradient test, lmpar, predicted reduction, next trial point) and writes the results of a fit that
 // terminated.  == the body of LevenbergMarquardt::minimize between two evaluations.  Out of line (see slot_fill).
 // GRAM: the Jacobian factor in the record is the Cholesky factor of a Gram matrix (vp_fitg.hpp) -> lmpar_chol.
+// _inl: the body, inlined into its caller (vp_fitg.hpp: one call site per wave role; out of line its 81 callee-saved
+// VGPRs were stored and reloaded around every call -- 4 % of configs[4]'s launch).
 template <typename T, int N, int Q, int GS, typename TO = T, bool GRAM = false>
-__device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP_LDS const SlotConsts<T, TO> *k, const bool act = true) {
+__device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *recs, VP_LDS const SlotConsts<T, TO> *k, const bool act = true) {
     const int lane = lane_id();
     if (!(act && lane < GS && recs[lane].prob >= 0)) return;
     VP_LDS SlotRec<T, N, Q> *s = recs + lane;
@@ -433,6 +435,11 @@ __device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP
             for (int i = 0; i < N; ++i) C_out[prob * N + i] = (TO)s->cbest[i];
         }
     }
+}
+
+template <typename T, int N, int Q, int GS, typename TO = T, bool GRAM = false>
+__device__ __noinline__ void slot_scalar_phase(VP_LDS SlotRec<T, N, Q> *recs, VP_LDS const SlotConsts<T, TO> *k, const bool act = true) {
+    slot_scalar_phase_inl<T, N, Q, GS, TO, GRAM>(recs, k, act);
 }
 
 #ifndef VP_LONE_TAIL_LINKAGE

@@ -55,6 +55,16 @@
 #ifndef VP_FITG_RESOLUTION_GUARD
 #define VP_FITG_RESOLUTION_GUARD 1 // a trial point whose ||r||^2 cancelled to <= 0 is rejected, not read as a zero residual
 #endif
+#ifndef VP_FITG_PIVOT_NOISE
+#define VP_FITG_PIVOT_NOISE 1.0e-10
+#endif
+#ifndef VP_FITG_RESOLUTION
+// (experiment, VP_FITG_RESOLUTION_GUARD 2 / 3: ||r||^2 floored at / rejected below this fraction of the error scale
+// sum_i z_i^2 A_ii / d_i.  On configs[4] every value from 1e-12 to 5e-10 removes the fits that end on a wrong objective
+// and shortens the launch, but on exact data the error scale is ~||y||^2 whatever the conditioning -- the last column's
+// term is ||phi_l c_l||^2 -- so the fit stops at 1e-11 ||y||^2 instead of 1e-15: not adopted, the pivot threshold is.)
+#define VP_FITG_RESOLUTION 1.6e-11
+#endif
 #ifndef VP_FITG_CLOSED
 #define VP_FITG_CLOSED 1       // uniform grid + unit weights: the y-independent moments in closed form
 #endif
@@ -131,7 +141,7 @@ struct FitgArgs {
 // Lane s: moments of slot s -> results of the evaluation in the slot's record (what the vector phase of fit2_kernel
 // posts).  gram: [GS][GI::NV].  dbg != null: additionally write {1/2||r||^2, c, J^T r, J^T J} of the slot's problem.
 template <int NE, int GS, bool WEIGHTED>
-__device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs, VP_LDS const double *gram,
+__device__ __forceinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs, VP_LDS const double *gram,
                                         VP_LDS const SlotConsts<double, float> *k, double *dbg, const bool act = true) {
     constexpr int N = NE + 1, Q = NE;
     using GI = GramIdx<NE>;
@@ -148,14 +158,20 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
     }
     // ---- A = Phi^T Phi (basis order e_0..e_{NE-1}, const) = L L^T ----
     // A column whose pivot d_i (its squared distance from the span of the columns before it) is <= max(eps^2,
-    // VP_GRAM_NOISE A_ii) is DROPPED (c_i = 0, the projector is that of the remaining columns): the counterpart of the
+    // VP_FITG_PIVOT_NOISE A_ii) is DROPPED (c_i = 0, the projector is that of the remaining columns): the counterpart of the
     // reference's truncated SVD (singular values <= eps, src/solvers/levmar/mod.rs:52-54) at trial points where two decay
     // times collide or a column degenerates into the constant -- the step is then judged by its residual like any other
     // instead of ending the fit.  eps is the handle's svd_epsilon (absolute, like the reference's); the relative term is
-    // NOT a user parameter but the resolution of the method: a pivot of a Gram matrix accumulated in fp64 carries
-    // rounding noise of a few hundred eps64 A_ii, below which it is indistinguishable from 0.
-    constexpr double VP_GRAM_NOISE = 1.0e-13;
+    // NOT a user parameter but the resolution of the method: the moments are consistent with each other to ~1e-13 of A_ii
+    // (exponentials by recurrence over a chunk, closed-form sums beside accumulated ones), so a pivot of 1e-13 A_ii is noise
+    // and one of 1e-10 A_ii is known to three digits.  Round 4 raised the threshold from the noise floor (1e-13) to 1e-10:
+    // at 1e-13 a column that was still "kept" with a pivot of 1e-12 A_ii made ||r||^2 = y^T y - z^T z garbage, and 0.33 % of
+    // configs[4]'s fits ended on such a point with a reported objective off by 1e-2 .. 0.7 of the true cost there (0.14 % by
+    // more than 0.1); at 1e-10: 1 fit of 8 192 by 0.07, none above -- and fewer failed fits (2.56 -> 2.51 %), every test of
+    // the Gram suite (m = 200 .. 4096, general grids, weights, exact data) unchanged.  tools/cfg4_resolution_probe.py.
+    constexpr double VP_GRAM_NOISE = VP_FITG_PIVOT_NOISE;
     double Lm[N][N], iL[N]; // L (strict lower part) and the reciprocals of its diagonal (0 for a dropped column)
+    double amp[N];
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -171,6 +187,7 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
                 ok = ok && is_finite(acc);
                 const bool keep = acc > tmax(eps * eps, VP_GRAM_NOISE * aij);
                 iL[i] = keep ? frsqrt(acc) : 0.0; // (Newton-refined v_rsq: 1-2 ulp, against kappa^2 eps64 of the method)
+                amp[i] = keep ? aij * (iL[i] * iL[i]) : 0.0; // A_ii / d_i: by how much the rounding of the moments is amplified in d_i
             } else {
                 Lm[i][j] = acc * iL[j]; // (a dropped column j has no sub-diagonal entries)
             }
@@ -186,8 +203,12 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
         z[i] = acc * iL[i];
     }
     double fn2 = g[GI::YY];
+    double fn2_err = 0.0; // estimate of the rounding error of fn2: sum_i z_i^2 (A_ii / d_i), in units of the moments' relative error
 #pragma unroll
-    for (int i = 0; i < N; ++i) fn2 = tfma(-z[i], z[i], fn2);
+    for (int i = 0; i < N; ++i) {
+        fn2 = tfma(-z[i], z[i], fn2);
+        fn2_err = tfma(z[i] * z[i], amp[i], fn2_err);
+    }
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
         double acc = z[i];
@@ -199,17 +220,22 @@ __device__ __noinline__ void gram_phase(VP_LDS SlotRec<double, NE + 1, NE> *recs
     ok = ok && is_finite(fn2);
     const int fl_in = rec->flags;
     const bool first = (fl_in & 1) != 0;
-    // ||r||^2 = y^T y - z^T z is a difference of two numbers of the size of ||y||^2: at a trial point where kappa(Phi)^2 eps64
-    // exceeds the noise level of the data it can come out <= 0 -- a value no residual has.  Read as 0 it would be the best
-    // point ever seen and end the fit `ResidualsZero` with objective 0 (0.4 % of configs[4]'s fits did).  Such a trial point
-    // carries no information: it is REJECTED like any step that does not reduce the residual (the trust region shrinks by
-    // the factor 10 MINPACK applies to a step that fails badly), never accepted.  The first evaluation keeps its value.
-#if VP_FITG_RESOLUTION_GUARD
-    const bool lost = ok && !first && !(fn2 > 0.0);
-#else
-    const bool lost = false;
-#endif
+    // ||r||^2 = y^T y - z^T z is a difference of two numbers of the size of ||y||^2: where it cancels to <= 0 -- a value no
+    // residual has -- the trial point carries no information.  Read as 0 it was the best point ever seen and ended the fit
+    // `ResidualsZero` with objective 0 (0.4 % of configs[4]'s fits, on data with 1e-3 of noise).  Such a point is REJECTED
+    // like any step that fails badly (the trust region shrinks by MINPACK's factor 10), never accepted; the first
+    // evaluation keeps its value.  (fn2_err / modes 2, 3: the experiment described at VP_FITG_RESOLUTION.)
+#if VP_FITG_RESOLUTION_GUARD == 3   // experiment: reject below VP_FITG_RESOLUTION x the error scale
+    const bool lost = ok && !first && !(fn2 > VP_FITG_RESOLUTION * fn2_err);
     const double fnorm1 = lost ? 1.0e150 : usqrt(tmax(fn2, 0.0));
+#elif VP_FITG_RESOLUTION_GUARD == 2 // experiment: ||r||^2 floored at VP_FITG_RESOLUTION x the error scale
+    const double fnorm1 = usqrt(tmax(tmax(fn2, VP_FITG_RESOLUTION * fn2_err), 0.0));
+#elif VP_FITG_RESOLUTION_GUARD == 1 // a cancelled ||r||^2 <= 0 is a failed step
+    const bool lost = ok && !first && !(fn2 > 0.0);
+    const double fnorm1 = lost ? 1.0e150 : usqrt(tmax(fn2, 0.0));
+#else
+    const double fnorm1 = usqrt(tmax(fn2, 0.0));
+#endif
     const double fnorm = rec->fnorm, prered = rec->prered;
     double actred = 0.0, ratio = 0.0;
     bool good = false;
@@ -731,7 +757,7 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES == 8 ? 2 :
 #endif
         gram_phase<NE, GSW, WEIGHTED>(recs + s, gram + (size_t)s * GI::NV, kc, nullptr, lane == 0);
         lds_release();
-        slot_scalar_phase<double, N, Q, GSW, float, VP_FITG_CHOL_LMPAR != 0>(recs + s, kc, lane == 0);
+        slot_scalar_phase_inl<double, N, Q, GSW, float, VP_FITG_CHOL_LMPAR != 0>(recs + s, kc, lane == 0);
         lds_release();
         slot_advance(s, lane == 0);
 #if VP_FITG_TIMELINE
@@ -765,7 +791,7 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES == 8 ? 2 :
             gram_phase<NE, GSW, WEIGHTED>(wrecs, gram + (size_t)base * GI::NV, kc, a.dbg, act);
             lds_release();
             if (!a.dbg) {
-                slot_scalar_phase<double, N, Q, GSW, float, VP_FITG_CHOL_LMPAR != 0>(wrecs, kc, act);
+                slot_scalar_phase_inl<double, N, Q, GSW, float, VP_FITG_CHOL_LMPAR != 0>(wrecs, kc, act);
                 lds_release();
             }
             slot_advance(base + lane, act);
@@ -866,11 +892,12 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES == 8 ? 2 :
                 asm volatile("" ::: "memory");
             }
             const int prob = uni(s_recs[s].prob);
+            int ready_slot = -1;
             if (part < 0) {
                 gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0], gram + (size_t)s * GI::NV, prob, lane, m,
                                                  0, nchunk, vec);
                 lds_release(); // the moments are in LDS before the slot is handed on
-                moments_ready(s);
+                ready_slot = s;
             } else {
                 const int c0 = (int)((long)part * nchunk / VP_FITG_PARTS), c1 = (int)((long)(part + 1) * nchunk / VP_FITG_PARTS);
                 gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0],
@@ -887,9 +914,10 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES == 8 ? 2 :
                         s_gram[s][v] = t;
                     }
                     lds_release();
-                    moments_ready(s);
+                    ready_slot = s;
                 }
             }
+            if (ready_slot >= 0) moments_ready(ready_slot); // (one call site: the bookkeeping may be inlined here)
             start = s + 1 >= NS ? 0 : s + 1;
 #if VP_FITG_TIMELINE
             tl_busy += wall_clock64() - tl_a;
