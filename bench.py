@@ -237,6 +237,7 @@ def main():
     evals_per_fit = n_evals / (world * B)
 
     out = None
+    cfg4_check = None
     if rank == 0:
         T = 8
 
@@ -600,6 +601,7 @@ def main():
                              "hbm_bytes_per_evaluation": 4 * m4, "y_reread_bytes_per_launch": 4.0 * m4 * float(r4["n_evals"].sum()),
                              "traffic": committed_traffic("fitg2_kernel"), "traffic_source": traffic_source("fitg2_kernel")},
             }
+            cfg4_check = (d4["x"], d4["Y"], _a4.cpu().numpy() if hasattr(_a4, "cpu") else np.asarray(_a4), r4)
             bp4.close()
             del Y4
 
@@ -793,6 +795,21 @@ def main():
         cen = CS.census(bp.report_to_numpy(rep_dev)[:n_cen], a_dev.cpu().numpy()[:n_cen], rep_cpu[:n_cen], a_cpu[:n_cen], max_listed=10)
         out["parity_census"] = dict(cen, what="vp_fit vs the oracle on the first %d problems of the timed workload: success class, "
                                               "termination codes, objective, evaluation counts per problem" % n_cen)
+        if cfg4_check is not None and "configs4" in out:
+            # configs[4]: the objective every successful fit REPORTS against the fp64 oracle's cost at the parameters it RETURNS
+            # (thin-SVD solve on the lattice the kernel defines the uniform grid as; tools/cfg4_resolution_probe.py)
+            x4c, Y4c, a4c, r4c = cfg4_check
+            ok4 = r4c["termination"] > 0
+            t04 = float(x4c[0])
+            grid4 = t04 + np.arange(x4c.shape[-1]) * ((float(x4c[-1]) - t04) / (x4c.shape[-1] - 1))
+            ref4 = O.evaluate_batch(vp.multi_exponential_model(grid4, a4c[0].astype(np.float64)), grid4, Y4c[ok4].astype(np.float64),
+                                    a4c[ok4].astype(np.float64), n_threads=threads, want_jac=False)
+            rel4 = np.abs(r4c["objective"][ok4] - ref4["cost"]) / ref4["cost"]
+            out["configs4"]["reported_objective_vs_oracle_cost_at_the_returned_point"] = {
+                "successes": int(ok4.sum()), "median": float(np.median(rel4)), "p99": float(np.percentile(rel4, 99)), "max": float(rel4.max()),
+                "share_above_1e-3": float((rel4 > 1e-3).mean()), "share_above_1e-2": float((rel4 > 1e-2).mean()),
+                "note": "fp64 Gram evaluation of fp32 data: exact to kappa(Phi)^2 x 1e-13; columns whose Cholesky pivot is below "
+                        "1e-10 A_ii are dropped (vp_fitg.hpp gram_phase)"}
         out["cpu_baseline"] = {
             "value": n_cpu / wall, "unit": "fits/s", "cores": threads, "kind": "port",
             "cpu_model": cpu_model, "sockets": sockets, "physical_cores": phys_cores, "logical_cpus_usable": usable,
