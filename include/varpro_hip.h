@@ -348,6 +348,17 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
  */
 int vp_debug_gram_evaluate(vp_batch *h, const void *alpha, double *out);
 
+/*
+ * Diagnostics for the parity test of the Gram fit kernel's LM step: the trust-region sub-problem of
+ * LevenbergMarquardt::minimize (levenberg-marquardt 0.14 == MINPACK lmpar; call site src/solvers/levmar/mod.rs:247) as that
+ * kernel solves it -- on the Cholesky factor of R^T R + par D^2 instead of qrsolv's Givens rotations (lmpar_chol,
+ * varpro_amd/csrc/vp_fit.hpp) -- run once per record on the device.  HOST pointers; q in {2, 3, 5}.
+ *   Rj [B][q][q] row-major upper-triangular factor of the pivoted Jacobian, ipvt [B][q], diag [B][q], qtb [B][q] (first q
+ *   entries of Q^T f), delta [B], par_in [B]  ->  out [B][q + 2] = { par, ||diag .* step||, step (q, unpivoted order) }.
+ */
+int vp_debug_lmpar_gram(int64_t B, int q, const double *Rj, const int32_t *ipvt, const double *diag, const double *qtb,
+                        const double *delta, const double *par_in, double *out);
+
 /* == FitResult::best_fit (src/fit.rs:55-59,87-91): UNWEIGHTED Phi(alpha) * C, [B][S][m] */
 int vp_best_fit(vp_batch *h, void *fit_out);
 

@@ -326,6 +326,24 @@ def evaluate_batch(model, t, Y, alpha, w=None, eps=-1.0, n_threads=1, want_jac=T
     return dict(r=r, J=J, C=Cc, cost=cost, status=st)
 
 
+def lmpar(R, ipvt, diag, qtb, delta, par):
+    """MINPACK lmpar of the restatement on an upper-triangular factor R (n x n) -> (par, step, ||diag * step||)"""
+    R = np.asarray(R, dtype=np.float64)
+    n = R.shape[0]
+    rc = np.asfortranarray(R).ravel(order="F").copy()
+    ip = np.ascontiguousarray(ipvt, dtype=np.int32)
+    dg = np.ascontiguousarray(diag, dtype=np.float64)
+    qb = np.ascontiguousarray(qtb, dtype=np.float64)
+    x = np.empty(n)
+    dx = C.c_double(0.0)
+    f = lib().vpo_lmpar
+    f.restype = C.c_double
+    f.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+                  C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    out = f(n, _dp(rc), ip.ctypes.data_as(C.POINTER(C.c_int32)), _dp(dg), _dp(qb), float(delta), float(par), _dp(x), C.byref(dx))
+    return float(out), x, float(dx.value)
+
+
 def max_threads():
     return lib().vpo_max_threads()
 

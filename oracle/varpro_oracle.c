@@ -792,6 +792,17 @@ static double lmpar(int n, double *r, const int *ipvt, const double *diag, const
     return par;
 }
 
+/* test hook: MINPACK lmpar as restated above on a caller's factor (r: n x n column-major upper triangle, left untouched) */
+double vpo_lmpar(int n, const double *r, const int *ipvt, const double *diag, const double *qtb, double delta, double par,
+                 double *x, double *dxnorm_out) {
+    double *w = (double *)malloc(sizeof(double) * (size_t)(n * n + 3 * n));
+    double *rw = w, *sdiag = w + n * n, *wa1 = sdiag + n, *wa2 = wa1 + n;
+    memcpy(rw, r, sizeof(double) * (size_t)(n * n));
+    const double out = lmpar(n, rw, ipvt, diag, qtb, delta, par, x, sdiag, wa1, wa2, dxnorm_out);
+    free(w);
+    return out;
+}
+
 void vpo_lm_opts_default(vp_lm_opts *o) {
     /* LevenbergMarquardt::new() without the minpack-compat feature (Cargo.toml:19 enables none) */
     o->ftol = 30.0 * DBL_EPSILON;

@@ -125,6 +125,10 @@ void vpo_thin_svd(int m, int n, const double *A, double *U, double *sigma, doubl
 
 /* MINPACK enorm as used by the levenberg-marquardt crate */
 double vpo_enorm(int n, const double *x);
+/* MINPACK lmpar (== the levenberg-marquardt crate's determine_lambda_and_parameter_update) on a caller's pivoted QR
+ * factor: r n x n column-major (upper triangle used), ipvt, diag, qtb = first n of Q^T f; returns par, x = step */
+double vpo_lmpar(int n, const double *r, const int *ipvt, const double *diag, const double *qtb, double delta, double par,
+                 double *x, double *dxnorm_out);
 
 /*
  * Batched convenience used by the tests and by bench.py's cpu_baseline leg: B independent

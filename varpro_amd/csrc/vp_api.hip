@@ -1558,6 +1558,70 @@ int vp_debug_gram_evaluate(vp_batch *h, const void *alpha, double *out) {
     return o.finish(h);
 }
 
+extern "C++" {
+namespace {
+// one lane per record: the Gram fit kernel's trust-region sub-problem (lmpar_chol, vp_fit.hpp) exactly as
+// slot_scalar_phase<..., GRAM> instantiates it
+template <int Q>
+__global__ void debug_lmpar_gram_kernel(int64_t B, const double *Rj, const int32_t *ipvt, const double *diag, const double *qtb,
+                                        const double *delta, const double *par_in, double *out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double r[Q][Q], dg[Q], qb[Q], step[Q];
+    int ip[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        dg[i] = diag[b * Q + i];
+        qb[i] = qtb[b * Q + i];
+        ip[i] = ipvt[b * Q + i];
+        step[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) r[i][j] = Rj[(b * Q + i) * Q + j];
+    }
+    double dxnorm = 0.0;
+    const double par = vp::lmpar_chol<double, Q, false, (Q > 3)>(r, ip, dg, qb, delta[b], par_in[b], step, dxnorm);
+    double *o = out + b * (Q + 2);
+    o[0] = par;
+    o[1] = dxnorm;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) o[2 + i] = step[i];
+}
+} // namespace
+} // extern "C++"
+
+int vp_debug_lmpar_gram(int64_t B, int q, const double *Rj, const int32_t *ipvt, const double *diag, const double *qtb,
+                        const double *delta, const double *par_in, double *out) {
+    if (B <= 0 || !Rj || !ipvt || !diag || !qtb || !delta || !par_in || !out) return fail(VP_ERR_INVALID, "null argument");
+    if (q != 2 && q != 3 && q != 5) return fail(VP_ERR_UNSUPPORTED, "q must be 2, 3 or 5");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VP_ERR_NO_DEVICE, "no device");
+    const size_t nq = (size_t)B * q;
+    const size_t sizes[7] = {nq * q * sizeof(double), nq * sizeof(int32_t), nq * sizeof(double), nq * sizeof(double),
+                             (size_t)B * sizeof(double), (size_t)B * sizeof(double), (size_t)B * (q + 2) * sizeof(double)};
+    const void *src[6] = {Rj, ipvt, diag, qtb, delta, par_in};
+    void *d[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = VP_ERR_OK;
+    for (int i = 0; i < 7 && rc == VP_ERR_OK; ++i)
+        if (hipMalloc(&d[i], sizes[i]) != hipSuccess) rc = VP_ERR_HIP;
+    for (int i = 0; i < 6 && rc == VP_ERR_OK; ++i)
+        if (hipMemcpy(d[i], src[i], sizes[i], hipMemcpyHostToDevice) != hipSuccess) rc = VP_ERR_HIP;
+    if (rc == VP_ERR_OK) {
+        const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+        auto go = [&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            hipLaunchKernelGGL((debug_lmpar_gram_kernel<Q>), grid, block, 0, 0, B, (const double *)d[0], (const int32_t *)d[1],
+                               (const double *)d[2], (const double *)d[3], (const double *)d[4], (const double *)d[5], (double *)d[6]);
+        };
+        if (q == 2) go(std::integral_constant<int, 2>());
+        else if (q == 3) go(std::integral_constant<int, 3>());
+        else go(std::integral_constant<int, 5>());
+        if (hipGetLastError() != hipSuccess || hipMemcpy(out, d[6], sizes[6], hipMemcpyDeviceToHost) != hipSuccess) rc = VP_ERR_HIP;
+    }
+    for (int i = 0; i < 7; ++i)
+        if (d[i]) (void)hipFree(d[i]);
+    return rc == VP_ERR_OK ? VP_ERR_OK : fail(rc, "vp_debug_lmpar_gram: HIP call failed");
+}
+
 int vp_set_rhs_allreduce(vp_batch *h, vp_allreduce_fn fn, void *user, int64_t global_rhs_count) {
     VP_ENTER(h);
     if (fn) {
