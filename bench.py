@@ -667,7 +667,8 @@ def main():
             x_full()
             torch.cuda.synchronize()
             okx = (st_ev == 0) & (st_x == 0)
-            dJ = float(((J_x - J_ev).abs().amax(dim=(1, 2)) / J_ev.abs().amax(dim=(1, 2)))[okx].max())
+            dJ_all = ((J_x - J_ev).abs().amax(dim=(1, 2)) / J_ev.abs().amax(dim=(1, 2)))[okx]
+            dJ, dJ_med, dJ_share = float(dJ_all.max()), float(dJ_all.median()), float((dJ_all <= 1e-10).double().mean())
             dr = float(((r_x - r_ev).abs().amax(dim=1) / Y.abs().amax(dim=1))[okx].max())
             dC = float(((C_x - C_ev).abs().amax(dim=1) / C_ev.abs().amax(dim=1))[okx].max())
             bytes_xin = B * T * m * (3 + 1)            # Phi (n) + y
@@ -676,7 +677,11 @@ def main():
                 "workload": "vp_evaluate_with_basis, B=%d, m=%d, fp64, n=3, q=2, p=2: caller-evaluated Phi / dPhi in (device "
                             "pointers), device weighting + QR / solve + residual + Kaufman J" % (B, m),
                 "ms_phi_dphi_in_r_J_out": xf_ms, "ms_phi_in_c_cost_out": xi_ms,
-                "max_rel_diff_vs_vp_evaluate": {"c": dC, "r": dr, "J": dJ},
+                "max_rel_diff_vs_vp_evaluate": {"c": dC, "r": dr, "J": dJ, "J_median": dJ_med, "J_share_within_1e-10": dJ_share,
+                                                "note": "max over the 65 536 problems; the J maximum sits on the ~0.1 % of guesses at which "
+                                                        "D_k c is almost inside span(Phi) (the projector cancels most of its input): "
+                                                        "tests/test_gpu_eval_census.py holds both handles against the oracle on every "
+                                                        "problem and arbitrates those by long double (profiles/r04_eval_census.json)"},
                 "roofline": {"kernel": "ext_evaluate_kernel<double, 3, 2, 16, true> (columns loaded, not built)", "bound": "hbm",
                              "achieved": bytes_xfull / (xf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": bytes_xfull / (xf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bytes_xfull,
