@@ -164,6 +164,51 @@ def test_mrhs_config2_full_size_properties():
     bp.close()
 
 
+def test_mrhs_config2_full_size_against_the_oracle():
+    # BASELINE configs[2] at FULL size against the ORACLE itself (single thread, ~20 s: set_params on 16 384 right-hand
+    # sides, the 33.5 M x 3 Kaufman Jacobian through the S > q association order of
+    # src/solvers/levmar/mod.rs:172-186, and MINPACK's lmder QR-factoring that tall J every iteration -- the driver the
+    # device's Gram-based step replaces): one trait-level evaluation (r, C, cost, J through the cooperative kernels) and
+    # the whole global fit (same termination class, evaluation count, decay times, objective).
+    import json
+    d = synth.mrhs_triple_exp()
+    S, m = d["Y"].shape
+    assert (S, m) == (16384, 2048)
+    mdl = _triple(d["x"], d["tau_guess"])
+    ref = O.Problem(mdl, d["x"], d["Y"])
+    ref.set_params(d["tau_guess"])
+    bp = vp.BatchProblem(mdl, d["Y"][None], x=d["x"])
+    ev = bp.evaluate(d["tau_guess"][None])
+    assert ev["status"][0] == 0
+    Cr, rr = ref.linear_coefficients(), ref.residuals()
+    ymax = np.abs(d["Y"]).max()
+    e_c = np.abs(ev["C"][0] - Cr).max() / np.abs(Cr).max()
+    e_r = np.abs(ev["r"][0] - rr).max() / ymax
+    e_cost = abs(ev["cost"][0] - 0.5 * (rr ** 2).sum()) / (0.5 * (rr ** 2).sum())
+    Jr = ref.jacobian()
+    e_J = max(np.abs(ev["J"][0, k] - Jr[k]).max() / np.abs(Jr[k]).max() for k in range(3))
+    del Jr, ev
+    assert e_c <= TOL and e_r <= TOL and e_cost <= TOL and e_J <= 1e-10, (e_c, e_r, e_cost, e_J)
+    alpha, Cf, rep = bp.fit(d["tau_guess"][None])
+    ro = ref.fit()
+    ao = ref.params()
+    Co = ref.linear_coefficients()
+    out = {"evaluation": {"c": e_c, "r": e_r, "cost": e_cost, "J": e_J},
+           "fit": {"termination": [int(rep["termination"][0]), int(ro.termination)],
+                   "n_evals": [int(rep["n_evals"][0]), int(ro.n_evals)],
+                   "objective": [float(rep["objective"][0]), float(ro.objective)],
+                   "max_abs_dalpha": float(np.abs(alpha[0] - ao).max()),
+                   "max_rel_dC": float(np.abs(Cf[0] - Co).max() / np.abs(Co).max())}}
+    print(json.dumps(out))
+    assert (rep["termination"][0] > 0) == (ro.termination > 0)
+    assert abs(int(rep["n_evals"][0]) - int(ro.n_evals)) <= 1
+    assert np.abs(alpha[0] - ao).max() <= 1e-8 * np.abs(ao).max()
+    assert np.abs(Cf[0] - Co).max() <= 1e-7 * np.abs(Co).max()
+    # noise-free data: both objectives are rounding residue of a 1e9-sized sum of squares
+    assert max(rep["objective"][0], ro.objective) <= 1e-12 * 0.5 * (d["Y"] ** 2).sum()
+    bp.close()
+
+
 @pytest.mark.parametrize("m", [200, 1000])
 def test_mrhs_runtime_descriptor_models_beyond_128_rows(m):
     # multiple right-hand sides on the run-time descriptor kernels at 16 rows per lane: the unit-test double
