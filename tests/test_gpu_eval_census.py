@@ -18,7 +18,10 @@ Contract (north_star: 1e-10 relative on c, r, J), asserted on EVERY problem:
     problem by problem, by an 80-bit long-double evaluation (three-pass Gram-Schmidt QR): on every such problem the device
     -- descriptor handle and external-model handle -- must be AT LEAST AS CLOSE to it as the oracle is (and within 1e-7).
     Measured: the device is closer than the oracle on all of them, typically by 10-100 x (the printed
-    `long_double_arbitration` record).
+    `long_double_arbitration` record).  Both are backward stable -- the error of P_perp T is c(m) eps cond(Phi) |T| in
+    either -- and differ in c(m): the oracle, like the reference's nalgebra loops, sums its m-term dot products one after
+    another (c ~ m at worst: 1024 eps x 1.7e4 = 3.9e-9 |T|, measured 3.2e-9), the device reduces them as lane-local
+    partial sums + a wave tree (c ~ log m).
 """
 import json
 

@@ -219,7 +219,7 @@ def test_device_pointer_mode_with_torch_tensors():
 
 
 def test_large_batch_properties_at_full_size():
-    # BASELINE configs[1] at full size: size-independent properties instead of the (slow) oracle:
+    # BASELINE configs[1] at full size: size-independent properties (the oracle on ALL 4 096 problems: test_gpu_census.py):
     # P_perp idempotence/orthogonality:  r ⟂ range(Phi_w)  and  J_k ⟂ range(Phi_w);  cost = 1/2 |r|^2.
     B, m = 4096, 1024
     d = synth.double_exp_batch(B, m=m, noise=1e-3)
@@ -278,7 +278,8 @@ def test_rank_deficient_basis_takes_the_truncated_svd_branch():
 
 
 def test_headline_batch_properties_at_65536():
-    # BASELINE configs[3] per-GPU shard / north_star headline size: properties that need no oracle.
+    # BASELINE configs[3] per-GPU shard / north_star headline size: properties that need no oracle (the oracle on all
+    # 65 536 problems -- whole fits and single evaluations: test_gpu_census.py, test_gpu_eval_census.py).
     B, m = 65536, 1024
     d = synth.double_exp_batch(B, m=m, noise=1e-3)
     mdl = double_exp_builder_model(d["x"], d["tau_guess"][0])
