@@ -25,8 +25,8 @@ from varpro_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _double_exp_census(B, first=0):
-    d = synth.double_exp_batch(B, m=1024, first_problem=first, noise=1e-3)
+def _double_exp_census(B, first=0, m=1024):
+    d = synth.double_exp_batch(B, m=m, first_problem=first, noise=1e-3)
     mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0])
     bp = vp.BatchProblem(mdl, d["Y"], x=d["x"])
     a, _c, rep = bp.fit(d["tau_guess"])
@@ -39,19 +39,28 @@ def _double_exp_census(B, first=0):
     return res
 
 
-def _assert_fp64_contract(res):
+def _assert_fp64_contract(res, max_evals_slack=0.0):
     assert res["success_class_disagreements"] == 0, res["disagreements"]
     assert res["failures_by_code_device"] == res["failures_by_code_oracle"]
     assert res["failed_on_both"] == res["failed_device"] == res["failed_oracle"]
     assert res["objective_rel_diff_median_common_successes"] <= 1e-12
     assert res["objective_rel_diff_max_common_successes"] <= 1e-6
     assert res["share_evals_within_3"] >= 0.95
-    assert res["max_evals_device"] == res["max_evals_oracle"]
+    assert abs(res["max_evals_device"] - res["max_evals_oracle"]) <= max_evals_slack * res["max_evals_oracle"]
     assert abs(res["sum_evals_device"] - res["sum_evals_oracle"]) <= 0.02 * res["sum_evals_oracle"]
 
 
 def test_census_configs1_all_4096_problems():
     _assert_fp64_contract(_double_exp_census(4096))
+
+
+def test_census_streamed_bench_leg_m10000_all_16384_problems():
+    # bench.py's `streamed` leg at full size (m = 10 000: beyond every register-resident set, the length-agnostic
+    # blk_fit_kernel of vp_block.hpp): the oracle fits all 16 384 problems (~10 s on 16 threads)
+    # (the longest fit creeps along a flat valley for > 100 evaluations; its count is 120 here and 126 in the oracle -- the
+    # TSQR carry and the oracle's Householder sweep round differently -- hence the 10 % on the largest count; every other
+    # clause is the contract of the resident kernels)
+    _assert_fp64_contract(_double_exp_census(16384, m=10000), max_evals_slack=0.1)
 
 
 def test_census_configs3_shard_all_65536_problems():
