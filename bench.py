@@ -625,6 +625,7 @@ def main():
                 _lib.check(bp.lib.vp_evaluate(bp._h, vptr(guess), vptr(r_ev), None, vptr(C_ev), vptr(cost_ev), vptr(st_ev)))
 
             ev_ms = event_ms_each(ev_call, 20, 3)
+            ev_ms_b2b = event_ms(ev_call, 20, 3)
             ev_r_ms = event_ms_each(ev_call_r, 20, 3)
             bytes_ev = B * T * (m * (2 + 2) + 3 + 2)
             bytes_ev_r = B * T * (m * 2 + 3 + 2)
@@ -639,7 +640,8 @@ def main():
                 "roofline": {"kernel": "evaluate_kernel<MODE 2, FULL> (split: [exp | y] factored and r written, then the derivative "
                                        "columns rebuilt, projected and written)", "bound": "hbm", "achieved": bytes_ev / (ev_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_ev / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "bytes_per_launch": bytes_ev, "traffic": committed_traffic("evaluate_kernel"),
+                             "bytes_per_launch": bytes_ev, "avg_launch_ms": ev_ms, "back_to_back_ms_per_launch": ev_ms_b2b,
+                             "traffic": committed_traffic("evaluate_kernel"),
                              "traffic_source": traffic_source("evaluate_kernel")},
             }
 
@@ -662,6 +664,7 @@ def main():
                                                           vptr(cost_x), vptr(st_x)))
 
             xf_ms = event_ms_each(x_full, 20, 3)
+            xf_ms_b2b = event_ms(x_full, 20, 3)
             xi_ms = event_ms_each(x_in, 20, 3)
             ev_call()
             x_full()
@@ -685,6 +688,7 @@ def main():
                 "roofline": {"kernel": "ext_evaluate_kernel<double, 3, 2, 16, true> (columns loaded, not built)", "bound": "hbm",
                              "achieved": bytes_xfull / (xf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": bytes_xfull / (xf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bytes_xfull,
+                             "avg_launch_ms": xf_ms, "back_to_back_ms_per_launch": xf_ms_b2b,
                              "input_stream_GBps": B * T * m * (3 + 2 + 1) / (xf_ms * 1e-3) / 1e9,
                              "traffic": committed_traffic("ext_evaluate_kernel"), "traffic_source": traffic_source("ext_evaluate_kernel")},
                 "roofline_set_params": {"kernel": "ext_evaluate_kernel<double, 3, 1, 16, false> (Phi and y in; c, cost out)", "bound": "hbm",
