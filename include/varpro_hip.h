@@ -301,9 +301,10 @@ int vp_basis(vp_batch *h, const void *alpha, void *Phi_out, void *dPhi_out, int 
  *                              one pass over the columns.  dPhi may be NULL when J_out is.
  *   vp_residuals, vp_jacobian (needs the dPhi of the last vp_set_params_with_basis), vp_linear_coeffs, vp_cost,
  *   vp_params, vp_weighted_data, vp_set_observations, vp_best_fit, vp_statistics, vp_synchronize work as on any handle.
- *   vp_set_params / vp_evaluate / vp_basis / vp_fit: VP_ERR_UNSUPPORTED -- the device cannot evaluate the model; the LM
- *   loop is the caller's (the reference's own LevenbergMarquardt::minimize over the trait, src/solvers/levmar/mod.rs:247;
- *   tests/c/test_external_model.c drives one).
+ *   vp_set_params / vp_evaluate / vp_basis / vp_fit: VP_ERR_UNSUPPORTED -- the device cannot evaluate the model.  A FIT
+ *   of such a batch runs by reverse communication: vp_fit_begin / vp_fit_step_with_basis / vp_fit_end below (the
+ *   device keeps the LM loop, the caller keeps the model); one LM driver per problem on the host over the trait-level
+ *   entries above (tests/c/test_external_model.c drives one) remains possible.
  */
 int vp_batch_create_external(vp_batch **h, int32_t n_basis, int32_t n_params, int32_t n_pairs, const int32_t *pair_basis,
                              const int32_t *pair_param, int dtype, int64_t m, int64_t S, int64_t B, const void *Y,
@@ -316,6 +317,52 @@ int vp_evaluate_with_basis(vp_batch *h, const void *alpha, const void *Phi, cons
 /* ---- solver surface ------------------------------------------------------------------- */
 
 void vp_lm_opts_default(vp_lm_opts *opts, int dtype);
+
+/*
+ * == LevMarSolver::fit (src/solvers/levmar/mod.rs:238-254) -> LevenbergMarquardt::minimize (call site :247) for a BATCH of
+ * problems whose model only the caller can evaluate -- any SeparableNonlinearModel (src/model/mod.rs:239-363) on a handle
+ * made by vp_batch_create_external -- by REVERSE COMMUNICATION.  The reference's driver talks to the problem through three
+ * trait calls: set_params(x_trial) (:42-73, which evaluates the model, :43-45), residuals() (:91-95) and, at accepted
+ * points only, jacobian() (:101-201, which asks the model for eval_partial_deriv(k), :141).  Here the device keeps the
+ * whole driver -- one LM record per problem: trust region, lmpar, accept / reject, the crate's termination tests -- and
+ * the model's answers cross the boundary as arrays; what comes back per step is alpha_trial [B][q] and one word per
+ * problem.  Neither the residuals nor the Jacobian J [B][q][m] are ever written to memory.
+ *
+ *   vp_fit_begin(h, opts, alpha0, flags)
+ *       starts a fit of all B problems from alpha0 [B][q] (opts == NULL: vp_lm_opts_default).  The first step takes the
+ *       columns at alpha0.  flags: 0, or VP_FIT_DERIVATIVES_ON_ACCEPT (below).
+ *   vp_fit_step_with_basis(h, Phi, dPhi, alpha_trial_out, want_out, n_active_out)
+ *       Phi  [B][n][m], dPhi [B][n_pairs][m]: UNWEIGHTED model columns at the trial points the previous step returned
+ *       (alpha0 for the first step), laid out as for vp_set_params_with_basis.  One launch runs, for every problem still
+ *       active, one LM iteration: the evaluation at the trial point, the accept / reject decision and termination tests,
+ *       at an accepted point the pivoted QR of the Kaufman Jacobian, and the next trust-region step.  Outputs (any may
+ *       be NULL; same address space as the handle's other arrays):
+ *         alpha_trial_out [B][q]  where the columns are wanted next; for a finished problem its final parameters
+ *         want_out        [B]     VP_WANT_BASIS | VP_WANT_DERIVATIVES bits, 0 = the problem has terminated.  Entries of
+ *                                 Phi / dPhi of problems that do not want them are never read.
+ *         n_active_out    host    number of problems still running (reading it synchronises the handle's stream; pass
+ *                                 NULL to keep a device-pointer pipeline asynchronous and look every few steps)
+ *       Default protocol: every step carries Phi AND dPhi (want is 3 or 0) and is one LM iteration of every problem.
+ *       VP_FIT_DERIVATIVES_ON_ACCEPT: the driver's own call order -- trial points want Phi only (want = 1, dPhi is not
+ *       read and may be NULL); a problem that ACCEPTS its trial point answers want = 3 with the same alpha_trial and
+ *       forms its Jacobian from the columns of the next step.  eval_partial_deriv is then evaluated exactly where the
+ *       reference evaluates it, at the price of a second pass over Phi per accepted point.
+ *   vp_fit_end(h, alpha_out, C_out, rep)
+ *       FitResult::nonlinear_parameters / linear_coefficients (src/fit.rs:113-115) and the MinimizationReport of every
+ *       problem (rep[b].termination == VP_TERM_NOT_RUN for a problem the caller stopped stepping before it terminated;
+ *       its best point so far is returned).  Afterwards the handle holds alpha, C, cost and status of the fitted point
+ *       (vp_params, vp_linear_coeffs, vp_cost, vp_summary*, vp_reduce_cost); entries that need the MODEL at that point
+ *       (vp_residuals, vp_jacobian, vp_best_fit, vp_statistics) first need its columns: vp_set_params_with_basis.
+ * Every problem terminates after at most patience*(q+1) evaluations (TerminationReason::LostPatience), so stepping until
+ * n_active == 0 always ends.  Covered shapes: single right-hand side, m >= n, the (n, q, pairs, m) of the compiled step
+ * kernels (VP_ERR_UNSUPPORTED from vp_fit_begin otherwise).
+ */
+enum { VP_FIT_DERIVATIVES_ON_ACCEPT = 1 };
+enum { VP_WANT_BASIS = 1, VP_WANT_DERIVATIVES = 2 };
+int vp_fit_begin(vp_batch *h, const vp_lm_opts *opts, const void *alpha0, int flags);
+int vp_fit_step_with_basis(vp_batch *h, const void *Phi, const void *dPhi, void *alpha_trial_out, int32_t *want_out,
+                           int64_t *n_active_out);
+int vp_fit_end(vp_batch *h, void *alpha_out, void *C_out, vp_report *rep);
 
 /*
  * == LevMarSolver::fit (src/solvers/levmar/mod.rs:238-254), i.e.

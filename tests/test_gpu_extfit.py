@@ -1,0 +1,316 @@
+"""Batched LM fit of CALLER-EVALUATED models by reverse communication: the reference's
+`LevMarSolver::fit` (/root/reference/src/solvers/levmar/mod.rs:238-254) works with ANY `SeparableNonlinearModel`
+(/root/reference/src/model/mod.rs:239-363); here the device keeps one LM driver per problem (vp_fit_begin /
+vp_fit_step_with_basis / vp_fit_end, varpro_amd/csrc/vp_extfit.hpp) and the model's columns enter step by step --
+evaluated by numpy on the host or by torch on the device.  The checker is the oracle driven by THE SAME closures
+(`oracle_problem`): same success class on every problem, same minimum (objective to rounding in the median, 1e-6 at
+worst), evaluation counts within 3 on >= 95 %.  Parameters agree to the sqrt(ftol)-limited accuracy of an
+ftol-terminated fit."""
+import numpy as np
+import pytest
+
+import varpro_amd as vp
+from test_gpu_external import (gauss, gauss_dmu, gauss_dsg, lorentz, lorentz_dga, lorentz_dmu, oracle_problem, peaks_data,
+                               peaks_model, pvoigt, voigt_model)
+
+pytestmark = pytest.mark.gpu
+
+
+def host_model(cm):
+    def evaluate(alpha, want):
+        a = np.asarray(alpha)
+        return cm.eval_batch(a), cm.derivs_batch(a)
+    return evaluate
+
+
+def torch_peaks_model(x, device):
+    """the Gauss + Lorentz + offset model of `peaks_model` evaluated by torch ON THE DEVICE for the whole batch"""
+    import torch
+    xt = torch.as_tensor(x, device=device)[None, :]
+
+    def evaluate(alpha, want):
+        mu1, s1, mu2, g2 = (alpha[:, k:k + 1] for k in range(4))
+        d1 = xt - mu1
+        gs = torch.exp(-0.5 * (d1 / s1) ** 2)
+        d2 = xt - mu2
+        den = d2 * d2 + g2 * g2
+        lz = g2 * g2 / den
+        Phi = torch.stack([gs, lz, torch.ones_like(gs)], 1)
+        dPhi = torch.stack([gs * d1 / s1 ** 2, gs * d1 ** 2 / s1 ** 3, 2 * g2 ** 2 * d2 / den ** 2, 2 * g2 * d2 ** 2 / den ** 2], 1)
+        return Phi.contiguous(), dPhi.contiguous()
+    return evaluate
+
+
+def oracle_fits(cm, Y, guess, w=None, opts=None):
+    B = Y.shape[0]
+    term = np.zeros(B, dtype=np.int32)
+    nev = np.zeros(B, dtype=np.int32)
+    obj = np.zeros(B)
+    alpha = np.zeros_like(guess)
+    for b in range(B):
+        p = oracle_problem(cm, Y[b], w=w)
+        p.set_params(guess[b])
+        rep = p.fit(opts)
+        term[b], nev[b], obj[b] = rep.termination, rep.n_evals, rep.objective
+        alpha[b] = p.params()
+    return alpha, term, nev, obj
+
+
+def compare_with_oracle(rep, alpha, ref, obj_median=1e-12, obj_max=1e-6, evals_share=0.95):
+    a_ref, term, nev, obj = ref
+    rep = vp.BatchProblem.report_to_numpy(rep)
+    ok = term > 0
+    assert ((rep["termination"] > 0) == ok).all(), "success class differs on problems %s" % np.nonzero((rep["termination"] > 0) != ok)[0][:8]
+    assert (rep["termination"][~ok] == term[~ok]).all()  # failures by the same termination reason
+    rel = np.abs(rep["objective"] - obj)[ok] / np.maximum(obj[ok], 1e-300)
+    assert np.median(rel) <= obj_median and rel.max() <= obj_max, (np.median(rel), rel.max())
+    dev = np.abs(rep["n_evals"] - nev)
+    assert (dev <= 3).mean() >= evals_share, (dev <= 3).mean()
+    rel_a = (np.abs(np.asarray(alpha) - a_ref) / np.abs(a_ref).max(1, keepdims=True)).max(1)[ok]
+    assert (rel_a <= 1e-6).mean() >= 0.9, np.sort(rel_a)[-5:]
+    return dict(same_evals=float((dev == 0).mean()), within3=float((dev <= 3).mean()), obj_median=float(np.median(rel)),
+                obj_max=float(rel.max()), failed=int((~ok).sum()))
+
+
+@pytest.mark.parametrize("m", [200, 1000])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_stepped_fit_matches_the_oracle_and_both_protocols_agree(m, weighted):
+    rng = np.random.default_rng(100 + m)
+    B = 48
+    x = np.linspace(0.0, 10.0, m)
+    cm = peaks_model(x)
+    truth, _c, Y, guess = peaks_data(rng, B, x, noise=1e-2)
+    w = (0.5 + rng.random(m)) if weighted else None
+    ref = oracle_fits(cm, Y, guess, w)
+    bp = vp.BatchProblem(cm.shape(), Y, weights=w)
+    a1, C1, rep1, steps1 = bp.fit_with_model(host_model(cm), guess)
+    compare_with_oracle(rep1, a1, ref)
+    # coefficients of the fitted point
+    for b in range(0, B, 7):
+        if ref[1][b] > 0:
+            p = oracle_problem(cm, Y[b], w=w)
+            p.set_params(a1[b])
+            assert np.abs(C1[b] - p.linear_coefficients()).max() <= 1e-9 * np.abs(C1[b]).max()
+    # the handle's cached state is the fitted point; the model at that point has to be supplied again
+    assert np.array_equal(np.asarray(bp.params()), a1)
+    assert np.array_equal(np.asarray(bp.linear_coefficients()), C1)
+    assert np.allclose(np.asarray(bp.cost()), rep1["objective"], rtol=0, atol=0, equal_nan=True)
+    with pytest.raises(vp.VarproHipError):
+        bp.residuals()
+    bp.set_params_with_basis(a1, cm.eval_batch(a1), cm.derivs_batch(a1))
+    r = np.asarray(bp.residuals())
+    okb = rep1["termination"] > 0
+    assert np.abs(0.5 * (r ** 2).sum(1) - rep1["objective"])[okb].max() <= 1e-9 * rep1["objective"][okb].max()
+    # the driver's own call order (derivatives only at accepted points): the same numbers, more steps
+    a2, C2, rep2, steps2 = bp.fit_with_model(host_model(cm), guess, derivatives_on_accept=True)
+    assert np.array_equal(rep1["termination"], rep2["termination"]) and np.array_equal(rep1["n_evals"], rep2["n_evals"])
+    assert np.array_equal(a1, a2) and np.array_equal(C1, C2)
+    assert np.array_equal(rep1["objective"], rep2["objective"])
+    assert steps2 > steps1
+    bp.close()
+
+
+def test_derivatives_are_only_requested_at_accepted_points():
+    """VP_FIT_DERIVATIVES_ON_ACCEPT: want == 1 for trial points, want == 3 with an unchanged alpha_trial right after an
+    accepted step, and the number of derivative requests per problem equals the oracle's jacobian() calls"""
+    rng = np.random.default_rng(5)
+    m, B = 256, 16
+    x = np.linspace(0.0, 10.0, m)
+    cm = peaks_model(x)
+    _t, _c, Y, guess = peaks_data(rng, B, x, noise=1e-2)
+    bp = vp.BatchProblem(cm.shape(), Y)
+    bp.fit_begin(guess, derivatives_on_accept=True)
+    alpha, want = guess.copy(), np.full(B, 3, dtype=np.int32)
+    n_deriv = np.zeros(B, dtype=int)
+    n_eval = np.zeros(B, dtype=int)
+    for step in range(400):
+        Phi = cm.eval_batch(alpha)
+        dPhi = cm.derivs_batch(alpha)
+        dPhi[(want & 2) == 0] = np.nan  # columns nobody asked for must not be read
+        Phi[want == 0] = np.nan
+        prev_alpha, prev_want = alpha.copy(), want.copy()
+        n_deriv += (want & 2) != 0
+        alpha, want, nact = bp.fit_step_with_basis(Phi, dPhi)
+        alpha, want = np.array(alpha), np.array(want)
+        # a problem that was asked for Phi alone and now wants derivatives stays at the same point
+        deferred = (prev_want == 1) & (want == 3)
+        assert np.array_equal(alpha[deferred], prev_alpha[deferred])
+        # residual evaluations: the first step, afterwards every step that was asked for Phi alone
+        n_eval += (prev_want != 0) if step == 0 else (prev_want == 1)
+        if nact == 0:
+            break
+    a, _C, rep = bp.fit_end()
+    assert (rep["termination"] != 0).all() and np.isfinite(a).all()
+    for b in range(B):
+        p = oracle_problem(cm, Y[b])
+        p.set_params(guess[b])
+        r = p.fit()
+        n_set, n_jac = p.counters()
+        if abs(r.n_evals - rep["n_evals"][b]) == 0:
+            assert n_deriv[b] == n_jac, (b, n_deriv[b], n_jac)
+    assert np.array_equal(n_eval, rep["n_evals"])
+    bp.close()
+
+
+def test_census_4096_gauss_lorentz_fits_host_and_device_models():
+    """B = 4096 Gauss + Lorentz + offset problems, the columns evaluated by numpy on the host AND by
+    torch on the device; the same success class as the oracle on EVERY problem, objective 1e-12 median / 1e-6 max,
+    evaluation counts within 3 on >= 95 %"""
+    import torch
+    rng = np.random.default_rng(2024)
+    m, B = 512, 4096
+    x = np.linspace(0.0, 10.0, m)
+    cm = peaks_model(x)
+    _truth, _c, Y, guess = peaks_data(rng, B, x, noise=1e-2)
+    ref = oracle_fits(cm, Y, guess)
+    # (a) the model evaluated by numpy on the host, host-pointer handle
+    bp = vp.BatchProblem(cm.shape(), Y)
+    a_h, _C, rep_h, _steps = bp.fit_with_model(host_model(cm), guess)
+    s_h = compare_with_oracle(rep_h, a_h, ref)
+    bp.close()
+    # (b) the model evaluated by a torch kernel on the device, device-pointer handle: nothing but alpha_trial crosses
+    dev = torch.device("cuda:0")
+    bpd = vp.BatchProblem(cm.shape(), torch.as_tensor(Y, device=dev))
+    a_d, _Cd, rep_d, steps = bpd.fit_with_model(torch_peaks_model(x, dev), torch.as_tensor(guess, device=dev), check_every=4)
+    s_d = compare_with_oracle(rep_d, a_d.cpu().numpy(), ref)
+    bpd.close()
+    print("census external fit: host model %s; device model %s; %d steps" % (s_h, s_d, steps))
+
+
+def test_census_4096_hard_starts():
+    """the same census from starts up to 27 % off (a few percent of the fits fail or wander for hundreds of evaluations
+    through regions where a peak has left the window and its column underflows).  Failures must be the oracle's failures;
+    what cannot be demanded is the same END of a 100+-evaluation trajectory through an ill-conditioned valley: device and
+    oracle agree to ~1e-10 per evaluation and such a path amplifies that.  Contract: same success class on >= 99.9 %, every
+    exception a fit that took more than 50 evaluations on one side or ended with a basis column in the denormal range"""
+    rng = np.random.default_rng(2024)
+    m, B = 512, 4096
+    x = np.linspace(0.0, 10.0, m)
+    cm = peaks_model(x)
+    _truth, _c, Y, guess = peaks_data(rng, B, x, noise=1e-2)
+    guess = guess * (1 + rng.uniform(-0.15, 0.15, guess.shape))
+    a_ref, term, nev, obj = oracle_fits(cm, Y, guess)
+    bp = vp.BatchProblem(cm.shape(), Y)
+    a, _C, rep, _steps = bp.fit_with_model(host_model(cm), guess)
+    bp.close()
+    same = (rep["termination"] > 0) == (term > 0)
+    assert same.mean() >= 0.999, np.nonzero(~same)[0]
+    for b in np.nonzero(~same)[0]:
+        # ... or a fit one side of which ended where a peak has left the window: its basis column (norm < 1e-100) and the
+        # Jacobian columns of its parameters are in the DENORMAL range, where the oracle's scaled norms (enorm) still see a
+        # column of 1e-313 and divide by it (-> Numerical) while the device's plain sums of squares see a zero column
+        tiny = min(np.linalg.norm(cm.eval_batch(np.asarray(pt)[None])[0], axis=1).min() for pt in (a[b], a_ref[b]))
+        assert max(rep["n_evals"][b], nev[b]) > 50 or tiny < 1e-100, (b, rep[b], term[b], nev[b], tiny)
+    both = (term > 0) & (rep["termination"] > 0)
+    rel = np.abs(rep["objective"] - obj)[both] / obj[both]
+    # (fits that converge to DIFFERENT local minima of this multi-modal problem are counted, not hidden)
+    assert np.median(rel) <= 1e-12 and (rel <= 1e-6).mean() >= 0.995, (np.median(rel), (rel <= 1e-6).mean())
+    dev = np.abs(rep["n_evals"] - nev)
+    assert (dev <= 3).mean() >= 0.95
+    assert (term <= 0).sum() >= 5  # the census does contain failures
+    print("hard starts: same class %.4f, failed (oracle) %d, objective within 1e-6 on %.4f, evals within 3 on %.4f"
+          % (same.mean(), (term <= 0).sum(), (rel <= 1e-6).mean(), (dev <= 3).mean()))
+
+
+def test_three_parameter_basis_weighted_and_fp32():
+    rng = np.random.default_rng(31)
+    m, B = 400, 32
+    x = np.linspace(0.0, 10.0, m)
+    cm = voigt_model(x)
+    mu, wd, eta = rng.uniform(4, 6, B), rng.uniform(0.5, 1.0, B), rng.uniform(0.2, 0.8, B)
+    truth = np.stack([mu, wd, eta], 1)
+    Y = 20 * pvoigt(x, mu[:, None], wd[:, None], eta[:, None]) + 3 * x / 10.0 + 1.0
+    Y = Y + 1e-2 * rng.standard_normal(Y.shape)
+    guess = truth * (1 + rng.uniform(-0.05, 0.05, (B, 3)))
+    w = 0.5 + rng.random(m)
+    ref = oracle_fits(cm, Y, guess, w)
+    bp = vp.BatchProblem(cm.shape(), Y, weights=w)
+    a, _C, rep, _s = bp.fit_with_model(host_model(cm), guess)
+    # (eta of a pseudo-Voigt peak is weakly determined: the fits end on ftol in a flat valley, where the last accept /
+    # reject decisions hang on the 12th digit of ||r|| -- counts differ by up to 5 on a few of the 32 problems)
+    compare_with_oracle(rep, a, ref, evals_share=0.8)
+    assert (np.abs(rep["n_evals"] - ref[2]) <= 6).all()
+    bp.close()
+    # fp32 handle: the same minimum to single precision
+    cm32 = voigt_model(x)
+    cm32.dtype = np.dtype(np.float32)
+    bp32 = vp.BatchProblem(cm32.shape(), Y.astype(np.float32), weights=w.astype(np.float32))
+    a32, _C32, rep32, _s = bp32.fit_with_model(host_model(cm32), guess.astype(np.float32))
+    ok = (ref[1] > 0) & (rep32["termination"] > 0)
+    assert ok.mean() >= 0.9
+    assert (np.abs(rep32["objective"] - ref[3])[ok] <= 2e-3 * ref[3][ok]).all()
+    assert (np.abs(a32 - ref[0])[ok] <= 2e-2 * np.abs(ref[0][ok])).all()
+    bp32.close()
+
+
+def test_lm_options_and_failures_follow_the_oracle():
+    """patience, tolerances, a model error at a trial point (residuals() == None -> TerminationReason::User)"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(41)
+    m, B = 300, 24
+    x = np.linspace(0.0, 10.0, m)
+    cm = peaks_model(x)
+    _t, _c, Y, guess = peaks_data(rng, B, x, noise=1e-2)
+    solver = vp.LevenbergMarquardt().with_patience(2).with_ftol(1e-6).with_xtol(1e-6).with_stepbound(10.0)
+    opts = O.default_opts(patience=2, ftol=1e-6, xtol=1e-6, stepbound=10.0)
+    ref = oracle_fits(cm, Y, guess, opts=opts)
+    bp = vp.BatchProblem(cm.shape(), Y)
+    a, _C, rep, _s = bp.fit_with_model(host_model(cm), guess, solver=solver)
+    assert np.array_equal(rep["termination"] > 0, ref[1] > 0)
+    assert (np.abs(rep["n_evals"] - ref[2]) <= 3).mean() >= 0.9
+    assert (rep["n_evals"] <= 2 * 5).all()
+    # a model that returns NaN for problem 3 from its second evaluation on
+    calls = [0]
+
+    def bad_model(alpha, want):
+        calls[0] += 1
+        Phi, dPhi = cm.eval_batch(np.asarray(alpha)), cm.derivs_batch(np.asarray(alpha))
+        if calls[0] >= 2:
+            Phi[3, 0, 10] = np.nan
+        return Phi, dPhi
+    a, _C, rep, _s = bp.fit_with_model(bad_model, guess)
+    assert rep["termination"][3] == -1 and rep["n_evals"][3] == 2  # VP_TERM_USER at the second evaluation
+    assert (rep["termination"][np.arange(B) != 3] > 0).all()
+    bp.close()
+
+
+def test_refusals():
+    x = np.linspace(0.0, 10.0, 64)
+    cm = peaks_model(x)
+    a = np.tile([3.0, 0.7, 6.4, 0.9], (2, 1))
+    bp = vp.BatchProblem(cm.shape(), np.ones((2, 64)))
+    with pytest.raises(vp.VarproHipError):  # step without begin
+        bp._xf_trial, bp._xf_want = bp._empty((2, 4)), bp._empty((2,), np.int32)
+        bp.fit_step_with_basis(cm.eval_batch(a), cm.derivs_batch(a))
+    bp.fit_begin(a)
+    with pytest.raises(vp.VarproHipError):  # end before the first step
+        bp.fit_end()
+    with pytest.raises(vp.VarproHipError):  # the default protocol needs dPhi
+        bp.fit_step_with_basis(cm.eval_batch(a), None)
+    bp.close()
+    # descriptor models fit with vp_fit
+    mdl = vp.multi_exponential_model(x, [1.0, 3.0])
+    bp = vp.BatchProblem(mdl, np.ones((2, 64)), x=x)
+    with pytest.raises(vp.VarproHipError) as e:
+        bp.fit_begin(a[:, :2])
+    assert e.value.code == -2
+    bp.close()
+
+
+def test_model_without_any_derivative_column_has_a_zero_jacobian():
+    """only invariant functions and q > 0 -- the resident evaluate kernel without derivative columns has no
+    Jacobian store; J must come back as zeros, not as uninitialised memory"""
+    rng = np.random.default_rng(3)
+    m, B = 128, 4
+    x = np.linspace(0.0, 1.0, m)
+    Phi = np.stack([[np.ones(m), x, x * x]] * B)
+    Y = rng.standard_normal((B, m))
+    bp = vp.BatchProblem(vp.ExternalModel(3, 2, []), Y)
+    alpha = rng.random((B, 2))
+    J0 = bp._empty((B, 2, m))
+    J0[:] = 7.0
+    got = bp.evaluate_with_basis(alpha, Phi, None)
+    assert got["J"] is not None and np.array_equal(np.asarray(got["J"]), np.zeros((B, 2, m)))
+    bp.set_params_with_basis(alpha, Phi)
+    assert np.array_equal(np.asarray(bp.jacobian()), np.zeros((B, 2, m)))
+    bp.close()

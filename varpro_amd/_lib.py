@@ -24,6 +24,8 @@ VP_FLAG_DEVICE_PTRS, VP_FLAG_T_PER_PROBLEM, VP_FLAG_W_PER_PROBLEM, VP_FLAG_OWN_S
 VP_FLAG_NO_GRID_RECURRENCE = 16
 VP_FLAG_STREAM_ROWS = 32
 VP_BASIS_SKIP_INVARIANT = 1
+VP_FIT_DERIVATIVES_ON_ACCEPT = 1
+VP_WANT_BASIS, VP_WANT_DERIVATIVES = 1, 2
 VP_KERNEL_EVALUATE, VP_KERNEL_BASIS, VP_KERNEL_FIT = 0, 1, 2
 VP_ST_OK, VP_ST_NONFINITE, VP_ST_NOT_EVALUATED = 0, 1, 2
 
@@ -46,7 +48,7 @@ ABI_SYMBOLS = [
     "vp_best_fit", "vp_debug_gram_evaluate", "vp_debug_lmpar_gram", "vp_statistics", "vp_summary", "vp_summary_device", "vp_set_rhs_allreduce", "vp_set_fit_kernel", "vp_set_timing", "vp_last_kernel_ms", "vp_synchronize", "vp_last_error",
     "vp_last_error_detail", "vp_version", "vp_device_count",
     "vp_batch_create_external", "vp_set_params_with_basis", "vp_jacobian_with_derivatives", "vp_evaluate_with_basis",
-    "vp_reduce_cost",
+    "vp_reduce_cost", "vp_fit_begin", "vp_fit_step_with_basis", "vp_fit_end",
 ]
 
 
@@ -109,6 +111,9 @@ def load():
     lib.vp_set_params_with_basis.argtypes = [vp, vp, vp, vp]
     lib.vp_jacobian_with_derivatives.argtypes = [vp, vp, vp, vp]
     lib.vp_evaluate_with_basis.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.vp_fit_begin.argtypes = [vp, C.POINTER(LmOpts), vp, C.c_int]
+    lib.vp_fit_step_with_basis.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int64)]
+    lib.vp_fit_end.argtypes = [vp, vp, vp, vp]
     lib.vp_batch_destroy.argtypes = [vp]
     lib.vp_batch_destroy.restype = None
     lib.vp_set_params.argtypes = [vp, vp]

@@ -414,6 +414,68 @@ class BatchProblem:
             Cm = Cm.reshape(self.B, self.n)
         return a, Cm, rep
 
+    # ---- batched fit of a caller-evaluated model by reverse communication (vp_fit_begin / _step_with_basis / _end) ----
+    @_device_entry
+    def fit_begin(self, alpha0, solver=None, derivatives_on_accept=False):
+        """== LevMarSolver::fit (src/solvers/levmar/mod.rs:238-254) for a batch whose model the CALLER evaluates: the
+        device keeps one LM driver per problem, the model's columns enter step by step (``fit_step_with_basis``).
+        The first step takes the columns at alpha0."""
+        solver = solver or LevenbergMarquardt(self.np_dtype)
+        opts = solver._c()
+        a = self._as_array(alpha0).reshape(self.B, self.q)
+        flags = _lib.VP_FIT_DERIVATIVES_ON_ACCEPT if derivatives_on_accept else 0
+        check(self.lib.vp_fit_begin(self._h, C.byref(opts), self._ptr(a), flags))
+        self._have_params = False
+        self._xf_trial = self._empty((self.B, self.q))
+        self._xf_want = self._empty((self.B,), np.int32)
+
+    @_device_entry
+    def fit_step_with_basis(self, Phi, dPhi=None, want_count=True):
+        """one LM iteration of every active problem (vp_fit_step_with_basis): Phi (B, n, m) / dPhi (B, p, m) at the trial
+        points of the previous step -> (alpha_trial (B, q), want (B,) int32 of VP_WANT_* bits, n_active or None).
+        The returned arrays are REUSED by the next step."""
+        Phi = self._as_array(Phi).reshape(self.B, self.n, self.m)
+        dPhi = None if dPhi is None else self._as_array(dPhi).reshape(self.B, self.p, self.m)
+        self._ext_keep = (Phi, dPhi)
+        nact = C.c_int64(0)
+        check(self.lib.vp_fit_step_with_basis(self._h, self._ptr(Phi), self._ptr(dPhi), self._ptr(self._xf_trial),
+                                              self._ptr(self._xf_want), C.byref(nact) if want_count else None))
+        return self._xf_trial, self._xf_want, (int(nact.value) if want_count else None)
+
+    @_device_entry
+    def fit_end(self, want_coefficients=True):
+        """(alpha, C, report) of the stepped fit (vp_fit_end); report as ``fit`` returns it"""
+        a = self._empty((self.B, self.q))
+        Cm = self._empty((self.B, self.n)) if want_coefficients else None
+        if self.device_mode:
+            rep = torch.empty((self.B, 16), dtype=torch.uint8, device=self._torch_device())
+            check(self.lib.vp_fit_end(self._h, self._ptr(a), self._ptr(Cm), self._ptr(rep)))
+        else:
+            rep = np.zeros(self.B, dtype=REPORT_DTYPE)
+            check(self.lib.vp_fit_end(self._h, self._ptr(a), self._ptr(Cm), C.c_void_p(rep.ctypes.data)))
+        self._have_params = True
+        return a, Cm, rep
+
+    def fit_with_model(self, evaluate, alpha0, solver=None, derivatives_on_accept=False, max_steps=None, check_every=1):
+        """The whole stepped fit: ``evaluate(alpha (B, q), want (B,) or None) -> (Phi, dPhi)`` is the caller's model (numpy
+        on host-pointer handles, torch on device-pointer handles; ``want`` is None for the first call, afterwards the
+        VP_WANT_* bits per problem -- entries of problems that want nothing are never read, a model may skip them).
+        Returns (alpha, C, report, steps)."""
+        self.fit_begin(alpha0, solver, derivatives_on_accept)
+        solver = solver or LevenbergMarquardt(self.np_dtype)
+        limit = max_steps if max_steps is not None else 2 * (solver.patience * (self.q + 1) + 2)
+        alpha, want = self._as_array(alpha0).reshape(self.B, self.q), None
+        steps = 0
+        while steps < limit:
+            Phi, dPhi = evaluate(alpha, want)
+            steps += 1
+            look = (steps % check_every == 0) or steps == limit
+            alpha, want, nact = self.fit_step_with_basis(Phi, dPhi, want_count=look)
+            if look and nact == 0:
+                break
+        a, Cm, rep = self.fit_end()
+        return a, Cm, rep, steps
+
     def fit_trace(self, alpha0, solver=None, max_rows=512):
         """diagnostics (host mode only): fit + per-evaluation trace (B, max_rows, q+4) with rows
         [alpha_trial, ||r||, ratio, delta, par]; unused rows are NaN"""

@@ -228,6 +228,17 @@ struct vp_batch {
     vp_lm_opts mrhs_graph_opts;
     hipStream_t cap_stream;
     bool mrhs_graph_failed;
+    // batched reverse-communication LM fit of a caller-evaluated model (vp_fit_begin / vp_fit_step_with_basis / vp_fit_end)
+    void *d_xf_state;       // [B] LM records of the step kernel
+    void *d_xf_trial;       // [B][q] trial points of the last step
+    int32_t *d_xf_want;     // [B] what every problem wants next
+    int32_t *d_xf_nactive;  // device counter of the last step
+    int32_t *h_xf_nactive;  // pinned host copy
+    bool xf_running;        // between vp_fit_begin and vp_fit_end
+    bool xf_init;           // the next step is the first
+    int xf_flags;
+    int64_t xf_steps;
+    vp_lm_opts xf_opts;
 };
 
 namespace {
@@ -464,6 +475,9 @@ int ensure_R(vp_batch *h) {
 
 // run the evaluate kernel at h->d_alpha; any output may be null
 int run_evaluate(vp_batch *h, void *r_dev, void *J_dev, void *C_dev) {
+    if (h->external && !h->ext_phi)
+        return fail(VP_ERR_INVALID, "the columns of the handle's current parameters are not known (after vp_fit_end: call "
+                                    "vp_set_params_with_basis with Phi / dPhi at the fitted parameters first)");
     if (h->external && !h->d_gen_ws &&
         !external_resident(h->dtype, h->n, h->ext_np, h->m, h->m_user ? h->m_user : h->m, J_dev != nullptr))
         if (int rc = ensure_gen_ws(h)) return rc;
@@ -1180,6 +1194,11 @@ void vp_batch_destroy(vp_batch *h) {
     (void)hipFree(h->tmp_b);
     (void)hipFree(h->ext_phi_own);
     (void)hipFree(h->ext_dphi_own);
+    (void)hipFree(h->d_xf_state);
+    (void)hipFree(h->d_xf_trial);
+    (void)hipFree(h->d_xf_want);
+    (void)hipFree(h->d_xf_nactive);
+    if (h->h_xf_nactive) (void)hipHostFree(h->h_xf_nactive);
     // (the struct is zero-initialised: freeing unconditionally also covers a create that failed half way)
     (void)hipFree(h->mrhs.qthin);
     (void)hipFree(h->mrhs.g);
@@ -1281,6 +1300,125 @@ int vp_evaluate_with_basis(vp_batch *h, const void *alpha, const void *Phi, cons
     if (int rc = copy_out(h, cost_out, h->d_cost, (size_t)h->B * sizeof(double))) return rc;
     if (int rc = copy_status(h, status)) return rc;
     if (!device_ptrs(h)) VP_HIP(hipStreamSynchronize(h->stream));
+    return VP_ERR_OK;
+}
+
+// ---- batched LM fit of a caller-evaluated model by reverse communication (vp_extfit.hpp) --------------------------
+// == LevMarSolver::fit (src/solvers/levmar/mod.rs:238-254) over the trait surface (src/model/mod.rs:239-363)
+int vp_fit_begin(vp_batch *h, const vp_lm_opts *opts, const void *alpha0, int flags) {
+    VP_ENTER(h);
+    if (!h->external)
+        return fail(VP_ERR_UNSUPPORTED, "vp_fit_begin needs a handle made by vp_batch_create_external (descriptor models: vp_fit)");
+    if (!alpha0) return fail(VP_ERR_INVALID, "null alpha0");
+    if (flags & ~VP_FIT_DERIVATIVES_ON_ACCEPT) return fail(VP_ERR_INVALID, "unknown vp_fit_begin flag");
+    if (h->q <= 0) return fail(VP_ERR_INVALID, "a fit needs at least one nonlinear parameter");
+    if (h->S != 1) return fail(VP_ERR_UNSUPPORTED, "the batched fit of caller-evaluated models covers single right-hand sides");
+    if (h->m_user) return fail(VP_ERR_UNSUPPORTED, "the batched fit of caller-evaluated models needs m >= n");
+    const size_t rec = external_fit_rec_bytes(h->dtype, h->n, h->ext_np, h->q, h->m);
+    if (!rec) return fail(VP_ERR_UNSUPPORTED, "no step kernel for this (n, q, pairs, m) of a caller-evaluated model");
+    const size_t ts = tsize(h->dtype);
+    if (!h->d_xf_state) {
+        VP_HIP(hipMalloc(&h->d_xf_state, (size_t)h->B * rec));
+        VP_HIP(hipMalloc(&h->d_xf_trial, (size_t)h->B * h->q * ts));
+        VP_HIP(hipMalloc((void **)&h->d_xf_want, (size_t)h->B * sizeof(int32_t)));
+        VP_HIP(hipMalloc((void **)&h->d_xf_nactive, sizeof(int32_t)));
+        VP_HIP(hipHostMalloc((void **)&h->h_xf_nactive, sizeof(int32_t), hipHostMallocDefault));
+    }
+    if (opts) h->xf_opts = *opts;
+    else vp_lm_opts_default(&h->xf_opts, h->dtype);
+    VP_HIP(hipMemcpyAsync(h->d_alpha, alpha0, (size_t)h->B * h->q * ts,
+                          device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+    if (!device_ptrs(h)) VP_HIP(hipStreamSynchronize(h->stream));
+    h->xf_running = true;
+    h->xf_init = true;
+    h->xf_flags = flags;
+    h->xf_steps = 0;
+    h->have_params = false;
+    h->r_valid = false;
+    h->have_report = false;
+    return VP_ERR_OK;
+}
+
+int vp_fit_step_with_basis(vp_batch *h, const void *Phi, const void *dPhi, void *alpha_trial_out, int32_t *want_out,
+                           int64_t *n_active_out) {
+    VP_ENTER(h);
+    if (!h->external || !h->xf_running) return fail(VP_ERR_INVALID, "vp_fit_step_with_basis without vp_fit_begin");
+    if (!Phi) return fail(VP_ERR_INVALID, "null Phi");
+    const bool lazy = (h->xf_flags & VP_FIT_DERIVATIVES_ON_ACCEPT) != 0;
+    if (!dPhi && h->ext_np > 0 && (!lazy || h->xf_init))
+        return fail(VP_ERR_INVALID, "null dPhi (only a VP_FIT_DERIVATIVES_ON_ACCEPT fit may omit it, and not in its first step)");
+    if (int rc = ext_stage(h, Phi, h->n, h->ext_phi, h->ext_phi_own)) return rc;
+    if (int rc = ext_stage(h, dPhi, h->ext_np, h->ext_dphi, h->ext_dphi_own)) return rc;
+    const size_t ts = tsize(h->dtype);
+    const bool direct = device_ptrs(h); // the kernel writes the caller's device arrays itself
+    VP_HIP(hipMemsetAsync(h->d_xf_nactive, 0, sizeof(int32_t), h->stream));
+    ExtFitParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.dtype = h->dtype;
+    p.n = h->n;
+    p.q = h->q;
+    p.np = h->ext_np;
+    p.m = h->m;
+    p.B = h->B;
+    p.phi = h->ext_phi;
+    p.dphi = h->ext_dphi;
+    p.w = h->d_w;
+    p.yw = h->d_yw;
+    p.w_stride = (h->flags & VP_FLAG_W_PER_PROBLEM) ? h->m : 0;
+    p.state = h->d_xf_state;
+    p.alpha0 = h->d_alpha;
+    p.alpha_best = h->d_alpha;
+    p.C_best = h->d_C;
+    p.cost = h->d_cost;
+    p.status = h->d_status;
+    p.report = h->d_report;
+    p.alpha_trial = (direct && alpha_trial_out) ? alpha_trial_out : h->d_xf_trial;
+    p.want = (direct && want_out) ? want_out : h->d_xf_want;
+    p.nactive = h->d_xf_nactive;
+    p.pb = h->ext_pb;
+    p.pp = h->ext_pp;
+    p.eps = h->eps;
+    p.opts = h->xf_opts;
+    p.init = h->xf_init ? 1 : 0;
+    p.lazy = lazy ? 1 : 0;
+    p.stream = h->stream;
+    Timer tm(h, VP_KERNEL_FIT);
+    const int rc = external_fit_step(p);
+    tm.stop();
+    if (rc != VP_ERR_OK) return fail(rc, "fit step kernel launch failed");
+    h->xf_init = false;
+    h->xf_steps += 1;
+    if (!direct) {
+        if (alpha_trial_out)
+            VP_HIP(hipMemcpyAsync(alpha_trial_out, h->d_xf_trial, (size_t)h->B * h->q * ts, hipMemcpyDeviceToHost, h->stream));
+        if (want_out)
+            VP_HIP(hipMemcpyAsync(want_out, h->d_xf_want, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (n_active_out) {
+        VP_HIP(hipMemcpyAsync(h->h_xf_nactive, h->d_xf_nactive, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        VP_HIP(hipStreamSynchronize(h->stream));
+        *n_active_out = *h->h_xf_nactive;
+    } else if (!direct) {
+        VP_HIP(hipStreamSynchronize(h->stream)); // host arrays: the caller reads them (and reuses Phi / dPhi) right away
+    }
+    return VP_ERR_OK;
+}
+
+int vp_fit_end(vp_batch *h, void *alpha_out, void *C_out, vp_report *rep) {
+    VP_ENTER(h);
+    if (!h->external || !h->xf_running) return fail(VP_ERR_INVALID, "vp_fit_end without vp_fit_begin");
+    if (h->xf_init) return fail(VP_ERR_INVALID, "vp_fit_end before the first vp_fit_step_with_basis");
+    const size_t ts = tsize(h->dtype);
+    h->xf_running = false;
+    h->have_params = true;
+    h->r_valid = false;
+    h->have_report = true;
+    // the columns the handle last saw belong to a trial point, not necessarily to the fitted one
+    h->ext_phi = nullptr;
+    h->ext_dphi = nullptr;
+    if (int rc = copy_out(h, alpha_out, h->d_alpha, (size_t)h->B * h->q * ts)) return rc;
+    if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->n * ts)) return rc;
+    if (int rc = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc;
     return VP_ERR_OK;
 }
 

@@ -56,11 +56,11 @@ __device__ __forceinline__ void stacked_qr(T (&K)[NC][2], T (&Cb)[NC][RB], G &gr
 #pragma unroll
         for (int j = 0; j < NREM; ++j) d[j] = tfma(top[0], top[j], d[j]);
         const T alpha = top[0], nrm2 = d[0];
-        const bool live = nrm2 > T(0) && is_finite(nrm2);
+        const bool live = nrm2 > num<T>::norm2_min && is_finite(nrm2);
         const T y = live ? frsqrt(nrm2) : T(0);
         const T s0 = nrm2 * y;
         const T sigma = tfma(tfma(-s0, s0, nrm2), T(0.5) * y, s0);
-        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 <= num<T>::norm2_min) ? alpha : nrm2);
         const T u = live ? alpha - beta : T(0);
         const T gk = live ? -y * frcp(tabs(alpha) + sigma) : T(0);
         K[k][reg] = (lane == own) ? beta : K[k][reg];
@@ -94,11 +94,11 @@ __device__ __forceinline__ void lane_trail_update(T (&Tl)[PT][PT], T (&Cb)[NC][R
             d[j - k] = acc;
         }
         const T alpha = Tl[k][k], nrm2 = d[0];
-        const bool live = nrm2 > T(0) && is_finite(nrm2);
+        const bool live = nrm2 > num<T>::norm2_min && is_finite(nrm2);
         const T y = live ? frsqrt(nrm2) : T(0);
         const T s0 = nrm2 * y;
         const T sigma = tfma(tfma(-s0, s0, nrm2), T(0.5) * y, s0);
-        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 <= num<T>::norm2_min) ? alpha : nrm2);
         const T u = live ? alpha - beta : T(0);
         const T gk = live ? -y * frcp(tabs(alpha) + sigma) : T(0);
         Tl[k][k] = beta;
@@ -486,11 +486,11 @@ __device__ __forceinline__ void stacked_qr_keep(T (&K)[NC][2], T (&Cb)[NC][RB], 
 #pragma unroll
         for (int j = 0; j < NREM; ++j) d[j] = tfma(top[0], top[j], d[j]);
         const T alpha = top[0], nrm2 = d[0];
-        const bool live = nrm2 > T(0) && is_finite(nrm2);
+        const bool live = nrm2 > num<T>::norm2_min && is_finite(nrm2);
         const T y = live ? frsqrt(nrm2) : T(0);
         const T s0 = nrm2 * y;
         const T sigma = tfma(tfma(-s0, s0, nrm2), T(0.5) * y, s0);
-        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 <= num<T>::norm2_min) ? alpha : nrm2);
         const T u = live ? alpha - beta : T(0);
         const T gk = live ? -y * frcp(tabs(alpha) + sigma) : T(0);
         uo[k] = u;

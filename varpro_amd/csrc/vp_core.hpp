@@ -72,11 +72,11 @@ __device__ __forceinline__ void house_qr(T (&C)[NC][R], T (&g)[N], T (&Rm)[N][N]
         // division / sqrt expansion on the critical path.  A zero column (d_k == 0) leaves H = I; a non-finite
         // norm is passed on into R so that the evaluation is flagged.
         const T alpha = top[0], nrm2 = d[0];
-        const bool live = nrm2 > T(0) && is_finite(nrm2);
+        const bool live = nrm2 > num<T>::norm2_min && is_finite(nrm2);
         const T y = live ? frsqrt(nrm2) : T(0);
         const T s0 = nrm2 * y;
         const T sigma = tfma(tfma(-s0, s0, nrm2), T(0.5) * y, s0);
-        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+        const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 <= num<T>::norm2_min) ? alpha : nrm2);
         const T u = live ? alpha - beta : T(0);
         const T gk = live ? -y * frcp(tabs(alpha) + sigma) : T(0);
         g[k] = gk;
@@ -415,7 +415,7 @@ __device__ __forceinline__ ConstReflector<T> make_const_reflector(const Src &src
     T top[1] = {s0};
     group_bcast<1>(grp, top, L::lane_of_row(0));
     ConstReflector<T> h;
-    h.live = uni(nrm2 > T(0) && is_finite(nrm2));
+    h.live = uni(nrm2 > num<T>::norm2_min && is_finite(nrm2));
     const T sigma = tsqrt(nrm2);
     h.beta = h.live ? -tcopysign(sigma, top[0]) : top[0];
     h.u = h.live ? top[0] - h.beta : T(0);

@@ -24,11 +24,16 @@ template <> struct num<double> {
     static constexpr double eps = 2.220446049250313e-16;
     static constexpr double tiny = 2.2250738585072014e-308; // min positive normal
     static constexpr double huge = 1.7976931348623157e+308;
+    // smallest squared column norm a Householder reflector is formed for: below it the unnormalised reflector's scalar
+    // g = -1/(sigma (|alpha| + sigma)) ~ 1/sigma^2 overflows; such a column is numerically zero for every consumer (its
+    // singular value is far below any svd_epsilon; a Jacobian column of that size does not move the step) and gets H = I
+    static constexpr double norm2_min = 1e-290;
 };
 template <> struct num<float> {
     static constexpr float eps = 1.1920929e-07f;
     static constexpr float tiny = 1.17549435e-38f;
     static constexpr float huge = 3.4028235e+38f;
+    static constexpr float norm2_min = 1e-30f;
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }

@@ -200,6 +200,12 @@ template <typename T> int launch_evaluate(const LaunchParams &p, int (*fallback)
     const bool with_d = p.J_out != nullptr && p.ext_np > 0;
     const ExtEntry<T> *e = (p.ext_rows == p.m && p.m >= n && (!with_d || p.ext_dphi)) ? find_ext<T>(n, p.ext_np, p.m, with_d) : nullptr;
     if (!e || !p.ext_phi) return fallback(p);
+    if (p.J_out && !with_d && q > 0) {
+        // a model without a single derivative column (every parameter unused): the kernel without derivative columns has no
+        // Jacobian store, and J = 0 -- as eval_partial_deriv leaves it (src/model/mod.rs:473-512)
+        if (hipMemsetAsync(p.J_out, 0, (size_t)p.B * (size_t)q * (size_t)p.S * (size_t)p.m * sizeof(T), p.stream) != hipSuccess)
+            return VP_ERR_HIP;
+    }
     ExtArgs<T> a;
     a.phi = (const T *)p.ext_phi;
     a.dphi = (const T *)p.ext_dphi;

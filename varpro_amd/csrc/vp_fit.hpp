@@ -122,6 +122,18 @@ __device__ __forceinline__ void qrsolv(T (&r)[Q][Q], const int (&ipvt)[Q], const
     for (int j = 0; j < Q; ++j) dyn_set_o<Q, O>(x, ipvt[j], wa[j]);
 }
 
+// ((fp/delta)/temp)/temp of MINPACK's lmpar with temp = ||w||, given the plain sum of squares t2 = sum w_j^2.  MINPACK
+// takes the norm with enorm (scaled: no over/underflow) and divides twice; the fast form x * rcp(t2) is the same number
+// whenever t2 is an ordinary one.  With a nearly singular factor (a Jacobian column that underflowed: diagonal entries of
+// 1e-189) w reaches 1e189, t2 overflows and rcp(inf) refined by Newton steps is NaN -- the step, and with it the fit,
+// ended `Numerical` where the reference's lmpar carries on with parc = 0.  Out-of-range sums take MINPACK's own route.
+template <typename T, int Q, bool U>
+__device__ __forceinline__ T lmpar_ratio(const T x, const T t2, const T (&w)[Q]) {
+    if (pol<U>(t2 > T(1e-280) && t2 < T(1e280))) return x * frcp(t2);
+    const T tn = enorm_small<T, Q, U>(w);
+    return (x / tn) / tn;
+}
+
 // MINPACK lmpar.  Returns par; step = p (new point is x - p); dxnorm = ||diag .* p||.
 template <typename T, int Q, bool U = true, bool O = false>
 __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (&diag)[Q], const T (&qtb)[Q],
@@ -174,7 +186,7 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
         T t2 = T(0);
 #pragma unroll
         for (int j = 0; j < Q; ++j) t2 = tfma(wa1[j], wa1[j], t2);
-        parl = (fp * idelta) * frcp(t2); // ((fp/delta)/temp)/temp
+        parl = lmpar_ratio<T, Q, U>(fp * idelta, t2, wa1); // ((fp/delta)/temp)/temp
     }
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
@@ -214,7 +226,7 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
         T t2 = T(0);
 #pragma unroll
         for (int j = 0; j < Q; ++j) t2 = tfma(wa1[j], wa1[j], t2);
-        const T parc = (fp * idelta) * frcp(t2);
+        const T parc = lmpar_ratio<T, Q, U>(fp * idelta, t2, wa1);
         if (fp > T(0)) parl = tmax(parl, par);
         if (fp < T(0)) paru = tmin(paru, par);
         par = tmax(parl, par + parc);
@@ -286,7 +298,7 @@ __device__ __forceinline__ T lmpar_chol(const T (&r)[Q][Q], const int (&ipvt)[Q]
         T t2 = T(0);
 #pragma unroll
         for (int j = 0; j < Q; ++j) t2 = tfma(z[j], z[j], t2);
-        parl = (fp * idelta) * frcp(t2);
+        parl = lmpar_ratio<T, Q, U>(fp * idelta, t2, z);
     }
     // G = R^T R (upper triangle) and b = R^T (Q^T f) = P^T J^T f
     T G[Q][Q], bp[Q], dp2[Q];
@@ -363,7 +375,7 @@ __device__ __forceinline__ T lmpar_chol(const T (&r)[Q][Q], const int (&ipvt)[Q]
             wa1[j] = a * is[j];
             t2 = tfma(wa1[j], wa1[j], t2);
         }
-        const T parc = (fp * idelta) * frcp(t2);
+        const T parc = lmpar_ratio<T, Q, U>(fp * idelta, t2, wa1);
         if (fp > T(0)) parl = tmax(parl, par);
         if (fp < T(0)) paru = tmin(paru, par);
         par = tmax(parl, par + parc);
@@ -522,7 +534,9 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
         top[NREM] = rv[L::reg_of_row(prow)];
         group_bcast<NREM + 1>(grp, top, L::lane_of_row(prow));
         T ajnorm = usqrt(dz[0]);
-        if (uni(ajnorm == T(0))) {
+        // (a column below norm2_min counts as a zero column: MINPACK normalises the pivot column before it forms the
+        // reflector; the unnormalised form here would overflow in 1/(ajnorm v_p))
+        if (uni(dz[0] <= num<T>::norm2_min)) {
             rdiag[j] = T(0);
             // remaining columns untouched: their row-prow entries are the R entries
 #pragma unroll
@@ -733,7 +747,7 @@ __device__ __forceinline__ void jac_qrfac_scaled(T (&Z)[Q][R], T (&rv)[R], const
         top[NREM] = rv[L::reg_of_row(prow)];
         group_bcast<NREM + 1>(grp, top, L::lane_of_row(prow));
         T an = usqrt(dz[0]); // norm of the unscaled pivot column
-        if (uni(sa[j] * an == T(0))) {
+        if (uni(sa[j] * an == T(0) || dz[0] <= num<T>::norm2_min)) {
             // zero (scaled) pivot column: no reflector; the remaining columns' row-prow entries are the R entries
             rdiag[j] = T(0);
 #pragma unroll

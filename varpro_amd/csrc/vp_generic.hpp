@@ -248,9 +248,9 @@ __device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b
         multi_reduce(sh, vals, nv);
         if (tid == 0) {
             const T alpha = ak[k], nrm2 = sh.red[0];
-            const bool live = nrm2 > T(0) && is_finite(nrm2);
+            const bool live = nrm2 > num<T>::norm2_min && is_finite(nrm2);
             const T sigma = live ? tsqrt(nrm2) : T(0);
-            const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+            const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 <= num<T>::norm2_min) ? alpha : nrm2);
             const T u = live ? alpha - beta : T(0);
             const T gk = live ? T(1) / (beta * u) : T(0);
             sh.g[k] = gk;
@@ -928,9 +928,9 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_stats_kernel(con
             multi_reduce(sh, vals, nv);
             if (tid == 0) {
                 const T alpha = ak[k], nrm2 = sh.red[0];
-                const bool live = nrm2 > T(0) && is_finite(nrm2);
+                const bool live = nrm2 > num<T>::norm2_min && is_finite(nrm2);
                 const T sigma = live ? tsqrt(nrm2) : T(0);
-                const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 == T(0)) ? alpha : nrm2);
+                const T beta = live ? -tcopysign(sigma, alpha) : ((nrm2 <= num<T>::norm2_min) ? alpha : nrm2);
                 const T u = live ? alpha - beta : T(0);
                 const T gk = live ? T(1) / (beta * u) : T(0);
                 Rk[k][k] = beta;

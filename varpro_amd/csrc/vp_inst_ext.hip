@@ -1,6 +1,7 @@
 // kernel set of caller-evaluated models (vp_batch_create_external): the resident evaluate kernels of vp_ext.hpp where the
 // shape is in their table, the generic kernels (vp_generic.hpp, reading the caller's columns) everywhere else
 #include "vp_ext.hpp"
+#include "vp_extfit.hpp"
 #include "vp_generic.hpp"
 #include "vp_registry.hpp"
 
@@ -21,6 +22,61 @@ const KernelEntry *external_kernels(int dtype, int n, int q, int np, int64_t m, 
     static const KernelEntry f32{VP_F32, FAMILY_GENERIC, 0, 0, 0, 0, 1, &gen::launch_evaluate<float>, nullptr, nullptr, nullptr,
                                  &gen::launch_best_fit<float>, nullptr, nullptr, nullptr, nullptr, 0, &gen::launch_stats<float>, nullptr, 0, 0, 0, 1};
     return dtype == VP_F64 ? &f64 : &f32;
+}
+
+namespace {
+template <typename T> int ext_fit_step_t(const ExtFitParams &p) {
+    const ext::ExtFitEntry<T> *e = ext::find_extfit<T>(p.n, p.np, p.q, p.m);
+    if (!e) return VP_ERR_UNSUPPORTED;
+    ext::ExtFitArgs<T> a;
+    a.phi = (const T *)p.phi;
+    a.dphi = (const T *)p.dphi;
+    a.w = (const T *)p.w;
+    a.yw = (const T *)p.yw;
+    a.state = p.state;
+    a.alpha0 = (const T *)p.alpha0;
+    a.alpha_best = (T *)p.alpha_best;
+    a.C_best = (T *)p.C_best;
+    a.cost = p.cost;
+    a.status = p.status;
+    a.report = p.report;
+    a.alpha_trial = (T *)p.alpha_trial;
+    a.want = p.want;
+    a.nactive = p.nactive;
+    for (int i = 0; i < VP_MAX_PAIRS; ++i) {
+        a.pb[i] = i < p.np ? p.pb[i] : 0;
+        a.pp[i] = i < p.np ? p.pp[i] : -1;
+    }
+    a.np = p.np;
+    a.m = (int)p.m;
+    a.B = p.B;
+    a.w_stride = p.w_stride;
+    a.eps = (T)p.eps;
+    a.o.ftol = (T)p.opts.ftol;
+    a.o.xtol = (T)p.opts.xtol;
+    a.o.gtol = (T)p.opts.gtol;
+    a.o.stepbound = (T)p.opts.stepbound;
+    a.o.patience = p.opts.patience;
+    a.o.scale_diag = p.opts.scale_diag;
+    a.init = p.init;
+    a.lazy = p.lazy;
+    a.vec = host_aligned<T>((int)p.m, {p.phi, p.dphi, p.w, p.yw}) ? 1 : 0;
+    if (a.B <= 0) return VP_ERR_OK;
+    return e->launch(a, p.stream);
+}
+} // namespace
+
+size_t external_fit_rec_bytes(int dtype, int n, int np, int q, int64_t m) {
+    if (dtype == VP_F64) {
+        const ext::ExtFitEntry<double> *e = ext::find_extfit<double>(n, np, q, m);
+        return e ? e->rec_bytes : 0;
+    }
+    const ext::ExtFitEntry<float> *e = ext::find_extfit<float>(n, np, q, m);
+    return e ? e->rec_bytes : 0;
+}
+
+int external_fit_step(const ExtFitParams &p) {
+    return p.dtype == VP_F64 ? ext_fit_step_t<double>(p) : ext_fit_step_t<float>(p);
 }
 
 bool external_resident(int dtype, int n, int np, int64_t m, int64_t ext_rows, bool with_d) {
