@@ -19,7 +19,11 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(vp_[a-z0-9_]+)\s*\(", header))
     declared -= {"vp_model_desc", "vp_lm_opts", "vp_report", "vp_batch"}
     assert declared, "no declarations found"
+    assert not any(name.startswith("vp_debug") for name in declared)  # test hooks live in varpro_hip_debug.h
+    debug = set(re.findall(r"\b(vp_debug_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "varpro_hip_debug.h")).read()))
+    assert debug == set(_lib.DEBUG_SYMBOLS)
     assert declared == set(_lib.ABI_SYMBOLS)
+    declared |= debug
     for name in sorted(declared):
         assert hasattr(lib, name), "libvarpro_hip.so does not export %s" % name
     assert b"gfx950" in lib.vp_version()

@@ -13,6 +13,7 @@
 #include <string>
 
 #include "../../include/varpro_hip.h"
+#include "../../include/varpro_hip_debug.h"
 #include "vp_registry.hpp"
 #include "vp_mrhs.hpp"
 
