@@ -765,11 +765,11 @@ def main():
                 "vs_vp_fit_of_the_same_problems": {"same_success_class": float(((rxf["termination"] > 0) == (rvf["termination"] > 0)).mean()),
                                                    "objective_rel_diff_median": float(np.median(rel_obj)), "objective_rel_diff_max": float(rel_obj.max()),
                                                    "evaluations": [int(rxf["n_evals"].sum()), int(rvf["n_evals"].sum())]},
-                "roofline": {"kernel": "ext_fit_step_kernel<double, 3, 2, 2, 16> (first step: every problem active)", "bound": "hbm",
+                "roofline": {"kernel": "ext_fit_eval_kernel<double, 3, 2, 2, 16, 1> + ext_fit_lm_kernel<double, 2> (first step: every problem active; events around both launches)", "bound": "hbm",
                              "achieved": bytes_step / (step0_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": bytes_step / (step0_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bytes_step,
-                             "avg_launch_ms": step0_ms, "traffic": committed_traffic("ext_fit_step_kernel"),
-                             "traffic_source": traffic_source("ext_fit_step_kernel")},
+                             "avg_launch_ms": step0_ms, "traffic": committed_traffic("ext_fit_eval_kernel"),
+                             "traffic_source": traffic_source("ext_fit_eval_kernel")},
             }
             bpx.close()
             del phi_x, dphi_x

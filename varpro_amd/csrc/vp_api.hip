@@ -15,6 +15,7 @@
 #include "../../include/varpro_hip.h"
 #include "../../include/varpro_hip_debug.h"
 #include "vp_registry.hpp"
+#include "vp_extfit_api.hpp"
 #include "vp_mrhs.hpp"
 
 using namespace vp;
@@ -1319,10 +1320,10 @@ int vp_fit_begin(vp_batch *h, const vp_lm_opts *opts, const void *alpha0, int fl
     if (!rec) return fail(VP_ERR_UNSUPPORTED, "no step kernel for this (n, q, pairs, m) of a caller-evaluated model");
     const size_t ts = tsize(h->dtype);
     if (!h->d_xf_state) {
-        VP_HIP(hipMalloc(&h->d_xf_state, (size_t)h->B * rec));
+        VP_HIP(hipMalloc(&h->d_xf_state, (size_t)h->B * rec + 16));
         VP_HIP(hipMalloc(&h->d_xf_trial, (size_t)h->B * h->q * ts));
         VP_HIP(hipMalloc((void **)&h->d_xf_want, (size_t)h->B * sizeof(int32_t)));
-        VP_HIP(hipMalloc((void **)&h->d_xf_nactive, sizeof(int32_t)));
+        VP_HIP(hipMalloc((void **)&h->d_xf_nactive, 2 * sizeof(int32_t)));
         VP_HIP(hipHostMalloc((void **)&h->h_xf_nactive, sizeof(int32_t), hipHostMallocDefault));
     }
     if (opts) h->xf_opts = *opts;
@@ -1330,6 +1331,7 @@ int vp_fit_begin(vp_batch *h, const vp_lm_opts *opts, const void *alpha0, int fl
     VP_HIP(hipMemcpyAsync(h->d_alpha, alpha0, (size_t)h->B * h->q * ts,
                           device_ptrs(h) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
     if (!device_ptrs(h)) VP_HIP(hipStreamSynchronize(h->stream));
+    VP_HIP(hipMemsetAsync(h->d_xf_nactive, 0, 2 * sizeof(int32_t), h->stream));
     h->xf_running = true;
     h->xf_init = true;
     h->xf_flags = flags;
@@ -1352,7 +1354,6 @@ int vp_fit_step_with_basis(vp_batch *h, const void *Phi, const void *dPhi, void 
     if (int rc = ext_stage(h, dPhi, h->ext_np, h->ext_dphi, h->ext_dphi_own)) return rc;
     const size_t ts = tsize(h->dtype);
     const bool direct = device_ptrs(h); // the kernel writes the caller's device arrays itself
-    VP_HIP(hipMemsetAsync(h->d_xf_nactive, 0, sizeof(int32_t), h->stream));
     ExtFitParams p;
     std::memset(&p, 0, sizeof(p));
     p.dtype = h->dtype;
@@ -1376,6 +1377,7 @@ int vp_fit_step_with_basis(vp_batch *h, const void *Phi, const void *dPhi, void 
     p.alpha_trial = (direct && alpha_trial_out) ? alpha_trial_out : h->d_xf_trial;
     p.want = (direct && want_out) ? want_out : h->d_xf_want;
     p.nactive = h->d_xf_nactive;
+    p.step = (int)(h->xf_steps & 1);
     p.pb = h->ext_pb;
     p.pp = h->ext_pp;
     p.eps = h->eps;
@@ -1396,7 +1398,7 @@ int vp_fit_step_with_basis(vp_batch *h, const void *Phi, const void *dPhi, void 
             VP_HIP(hipMemcpyAsync(want_out, h->d_xf_want, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     }
     if (n_active_out) {
-        VP_HIP(hipMemcpyAsync(h->h_xf_nactive, h->d_xf_nactive, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        VP_HIP(hipMemcpyAsync(h->h_xf_nactive, h->d_xf_nactive + ((h->xf_steps - 1) & 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         VP_HIP(hipStreamSynchronize(h->stream));
         *n_active_out = *h->h_xf_nactive;
     } else if (!direct) {

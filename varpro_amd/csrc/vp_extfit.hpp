@@ -6,20 +6,26 @@
 // jacobian() -> model.eval_partial_deriv(k) (:141).  A model the device cannot evaluate crosses the C ABI as those VALUES;
 // everything else of the loop stays on the device:
 //
-//   vp_fit_begin            one LM record per problem (LmVars, vp_lm_core.hpp) from alpha0
-//   vp_fit_step_with_basis  ONE launch of ext_fit_step_kernel: per problem, with Phi (and dPhi) at the current trial point
-//                             Phi_w = W Phi, Householder QR applied to [y_w | W dPhi], truncated solve, ||r||     :42-73
-//                             trust-region update, accept / reject, termination tests            (lm_after_eval)
-//                             at an accepted point: Kaufman columns in Q-coordinates, MINPACK qrfac of the m x q
-//                             Jacobian with Q_J^T r alongside (jac_qrfac)                                      :101-201
-//                             gradient test, diag, lmpar, predicted reduction, next trial point   (lm_next_step)
-//                           and hands back ONLY alpha_trial [B][q] + what it wants next [B] (+ the active count)
+//   vp_fit_begin            one LM record per problem (the LmVars of vp_lm_core.hpp, structure-of-arrays) from alpha0
+//   vp_fit_step_with_basis  TWO launches per step, with Phi (and dPhi) at the current trial points:
+//     ext_fit_eval_kernel   one WAVEFRONT per active problem, columns in registers exactly as ext_evaluate_kernel (vp_ext.hpp):
+//                             Phi_w = W Phi, Householder QR applied to [y_w | W dPhi], truncated solve, ||r||        :42-73
+//                             with derivative columns at hand: Kaufman columns in Q-coordinates, MINPACK qrfac of the
+//                             m x q Jacobian with Q_J^T r alongside (jac_qrfac)                                   :101-201
+//                           -> per problem { ||r||, ok, c, [R_J, Q_J^T r, column norms, pivots] }: ~q^2 + 3q + n + 2 scalars.
+//                           HBM-bound: it streams m (n + 1 + p) scalars per active problem in and nothing else out.
+//     ext_fit_lm_kernel     one LANE per problem (the wave-uniform bookkeeping of 64 problems at once instead of 64 times in a
+//                           row on 64 redundant lanes: lmpar alone is thousands of dependent fp64 instructions at q = 4):
+//                             trust-region update, accept / reject, termination tests              (lm_after_eval)
+//                             gradient test, diag, lmpar, predicted reduction, next trial point    (lm_next_step)
+//                           -> alpha_trial [B][q], what every problem wants next [B], the best point so far
 //   vp_fit_end              parameters, coefficients and MinimizationReport of every problem
 //
 // The Jacobian J [B][q][m] and the residuals never leave the chip (the trait-level route -- vp_evaluate_with_basis and one
 // host LM driver per problem -- writes and copies them at every accepted point: 1 GB per step at the headline shape).
-// One wavefront per problem, columns in registers (R rows per lane) exactly as ext_evaluate_kernel (vp_ext.hpp); a step
-// streams m (n + 1 + p) scalars per active problem in and q + 1 scalars out and is HBM-bound.
+// The Jacobian factor of a trial point is formed BEFORE the LM kernel decides whether the point is accepted (the columns
+// are in registers then, not later): it lands in a candidate slot of the record and replaces the current factor on
+// acceptance; on a rejected step it is dropped, as the reference never asks for it.
 //
 // Two protocols (vp_fit_begin flags):
 //   eager (default)              every step carries Phi AND dPhi at the trial point; a step is one LM iteration
@@ -38,47 +44,33 @@
 namespace vp {
 namespace ext {
 
+#ifndef VP_EXTFIT_TWO_WAVE_VGPRS
+#define VP_EXTFIT_TWO_WAVE_VGPRS 200
+#endif
 enum { EXTFIT_WANT_BASIS = 1, EXTFIT_WANT_DERIVS = 2 }; // == VP_WANT_* (include/varpro_hip.h)
 enum { EXTFIT_PH_EVAL = 0, EXTFIT_PH_JAC = 1 };
 
-template <typename T, int N, int Q> struct ExtFitRec {
-    LmVars<T, N, Q> lm;
-    T cbest[N];
-    int want;  // what the caller was asked to provide for THIS step
-    int phase; // EXTFIT_PH_*
+// The per-problem state, structure-of-arrays: field f of problem b is base[f * B + b] (the LM kernel's lane b reads and
+// writes it coalesced; the evaluation kernel's wave b touches a handful of scalars).  Q parameters, up to VP_MAX_BASIS
+// coefficients.
+template <int Q> struct ExtFitLayout {
+    // fields of the problem's scalar type
+    static constexpr int X = 0, XT = X + Q, DIAG = XT + Q, QTF = DIAG + Q, ACN = QTF + Q, RJ = ACN + Q, SC = RJ + Q * Q;
+    // SC + {0 fnorm, 1 delta, 2 par, 3 xnorm, 4 gnorm, 5 pnorm, 6 prered, 7 dirder, 8 objective}
+    static constexpr int CBEST = SC + 9, C_FN = CBEST + VP_MAX_BASIS, C_C = C_FN + 1, C_RJ = C_C + VP_MAX_BASIS;
+    static constexpr int C_ACN = C_RJ + Q * Q, C_QTF = C_ACN + Q, NT = C_QTF + Q;
+    // 32-bit fields
+    static constexpr int IPVT = 0, FIRST = IPVT + Q, FIRST_TR = FIRST + 1, FIRST_UP = FIRST_TR + 1, NFEV = FIRST_UP + 1;
+    static constexpr int TERM = NFEV + 1, STATUS = TERM + 1, WANT = STATUS + 1, PHASE = WANT + 1, C_OK = PHASE + 1;
+    static constexpr int C_HASJ = C_OK + 1, C_IPVT = C_HASJ + 1, NI = C_IPVT + Q;
+    // bytes per problem (+ 8 per handle for the alignment of the 32-bit block: added by the host)
+    static constexpr size_t bytes(size_t tsize) { return (size_t)NT * tsize + (size_t)NI * 4; }
 };
-
-// field-by-field copies of an LM record (a struct assignment is a memcpy through a stack object: the whole record would
-// live in scratch memory for the duration of the kernel)
-template <typename T, int N, int Q>
-__device__ __forceinline__ void lm_copy(LmVars<T, N, Q> &d, const LmVars<T, N, Q> &s) {
-#pragma unroll
-    for (int k = 0; k < Q; ++k) {
-        d.x[k] = s.x[k];
-        d.xt[k] = s.xt[k];
-        d.diag[k] = s.diag[k];
-        d.qtf[k] = s.qtf[k];
-        d.acnorm[k] = s.acnorm[k];
-        d.ipvt[k] = s.ipvt[k];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) d.Rj[k][j] = s.Rj[k][j];
-    }
-    d.fnorm = s.fnorm;
-    d.delta = s.delta;
-    d.par = s.par;
-    d.xnorm = s.xnorm;
-    d.gnorm = s.gnorm;
-    d.pnorm = s.pnorm;
-    d.prered = s.prered;
-    d.dirder = s.dirder;
-    d.objective = s.objective;
-    d.first = s.first;
-    d.first_tr = s.first_tr;
-    d.first_update = s.first_update;
-    d.nfev = s.nfev;
-    d.term = s.term;
-    d.status = s.status;
-    d.accepted = s.accepted;
+// the 32-bit fields start behind the NT * B scalars, 8-byte aligned
+template <typename T, int Q> __host__ __device__ inline int32_t *extfit_ints(void *state, int64_t B) {
+    size_t off = (size_t)ExtFitLayout<Q>::NT * sizeof(T) * (size_t)B;
+    off = (off + 7) & ~(size_t)7;
+    return reinterpret_cast<int32_t *>(reinterpret_cast<char *>(state) + off);
 }
 
 template <typename T> struct ExtFitArgs {
@@ -86,7 +78,7 @@ template <typename T> struct ExtFitArgs {
     const T *dphi; // [B][np][m]  UNWEIGHTED, pair-table order (null: no problem may want derivatives)
     const T *w;
     const T *yw;   // [B][m]
-    void *state;   // [B] ExtFitRec
+    void *state;   // ExtFitLayout arrays
     const T *alpha0; // [B][q]: read when init != 0
     T *alpha_best;   // [B][q] best point so far      (the handle's parameter array)
     T *C_best;       // [B][n] its coefficients       (the handle's coefficient array)
@@ -95,9 +87,12 @@ template <typename T> struct ExtFitArgs {
     vp_report *report; // [B] termination == 0 while the problem is running
     T *alpha_trial;  // [B][q] out: where Phi (and dPhi) are wanted next; the final parameters once a problem is done
     int32_t *want;   // [B] out: EXTFIT_WANT_* bits, 0 = done
-    int32_t *nactive; // out: number of problems still running after this step (atomic; zeroed by the host)
+    int32_t *nactive; // [2] device counters: [step & 1] receives this step's number of still-active problems (one atomic per
+                      // wavefront of the LM kernel), [(step + 1) & 1] is zeroed for the next step
+    int step;
     int32_t pb[VP_MAX_PAIRS], pp[VP_MAX_PAIRS];
     int np;
+    int n; // basis functions (the LM kernel is compiled per Q only)
     int m;
     int64_t B;
     int64_t w_stride;
@@ -108,49 +103,40 @@ template <typename T> struct ExtFitArgs {
     int vec;
 };
 
-template <typename T, int R, int N, int P, int Q> constexpr int extfit_waves() {
-    // resident: N + 1 + P columns during the sweep, 1 + P + Q afterwards, plus ~(2N^2 + 6N + Q^2 + 8Q) wave-uniform values
+template <typename T, int R, int N, int P, int Q, int W> constexpr int extfit_waves() {
+    // resident: N + 1 + P columns during the sweep, 1 + P + Q afterwards.  Two waves per SIMD (256 VGPRs) whenever the
+    // columns leave ~60 registers for the rest: one wave computes while the other loads -- a wave cannot overlap its own
+    // loads with its own sweep (the columns ARE the registers).  (2nd launch-bound argument: waves per SIMD of a workgroup
+    // of W waves -- W >= 4 spreads over the 4 SIMDs of the CU.)
     constexpr int cols = (N + 1 + P) > (1 + P + Q) ? (N + 1 + P) : (1 + P + Q);
-    return ((cols * R + 2 * N * N + 6 * N + 2 * Q * Q + 8 * Q) * (int)(sizeof(T) / 4) <= 200) ? 2 : 1;
+    constexpr int per_simd = (cols * R * (int)(sizeof(T) / 4) <= VP_EXTFIT_TWO_WAVE_VGPRS) ? 2 : 1;
+    return W >= 4 ? (per_simd * W) / 4 : per_simd;
 }
 
-template <typename T, int N, int P, int Q, int R>
-__global__ void __launch_bounds__(64, (extfit_waves<T, R, N, P, Q>())) ext_fit_step_kernel(const ExtFitArgs<T> a) {
+// ---- launch 1: the evaluation (and, with derivative columns at hand, the Jacobian factor) of every active problem ----
+// W wavefronts per problem (one workgroup): rows dealt to 64 W lanes, R per lane -- m <= 64 R W.  W > 1 where the columns of
+// one problem do not leave a single wave room for a second wave on its SIMD (vp_device.hpp Grp: reductions through LDS)
+template <typename T, int N, int P, int Q, int R, int W>
+__global__ void __launch_bounds__(64 * W, (extfit_waves<T, R, N, P, Q, W>())) ext_fit_eval_kernel(const ExtFitArgs<T> a) {
     constexpr int NC = N + 1 + P;
-    using G = Grp<1>;
-    using L = Layout<R, 1>;
-    using Rec = ExtFitRec<T, N, Q>;
-    G grp = G::make(nullptr);
+    static_assert(W == 1 || Q * (Q + 1) / 2 + Q <= VP_XV, "the Gram round of jac_qrfac must fit the group's exchange area");
+    using G = Grp<W>;
+    using L = Layout<R, W>;
+    using F = ExtFitLayout<Q>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char extfit_smem[];
+    G grp = G::make(W > 1 ? extfit_smem : nullptr);
     const int lane = grp.gl;
     const int64_t b = blockIdx.x;
     if (b >= a.B) return;
     const int m = a.m;
     const bool vec = a.vec != 0;
-    Rec *rec = reinterpret_cast<Rec *>(a.state) + b;
+    T *st = reinterpret_cast<T *>(a.state);
+    int32_t *si = extfit_ints<T, Q>(a.state, a.B);
 
-    LmVars<T, N, Q> s;
-    T cbest[N];
-    int want, phase;
-    if (a.init) {
-        lm_init<T, N, Q>(s, a.alpha0 + b * Q);
-#pragma unroll
-        for (int k = 0; k < N; ++k) cbest[k] = T(0);
-        want = EXTFIT_WANT_BASIS | EXTFIT_WANT_DERIVS;
-        phase = EXTFIT_PH_EVAL;
-    } else {
-        if (uni(rec->lm.term) != 0) return; // finished in an earlier step: nothing is read, nothing changes
-        lm_copy<T, N, Q>(s, rec->lm);
-#pragma unroll
-        for (int k = 0; k < Q; ++k) s.ipvt[k] = uni(s.ipvt[k]);
-        s.first = uni(s.first);
-        s.first_tr = uni(s.first_tr);
-        s.first_update = uni(s.first_update);
-        s.nfev = uni(s.nfev);
-        s.term = 0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) cbest[k] = rec->cbest[k];
-        want = uni(rec->want);
-        phase = uni(rec->phase);
+    int want = EXTFIT_WANT_BASIS | EXTFIT_WANT_DERIVS;
+    if (!a.init) {
+        if (uni(si[F::TERM * a.B + b]) != 0) return; // finished in an earlier step: nothing is read, nothing changes
+        want = uni(si[F::WANT * a.B + b]);
     }
     const bool with_d = (want & EXTFIT_WANT_DERIVS) != 0 && a.dphi != nullptr; // (uniform)
 
@@ -158,13 +144,13 @@ __global__ void __launch_bounds__(64, (extfit_waves<T, R, N, P, Q>())) ext_fit_s
     {
         const T *ph = a.phi + b * (int64_t)N * m;
 #pragma unroll
-        for (int j = 0; j < N; ++j) load_rows<T, R, 1>(ph + (int64_t)j * m, m, lane, vec, C[j]);
-        load_rows<T, R, 1>(a.yw + b * (int64_t)m, m, lane, vec, C[N]);
+        for (int j = 0; j < N; ++j) load_rows<T, R, W>(ph + (int64_t)j * m, m, lane, vec, C[j]);
+        load_rows<T, R, W>(a.yw + b * (int64_t)m, m, lane, vec, C[N]);
         const T *dp = a.dphi + b * (int64_t)a.np * m;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             if (with_d && p < a.np) {
-                load_rows<T, R, 1>(dp + (int64_t)p * m, m, lane, vec, C[N + 1 + p]);
+                load_rows<T, R, W>(dp + (int64_t)p * m, m, lane, vec, C[N + 1 + p]);
             } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r) C[N + 1 + p][r] = T(0);
@@ -172,7 +158,7 @@ __global__ void __launch_bounds__(64, (extfit_waves<T, R, N, P, Q>())) ext_fit_s
         }
         if (a.w) { // `&self.weights * ...` (src/util/weights.rs:82-99)
             T wt[R];
-            load_rows<T, R, 1>(a.w + b * a.w_stride, m, lane, vec, wt);
+            load_rows<T, R, W>(a.w + b * a.w_stride, m, lane, vec, wt);
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 if (j == N) continue; // y_w was weighted when the handle was made
@@ -202,70 +188,132 @@ __global__ void __launch_bounds__(64, (extfit_waves<T, R, N, P, Q>())) ext_fit_s
     for (int k = 0; k < N; ++k) ok = ok && is_finite(c[k]) && is_finite(Rm[k][k]);
     ok = uni(ok);
 
-    // ---- the driver's bookkeeping around that evaluation ----
+    if (lane == 0) {
+        st[F::C_FN * a.B + b] = usqrt(fn2);
+#pragma unroll
+        for (int k = 0; k < N; ++k) st[(F::C_C + k) * a.B + b] = c[k];
+        si[F::C_OK * a.B + b] = ok ? 1 : 0;
+        si[F::C_HASJ * a.B + b] = (with_d && ok) ? 1 : 0;
+    }
+    if (!with_d || !ok) return;
+
+    // ---- jacobian at the same point: Kaufman columns in Q-coordinates (rows < N: the P_perp), MINPACK qrfac with
+    // Q_J^T r alongside (:101-201).  Whether the LM driver wants it is decided by the LM kernel. ----
+    residual_qcoords<T, R, N>(C[N], e, grp);
+    T Zs[Q][R];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) Zs[k][r] = T(0);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (p < a.np && a.pp[p] == k) { // (uniform)
+                const T cj = -dyn_get<N>(c, a.pb[p]);
+#pragma unroll
+                for (int r = 0; r < R; ++r) Zs[k][r] = tfma(cj, C[N + 1 + p][r], Zs[k][r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < L::VW && r < R; ++r)
+            if (L::row_of(r, lane) < N) Zs[k][r] = T(0);
+    }
+    T Rj[Q][Q], acn[Q], qtf[Q];
+    int ipv[Q];
+    jac_qrfac<T, R, Q, N>(Zs, C[N], Rj, acn, ipv, qtf, grp);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            st[(F::C_ACN + k) * a.B + b] = acn[k];
+            st[(F::C_QTF + k) * a.B + b] = qtf[k];
+            si[(F::C_IPVT + k) * a.B + b] = ipv[k];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) st[(F::C_RJ + k * Q + j) * a.B + b] = Rj[k][j];
+        }
+    }
+}
+
+// ---- launch 2: the LM driver of every problem, one lane each ----
+template <typename T, int Q> __global__ void __launch_bounds__(64) ext_fit_lm_kernel(const ExtFitArgs<T> a) {
+    using F = ExtFitLayout<Q>;
+    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (b == 0) a.nactive[(a.step + 1) & 1] = 0;
+    if (b >= a.B) return;
+    const int64_t B = a.B;
+    T *st = reinterpret_cast<T *>(a.state);
+    int32_t *si = extfit_ints<T, Q>(a.state, B);
+    const int n = a.n;
+
+    LmVars<T, 1, Q> s;
+    int phase = EXTFIT_PH_EVAL;
+    if (a.init) {
+        lm_init<T, 1, Q>(s, a.alpha0 + b * Q);
+#pragma unroll
+        for (int k = 0; k < VP_MAX_BASIS; ++k) st[(F::CBEST + k) * B + b] = T(0);
+    } else {
+        if (si[F::TERM * B + b] != 0) return;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            s.x[k] = st[(F::X + k) * B + b];
+            s.xt[k] = st[(F::XT + k) * B + b];
+            s.diag[k] = st[(F::DIAG + k) * B + b];
+            s.qtf[k] = st[(F::QTF + k) * B + b];
+            s.acnorm[k] = st[(F::ACN + k) * B + b];
+            s.ipvt[k] = si[(F::IPVT + k) * B + b];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) s.Rj[k][j] = st[(F::RJ + k * Q + j) * B + b];
+        }
+        s.fnorm = st[(F::SC + 0) * B + b];
+        s.delta = st[(F::SC + 1) * B + b];
+        s.par = st[(F::SC + 2) * B + b];
+        s.xnorm = st[(F::SC + 3) * B + b];
+        s.gnorm = st[(F::SC + 4) * B + b];
+        s.pnorm = st[(F::SC + 5) * B + b];
+        s.prered = st[(F::SC + 6) * B + b];
+        s.dirder = st[(F::SC + 7) * B + b];
+        s.objective = st[(F::SC + 8) * B + b];
+        s.first = si[F::FIRST * B + b];
+        s.first_tr = si[F::FIRST_TR * B + b];
+        s.first_update = si[F::FIRST_UP * B + b];
+        s.nfev = si[F::NFEV * B + b];
+        s.term = 0;
+        s.status = si[F::STATUS * B + b];
+        s.accepted = 0;
+        phase = si[F::PHASE * B + b];
+    }
+    const T fnorm1 = st[F::C_FN * B + b];
+    const bool ok = si[F::C_OK * B + b] != 0;
+    const bool has_jac = si[F::C_HASJ * B + b] != 0;
+
     bool need_jac;
     if (phase == EXTFIT_PH_JAC) {
-        need_jac = true; // the columns are those of the point accepted in the previous step: no new evaluation
+        need_jac = true; // the columns were those of the point accepted in the previous step: no new evaluation
+        if (!ok) {       // (the caller's columns at that point are not the ones it showed before: residuals() == None)
+            s.term = VP_TERM_USER;
+            s.status = VP_ST_NONFINITE;
+        }
     } else {
-        need_jac = lm_after_eval<T, N, Q, true>(s, a.o, usqrt(fn2), ok, (long)m);
+        need_jac = lm_after_eval<T, 1, Q, false>(s, a.o, fnorm1, ok, (long)a.m);
         if (s.accepted) {
-#pragma unroll
-            for (int k = 0; k < N; ++k) cbest[k] = c[k];
+            for (int k = 0; k < n; ++k) st[(F::CBEST + k) * B + b] = st[(F::C_C + k) * B + b];
         }
     }
     bool deferred = false;
-    if (s.term == 0 && need_jac && !with_d) {
-        // accepted without derivative columns at hand (second protocol): ask for them at this very point
-        deferred = true;
+    if (s.term == 0 && need_jac && !has_jac) {
+        deferred = true; // accepted without derivative columns at hand (second protocol): ask for them at this very point
     } else if (s.term == 0) {
-        if (need_jac) {
-            // Kaufman columns in Q-coordinates (rows < N: the P_perp), MINPACK qrfac with Q_J^T r alongside: :101-201
-            residual_qcoords<T, R, N>(C[N], e, grp);
-            T Zs[Q][R];
+        if (need_jac) { // the candidate factor becomes the factor of the current point
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
+                s.acnorm[k] = st[(F::C_ACN + k) * B + b];
+                s.qtf[k] = st[(F::C_QTF + k) * B + b];
+                s.ipvt[k] = si[(F::C_IPVT + k) * B + b];
 #pragma unroll
-                for (int r = 0; r < R; ++r) Zs[k][r] = T(0);
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if (p < a.np && a.pp[p] == k) { // (uniform)
-                        const T cj = -dyn_get<N>(c, a.pb[p]);
-#pragma unroll
-                        for (int r = 0; r < R; ++r) Zs[k][r] = tfma(cj, C[N + 1 + p][r], Zs[k][r]);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < L::VW && r < R; ++r)
-                    if (L::row_of(r, lane) < N) Zs[k][r] = T(0);
-            }
-            // (factor into locals: handing the record's own arrays to the factorisation pins the whole record in scratch)
-            T Rj[Q][Q], acn[Q], qtf[Q];
-            int ipv[Q];
-            jac_qrfac<T, R, Q, N>(Zs, C[N], Rj, acn, ipv, qtf, grp);
-#pragma unroll
-            for (int k = 0; k < Q; ++k) {
-                s.acnorm[k] = acn[k];
-                s.qtf[k] = qtf[k];
-                s.ipvt[k] = ipv[k];
-#pragma unroll
-                for (int j = 0; j < Q; ++j) s.Rj[k][j] = Rj[k][j];
+                for (int j = 0; j < Q; ++j) s.Rj[k][j] = st[(F::C_RJ + k * Q + j) * B + b];
             }
         }
-        lm_next_step<T, N, Q, true>(s, a.o, need_jac);
-#ifdef VP_EXTFIT_DEBUG
-        if (s.term == VP_TERM_NUMERICAL && lane == 0) {
-            printf("extfit b=%ld nfev=%d NUMERICAL after step: need_jac=%d fnorm=%g gnorm=%g xnorm=%g delta=%g par=%g pnorm=%g prered=%g\n",
-                   (long)b, s.nfev, (int)need_jac, (double)s.fnorm, (double)s.gnorm, (double)s.xnorm, (double)s.delta, (double)s.par,
-                   (double)s.pnorm, (double)s.prered);
-            for (int k = 0; k < Q; ++k)
-                printf("   k=%d x=%g acnorm=%g diag=%g qtf=%g ipvt=%d R=[%g %g %g %g] c=%g\n", k, (double)s.x[k], (double)s.acnorm[k],
-                       (double)s.diag[k], (double)s.qtf[k], s.ipvt[k], (double)s.Rj[k][0], (double)s.Rj[k][Q > 1 ? 1 : 0],
-                       (double)s.Rj[k][Q > 2 ? 2 : 0], (double)s.Rj[k][Q > 3 ? 3 : 0], (double)c[k < N ? k : 0]);
-        }
-#endif
+        lm_next_step<T, 1, Q, false>(s, a.o, need_jac);
     }
 
-    // ---- hand back: the next request, the record, the best point so far ----
     int want_next;
     if (s.term != 0) {
         want_next = 0;
@@ -277,64 +325,107 @@ __global__ void __launch_bounds__(64, (extfit_waves<T, R, N, P, Q>())) ext_fit_s
         want_next = a.lazy ? EXTFIT_WANT_BASIS : (EXTFIT_WANT_BASIS | EXTFIT_WANT_DERIVS);
         phase = EXTFIT_PH_EVAL;
     }
-    if (lane == 0) {
-        lm_copy<T, N, Q>(rec->lm, s);
 #pragma unroll
-        for (int k = 0; k < N; ++k) rec->cbest[k] = cbest[k];
-        rec->want = want_next;
-        rec->phase = phase;
-        a.want[b] = want_next;
+    for (int k = 0; k < Q; ++k) {
+        st[(F::X + k) * B + b] = s.x[k];
+        st[(F::XT + k) * B + b] = s.xt[k];
+        st[(F::DIAG + k) * B + b] = s.diag[k];
+        st[(F::QTF + k) * B + b] = s.qtf[k];
+        st[(F::ACN + k) * B + b] = s.acnorm[k];
+        si[(F::IPVT + k) * B + b] = s.ipvt[k];
 #pragma unroll
-        for (int k = 0; k < Q; ++k) {
-            // a finished problem reports its final parameters; a deferred one repeats the accepted point (x == xt)
-            a.alpha_trial[b * Q + k] = (s.term != 0 || deferred) ? s.x[k] : s.xt[k];
-            a.alpha_best[b * Q + k] = s.x[k];
-        }
-#pragma unroll
-        for (int k = 0; k < N; ++k) a.C_best[b * N + k] = cbest[k];
-        vp_report rep;
-        rep.termination = s.term;
-        rep.n_evals = s.nfev;
-        rep.objective = (double)s.objective;
-        a.report[b] = rep;
-        a.cost[b] = (double)s.objective;
-        a.status[b] = s.status;
-        if (s.term == 0) atomicAdd(a.nactive, 1);
+        for (int j = 0; j < Q; ++j) st[(F::RJ + k * Q + j) * B + b] = s.Rj[k][j];
+        // a finished problem reports its final parameters; a deferred one repeats the accepted point (x == xt)
+        a.alpha_trial[b * Q + k] = (s.term != 0 || deferred) ? s.x[k] : s.xt[k];
+        a.alpha_best[b * Q + k] = s.x[k];
     }
+    st[(F::SC + 0) * B + b] = s.fnorm;
+    st[(F::SC + 1) * B + b] = s.delta;
+    st[(F::SC + 2) * B + b] = s.par;
+    st[(F::SC + 3) * B + b] = s.xnorm;
+    st[(F::SC + 4) * B + b] = s.gnorm;
+    st[(F::SC + 5) * B + b] = s.pnorm;
+    st[(F::SC + 6) * B + b] = s.prered;
+    st[(F::SC + 7) * B + b] = s.dirder;
+    st[(F::SC + 8) * B + b] = s.objective;
+    si[F::FIRST * B + b] = s.first;
+    si[F::FIRST_TR * B + b] = s.first_tr;
+    si[F::FIRST_UP * B + b] = s.first_update;
+    si[F::NFEV * B + b] = s.nfev;
+    si[F::TERM * B + b] = s.term;
+    si[F::STATUS * B + b] = s.status;
+    si[F::WANT * B + b] = want_next;
+    si[F::PHASE * B + b] = phase;
+    a.want[b] = want_next;
+    for (int k = 0; k < n; ++k) a.C_best[b * n + k] = st[(F::CBEST + k) * B + b];
+    vp_report rep;
+    rep.termination = s.term;
+    rep.n_evals = s.nfev;
+    rep.objective = (double)s.objective;
+    a.report[b] = rep;
+    a.cost[b] = (double)s.objective;
+    a.status[b] = s.status;
+    // the number of problems still running: one atomic per wavefront (lanes that returned early count as finished)
+    const unsigned long long running = __builtin_amdgcn_ballot_w64(s.term == 0);
+    if (running != 0 && (int)(threadIdx.x & 63u) == __builtin_ctzll(running)) atomicAdd(&a.nactive[a.step & 1], __builtin_popcountll(running));
 }
 
-template <typename T, int N, int P, int Q, int R> int launch_fit_step(const ExtFitArgs<T> &a, hipStream_t stream) {
-    hipLaunchKernelGGL((ext_fit_step_kernel<T, N, P, Q, R>), dim3((unsigned)a.B), dim3(64), 0, stream, a);
+template <typename T, int N, int P, int Q, int R, int W> int launch_fit_eval(const ExtFitArgs<T> &a, hipStream_t stream) {
+    hipLaunchKernelGGL((ext_fit_eval_kernel<T, N, P, Q, R, W>), dim3((unsigned)a.B), dim3(64 * W), group_xch_bytes<W>(), stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+template <typename T, int Q> int launch_fit_lm(const ExtFitArgs<T> &a, hipStream_t stream) {
+    hipLaunchKernelGGL((ext_fit_lm_kernel<T, Q>), dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
-// one row of the table of compiled shapes (vp_inst_extfit*.hip)
+// one row of the table of compiled evaluation shapes (vp_inst_extfit*.hip) ...
 template <typename T> struct ExtFitEntry {
-    int N, P, Q, R;
-    size_t rec_bytes;
+    int N, P, Q, R, W; // covers m <= 64 R W
+    int (*launch)(const ExtFitArgs<T> &, hipStream_t);
+};
+// ... and of the LM kernels (one per parameter count)
+template <typename T> struct ExtFitLmEntry {
+    int Q;
+    size_t rec_bytes; // state bytes per problem
     int (*launch)(const ExtFitArgs<T> &, hipStream_t);
 };
 template <typename T> std::vector<ExtFitEntry<T>> &extfit_table() {
     static std::vector<ExtFitEntry<T>> t;
     return t;
 }
+template <typename T> std::vector<ExtFitLmEntry<T>> &extfit_lm_table() {
+    static std::vector<ExtFitLmEntry<T>> t;
+    return t;
+}
 template <typename T> struct ExtFitRegistrar {
     explicit ExtFitRegistrar(const ExtFitEntry<T> &e) { extfit_table<T>().push_back(e); }
+    explicit ExtFitRegistrar(const ExtFitLmEntry<T> &e) { extfit_lm_table<T>().push_back(e); }
 };
 
-// the step kernel that covers (n, np pairs, q, m): exact n and q, the fewest rows per lane, then the fewest spare pairs
+// the evaluation kernel that covers (n, np pairs, q, m): exact n and q, the smallest capacity 64 R W, then the fewest spare
+// pairs, then the FIRST registered of equal ones (the instantiation files list the preferred split R x W first)
 template <typename T> const ExtFitEntry<T> *find_extfit(int n, int np, int q, int64_t m) {
     const ExtFitEntry<T> *best = nullptr;
     for (const ExtFitEntry<T> &e : extfit_table<T>()) {
-        if (e.N != n || e.Q != q || e.P < np || 64 * (int64_t)e.R < m) continue;
-        if (!best || e.R < best->R || (e.R == best->R && e.P < best->P)) best = &e;
+        if (e.N != n || e.Q != q || e.P < np || 64 * (int64_t)e.R * e.W < m) continue;
+        if (!best || e.R * e.W < best->R * best->W || (e.R * e.W == best->R * best->W && e.P < best->P)) best = &e;
     }
     return best;
+}
+template <typename T> const ExtFitLmEntry<T> *find_extfit_lm(int q) {
+    for (const ExtFitLmEntry<T> &e : extfit_lm_table<T>())
+        if (e.Q == q) return &e;
+    return nullptr;
 }
 
 } // namespace ext
 } // namespace vp
 
-#define VP_REGISTER_EXTFIT(T, NN, PP, QQ, RR)                                                                          \
-    static ::vp::ext::ExtFitRegistrar<T> VP_EXT_CAT(vp_extfit_reg_, __COUNTER__)(::vp::ext::ExtFitEntry<T>{            \
-        NN, PP, QQ, RR, sizeof(::vp::ext::ExtFitRec<T, NN, QQ>), &::vp::ext::launch_fit_step<T, NN, PP, QQ, RR>});
+#define VP_REGISTER_EXTFIT_W(T, NN, PP, QQ, RR, WW)                                                                    \
+    static ::vp::ext::ExtFitRegistrar<T> VP_EXT_CAT(vp_extfit_reg_, __COUNTER__)(                                     \
+        ::vp::ext::ExtFitEntry<T>{NN, PP, QQ, RR, WW, &::vp::ext::launch_fit_eval<T, NN, PP, QQ, RR, WW>});
+#define VP_REGISTER_EXTFIT(T, NN, PP, QQ, RR) VP_REGISTER_EXTFIT_W(T, NN, PP, QQ, RR, 1)
+#define VP_REGISTER_EXTFIT_LM(T, QQ)                                                                                   \
+    static ::vp::ext::ExtFitRegistrar<T> VP_EXT_CAT(vp_extfit_lm_reg_, __COUNTER__)(::vp::ext::ExtFitLmEntry<T>{       \
+        QQ, ::vp::ext::ExtFitLayout<QQ>::bytes(sizeof(T)), &::vp::ext::launch_fit_lm<T, QQ>});

@@ -4,6 +4,7 @@
 #include "vp_extfit.hpp"
 #include "vp_generic.hpp"
 #include "vp_registry.hpp"
+#include "vp_extfit_api.hpp"
 
 namespace vp {
 namespace {
@@ -27,7 +28,8 @@ const KernelEntry *external_kernels(int dtype, int n, int q, int np, int64_t m, 
 namespace {
 template <typename T> int ext_fit_step_t(const ExtFitParams &p) {
     const ext::ExtFitEntry<T> *e = ext::find_extfit<T>(p.n, p.np, p.q, p.m);
-    if (!e) return VP_ERR_UNSUPPORTED;
+    const ext::ExtFitLmEntry<T> *l = ext::find_extfit_lm<T>(p.q);
+    if (!e || !l) return VP_ERR_UNSUPPORTED;
     ext::ExtFitArgs<T> a;
     a.phi = (const T *)p.phi;
     a.dphi = (const T *)p.dphi;
@@ -43,11 +45,13 @@ template <typename T> int ext_fit_step_t(const ExtFitParams &p) {
     a.alpha_trial = (T *)p.alpha_trial;
     a.want = p.want;
     a.nactive = p.nactive;
+    a.step = p.step;
     for (int i = 0; i < VP_MAX_PAIRS; ++i) {
         a.pb[i] = i < p.np ? p.pb[i] : 0;
         a.pp[i] = i < p.np ? p.pp[i] : -1;
     }
     a.np = p.np;
+    a.n = p.n;
     a.m = (int)p.m;
     a.B = p.B;
     a.w_stride = p.w_stride;
@@ -62,17 +66,19 @@ template <typename T> int ext_fit_step_t(const ExtFitParams &p) {
     a.lazy = p.lazy;
     a.vec = host_aligned<T>((int)p.m, {p.phi, p.dphi, p.w, p.yw}) ? 1 : 0;
     if (a.B <= 0) return VP_ERR_OK;
-    return e->launch(a, p.stream);
+    // the evaluation of every active problem (one wavefront each), then the LM drivers (one lane each)
+    if (int rc = e->launch(a, p.stream)) return rc;
+    return l->launch(a, p.stream);
 }
 } // namespace
 
 size_t external_fit_rec_bytes(int dtype, int n, int np, int q, int64_t m) {
     if (dtype == VP_F64) {
-        const ext::ExtFitEntry<double> *e = ext::find_extfit<double>(n, np, q, m);
-        return e ? e->rec_bytes : 0;
+        const ext::ExtFitLmEntry<double> *l = ext::find_extfit_lm<double>(q);
+        return (l && ext::find_extfit<double>(n, np, q, m)) ? l->rec_bytes : 0;
     }
-    const ext::ExtFitEntry<float> *e = ext::find_extfit<float>(n, np, q, m);
-    return e ? e->rec_bytes : 0;
+    const ext::ExtFitLmEntry<float> *l = ext::find_extfit_lm<float>(q);
+    return (l && ext::find_extfit<float>(n, np, q, m)) ? l->rec_bytes : 0;
 }
 
 int external_fit_step(const ExtFitParams &p) {

@@ -53,31 +53,4 @@ bool external_resident(int dtype, int n, int np, int64_t m, int64_t ext_rows, bo
 // the generic fallback set (vp_generic.hpp): any descriptor, any m, single right-hand side fits
 const KernelEntry *generic_kernels(int dtype);
 
-// One step of the batched reverse-communication LM fit of a caller-evaluated model (vp_extfit.hpp; vp_fit_begin /
-// vp_fit_step_with_basis / vp_fit_end).  Type-erased; every pointer is a device pointer except the pair table.
-struct ExtFitParams {
-    int dtype, n, q, np;
-    int64_t m, B;
-    const void *phi, *dphi; // [B][n][m], [B][np][m] (dphi may be null when no problem wants derivatives)
-    const void *w, *yw;
-    int64_t w_stride;
-    void *state;            // [B] records of external_fit_rec_bytes() each
-    const void *alpha0;     // [B][q], read when init
-    void *alpha_best, *C_best;
-    double *cost;
-    int32_t *status;
-    vp_report *report;
-    void *alpha_trial;      // [B][q]
-    int32_t *want;          // [B]
-    int32_t *nactive;       // device int, zeroed by the caller
-    const int32_t *pb, *pp; // [np] host
-    double eps;
-    vp_lm_opts opts;
-    int init, lazy;
-    hipStream_t stream;
-};
-// bytes of one LM record of the step kernel that covers this shape; 0 = no kernel (the caller reports VP_ERR_UNSUPPORTED)
-size_t external_fit_rec_bytes(int dtype, int n, int np, int q, int64_t m);
-int external_fit_step(const ExtFitParams &p);
-
 } // namespace vp
