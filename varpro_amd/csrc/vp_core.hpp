@@ -490,17 +490,19 @@ __device__ __forceinline__ void apply_qt(const T (&V)[NC][R], const T (&g)[N], T
 //   YPRE: the data column arrives as H_0 y_w (the slot kernel applies the alpha-independent reflector once per fit,
 //         vp_fit2.hpp) and skips reflector 0 here; qty0 = (H_0 y_w)[0]
 //   NOD:  no derivative columns (NCX = N: exponentials + data) -- phase 1 of the split evaluate kernel
-template <typename T, class M, int R, int NCX, class Src, class G, bool YPRE = false, bool NOD = false>
+//   SHIFT: the derivative column of exponential j carries the factor 2^-ks[j] (build_columns); everything the basis
+//          columns produce (R, c, the residual) is the unshifted evaluation's bit for bit
+template <typename T, class M, int R, int NCX, class Src, class G, bool YPRE = false, bool NOD = false, bool SHIFT = false>
 __device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T (&alpha)[M::Q], const Src &src, T eps,
                                                           G &grp, const ConstReflector<T> &h0, T (&C)[NCX][R],
                                                           EvalUniform<T, M::N> &u, SectionClock *clk = nullptr,
-                                                          const T qty0 = T(0)) {
+                                                          const T qty0 = T(0), const int *ks = nullptr) {
     constexpr int N = M::N, NE = M::N - 1;
     static_assert(M::kConstLast && NCX == M::N + (NOD ? 0 : M::P), "const-first sweep: N-1 exponentials + data + P derivatives");
     using L = Layout<R, G::W>;
     constexpr int VW = L::VW;
     const int lane = grp.gl;
-    build_columns<T, M, R, NCX, Src, NE + 1, true, true, !NOD>(mdl, alpha, src, C);
+    build_columns<T, M, R, NCX, Src, NE + 1, true, true, !NOD, -1, SHIFT>(mdl, alpha, src, C, ks);
     VP_TICK(clk, 1);
     __builtin_amdgcn_sched_barrier(0);
     // ---- reflector 0: the implicit scale column ----

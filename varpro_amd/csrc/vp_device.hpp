@@ -355,6 +355,8 @@ __device__ __forceinline__ double tabs(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float tabs(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double tcopysign(double x, double s) { return __builtin_copysign(x, s); }
 __device__ __forceinline__ float tcopysign(float x, float s) { return __builtin_copysignf(x, s); }
+__device__ __forceinline__ double tldexp(double x, int e) { return __builtin_ldexp(x, e); }
+__device__ __forceinline__ float tldexp(float x, int e) { return __builtin_ldexpf(x, e); }
 __device__ __forceinline__ double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 

@@ -235,6 +235,98 @@ __device__ __forceinline__ T lmpar(T (&r)[Q][Q], const int (&ipvt)[Q], const T (
     return par;
 }
 
+// lmpar for TWO nonlinear parameters (round 5): MINPACK's lmpar statement by statement -- Gauss-Newton shortcut, the bounds
+// parl / paru, the Newton iteration on par and its exits -- with qrsolv's three Givens rotations per iteration (a chain of
+// three reciprocal square roots with their sign selects and zero branches, ~60 dependent instructions) replaced by the
+// 2 x 2 triangular factor S of  R^T R + par D^2  written out:  s00^2 = r00^2 + par d0^2,  s01 = r00 r01 / s00,
+// s11^2 = r11^2 + par d1^2 + r01^2 (par d0^2 / s00^2)  -- the Schur complement as a sum of non-negative terms, so every
+// entry of S carries a few ulp of RELATIVE error whatever the conditioning of R (the subtraction c - s01^2 of a generic
+// Cholesky is what loses digits).  S is the matrix qrsolv produces (it is unique up to row signs, which cancel in the
+// step).  One function for every fp64 Householder kernel (fit_kernel, the slot kernel's scalar phase and its lone tail):
+// their reports stay bit-identical to each other.
+#ifndef VP_LMPAR_Q2
+#define VP_LMPAR_Q2 1
+#endif
+template <typename T, bool U = true>
+__device__ __forceinline__ T lmpar_q2(const T (&r)[2][2], const int (&ipvt)[2], const T (&diag)[2], const T (&qtb)[2],
+                                      const T delta, T par, T (&x)[2], T &dxnorm_out) {
+    const T p1 = T(0.1), p001 = T(0.001), dwarf = num<T>::tiny;
+    const T r00 = r[0][0], r01 = r[0][1], r11 = r[1][1];
+    const bool swapped = ipvt[0] != 0;
+    const T d0 = swapped ? diag[1] : diag[0], d1 = swapped ? diag[0] : diag[1]; // D in pivoted order
+    const T b0 = qtb[0], b1 = qtb[1];
+    const bool full = (r00 != T(0)) && (r11 != T(0)); // nsing == 2
+    const T i00 = (r00 != T(0)) ? frcp(r00) : T(0), i11 = full ? frcp(r11) : T(0);
+    // Gauss-Newton direction, zero beyond the numerical rank
+    T q1 = b1 * i11;
+    T q0 = tfma(-r01, q1, b0) * i00;
+    T w[2] = {d0 * q0, d1 * q1};
+    T dxnorm = enorm_small<T, 2, U>(w);
+    T fp = dxnorm - delta;
+    if (pol<U>(fp <= p1 * delta)) {
+        x[0] = swapped ? q1 : q0;
+        x[1] = swapped ? q0 : q1;
+        dxnorm_out = dxnorm;
+        return T(0);
+    }
+    const T idelta = frcp(delta);
+    T parl = T(0);
+    if (full) {
+        const T idx = frcp(dxnorm);
+        T z[2];
+        z[0] = (d0 * (w[0] * idx)) * i00;                      // R^T z = D^2 p / ||D p||
+        z[1] = tfma(-r01, z[0], d1 * (w[1] * idx)) * i11;
+        parl = lmpar_ratio<T, 2, U>(fp * idelta, tfma(z[0], z[0], z[1] * z[1]), z);
+    }
+    const T g0 = r00 * b0, g1 = tfma(r01, b0, r11 * b1); // R^T (Q^T f) = P^T J^T f
+    T u[2] = {g0 * frcp(d0), g1 * frcp(d1)};
+    const T gnorm = enorm_small<T, 2, U>(u);
+    T paru = gnorm * idelta;
+    if (paru == T(0)) paru = dwarf / tmin(delta, p1);
+    par = tmax(par, parl);
+    par = tmin(par, paru);
+    if (par == T(0)) par = gnorm * frcp(dxnorm);
+    const T d02 = d0 * d0, d12 = d1 * d1, r00s = r00 * r00, r01s = r01 * r01, r11s = r11 * r11, r0001 = r00 * r01;
+    for (int iter = 1;; ++iter) {
+        if (par == T(0)) par = tmax(dwarf, p001 * paru);
+        const T pd0 = par * d02, pd1 = par * d12;
+        const T a = r00s + pd0;
+        const T is0 = (a > T(0)) ? frsqrt(a) : T(0); // 1 / s00
+        const T s01 = r0001 * is0;
+        const T c = tfma(r01s, pd0 * (is0 * is0), r11s + pd1);
+        const T is1 = (c > T(0)) ? frsqrt(c) : T(0); // 1 / s11
+        const T w0 = g0 * is0;                        // S^T w = g
+        const T w1 = tfma(-s01, w0, g1) * is1;
+        q1 = w1 * is1;                                // S p = w
+        q0 = tfma(-s01, q1, w0) * is0;
+        w[0] = d0 * q0;
+        w[1] = d1 * q1;
+        dxnorm = enorm_small<T, 2, U>(w);
+        const T temp = fp;
+        fp = dxnorm - delta;
+        if (pol<U>(tabs(fp) <= p1 * delta || (parl == T(0) && fp <= temp && temp < T(0)) || iter == 10)) break;
+        const T idx = frcp(dxnorm);
+        T z[2];
+        z[0] = (d0 * (w[0] * idx)) * is0;             // S^T z = D^2 p / ||D p||
+        z[1] = tfma(-s01, z[0], d1 * (w[1] * idx)) * is1;
+        const T parc = lmpar_ratio<T, 2, U>(fp * idelta, tfma(z[0], z[0], z[1] * z[1]), z);
+        if (fp > T(0)) parl = tmax(parl, par);
+        if (fp < T(0)) paru = tmin(paru, par);
+        par = tmax(parl, par + parc);
+    }
+    x[0] = swapped ? q1 : q0;
+    x[1] = swapped ? q0 : q1;
+    dxnorm_out = dxnorm;
+    return par;
+}
+// the trust-region sub-problem of the fp64 Householder kernels: MINPACK's lmpar, or its two-parameter form
+template <typename T, int Q, bool U = true, bool O = false>
+__device__ __forceinline__ T lmpar_any(T (&r)[Q][Q], const int (&ipvt)[Q], const T (&diag)[Q], const T (&qtb)[Q],
+                                       const T delta, T par, T (&x)[Q], T &dxnorm_out) {
+    if constexpr (Q == 2 && VP_LMPAR_Q2 && sizeof(T) == 8) return lmpar_q2<T, U>(r, ipvt, diag, qtb, delta, par, x, dxnorm_out);
+    else return lmpar<T, Q, U, O>(r, ipvt, diag, qtb, delta, par, x, dxnorm_out);
+}
+
 // lmpar for callers whose R is itself the Cholesky factor of a Gram matrix J^T J (vp_fitg.hpp: J is never materialised).
 // Same trust-region sub-problem, same Newton iteration on par, same exits as lmpar above; what differs is how the
 // regularised factor S  (S^T S = R^T R + par D_p^2, what qrsolv's Q(Q+1)/2 Givens rotations produce) is obtained: as the
@@ -588,6 +680,98 @@ __device__ __forceinline__ void jac_qrfac(T (&Z)[Q][R], T (&rv)[R], T (&Rj)[Q][Q
     for (int j = 0; j < Q; ++j) Rj[j][j] = rdiag[j];
 }
 
+// jac_qrfac_scaled for TWO columns with the pivot order as a compile-time constant (round 5): the generic routine brings the
+// pivot column into position 0 by exchanging the register columns (2 R moves per exchange, taken by half of all accepted
+// steps); here the two orders are two instantiations of the same statements and the choice is one scalar branch.  Same
+// operations on the same operands in the same order as the generic routine: results bit-identical.
+#ifndef VP_JAC_Q2_NOSWAP
+#define VP_JAC_Q2_NOSWAP 1
+#endif
+template <typename T, int R, int ROW0, bool SWAP, class G>
+__device__ __forceinline__ void jac_q2_ordered(T (&Z)[2][R], T (&rv)[R], const T (&s_in)[2], const T (&Gm)[2][2], const T (&bz)[2],
+                                               T (&Rj)[2][2], int (&ipvt)[2], T (&qtf)[2], G &grp) {
+    using L = Layout<R, G::W>;
+    const int lane = grp.gl;
+    constexpr int PC = SWAP ? 1 : 0, OC = SWAP ? 0 : 1; // pivot column, other column
+    ipvt[0] = PC;
+    ipvt[1] = OC;
+    const T sc0 = s_in[PC], sc1 = s_in[OC];
+    T rdiag0, rdiag1;
+    Rj[1][0] = T(0);
+    { // ---- step 0: raw dots from the Gram round
+        constexpr int prow = ROW0;
+        T top[3] = {Z[PC][L::reg_of_row(prow)], Z[OC][L::reg_of_row(prow)], rv[L::reg_of_row(prow)]};
+        group_bcast<3>(grp, top, L::lane_of_row(prow));
+        const T dz0 = Gm[PC][PC], dz1 = Gm[PC][OC], dr = bz[PC];
+        T an = usqrt(dz0);
+        if (uni(tabs(sc0) * an == T(0) || dz0 <= num<T>::norm2_min)) {
+            rdiag0 = T(0);
+            Rj[0][1] = sc1 * top[1];
+            qtf[0] = top[2];
+        } else {
+            const T piv = top[0];
+            if (piv < T(0)) an = -an;
+            const T vp = piv + an;
+            const T gj = -frcp(an * vp);
+#pragma unroll
+            for (int r = 0; r < L::VW && r < R; ++r) {
+                const int i = L::row_of(r, lane);
+                Z[PC][r] = (i == prow) ? vp : Z[PC][r];
+            }
+            {
+                const T f = gj * tfma(an, top[1], dz1);
+#pragma unroll
+                for (int r = 0; r < R; ++r) Z[OC][r] = tfma(f, Z[PC][r], Z[OC][r]);
+                Rj[0][1] = sc1 * tfma(f, vp, top[1]);
+            }
+            {
+                const T f = gj * tfma(an, top[2], dr);
+#pragma unroll
+                for (int r = 0; r < R; ++r) rv[r] = tfma(f, Z[PC][r], rv[r]);
+                qtf[0] = tfma(f, vp, top[2]);
+            }
+            rdiag0 = -an;
+        }
+    }
+    { // ---- step 1: one reduction round (the remaining column's norm below the pivot row and its dot with rv)
+        constexpr int prow = ROW0 + 1;
+#pragma unroll
+        for (int r = 0; r < L::VW && r < R; ++r) {
+            const int i = L::row_of(r, lane);
+            Z[OC][r] = (i >= prow) ? Z[OC][r] : T(0);
+        }
+        T w[2];
+        {
+            T a0 = T(0), a1 = T(0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) a0 = tfma(Z[OC][r], Z[OC][r], a0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) a1 = tfma(Z[OC][r], rv[r], a1);
+            w[0] = a0;
+            w[1] = a1;
+        }
+        group_allreduce(grp, w);
+        T top[2] = {Z[OC][L::reg_of_row(prow)], rv[L::reg_of_row(prow)]};
+        group_bcast<2>(grp, top, L::lane_of_row(prow));
+        T an = usqrt(w[0]);
+        if (uni(tabs(sc1) * an == T(0) || w[0] <= num<T>::norm2_min)) {
+            rdiag1 = T(0);
+            qtf[1] = top[1];
+        } else {
+            const T piv = top[0];
+            if (piv < T(0)) an = -an;
+            const T vp = piv + an;
+            const T gj = -frcp(an * vp);
+            const T f = gj * tfma(an, top[1], w[1]);
+            // (rv is not used after this routine: only its pivot-row entry is formed)
+            qtf[1] = tfma(f, vp, top[1]);
+            rdiag1 = -an;
+        }
+    }
+    Rj[0][0] = sc0 * rdiag0;
+    Rj[1][1] = sc1 * rdiag1;
+}
+
 // The same factorisation for a Jacobian given as COLUMN-SCALED columns  z_k = s_k g_k  (Kaufman: z_k = -c_k Q^T D_k for
 // models whose pair p is (basis p, parameter p)):  the reflectors depend only on the directions g_k, so all vector
 // work runs on the unscaled columns G in place -- no scaling pass over the q columns -- and the scales enter as wave-
@@ -646,6 +830,12 @@ __device__ __forceinline__ void jac_qrfac_scaled(T (&Z)[Q][R], T (&rv)[R], const
             acnorm[a] = sa[a] * rdiag[a];
             ipvt[a] = a;
         }
+    }
+    if constexpr (Q == 2 && VP_JAC_Q2_NOSWAP) {
+        // (acnorm is already set, in model order)
+        if (uni(sa[1] * rdiag[1] > sa[0] * rdiag[0])) jac_q2_ordered<T, R, ROW0, true, G>(Z, rv, s_in, Gm, bz, Rj, ipvt, qtf, grp);
+        else jac_q2_ordered<T, R, ROW0, false, G>(Z, rv, s_in, Gm, bz, Rj, ipvt, qtf, grp);
+        return;
     }
 #pragma unroll
     for (int i = 0; i < Q; ++i)
@@ -803,6 +993,77 @@ __device__ __forceinline__ void jac_qrfac_scaled(T (&Z)[Q][R], T (&rv)[R], const
     for (int j = 0; j < Q; ++j) Rj[j][j] = sc[j] * rdiag[j];
 }
 
+// ---- rescue of a Jacobian that is not representable column by column (round 5) ---------------------------------------
+// The fit kernels carry the UNSCALED derivative columns dPhi_k through the sweep and let the coefficient c_k enter the
+// Jacobian QR as a wave-uniform factor (jac_qrfac_scaled).  The reference forms D_k c first and projects afterwards
+// (src/solvers/levmar/mod.rs:156-171), so a trial point at which a basis column is huge and its coefficient tiny -- a decay
+// time stepping through zero: exp(+t/0.035) = 1e153, c = 1e-152 -- is an ordinary evaluation there (D_k c = 1e5), while
+// here the dot product of the 1e153 column with its 1e157 derivative column overflows and the fit would end `Numerical`
+// (one problem in the 524 288 of BASELINE configs[3]).  When a Jacobian comes out non-finite after an evaluation that
+// was itself ok, evaluation and Jacobian are REPEATED out of line with every derivative column scaled by 2^-ks, ks = the
+// binary exponent of its basis column's largest entry, and the coefficient by 2^ks: the basis part (R, c, the residual) is
+// bit for bit the evaluation that was just made, c_k D_k is unchanged, nothing overflows; power-of-two factors are exact, so
+// where the unscaled Jacobian IS representable the two agree to the last bit.  The results go to LDS (the caller's parked
+// LM record): the call sites sit where little is live, and the hot path pays the finiteness test of acnorm only.
+template <typename T, int Q> struct ParamPack {
+    T v[Q];
+};
+template <typename T, class M, int W>
+inline constexpr bool jac_rescue_v = sizeof(T) == 8 && W == 1 && M::kStatic && M::kConstLast && M::kDiagonalPairs;
+
+template <typename T, class M, int R, class Src, bool YPRE>
+__device__ __noinline__ void rescue_jacobian(const ParamPack<T, M::Q> al, const Src src, const T eps, const T h0_beta,
+                                             const T h0_u, const T h0_g, const T *s_col, const T qty0, VP_LDS T *Rj_out,
+                                             VP_LDS T *acnorm_out, VP_LDS T *qtf_out, VP_LDS int *ipvt_out) {
+    constexpr int N = M::N, P = M::P, Q = M::Q, NE = N - 1;
+    constexpr int NC = N + P, YC = N - 1, DC = YC + 1;
+    using G = Grp<1>;
+    G grp = G::make(nullptr);
+    const int lane = grp.gl;
+    const M mdl{};
+    ConstReflector<T> h0;
+    h0.beta = h0_beta;
+    h0.u = h0_u;
+    h0.g = h0_g;
+    h0.live = true;
+    T alpha[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) alpha[k] = al.v[k];
+    // largest exponent of exp(-t/tau_j) over the grid, from its two ends (grids are sorted; an unsorted one keeps ks = 0 and
+    // with it the unscaled result)
+    const T t_first = src.t[0], t_last = src.t[src.m - 1];
+    int ks[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) ks[j] = 0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const T rt = T(1) / alpha[j];
+        const T e2 = tmax(-t_first * rt, -t_last * rt) * T(1.4426950408889634);
+        ks[j] = uni((e2 > T(64) && e2 < T(1100)) ? (int)e2 : 0);
+    }
+    T C[NC][R];
+    EvalUniform<T, N> u;
+    load_rows_lds<T, R, 1>(s_col, lane, C[YC]);
+    evaluate_core_const_first<T, M, R, NC, Src, G, YPRE, false, true>(mdl, alpha, src, eps, grp, h0, C, u, nullptr, qty0, ks);
+    residual_qcoords<T, R, N>(C[YC], u.e, grp);
+    T zs[Q], Rj[Q][Q], acnorm[Q], qtf[Q];
+    int ipvt[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) zs[k] = -tldexp(u.c[k], ks[k]);
+    jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            acnorm_out[k] = acnorm[k];
+            qtf_out[k] = qtf[k];
+            ipvt_out[k] = ipvt[k];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) Rj_out[k * Q + j] = Rj[k][j];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <typename T, class M> struct FitArgs {
     M mdl;
     const T *t;
@@ -941,8 +1202,7 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
 #else
     SectionClock *clk = nullptr;
 #endif
-    for (;;) {
-        // ---- park the LM state in LDS for the duration of the sweep (each wave parks its own copy) ----
+    auto park = [&]() __attribute__((always_inline)) {
         if (grp.lane == 0) {
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
@@ -968,20 +1228,8 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
             st->flags = (first ? 1 : 0) | (first_tr ? 2 : 0) | (first_update ? 4 : 0);
             st->nfev = nfev;
         }
-        asm volatile("" ::: "memory");
-
-        // ================= evaluate the VarPro functional at xt =================
-        T C[NC][R];
-        EvalUniform<T, N> u;
-        if constexpr (R >= 2) load_rows_lds<T, R, W>(s_y, lane, C[YC]);
-        else load_rows<T, R, W>(s_y, MP, lane, true, C[YC]);
-        VP_TICK(clk, 0);
-        if constexpr (CF) evaluate_core_const_first<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, h0, C, u, clk);
-        else evaluate_core<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, C, u, clk);
-        VP_TICK(clk, 3);
-
-        asm volatile("" ::: "memory");
-        // ---- un-park ----
+    };
+    auto unpark = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
             x[k] = st->x[k];
@@ -1010,6 +1258,25 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
             first_update = (fl & 4) != 0;
             nfev = uni(st->nfev);
         }
+    };
+    for (;;) {
+        // ---- park the LM state in LDS for the duration of the sweep (each wave parks its own copy) ----
+        park();
+        asm volatile("" ::: "memory");
+
+        // ================= evaluate the VarPro functional at xt =================
+        T C[NC][R];
+        EvalUniform<T, N> u;
+        if constexpr (R >= 2) load_rows_lds<T, R, W>(s_y, lane, C[YC]);
+        else load_rows<T, R, W>(s_y, MP, lane, true, C[YC]);
+        VP_TICK(clk, 0);
+        if constexpr (CF) evaluate_core_const_first<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, h0, C, u, clk);
+        else evaluate_core<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, C, u, clk);
+        VP_TICK(clk, 3);
+
+        asm volatile("" ::: "memory");
+        // ---- un-park ----
+        unpark();
 
         const T fnorm1 = usqrt(u.fn2);
         bool need_jac = false;
@@ -1114,6 +1381,21 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
 #pragma unroll
                 for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
                 jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
+                if constexpr (CF && jac_rescue_v<T, M, W>) {
+                    bool bad = false;
+#pragma unroll
+                    for (int k = 0; k < Q; ++k) bad = bad || !is_finite(acnorm[k]);
+                    if (uni(bad)) { // (rare: rescue_jacobian; the LM state goes through its LDS record, nothing is live across the call)
+                        park();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        ParamPack<T, Q> al;
+#pragma unroll
+                        for (int k = 0; k < Q; ++k) al.v[k] = xt[k];
+                        rescue_jacobian<T, M, R, Src, false>(al, src, a.eps, h0.beta, h0.u, h0.g, s_y, T(0), (VP_LDS T *)&st->Rj[0][0],
+                                                             (VP_LDS T *)st->acnorm, (VP_LDS T *)st->qtf, (VP_LDS int *)st->ipvt);
+                        unpark();
+                    }
+                }
             } else {
                 T Zs[Q][R];
                 jacobian_qcoords<T, M, R, NC, G, DC>(a.mdl, C, u.c, Zs, grp);
@@ -1167,7 +1449,7 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
 
         // ================= trust-region step =================
         VP_TICK(clk, 6);
-        par = lmpar<T, Q>(Rj, ipvt, diag, qtf, delta, par, step, pnorm);
+        par = lmpar_any<T, Q>(Rj, ipvt, diag, qtf, delta, par, step, pnorm);
         VP_TICK(clk, 7);
         if (uni(!is_finite(pnorm))) {
             term = VP_TERM_NUMERICAL;

@@ -359,7 +359,7 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
 #pragma unroll
             for (int j = 0; j < Q; ++j) Rw[i][j] = Rj[i][j];
         if constexpr (GRAM) par = lmpar_chol<T, Q, false, (Q > 3)>(Rj, ipvt, diag, qtf, delta, par, step, pnorm);
-        else par = lmpar<T, Q, false, (Q > 3)>(Rw, ipvt, diag, qtf, delta, par, step, pnorm);
+        else par = lmpar_any<T, Q, false, (Q > 3)>(Rw, ipvt, diag, qtf, delta, par, step, pnorm);
         if (!is_finite(pnorm)) {
             term = VP_TERM_NUMERICAL;
         } else {
@@ -503,14 +503,34 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
         }
         ++trow;
     };
-    for (;;) {
-        // the LM state stays parked in the slot's record during the sweep (the register-pressure peak); only the trial
-        // parameters are live across it
-        T C[NC][R];
-        EvalUniform<T, N> u;
-        load_rows_lds<T, R, 1>((const T *)s_col, lane, C[YC]);
-        evaluate_core_const_first<T, M, R, NC, Src, G, true>(mdl, xt, src, eps, grp, h0, C, u, nullptr, qty0);
-        asm volatile("" ::: "memory");
+    auto park = [&]() __attribute__((always_inline)) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                rec->x[k] = x[k];
+                rec->diag[k] = diag[k];
+                rec->qtf[k] = qtf[k];
+                rec->acnorm[k] = acnorm[k];
+                rec->ipvt[k] = ipvt[k];
+#pragma unroll
+                for (int j = 0; j < Q; ++j) rec->Rj[k][j] = Rj[k][j];
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) rec->cbest[k] = cbest[k];
+            rec->fnorm = fnorm;
+            rec->delta = delta;
+            rec->par = par;
+            rec->xnorm = xnorm;
+            rec->gnorm = gnorm;
+            rec->pnorm = pnorm;
+            rec->prered = prered;
+            rec->dirder = dirder;
+            rec->objective = objective;
+            rec->flags = (first ? 1 : 0) | (first_tr ? 2 : 0) | (first_update ? 4 : 0);
+            rec->nfev = nfev;
+        }
+    };
+    auto unpark = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
             x[k] = rec->x[k];
@@ -539,6 +559,16 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
             first_update = (fl & 4) != 0;
             nfev = uni(rec->nfev);
         }
+    };
+    for (;;) {
+        // the LM state stays parked in the slot's record during the sweep (the register-pressure peak); only the trial
+        // parameters are live across it
+        T C[NC][R];
+        EvalUniform<T, N> u;
+        load_rows_lds<T, R, 1>((const T *)s_col, lane, C[YC]);
+        evaluate_core_const_first<T, M, R, NC, Src, G, true>(mdl, xt, src, eps, grp, h0, C, u, nullptr, qty0);
+        asm volatile("" ::: "memory");
+        unpark();
         const T fnorm1 = usqrt(u.fn2);
         bool need_jac = false;
         if (first) {
@@ -635,6 +665,22 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
 #pragma unroll
             for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
             jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
+            if constexpr (jac_rescue_v<T, M, 1>) {
+                bool bad = false;
+#pragma unroll
+                for (int k = 0; k < Q; ++k) bad = bad || !is_finite(acnorm[k]);
+                if (uni(bad)) { // (rare: rescue_jacobian, vp_fit.hpp; the LM state goes through the slot's record)
+                    park();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    ParamPack<T, Q> al;
+#pragma unroll
+                    for (int k = 0; k < Q; ++k) al.v[k] = xt[k];
+                    rescue_jacobian<T, M, R, Src, true>(al, src, eps, h0.beta, h0.u, h0.g, (const T *)s_col, qty0,
+                                                        (VP_LDS T *)&rec->Rj[0][0], (VP_LDS T *)rec->acnorm,
+                                                        (VP_LDS T *)rec->qtf, (VP_LDS int *)rec->ipvt);
+                    unpark();
+                }
+            }
             T gmax = T(0);
             bool degenerate = false;
             const T ifn = frcp(fnorm);
@@ -678,7 +724,7 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
                 for (int k = 0; k < Q; ++k) diag[k] = tmax(diag[k], acnorm[k]);
             }
         }
-        par = lmpar<T, Q>(Rj, ipvt, diag, qtf, delta, par, step, pnorm);
+        par = lmpar_any<T, Q>(Rj, ipvt, diag, qtf, delta, par, step, pnorm);
         if (uni(!is_finite(pnorm))) {
             term = VP_TERM_NUMERICAL;
             break;
@@ -710,31 +756,7 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
 #pragma unroll
         for (int k = 0; k < Q; ++k) xt[k] = x[k] - step[k];
         // park for the next sweep
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < Q; ++k) {
-                rec->x[k] = x[k];
-                rec->diag[k] = diag[k];
-                rec->qtf[k] = qtf[k];
-                rec->acnorm[k] = acnorm[k];
-                rec->ipvt[k] = ipvt[k];
-#pragma unroll
-                for (int j = 0; j < Q; ++j) rec->Rj[k][j] = Rj[k][j];
-            }
-#pragma unroll
-            for (int k = 0; k < N; ++k) rec->cbest[k] = cbest[k];
-            rec->fnorm = fnorm;
-            rec->delta = delta;
-            rec->par = par;
-            rec->xnorm = xnorm;
-            rec->gnorm = gnorm;
-            rec->pnorm = pnorm;
-            rec->prered = prered;
-            rec->dirder = dirder;
-            rec->objective = objective;
-            rec->flags = (first ? 1 : 0) | (first_tr ? 2 : 0) | (first_update ? 4 : 0);
-            rec->nfev = nfev;
-        }
+        park();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // results of the finished problem
@@ -872,6 +894,7 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
 #endif
     while (nactive > 0) {
         // =============================== VECTOR phase ===============================
+        bool anybad = false;
 #pragma nounroll
         for (int s = 0; s < GS; ++s) {
             Rec *rec = recs + s;
@@ -901,6 +924,7 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
             const bool need_jac = u.ok && (first || good);
             T Rj[Q][Q], acnorm[Q], qtf[Q];
             int ipvt[Q];
+            bool jbad = false;
             if (need_jac) {
                 // z_k = -c_k Q^T D_k: factor the unscaled columns in place, the coefficients enter as column scales
                 residual_qcoords<T, R, N>(C[YC], u.e, grp);
@@ -908,6 +932,13 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
 #pragma unroll
                 for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
                 jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
+                if constexpr (jac_rescue_v<T, M, W>) {
+                    // a Jacobian that is not finite after a good evaluation is redone after the slot loop (rescue_jacobian)
+#pragma unroll
+                    for (int k = 0; k < Q; ++k) jbad = jbad || !is_finite(acnorm[k]);
+                    jbad = uni(jbad);
+                    anybad = anybad || jbad;
+                }
             }
             if (lane == 0) { // group lane 0
                 rec->fnorm1 = fnorm1;
@@ -929,10 +960,27 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
                     }
                 }
                 if (good) fl |= 32;
+                if (jbad) fl |= 64;
                 rec->flags = fl;
             }
         }
         group_sync();
+        if constexpr (jac_rescue_v<T, M, W>) {
+            if (anybad) { // (rare) out of line, between the phases: only the kernel's own constants are live here
+#pragma nounroll
+                for (int s = 0; s < GS; ++s) {
+                    Rec *rec = recs + s;
+                    if (uni(rec->prob) < 0 || (uni(rec->flags) & 64) == 0) continue;
+                    ParamPack<T, Q> al;
+#pragma unroll
+                    for (int k = 0; k < Q; ++k) al.v[k] = rec->xt[k];
+                    rescue_jacobian<T, M, R, Src, true>(al, src, eps_, h0.beta, h0.u, h0.g, s_y + (size_t)s * MP, rec->qty0,
+                                                        (VP_LDS T *)&rec->Rj[0][0], (VP_LDS T *)rec->acnorm,
+                                                        (VP_LDS T *)rec->qtf, (VP_LDS int *)rec->ipvt);
+                }
+                group_sync();
+            }
+        }
         VP_CK2(0);
 
         // =============================== SCALAR phase: lane s of wave 0 <-> slot s ===============================

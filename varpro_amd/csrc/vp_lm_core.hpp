@@ -184,7 +184,7 @@ __device__ __forceinline__ void lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T>
     for (int i = 0; i < Q; ++i)
 #pragma unroll
         for (int j = 0; j < Q; ++j) Rwork[i][j] = s.Rj[i][j];
-    s.par = lmpar<T, Q, U, true>(Rwork, s.ipvt, s.diag, s.qtf, s.delta, s.par, step, s.pnorm);
+    s.par = lmpar_any<T, Q, U, true>(Rwork, s.ipvt, s.diag, s.qtf, s.delta, s.par, step, s.pnorm);
     if (pol<U>(!is_finite(s.pnorm))) {
         s.term = VP_TERM_NUMERICAL;
         return;

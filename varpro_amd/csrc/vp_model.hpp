@@ -302,9 +302,14 @@ struct RowSource {
 //   WF / WD: write the basis columns / the derivative columns (the split evaluate kernel builds them in two phases; the
 //            arithmetic of the phase that is not written is dead code)
 //   JSEL:    >= 0: only basis JSEL is processed (with WF = false, WD = true and DOFF = -pair: ONE derivative column into C[0])
+//   SHIFT:   (exponential kinds) the DERIVATIVE columns of basis j are built as 2^-ks[j] times their values, the factor
+//            applied to the exponential before t / tau^2 multiplies it; the basis columns are untouched (rescue_jacobian,
+//            vp_fit.hpp: a basis column within a few decades of overflow whose derivative column, or whose dot product with
+//            it, is not representable)
 template <typename T, class M, int R, int NC, class Src, int DOFF = M::N + 1, bool SKIP_CONST = false, bool WF = true,
-          bool WD = true, int JSEL = -1>
-__device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::Q], const Src &src, T (&C)[NC][R]) {
+          bool WD = true, int JSEL = -1, bool SHIFT = false>
+__device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::Q], const Src &src, T (&C)[NC][R],
+                                              const int *ks = nullptr) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
     constexpr int VW = Layout<R>::VW;
     static_assert(!WD || JSEL >= 0 || NC >= DOFF + P, "column array too small");
@@ -377,6 +382,10 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
             }
         }
     }
+    auto shifted = [&](T v, int j) __attribute__((always_inline)) {
+        if constexpr (SHIFT) return tldexp(v, -ks[j]);
+        else return v;
+    };
     // rows outermost: the grid value and row scale of a row pair are fetched (and masked) ONCE and feed all N
     // columns, whose independent transcendental pipelines interleave
     auto rows = [&](auto fast_c) __attribute__((always_inline)) {
@@ -415,7 +424,7 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                         } else {
                             f = texp(-div_refined(t, p0[j], rt[j])) * scl;
                         }
-                        d0 = (f * t) * rt2[j];
+                        d0 = (shifted(f, j) * t) * rt2[j];
                     } else if (kind[j] == VP_BASIS_EXP_RATE) {
                         if constexpr (FAST) {
                             if constexpr (kBatchExp) {
@@ -427,7 +436,7 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                         } else {
                             f = texp(-p0[j] * t) * scl;
                         }
-                        d0 = -t * f;
+                        d0 = -t * shifted(f, j);
                     } else if (kind[j] == VP_BASIS_EXP_COS) {
                         // exp(-a t) cos(b t)   (shared_test_code/src/models.rs:313-314, 349-372)
                         const T ex = texp(-p0[j] * t) * scl;

@@ -152,6 +152,13 @@ class ClosureModel:
 
     def __init__(self, parameter_names, x, dtype=np.float64):
         self.names = list(parameter_names)
+        # the builder's checks on the model parameter list (src/model/builder/mod.rs:338-370, error.rs variant names)
+        if len(self.names) == 0:
+            raise ModelBuildError("EmptyParameters", "A function or model parameter list is empty!")
+        if len(set(self.names)) != len(self.names):
+            raise ModelBuildError("DuplicateParameterNames", "Parameter list %r contains duplicates!" % (self.names,))
+        if any("," in n for n in self.names):
+            raise ModelBuildError("CommaInParameterNameNotAllowed", "Parameter names may not contain comma separator")
         self.x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
         self.dtype = np.dtype(dtype)
         self._functions = []  # (param indices, f, {param index: df})
@@ -161,12 +168,26 @@ class ClosureModel:
         return self
 
     def function(self, function_params, f):
-        idx = tuple(self.names.index(p) for p in function_params)  # FunctionParameterNotInModel -> ValueError
+        fp = list(function_params)
+        if len(fp) == 0:
+            raise ModelBuildError("EmptyParameters", "A function or model parameter list is empty!")
+        if len(set(fp)) != len(fp):
+            raise ModelBuildError("DuplicateParameterNames", "Parameter list %r contains duplicates!" % (fp,))
+        for p in fp:
+            if p not in self.names:
+                raise ModelBuildError("FunctionParameterNotInModel",
+                                      "Function parameter '%s' is not part of the model parameters." % p)
+        idx = tuple(self.names.index(p) for p in fp)
         self._functions.append((idx, f, {}))
         return self
 
     def partial_deriv(self, parameter, df):
+        if not self._functions or not self._functions[-1][0]:
+            # (the reference's builder has no partial_deriv in the state that follows an invariant function: a type error there)
+            raise ModelBuildError("InvalidDerivative", "partial_deriv needs a preceding function with parameters")
         idx, _f, derivs = self._functions[-1]
+        if parameter not in self.names:
+            raise ModelBuildError("InvalidDerivative", "Parameter '%s' is not in the function's parameter list" % parameter)
         k = self.names.index(parameter)
         if k not in idx:
             raise ModelBuildError("InvalidDerivative", "Parameter '%s' is not in the function's parameter list" % parameter)
@@ -179,10 +200,17 @@ class ClosureModel:
         return [(j, k) for j, (idx, _f, _d) in enumerate(self._functions) for k in idx]
 
     def shape(self):
+        # == SeparableModelBuilder::build (src/model/builder/mod.rs:527-553): EmptyModel, MissingDerivative, UnusedParameter
+        if not self._functions:
+            raise ModelBuildError("EmptyModel", "A model must contain at least one function")
         for idx, _f, derivs in self._functions:
             for k in idx:
                 if k not in derivs:
                     raise ModelBuildError("MissingDerivative", "missing derivative for parameter '%s'" % self.names[k])
+        used = {k for idx, _f, _d in self._functions for k in idx}
+        for k, name in enumerate(self.names):
+            if k not in used:
+                raise ModelBuildError("UnusedParameter", "Parameter '%s' is not used by any function of the model" % name)
         return ExternalModel(len(self._functions), len(self.names), self.pairs(), dtype=self.dtype)
 
     def eval_batch(self, alpha):
