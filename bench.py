@@ -708,6 +708,48 @@ def main():
                                         "achieved": bytes_xin / (xi_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": bytes_xin / (xi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": bytes_xin},
             }
+            # ---- the same boundary for LONG problems and fp32 (round 5): W waves of a workgroup share the columns of one problem
+            # (ext_evaluate_kernel<.., W>): one pass over the caller's arrays up to 4 096 rows (four waves), 8 192 fp64 /
+            # 16 384 fp32 (eight); beyond that the streamed kernel of vp_blk_ext.hpp (any m, two passes over the columns)
+            long_legs = {}
+            for tdt, ml, Bl, kern in ((torch.float32, 4096, 32768, "ext_evaluate_kernel<float, 3, 2, 16, true, 4> (four waves per problem)"),
+                                      (torch.float64, 8192, 8192, "ext_evaluate_kernel<double, 3, 2, 16, true, 8> (eight waves per problem)"),
+                                      (torch.float64, 10000, 4096, "blk::ext_stream_evaluate_kernel<double, 3, 2, 4> (rows streamed in blocks, two passes over the caller's columns: 15 column transfers for 9 algorithmic)")):
+                Tl = 4 if tdt == torch.float32 else 8
+                gl_ = torch.Generator(device=dev)
+                gl_.manual_seed(0x5EED77)
+                xl = torch.linspace(0.0, 12.5, ml, dtype=torch.float64, device=dev)
+                t1 = 0.5 + 1.5 * torch.rand((Bl, 1), generator=gl_, dtype=torch.float64, device=dev)
+                t2 = 2.5 + 5.5 * torch.rand((Bl, 1), generator=gl_, dtype=torch.float64, device=dev)
+                cl = 1.0 + 99.0 * torch.rand((Bl, 3), generator=gl_, dtype=torch.float64, device=dev)
+                phl = torch.empty((Bl, 3, ml), dtype=tdt, device=dev)
+                dpl = torch.empty((Bl, 2, ml), dtype=tdt, device=dev)
+                e1_, e2_ = torch.exp(-xl[None] / t1), torch.exp(-xl[None] / t2)
+                phl[:, 0], phl[:, 1], phl[:, 2] = e1_.to(tdt), e2_.to(tdt), 1.0
+                dpl[:, 0], dpl[:, 1] = (e1_ * xl[None] / (t1 * t1)).to(tdt), (e2_ * xl[None] / (t2 * t2)).to(tdt)
+                Yl = (cl[:, 0:1] * e1_ + cl[:, 1:2] * e2_ + cl[:, 2:3])
+                Yl = (Yl + args.noise * Yl.abs().amax(dim=1, keepdim=True) * torch.randn(Yl.shape, generator=gl_, dtype=torch.float64, device=dev)).to(tdt)
+                del e1_, e2_
+                al = torch.cat([t1, t2], 1).to(tdt) * 1.1
+                bpl = vp.BatchProblem(vp.ExternalModel(3, 2, [(0, 0), (1, 1)], dtype=np.float32 if tdt == torch.float32 else np.float64), Yl)
+                rl, Jl = torch.empty((Bl, ml), dtype=tdt, device=dev), torch.empty((Bl, 2, ml), dtype=tdt, device=dev)
+                Cl, costl, stl = torch.empty((Bl, 3), dtype=tdt, device=dev), torch.empty((Bl,), dtype=torch.float64, device=dev), torch.empty((Bl,), dtype=torch.int32, device=dev)
+
+                def xl_full():
+                    _lib.check(bpl.lib.vp_evaluate_with_basis(bpl._h, vptr(al), vptr(phl), vptr(dpl), vptr(rl), vptr(Jl), vptr(Cl), vptr(costl), vptr(stl)))
+
+                xl_ms = event_ms_each(xl_full, 8, 2)
+                torch.cuda.synchronize()
+                byl = Bl * Tl * ml * 9
+                long_legs["%s_m%d" % ("f32" if Tl == 4 else "f64", ml)] = {
+                    "workload": "vp_evaluate_with_basis, B=%d, m=%d, %s, n=3, q=2, p=2 (Phi, dPhi, y in; r, J out)" % (Bl, ml, "fp32" if Tl == 4 else "fp64"),
+                    "ms": xl_ms, "status_ok_share": float((stl == 0).double().mean()),
+                    "roofline": {"kernel": kern, "bound": "hbm", "achieved": byl / (xl_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": byl / (xl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": byl, "avg_launch_ms": xl_ms, "traffic": None}}
+                bpl.close()
+                del phl, dpl, Yl, rl, Jl
+            out["external_model"]["long_problems"] = long_legs
+
             # ---- the FIT of such a batch by reverse communication (vp_fit_begin / vp_fit_step_with_basis / vp_fit_end): the LM
             # driver of every problem on the device, the model with the caller.  The caller here is the double-exponential model
             # evaluated ON THE DEVICE by the caller's own kernels (vp_basis of the descriptor handle while most problems are

@@ -152,7 +152,8 @@ def _check_against_oracle(cm, Y, alpha, w=None, tol=TOL, rhs_major=False):
     return got
 
 
-@pytest.mark.parametrize("m", [5, 50, 257, 1000, 1024, 3000])
+# (m = 3000, 4096: four waves per problem; 5000: beyond the kernels of this 8-column shape -> the generic kernels)
+@pytest.mark.parametrize("m", [5, 50, 257, 1000, 1024, 3000, 4096, 5000])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_gauss_lorentz_peaks_match_the_oracle(m, weighted):
     rng = np.random.default_rng(7 + m)
@@ -249,6 +250,67 @@ def test_fp32_handle():
         assert np.abs(got["r"][b] - r_ref).max() <= 2e-4 * np.abs(Y32[b]).max()
         fit = Y32[b] - got["r"][b]
         assert np.abs(fit - (Y32[b] - r_ref)).max() <= 2e-4 * np.abs(Y32[b]).max()
+    bp.close()
+
+
+def decay_model(x, dtype=np.float64):
+    """c1 exp(-x/t1) + c2 exp(-x/t2) + c3 as a CLOSURE model: n = 3, q = 2, p = 2 (the headline shape, caller-evaluated)"""
+    return (vp.ClosureModel(["t1", "t2"], x, dtype=dtype)
+            .function(["t1"], lambda x, t: np.exp(-x / t)).partial_deriv("t1", lambda x, t: np.exp(-x / t) * x / t ** 2)
+            .function(["t2"], lambda x, t: np.exp(-x / t)).partial_deriv("t2", lambda x, t: np.exp(-x / t) * x / t ** 2)
+            .invariant_function(lambda x: np.ones_like(x)))
+
+
+# the register-resident kernels for LONG problems (round 5, vp_ext.hpp: W waves of a workgroup share the columns of one
+# problem -- one pass over the caller's arrays): fp64 four waves to 4 096 rows, eight to 8 192; beyond: the generic kernels
+@pytest.mark.parametrize("m", [2048, 2500, 4096, 5000, 8192, 10000])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_long_problems_fp64(m, weighted):
+    rng = np.random.default_rng(100 + m)
+    B = 3
+    x = np.linspace(0.0, 12.5, m)
+    cm = decay_model(x)
+    tau = np.stack([rng.uniform(0.5, 2.0, B), rng.uniform(2.5, 8.0, B)], 1)
+    c = rng.uniform(1.0, 100.0, (B, 3))
+    Y = c[:, 0:1] * np.exp(-x / tau[:, 0:1]) + c[:, 1:2] * np.exp(-x / tau[:, 1:2]) + c[:, 2:3]
+    Y = Y + 1e-3 * np.abs(Y).max(1, keepdims=True) * rng.standard_normal(Y.shape)
+    w = (0.5 + rng.random(m)) if weighted else None
+    _check_against_oracle(cm, Y, tau * (1 + rng.uniform(-0.2, 0.2, tau.shape)), w=w)
+
+
+# fp32 handles had no resident kernels before round 5 (generic kernels at every shape): one wave to 1 024 rows, four to
+# 4 096, eight to 16 384.  Checked against the fp64 oracle of the converted inputs at fp32 resolution x cond(Phi)
+@pytest.mark.parametrize("m", [200, 1000, 4096, 5000, 16384, 20000])
+def test_long_problems_fp32(m):
+    rng = np.random.default_rng(200 + m)
+    B = 3
+    x = np.linspace(0.0, 12.5, m)
+    cm32, cm64 = decay_model(x, dtype=np.float32), decay_model(x)
+    tau = np.stack([rng.uniform(0.5, 1.0, B), rng.uniform(4.0, 8.0, B)], 1).astype(np.float32)
+    c = rng.uniform(10.0, 100.0, (B, 3))
+    Y = c[:, 0:1] * np.exp(-x / tau[:, 0:1]) + c[:, 1:2] * np.exp(-x / tau[:, 1:2]) + c[:, 2:3]
+    Y32 = (Y + 1e-3 * np.abs(Y).max(1, keepdims=True) * rng.standard_normal(Y.shape)).astype(np.float32)
+    a32 = (tau * (1 + rng.uniform(-0.1, 0.1, tau.shape))).astype(np.float32)
+    Phi, dPhi = cm32.eval_batch(a32), cm32.derivs_batch(a32)
+    bp = vp.BatchProblem(cm32.shape(), Y32)
+    got = bp.evaluate_with_basis(a32, Phi, dPhi)
+    assert (np.asarray(got["status"]) == 0).all()
+    for b in range(B):
+        # the oracle gets the SAME fp32 columns (converted), so that only the solve differs
+        ev = lambda a, b=b: Phi[b].astype(np.float64)
+        def dv(a, k, b=b):
+            out = np.zeros((3, m))
+            out[k] = dPhi[b, k].astype(np.float64)
+            return out
+        p = O.Problem(O.make_shape_desc(3, 2), None, Y32[b].astype(np.float64), external=(ev, dv))
+        p.set_params(a32[b].astype(np.float64))
+        c_ref, r_ref, J_ref = p.linear_coefficients(), p.residuals(), p.jacobian()
+        ymax = np.abs(Y32[b]).max()
+        assert np.abs(got["r"][b] - r_ref).max() <= 3e-4 * ymax, (m, np.abs(got["r"][b] - r_ref).max() / ymax)
+        assert np.abs(np.asarray(got["C"][b]) - c_ref).max() <= 3e-3 * np.abs(c_ref).max()
+        for k in range(2):
+            unproj = np.abs(dPhi[b, k].astype(np.float64) * c_ref[k]).max()
+            assert np.abs(got["J"][b, k] - J_ref[k]).max() <= 1e-3 * unproj, (m, k)
     bp.close()
 
 

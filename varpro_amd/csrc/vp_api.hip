@@ -223,6 +223,8 @@ struct vp_batch {
     void *ext_phi_own, *ext_dphi_own;
     int mrhs_graph_len;     // LM iterations mrhs_graph holds
     int mrhs_graph_iters;   // ... and what the next capture should hold (evaluations of the previous fit + 1, >= 6)
+    int mrhs_prev_nfev;     // largest evaluation count of the previous fit, and for how many fits in a row it has been the
+    int mrhs_same_count;    // same: a stream of fits of one length runs a graph WITHOUT the spare iteration
     int32_t *h_nactive;     // pinned, device-mapped: the active count as the graph's last kernel leaves it
     int32_t *h_nactive_dev; // its device address
     MrhsIo *h_io;           // pinned, device-mapped: the caller's arrays of the current vp_fit (whole-fit graph, device-pointer handles)
@@ -728,7 +730,11 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
     // short of it by 4 or more (each idle iteration is two empty launches, ~10 us); the 12-iteration tail graph does not
     // depend on the length and is only re-captured with the options.
     const bool opts_changed = !h->mrhs_graph || std::memcmp(&h->mrhs_graph_opts, &o, sizeof(o)) != 0;
-    if (want_graph && (opts_changed || want_iters > h->mrhs_graph_len || want_iters + 4 <= h->mrhs_graph_len)) {
+    // (a handle whose last three fits took the same number of evaluations drops the spare iteration -- two empty launches,
+    // ~10 us of a 0.7 ms fit: want_iters is then exact and the head is re-captured once to that length)
+    const bool exact = h->mrhs_same_count >= 2;
+    if (want_graph && (opts_changed || want_iters > h->mrhs_graph_len || want_iters + 4 <= h->mrhs_graph_len ||
+                       (exact && want_iters != h->mrhs_graph_len))) {
         if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
         h->mrhs_graph = nullptr;
         bool ok = capture(h->mrhs_graph, true, want_iters);
@@ -769,7 +775,9 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         }
         // the next capture: as many iterations as this fit's longest problem took evaluations, plus one spare
         const int nfev_max = ((volatile int32_t *)h->h_nactive)[1];
-        int it_next = nfev_max + 1;
+        h->mrhs_same_count = (nfev_max == h->mrhs_prev_nfev) ? h->mrhs_same_count + 1 : 0;
+        h->mrhs_prev_nfev = nfev_max;
+        int it_next = nfev_max + (h->mrhs_same_count >= 2 ? 0 : 1);
         it_next = it_next < 6 ? 6 : (it_next > 24 ? 24 : it_next);
         h->mrhs_graph_iters = it_next;
     } else {

@@ -1,0 +1,217 @@
+// vp_blk_ext.hpp -- caller-evaluated models at ANY length: the evaluation of vp_ext.hpp with the rows streamed in blocks.
+//
+// The reference takes any `output_len()` (src/model/mod.rs:263) and any `SeparableNonlinearModel` (:239-363).  The
+// register-resident kernels of vp_ext.hpp hold all m rows of Phi, y and dPhi on chip (one wave to 1 024 rows fp64, eight
+// waves to 8 192); six fp64 columns of 10 000 rows are a CU's whole register file.  Here m is a run-time number, as in
+// vp_block.hpp -- the same two passes as blk_evaluate_kernel, with the column BUILD replaced by column LOADS:
+//
+//   pass 1 (forward)   block by block: load the rows of [W Phi | y_w | W dPhi_1 .. W dPhi_P], fold them into the
+//                      (N + 1 + P)-column carry by the N reflectors of Phi (stacked_qr<NREF = N>): R, Q^T y, ||r||^2 -> c,
+//                      cost, status (src/solvers/levmar/mod.rs:42-73); the carry rows every block started from are kept in
+//                      LDS (N x NC values per block);
+//   pass 2 (backward)  block by block in reverse: reload the rows, recompute the block's reflectors from the recorded carry
+//                      (identical arithmetic), take the block's rows of Q^T y and Q^T dPhi_p, carry [r~ | D~_1 .. D~_P] back
+//                      through the reflectors (stacked_apply_q) and store r and  J_k = -sum_{pairs p of k} c_{j(p)} Q D~_p
+//                      (:91-95, 101-201; assembled at the store, q and the pair table are run-time as in vp_ext.hpp).
+//
+// Exact Householder arithmetic on both passes.  The caller's columns cross HBM TWICE (forward and backward), r and J once:
+// 2 (n + p + 1) + 1 + q column transfers against the n + p + 2 + q of the resident kernels -- the price of not holding m rows
+// on chip.  Blocks are double-buffered in registers (the loads of block i + 1 are in flight while block i is folded).
+#pragma once
+#include "vp_block.hpp"
+#include "vp_ext.hpp"
+
+namespace vp {
+namespace blk {
+
+// rows per lane and block of the streamed external kernels: two blocks are resident (double buffer)
+template <typename T, int NC> constexpr int ext_block_rows() {
+    constexpr int words = NC * (int)(sizeof(T) / 4);
+    return words <= 8 ? 8 : (words <= 18 ? 4 : 2);
+}
+
+template <typename T, int N, int P, int RB>
+__global__ void __launch_bounds__(64, 2) ext_stream_evaluate_kernel(const ext::ExtArgs<T> a) {
+    constexpr int NC = N + 1 + P, NW = 1 + P;
+    constexpr int ROWS = 64 * RB;
+    using G = Grp<1>;
+    G grp = G::make(nullptr);
+    const int lane = grp.gl;
+    const int64_t prob = blockIdx.x; // problem * S + rhs
+    if (prob >= a.nprob) return;
+    const int64_t b = prob / a.S;
+    const int s = (int)(prob - b * a.S);
+    const int m = a.m;
+    const bool vec = a.vec != 0;
+    const T *ph = a.phi + b * (int64_t)N * m;
+    const T *yp = a.yw + prob * (int64_t)m;
+    const T *dp = (P > 0 && a.dphi) ? a.dphi + b * (int64_t)a.np * m : nullptr;
+    const T *wp = a.w ? a.w + b * a.w_stride : nullptr;
+    const int np = a.np;
+    const bool want_j = P > 0 && a.J_out != nullptr && dp != nullptr && np > 0;
+    const bool want_rj = a.r_out != nullptr || want_j;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *snap = reinterpret_cast<T *>(smem_raw); // [block][N][NC]: the carry rows block i started from
+
+    // the block of ROWS rows at `off`: every column of this lane's RB rows (zero past the end), weighted
+    auto load_block = [&](const int off, T (&Cb)[NC][RB]) __attribute__((always_inline)) {
+        const int mrem = m - off;
+#pragma unroll
+        for (int j = 0; j < N; ++j) load_rows<T, RB, 1>(ph + (int64_t)j * m + off, mrem, lane, vec, Cb[j]);
+        load_rows<T, RB, 1>(yp + off, mrem, lane, vec, Cb[N]);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (dp && p < np) { // (uniform)
+                load_rows<T, RB, 1>(dp + (int64_t)p * m + off, mrem, lane, vec, Cb[N + 1 + p]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < RB; ++r) Cb[N + 1 + p][r] = T(0);
+            }
+        }
+        if (wp) { // `&self.weights * ...` (src/util/weights.rs:82-99); y_w was weighted when the handle was made
+            T wt[RB];
+            load_rows<T, RB, 1>(wp + off, mrem, lane, vec, wt);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                if (j == N) continue;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) Cb[j][r] *= wt[r];
+            }
+        }
+    };
+
+    // ================= pass 1: forward, N reflectors per block =================
+    T K[NC][2];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) K[j][0] = K[j][1] = T(0);
+    T sq = T(0);
+    const int nb = (m + ROWS - 1) / ROWS;
+    auto fold = [&](T (&Cb)[NC][RB], const int ib) __attribute__((always_inline)) {
+        if (want_rj) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (lane == i / 2) {
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) snap[((size_t)ib * N + i) * NC + j] = K[j][i % 2];
+                }
+        }
+        stacked_qr<T, NC, N, RB, G>(K, Cb, grp);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) sq = tfma(Cb[N][r], Cb[N][r], sq);
+    };
+    {
+        T Ca[NC][RB], Cc[NC][RB];
+        load_block(0, Ca);
+        for (int ib = 0; ib < nb; ib += 2) {
+            if (ib + 1 < nb) load_block((ib + 1) * ROWS, Cc);
+            fold(Ca, ib);
+            if (ib + 1 < nb) {
+                if (ib + 2 < nb) load_block((ib + 2) * ROWS, Ca);
+                fold(Cc, ib + 1);
+            }
+        }
+    }
+    T Rm[N][N], qty[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) Rm[i][j] = (j >= i) ? readlane(K[j][i % 2], i / 2) : T(0);
+        qty[i] = readlane(K[N][i % 2], i / 2);
+    }
+    T c[N], e[N];
+    bool truncated;
+    solve_coeffs<T, N>(Rm, qty, a.eps, c, e, truncated);
+    T fn2 = group_sum(grp, sq);
+#pragma unroll
+    for (int k = 0; k < N; ++k) fn2 = tfma(e[k], e[k], fn2);
+    bool ok = is_finite(fn2);
+#pragma unroll
+    for (int k = 0; k < N; ++k) ok = ok && is_finite(c[k]) && is_finite(Rm[k][k]);
+    ok = uni(ok);
+    if (lane == 0) {
+        if (a.status) a.status[prob] = ok ? VP_ST_OK : VP_ST_NONFINITE;
+        if (a.cost_out) a.cost_out[prob] = 0.5 * (double)fn2;
+    }
+    if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(c, lane);
+    if (!want_rj) return;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the recorded carries are in LDS
+
+    // ================= pass 2: backward, r and J block by block =================
+    T Wc[NW][2]; // carry part of [r~ | D~_1 .. D~_P]: rows < N hold e (residual) and 0 (P_perp drops the range(Q) part)
+#pragma unroll
+    for (int z = 0; z < NW; ++z) Wc[z][0] = Wc[z][1] = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) Wc[0][i % 2] = (lane == i / 2) ? e[i] : Wc[0][i % 2];
+    auto unfold = [&](T (&Cb)[NC][RB], const int ib) __attribute__((always_inline)) {
+        const int off = ib * ROWS;
+        T Kb[NC][2];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) Kb[j][0] = Kb[j][1] = T(0);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (lane == i / 2) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) Kb[j][i % 2] = snap[((size_t)ib * N + i) * NC + j];
+            }
+        T u[N], g[N];
+        stacked_qr_keep<T, NC, N, RB, G>(Kb, Cb, u, g, grp);
+        T Wb[NW][RB];
+#pragma unroll
+        for (int z = 0; z < NW; ++z)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) Wb[z][r] = Cb[N + z][r];
+        stacked_apply_q<T, NC, N, NW, RB, G>(Cb, u, g, Wc, Wb, grp);
+        if (a.r_out) store_rows<T, RB, 1>(a.r_out + prob * (int64_t)m + off, m - off, lane, vec, Wb[0]);
+        if (want_j) {
+            for (int k = 0; k < a.q; ++k) { // J[b][k][s][m]
+                T cj[P > 0 ? P : 1];
+#pragma unroll
+                for (int p = 0; p < P; ++p) cj[p] = (p < np && a.pp[p] == k) ? -dyn_get<N>(c, a.pb[p]) : T(0);
+                T v[RB];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    T acc = T(0);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc = tfma(cj[p], Wb[1 + p][r], acc);
+                    v[r] = acc;
+                }
+                T *jp = a.J_out + ((b * a.q + k) * (int64_t)a.S + s) * (int64_t)m + off;
+                store_rows<T, RB, 1>(jp, m - off, lane, vec, v);
+            }
+        }
+    };
+    {
+        T Ca[NC][RB], Cc[NC][RB];
+        load_block((nb - 1) * ROWS, Ca);
+        for (int ib = nb - 1; ib >= 0; ib -= 2) {
+            if (ib - 1 >= 0) load_block((ib - 1) * ROWS, Cc);
+            unfold(Ca, ib);
+            if (ib - 1 >= 0) {
+                if (ib - 2 >= 0) load_block((ib - 2) * ROWS, Ca);
+                unfold(Cc, ib - 1);
+            }
+        }
+    }
+}
+
+// LDS of the recorded carries; beyond the cap the generic kernels (m > ~70 000 rows of a six-column fp64 shape)
+template <typename T, int N, int P, int RB> constexpr size_t ext_stream_snap_bytes(int64_t m) {
+    return (size_t)((m + 64 * RB - 1) / (64 * RB)) * N * (N + 1 + P) * sizeof(T);
+}
+
+template <typename T, int N, int P> int launch_ext_stream(const ext::ExtArgs<T> &a, hipStream_t stream) {
+    constexpr int RB = ext_block_rows<T, N + 1 + P>();
+    const bool want_rj = a.r_out != nullptr || a.J_out != nullptr;
+    const size_t snap = want_rj ? ext_stream_snap_bytes<T, N, P, RB>(a.m) : 0;
+    if (snap > kEvalSnapMax) return VP_ERR_UNSUPPORTED; // (the caller falls back to the generic kernels)
+    hipLaunchKernelGGL((ext_stream_evaluate_kernel<T, N, P, RB>), dim3((unsigned)a.nprob), dim3(64), snap, stream, a);
+    return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+} // namespace blk
+} // namespace vp
+
+// one streamed shape: n basis functions, up to PP derivative columns (PP = 0: the pass without them)
+#define VP_REGISTER_EXT_STREAM(T, NN, PP)                                                                              \
+    static ::vp::ext::ExtStreamRegistrar<T> VP_EXT_CAT(vp_ext_reg_, __COUNTER__)(                                     \
+        ::vp::ext::ExtStreamEntry<T>{NN, PP, &::vp::blk::launch_ext_stream<T, NN, PP>});

@@ -247,6 +247,13 @@ template <typename T, int RB, bool WEIGHTED> struct RowRing {
 #ifndef VP_BLK_WAVES
 #define VP_BLK_WAVES 2
 #endif
+#ifndef VP_BLK_LANE_ALL
+#define VP_BLK_LANE_ALL 0 /* blk_fit_kernel: ALL columns folded lane-privately (no reduction inside the block loop).
+   Measured in round 5 (tools/stream_ab_probe.py): 28 % faster per evaluation at m = 10 000 -- and 25 % MORE evaluations per
+   fit (178 747 vs 143 560; a plain Householder sweep on the CPU takes 146 161): the residual norm that comes out of 64 merged lane triangles is ~10x
+   noisier than the one the wave-wide reflectors leave, actred drowns in it and ftol fires late.  Same minima, same
+   success classes, no gain in fits/s, worse parity of the trajectories: off. */
+#endif
 // (run-time-descriptor models evaluate every basis kind per element and their column build needs about as many registers
 // again as the block itself: their kernels run ONE wave per SIMD -- 512 VGPRs -- like the resident ones, model_waves_for)
 template <class M> constexpr int blk_waves() { return M::kStatic ? VP_BLK_WAVES : 1; }
@@ -304,6 +311,8 @@ __global__ void __launch_bounds__(64 * W, (blk_waves<M>())) blk_fit_kernel(const
     using Ring = RowRing<T, RB, WEIGHTED>;
     __shared__ __attribute__((aligned(16))) T ring_mem[W * 2 * Ring::NARR * ROWS];
     __shared__ T s_merge[W > 1 ? 2 * W * NTRI : 1]; // the waves' carries, double-buffered by the evaluation's parity
+    __shared__ LmVars<T, N, Q> s_lm[W];             // the parked LM records
+    __shared__ T s_cb[W][N];
     Ring ring;
     ring.init(ring_mem + (size_t)wave * 2 * Ring::NARR * ROWS, tp, yp, wp, m, lane);
     int parity = 0;
@@ -315,14 +324,36 @@ __global__ void __launch_bounds__(64 * W, (blk_waves<M>())) blk_fit_kernel(const
         T K[NC][2];
 #pragma unroll
         for (int j = 0; j < NC; ++j) K[j][0] = K[j][1] = T(0);
-        constexpr int PT = P + 1;
-        constexpr bool kLaneTrail = PT <= 6; // (the private triangle: PT (PT + 1) / 2 values per lane)
+        // kLaneAll (round 5): EVERY column is folded lane-privately -- each lane keeps an NC x NC triangle of its own rows
+        // (TSQR over the 64 lanes' row sets) and a block costs NO wave-wide reduction at all; the 64 triangles are merged once
+        // per evaluation (NC rounds on 64 NC rows).  A block was N dependent reduction rounds + the private trailing update
+        // (~620 instructions per 512 rows, three round trips through the packed reduction); it is ~460 without a single
+        // cross-lane dependency, and the reflector scalars -- private to a lane -- are useful work on all 64 lanes.
+        constexpr bool kLaneAll = VP_BLK_LANE_ALL && NC <= 7;
+        constexpr bool kPark = true; // the LM record waits in LDS while the rows stream (see below)
+        constexpr int PT = kLaneAll ? NC : P + 1;  // columns folded lane-privately ...
+        constexpr int NF = kLaneAll ? 0 : N;       // ... after NF wave-wide reflectors per block
+        constexpr bool kLaneTrail = PT <= 7; // (the private triangle: PT (PT + 1) / 2 values per lane)
         T Tl[kLaneTrail ? PT : 1][kLaneTrail ? PT : 1];
         if constexpr (kLaneTrail) {
 #pragma unroll
             for (int i = 0; i < PT; ++i)
 #pragma unroll
                 for (int j = 0; j < PT; ++j) Tl[i][j] = T(0);
+        }
+        // the wave-uniform LM record (~45 values: twice as many VGPRs on gfx950, which has no scalar fp64 registers) is PARKED
+        // in LDS while the rows stream -- the block loop is where the registers are short (round 5: 16-55 spilled VGPRs -> 0-5
+        // on the double-exponential sets, the run-time-descriptor sets from 24-44 to 0-12); only the trial point stays
+        T xt_now[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) xt_now[k] = S.xt[k];
+        if constexpr (kPark) {
+            if (lane == 0) {
+                s_lm[wave] = S;
+#pragma unroll
+                for (int k = 0; k < N; ++k) s_cb[wave][k] = cbest[k];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if (wave * ROWS < m) ring.begin(wave * ROWS);
         for (int off = wave * ROWS; off < m; off += W * ROWS) {
@@ -339,17 +370,32 @@ __global__ void __launch_bounds__(64 * W, (blk_waves<M>())) blk_fit_kernel(const
             src.delta = dpair;
             T Cb[NC][RB];
             load_rows_lds<T, RB, 1>(s_y, lane, Cb[N]);
-            build_columns<T, M, RB, NC, Src>(a.mdl, S.xt, src, Cb);
+            build_columns<T, M, RB, NC, Src>(a.mdl, xt_now, src, Cb);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (kLaneTrail) {
-                stacked_qr<T, NC, N, RB, G>(K, Cb, grp);
-                lane_trail_update<T, NC, N, PT, RB>(Tl, Cb);
+                if constexpr (NF > 0) stacked_qr<T, NC, NF, RB, G>(K, Cb, grp);
+                lane_trail_update<T, NC, NF, PT, RB>(Tl, Cb);
             } else {
                 stacked_qr<T, NC, NC, RB, G>(K, Cb, grp);
             }
             asm volatile("" ::: "memory");
         }
-        if constexpr (kLaneTrail) lane_trail_merge<T, NC, N, PT, G>(Tl, K, grp);
+        if constexpr (kLaneTrail) lane_trail_merge<T, NC, NF, PT, G>(Tl, K, grp);
+        if constexpr (kPark) { // un-park
+            asm volatile("" ::: "memory");
+            S = s_lm[wave];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) S.ipvt[k] = uni(S.ipvt[k]);
+            S.first = uni(S.first);
+            S.first_tr = uni(S.first_tr);
+            S.first_update = uni(S.first_update);
+            S.nfev = uni(S.nfev);
+            S.term = uni(S.term);
+            S.status = uni(S.status);
+            S.accepted = uni(S.accepted);
+#pragma unroll
+            for (int k = 0; k < N; ++k) cbest[k] = s_cb[wave][k];
+        }
         if constexpr (W > 1) {
             // ---- merge the W carries: stack them through LDS, every wave reduces the same stack ----
             T *mg = s_merge + (size_t)parity * W * NTRI;

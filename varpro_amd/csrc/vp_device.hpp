@@ -259,12 +259,24 @@ template <int V, typename T, class G> __device__ __forceinline__ void group_allr
             for (int v = 0; v < V; ++v) buf[g.wave * VP_XV + v] = x[v];
         }
         __syncthreads();
+        if constexpr (G::W <= 4) {
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            T s = buf[v];
+            for (int v = 0; v < V; ++v) {
+                T s = buf[v];
 #pragma unroll
-            for (int w = 1; w < G::W; ++w) s += buf[w * VP_XV + v];
-            x[v] = s;
+                for (int w = 1; w < G::W; ++w) s += buf[w * VP_XV + v];
+                x[v] = s;
+            }
+        } else {
+            // (8 / 16 waves: unrolled, all V * W loads are hoisted above the additions -- V * W live registers in kernels that
+            // have none to spare; the partials are added wave by wave in the same fixed order)
+#pragma unroll
+            for (int v = 0; v < V; ++v) x[v] = buf[v];
+#pragma nounroll
+            for (int w = 1; w < G::W; ++w) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) x[v] += buf[w * VP_XV + v];
+            }
         }
         g.phase ^= 1;
     }

@@ -13,7 +13,9 @@
 //
 // Shapes: compile-time (N, P, R); the parameter count q and the pair table are run-time (J_k is assembled from the P
 // back-transformed derivative columns when it is stored), and a model with fewer pairs than P runs with zero columns that
-// are never loaded.  Shapes / lengths outside the table (and fp32) run on the generic kernels (vp_generic.hpp).
+// are never loaded.  Longer problems (round 5): W = 4 / 8 / 16 waves per problem, fp64 to 8 192 rows, fp32 to 16 384.
+// Beyond those lengths: the streamed kernels of vp_blk_ext.hpp (any m, two passes over the caller's columns); shapes in
+// neither table run on the generic kernels (vp_generic.hpp).
 #pragma once
 #include <vector>
 
@@ -42,17 +44,23 @@ template <typename T> struct ExtArgs {
 
 // waves per SIMD the register allocator must leave room for: the NC resident columns plus the wave-uniform state of the
 // factorisation (R, R^-1, Q^T y, c, e, the reflector's dot products: ~2N^2 + 6N values -- gfx950 has no scalar fp64 registers, they sit in VGPRs)
-template <typename T, int R, int N, int NC> constexpr int ext_waves() {
-    return ((NC * R + 2 * N * N + 6 * N) * (int)(sizeof(T) / 4) <= 200) ? 2 : 1;
+// W > 1 (round 5): the columns of ONE problem spread over the W waves of a workgroup (Layout<R, W>, reductions through the
+// group's LDS exchange area) -- problems longer than one wave's registers stay ONE pass over the caller's columns: a
+// workgroup of W waves must be resident on one CU, i.e. at least W / 4 waves per SIMD
+template <typename T, int R, int N, int NC, int W = 1> constexpr int ext_waves() {
+    constexpr int words = (NC * R + 2 * N * N + 6 * N + (W > 1 ? 24 : 0)) * (int)(sizeof(T) / 4);
+    constexpr int fit = words <= 100 ? 4 : (words <= 200 ? 2 : 1);
+    return fit > W / 4 ? fit : (W / 4 > 0 ? W / 4 : 1);
 }
 
-template <typename T, int N, int P, int R, bool WITH_D>
-__global__ void __launch_bounds__(64, (ext_waves<T, R, N, N + 1 + (WITH_D ? P : 0)>())) ext_evaluate_kernel(const ExtArgs<T> a) {
+template <typename T, int N, int P, int R, bool WITH_D, int W = 1>
+__global__ void __launch_bounds__(64 * W, (ext_waves<T, R, N, N + 1 + (WITH_D ? P : 0), W>())) ext_evaluate_kernel(const ExtArgs<T> a) {
     constexpr int NC = N + 1 + (WITH_D ? P : 0);
-    using G = Grp<1>;
-    using L = Layout<R, 1>;
-    G grp = G::make(nullptr);
-    const int lane = grp.gl;
+    using G = Grp<W>;
+    using L = Layout<R, W>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ext_smem[];
+    G grp = G::make(W > 1 ? ext_smem : nullptr);
+    const int lane = grp.gl; // GROUP lane: row ownership
     const int64_t prob = blockIdx.x; // problem * S + rhs
     if (prob >= a.nprob) return;
     const int64_t b = prob / a.S;
@@ -64,14 +72,14 @@ __global__ void __launch_bounds__(64, (ext_waves<T, R, N, N + 1 + (WITH_D ? P : 
     {
         const T *ph = a.phi + b * (int64_t)N * m;
 #pragma unroll
-        for (int j = 0; j < N; ++j) load_rows<T, R, 1>(ph + (int64_t)j * m, m, lane, vec, C[j]);
-        load_rows<T, R, 1>(a.yw + prob * (int64_t)m, m, lane, vec, C[N]);
+        for (int j = 0; j < N; ++j) load_rows<T, R, W>(ph + (int64_t)j * m, m, lane, vec, C[j]);
+        load_rows<T, R, W>(a.yw + prob * (int64_t)m, m, lane, vec, C[N]);
         if constexpr (WITH_D) {
             const T *dp = a.dphi + b * (int64_t)a.np * m;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if (p < a.np) { // (uniform)
-                    load_rows<T, R, 1>(dp + (int64_t)p * m, m, lane, vec, C[N + 1 + p]);
+                    load_rows<T, R, W>(dp + (int64_t)p * m, m, lane, vec, C[N + 1 + p]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < R; ++r) C[N + 1 + p][r] = T(0);
@@ -80,7 +88,7 @@ __global__ void __launch_bounds__(64, (ext_waves<T, R, N, N + 1 + (WITH_D ? P : 
         }
         if (a.w) { // `&self.weights * ...` (src/util/weights.rs:82-99): row i of every model column times w_i
             T wt[R];
-            load_rows<T, R, 1>(a.w + b * a.w_stride, m, lane, vec, wt);
+            load_rows<T, R, W>(a.w + b * a.w_stride, m, lane, vec, wt);
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 if (j == N) continue; // y_w was weighted when the handle was made (src/problem/builder.rs:307)
@@ -121,7 +129,7 @@ __global__ void __launch_bounds__(64, (ext_waves<T, R, N, N + 1 + (WITH_D ? P : 
     residual_qcoords<T, R, N>(C[N], e, grp);
     if constexpr (!WITH_D) {
         apply_q_cols<T, R, N, NC, N, N + 1>(C, g, grp);
-        store_rows<T, R, 1>(a.r_out + prob * (int64_t)m, m, lane, vec, C[N]);
+        store_rows<T, R, W>(a.r_out + prob * (int64_t)m, m, lane, vec, C[N]);
     } else {
         // P_perp: the rows < N of the derivative columns in Q-coordinates do not enter the Kaufman columns
 #pragma unroll
@@ -130,7 +138,7 @@ __global__ void __launch_bounds__(64, (ext_waves<T, R, N, N + 1 + (WITH_D ? P : 
             for (int r = 0; r < L::VW && r < R; ++r)
                 if (L::row_of(r, lane) < N) C[N + 1 + p][r] = T(0);
         apply_q_cols<T, R, N, NC, N, NC>(C, g, grp); // [r~ | D~_1 .. D~_P] <- Q (.)  in ONE back-sweep
-        if (a.r_out) store_rows<T, R, 1>(a.r_out + prob * (int64_t)m, m, lane, vec, C[N]);
+        if (a.r_out) store_rows<T, R, W>(a.r_out + prob * (int64_t)m, m, lane, vec, C[N]);
         if (a.J_out) {
             for (int k = 0; k < a.q; ++k) { // J[b][k][s][m] = -sum over the pairs p of parameter k of c_{basis(p)} Q D~_p
                 T cj[P];
@@ -165,8 +173,9 @@ __global__ void __launch_bounds__(64, (ext_waves<T, R, N, N + 1 + (WITH_D ? P : 
     }
 }
 
-template <typename T, int N, int P, int R, bool WITH_D> int launch_one(const ExtArgs<T> &a, hipStream_t stream) {
-    hipLaunchKernelGGL((ext_evaluate_kernel<T, N, P, R, WITH_D>), dim3((unsigned)a.nprob), dim3(64), 0, stream, a);
+template <typename T, int N, int P, int R, bool WITH_D, int W = 1> int launch_one(const ExtArgs<T> &a, hipStream_t stream) {
+    hipLaunchKernelGGL((ext_evaluate_kernel<T, N, P, R, WITH_D, W>), dim3((unsigned)a.nprob), dim3(64 * W),
+                       (size_t)group_xch_bytes<W>(), stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
@@ -174,6 +183,7 @@ template <typename T, int N, int P, int R, bool WITH_D> int launch_one(const Ext
 template <typename T> struct ExtEntry {
     int N, P, R;   // P == 0: the kernel without derivative columns (set_params / residuals only)
     int (*launch)(const ExtArgs<T> &, hipStream_t);
+    int W = 1;     // waves per problem: the kernel holds 64 R W rows
 };
 template <typename T> std::vector<ExtEntry<T>> &ext_table() {
     static std::vector<ExtEntry<T>> t;
@@ -183,13 +193,37 @@ template <typename T> struct ExtRegistrar {
     explicit ExtRegistrar(const ExtEntry<T> &e) { ext_table<T>().push_back(e); }
 };
 
+// the streamed kernels of vp_blk_ext.hpp (any m): one row per (N, P) shape; P == 0: the pass without derivative columns
+template <typename T> struct ExtStreamEntry {
+    int N, P;
+    int (*launch)(const ExtArgs<T> &, hipStream_t);
+};
+template <typename T> std::vector<ExtStreamEntry<T>> &ext_stream_table() {
+    static std::vector<ExtStreamEntry<T>> t;
+    return t;
+}
+template <typename T> struct ExtStreamRegistrar {
+    explicit ExtStreamRegistrar(const ExtStreamEntry<T> &e) { ext_stream_table<T>().push_back(e); }
+};
+template <typename T> const ExtStreamEntry<T> *find_ext_stream(int n, int np, bool with_d) {
+    const ExtStreamEntry<T> *best = nullptr;
+    for (const ExtStreamEntry<T> &e : ext_stream_table<T>()) {
+        if (e.N != n) continue;
+        if (with_d ? (e.P == 0 || e.P < np) : e.P != 0) continue;
+        if (!best || e.P < best->P) best = &e;
+    }
+    return best;
+}
+
 // the resident kernel that covers (n, np pairs, m) with / without derivative columns, or null
 template <typename T> const ExtEntry<T> *find_ext(int n, int np, int m, bool with_d) {
     const ExtEntry<T> *best = nullptr;
     for (const ExtEntry<T> &e : ext_table<T>()) {
-        if (e.N != n || 64 * e.R < m) continue;
+        if (e.N != n || 64 * e.R * e.W < m) continue;
         if (with_d ? (e.P == 0 || e.P < np) : e.P != 0) continue;
-        if (!best || e.R < best->R || (e.R == best->R && e.P < best->P)) best = &e;
+        // the smallest capacity that holds the problem, on the fewest waves, with the fewest spare derivative columns
+        const int cap = e.R * e.W, bcap = best ? best->R * best->W : 0;
+        if (!best || cap < bcap || (cap == bcap && (e.W < best->W || (e.W == best->W && e.P < best->P)))) best = &e;
     }
     return best;
 }
@@ -198,8 +232,11 @@ template <typename T> const ExtEntry<T> *find_ext(int n, int np, int m, bool wit
 template <typename T> int launch_evaluate(const LaunchParams &p, int (*fallback)(const LaunchParams &)) {
     const int n = p.model->n_basis, q = p.model->n_params;
     const bool with_d = p.J_out != nullptr && p.ext_np > 0;
-    const ExtEntry<T> *e = (p.ext_rows == p.m && p.m >= n && (!with_d || p.ext_dphi)) ? find_ext<T>(n, p.ext_np, p.m, with_d) : nullptr;
-    if (!e || !p.ext_phi) return fallback(p);
+    const bool usable = p.ext_rows == p.m && p.m >= n && (!with_d || p.ext_dphi) && p.ext_phi;
+    const ExtEntry<T> *e = usable ? find_ext<T>(n, p.ext_np, p.m, with_d) : nullptr;
+    // no resident kernel holds the shape at this length: the streamed kernel (vp_blk_ext.hpp) if the shape has one
+    const ExtStreamEntry<T> *es = (usable && !e) ? find_ext_stream<T>(n, p.ext_np, with_d) : nullptr;
+    if (!e && !es) return fallback(p);
     if (p.J_out && !with_d && q > 0) {
         // a model without a single derivative column (every parameter unused): the kernel without derivative columns has no
         // Jacobian store, and J = 0 -- as eval_partial_deriv leaves it (src/model/mod.rs:473-512)
@@ -229,7 +266,9 @@ template <typename T> int launch_evaluate(const LaunchParams &p, int (*fallback)
     a.eps = (T)p.eps;
     a.vec = host_aligned<T>(p.m, {p.ext_phi, p.ext_dphi, p.w, p.yw, p.r_out, p.J_out}) ? 1 : 0;
     if (a.nprob <= 0) return VP_ERR_OK;
-    return e->launch(a, p.stream);
+    if (e) return e->launch(a, p.stream);
+    const int rc = es->launch(a, p.stream);
+    return rc == VP_ERR_UNSUPPORTED ? fallback(p) : rc; // (more blocks than the LDS carry record holds)
 }
 
 } // namespace ext
@@ -245,3 +284,10 @@ template <typename T> int launch_evaluate(const LaunchParams &p, int (*fallback)
 #define VP_REGISTER_EXT0(T, NN, RR)                                                                                    \
     static ::vp::ext::ExtRegistrar<T> VP_EXT_CAT(vp_ext_reg_, __COUNTER__)(                                           \
         ::vp::ext::ExtEntry<T>{NN, 0, RR, &::vp::ext::launch_one<T, NN, 1, RR, false>});
+// the same pair for problems spread over WW waves (64 RR WW rows)
+#define VP_REGISTER_EXT_W(T, NN, PP, RR, WW)                                                                           \
+    static ::vp::ext::ExtRegistrar<T> VP_EXT_CAT(vp_ext_reg_, __COUNTER__)(                                           \
+        ::vp::ext::ExtEntry<T>{NN, PP, RR, &::vp::ext::launch_one<T, NN, PP, RR, true, WW>, WW});
+#define VP_REGISTER_EXT0_W(T, NN, RR, WW)                                                                              \
+    static ::vp::ext::ExtRegistrar<T> VP_EXT_CAT(vp_ext_reg_, __COUNTER__)(                                           \
+        ::vp::ext::ExtEntry<T>{NN, 0, RR, &::vp::ext::launch_one<T, NN, 1, RR, false, WW>, WW});

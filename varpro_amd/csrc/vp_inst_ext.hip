@@ -9,6 +9,7 @@
 namespace vp {
 namespace {
 int ext_evaluate_f64(const LaunchParams &p) { return ext::launch_evaluate<double>(p, &gen::launch_evaluate<double>); }
+int ext_evaluate_f32(const LaunchParams &p) { return ext::launch_evaluate<float>(p, &gen::launch_evaluate<float>); }
 } // namespace
 
 const KernelEntry *external_kernels(int dtype, int n, int q, int np, int64_t m, int64_t S) {
@@ -20,7 +21,7 @@ const KernelEntry *external_kernels(int dtype, int n, int q, int np, int64_t m, 
     // (no basis / fit entries: the device cannot evaluate the model; vp_api.hip refuses those calls)
     static const KernelEntry f64{VP_F64, FAMILY_GENERIC, 0, 0, 0, 0, 1, &ext_evaluate_f64, nullptr, nullptr, nullptr,
                                  &gen::launch_best_fit<double>, nullptr, nullptr, nullptr, nullptr, 0, &gen::launch_stats<double>, nullptr, 0, 0, 0, 1};
-    static const KernelEntry f32{VP_F32, FAMILY_GENERIC, 0, 0, 0, 0, 1, &gen::launch_evaluate<float>, nullptr, nullptr, nullptr,
+    static const KernelEntry f32{VP_F32, FAMILY_GENERIC, 0, 0, 0, 0, 1, &ext_evaluate_f32, nullptr, nullptr, nullptr,
                                  &gen::launch_best_fit<float>, nullptr, nullptr, nullptr, nullptr, 0, &gen::launch_stats<float>, nullptr, 0, 0, 0, 1};
     return dtype == VP_F64 ? &f64 : &f32;
 }
