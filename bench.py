@@ -838,7 +838,8 @@ def main():
                                  "achieved": evs * fl / (mss * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": evs * fl / (mss * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                  "y_stream_GBps": evs * ms * T / (mss * 1e-3) / 1e9, "algorithmic_bytes_per_launch": evs * ms * T,
-                                 "traffic": committed_traffic_grid("blk_fit_kernel", Bs * 64), "traffic_source": traffic_source("blk_fit_kernel"),
+                                 "traffic": committed_traffic_grid("blk_fit_kernel", Bs * 64) or committed_traffic_grid("blk_fit_kernel", Bs * 256),  # (launches smaller than the device: four waves per problem)
+                                 "traffic_source": traffic_source("blk_fit_kernel"),
                                  "note": "y (8 m bytes) is re-read per evaluation through the LDS ring; the grid comes from L2"},
                 }
                 bps.close()

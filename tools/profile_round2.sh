@@ -21,7 +21,9 @@ def short(name):
     if not m: return name.split("(")[0][:50]
     k, targs = m.group(1), m.group(2)
     if k in ("blk_fit_kernel", "blk_evaluate_kernel") and "RtModel" in targs: return k + "_rt"
-    if k == "ext_evaluate_kernel": return k + ("" if targs.rstrip().endswith("true") else "_no_derivatives")
+    if k == "ext_evaluate_kernel":  # <T, N, P, R, WITH_D, W>
+        wv = targs.split(",")[-1].strip()
+        return k + ("" if "true" in targs else "_no_derivatives") + ("" if wv in ("1", "true", "false") else "_w" + wv)
     if k == "mrhs_stream_kernel": return "%s_mode%s" % (k, targs.split(",")[-1].strip())
     if k == "evaluate_kernel":  # MODE (0: c / cost, 1: + r, 2: + r + J) is the 5th template argument
         flat = re.sub(r"<[^<>]*>", "", targs).split(",")

@@ -526,7 +526,9 @@ __device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T 
     group_bcast<NCX>(grp, top, L::lane_of_row(0));
     T Rm[N][N], qty[N];
     T tau[NCX];
-    Rm[0][0] = h0.beta;
+    // (opaque: 1 / beta_0 and its square in solve_coeffs are loop invariants of the caller's LM loop -- hoisted, they are two
+    // more spilled registers whose reload is a VMEM wait in every evaluation)
+    Rm[0][0] = dyn_opq(h0.beta);
 #pragma unroll
     for (int j = 0; j < NCX; ++j) {
         if (YPRE && j == NE) {

@@ -37,6 +37,14 @@ template <> struct num<float> {
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+// the lane index recomputed on the spot (two instructions) and opaque to the optimiser: a lane-dependent address that is
+// needed once per loop iteration is otherwise kept -- i.e. SPILLED and reloaded -- across the register-critical part of the
+// iteration, and a scratch reload is a VMEM wait (vmcnt) the asynchronous refill of vp_fit2.hpp cannot afford
+__device__ __forceinline__ int lane_fresh() {
+    unsigned z = 0u; // (the count starts from an opaque zero: the mbcnt pair itself must not be hoisted out of the caller's loop)
+    asm volatile("" : "+v"(z));
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+}
 
 // make a wave-uniform predicate visible to the compiler as scalar so that branches on it are
 // s_cbranch (no exec-mask juggling around the DPP/readlane code below)

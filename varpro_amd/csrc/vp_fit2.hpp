@@ -909,7 +909,7 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
 
             T C[NC][R];
             EvalUniform<T, N> u;
-            load_rows_lds<T, R, W>(s_y + (size_t)s * MP, lane, C[YC]);
+            load_rows_lds<T, R, W>(s_y + (size_t)s * MP, W == 1 ? lane_fresh() : lane, C[YC]);
             evaluate_core_const_first<T, M, R, NC, Src, G, true>(mdl, alpha, src, eps_, grp, h0, C, u, nullptr, qty0);
 
             const T fnorm1 = usqrt(u.fn2);
