@@ -1,0 +1,6 @@
+// length-agnostic fit / evaluate kernels (vp_block.hpp), four exponentials (+ offset), f64 (round 5: the shape ran on the
+// generic kernels at every length; five exponentials still do -- their streamed fit kernel spills 176-570 VGPRs)
+#include "vp_inst_blk.hpp"
+
+VP_REGISTER_BLOCKED_MULTIEXP(double, VP_F64, 4, 1)
+VP_REGISTER_BLOCKED_MULTIEXP(double, VP_F64, 4, 0)

@@ -790,7 +790,8 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
                 }
         }
         // ---- partial T = Q^T y | carried squared norms ----
-        T red[NX];
+        T red[NRED]; // (exactly the NRED values of a batch: padded to the flush round's NX = 14 the packed reduction merged
+                     // two more register pairs per level, round 5)
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
 #pragma unroll
@@ -802,9 +803,7 @@ __global__ void __launch_bounds__(64 * NW) mrhs_coop_dma_kernel(const MrhsStream
             }
             red[N * NB + c] = r2prev[c];
         }
-#pragma unroll
-        for (int v = NRED; v < NX; ++v) red[v] = T(0);
-        wave_reduce_store_g<NX>(red, s_x + ((size_t)ph * NW + wave) * NX);
+        wave_reduce_store_g<NRED>(red, s_x + ((size_t)ph * NW + wave) * NX);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier(); // (a bare barrier: __syncthreads() would carry a full memory fence, i.e. drain the DMA)
         asm volatile("" ::: "memory");
