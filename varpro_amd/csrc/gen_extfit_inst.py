@@ -28,9 +28,23 @@ def emit(fname, T, ns, head):
     open(fname, 'w').write('\n'.join(lines) + '\n')
 
 
+def emit_long(fname, T, head):
+    # round 5: problems longer than one wave's 1 024 rows -- four waves per problem to 4 096 rows (shapes of up to eight
+    # columns).  Eight-wave groups (8 192 rows) were compiled and dropped: the kernel's launch bounds leave them 128 VGPRs
+    # per lane (89-746 spilled)
+    lines = [head, '#include "vp_extfit.hpp"', '']
+    for n in sorted(shapes):
+        for (P, Q) in shapes[n]:
+            if n + 1 + P <= 8:
+                lines.append('VP_REGISTER_EXTFIT_W(%s, %d, %d, %d, %d, %d)' % (T, n, P, Q, 16, 4))
+    open(fname, 'w').write('\n'.join(lines) + '\n')
+
+
 H = '// batched LM fit of caller-evaluated models (vp_extfit.hpp): evaluation kernels, %s, n = %s: (N, P pair slots, Q parameters, R rows per lane, W waves per problem); written by gen_extfit_inst.py'
 emit('vp_inst_extfit_a_f64.hip', 'double', [1, 2], H % ('f64', '1, 2'))
 emit('vp_inst_extfit_b_f64.hip', 'double', [3], H % ('f64', '3'))
 emit('vp_inst_extfit_c_f64.hip', 'double', [4, 5, 6], H % ('f64', '4, 5, 6'))
 emit('vp_inst_extfit_a_f32.hip', 'float', [1, 2, 3], H % ('f32', '1, 2, 3'))
 emit('vp_inst_extfit_b_f32.hip', 'float', [4, 5, 6], H % ('f32', '4, 5, 6'))
+emit_long('vp_inst_extfit_long_f64.hip', 'double', '// batched LM fit of caller-evaluated models (vp_extfit.hpp): evaluation kernels for LONG problems, f64 (four / eight waves per problem); written by gen_extfit_inst.py')
+emit_long('vp_inst_extfit_long_f32.hip', 'float', '// batched LM fit of caller-evaluated models (vp_extfit.hpp): evaluation kernels for LONG problems, f32 (four / eight waves per problem); written by gen_extfit_inst.py')
