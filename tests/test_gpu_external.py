@@ -314,6 +314,25 @@ def test_long_problems_fp32(m):
     bp.close()
 
 
+# lengths that are not a multiple of anything (odd m: element-wise accesses instead of 16-byte groups), just past a kernel's
+# capacity, several right-hand sides per problem -- on the multi-wave kernels (1025 .. 8191) and the streamed one (beyond)
+@pytest.mark.parametrize("m,S", [(1025, 1), (3001, 3), (4097, 1), (8191, 2), (9001, 1), (12345, 3)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_long_problems_ragged_lengths_and_right_hand_sides(m, S, weighted):
+    rng = np.random.default_rng(300 + m + S)
+    B = 2
+    x = np.linspace(0.0, 12.5, m)
+    cm = decay_model(x)
+    tau = np.stack([rng.uniform(0.5, 2.0, B), rng.uniform(2.5, 8.0, B)], 1)
+    c = rng.uniform(1.0, 100.0, (B, S, 3))
+    Y = (c[..., 0:1] * np.exp(-x / tau[:, None, 0:1]) + c[..., 1:2] * np.exp(-x / tau[:, None, 1:2]) + c[..., 2:3])
+    Y = Y + 1e-3 * np.abs(Y).max(-1, keepdims=True) * rng.standard_normal(Y.shape)
+    if S == 1:
+        Y = Y[:, 0]
+    w = (0.5 + rng.random(m)) if weighted else None
+    _check_against_oracle(cm, Y, tau * (1 + rng.uniform(-0.2, 0.2, tau.shape)), w=w)
+
+
 def test_best_fit_and_statistics_against_the_oracle():
     rng = np.random.default_rng(29)
     m, B = 500, 4
