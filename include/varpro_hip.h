@@ -409,6 +409,15 @@ int vp_statistics(vp_batch *h, void *cov_out, double *reduced_chi2_out, void *co
  */
 int vp_summary(vp_batch *h, double out[4]);
 
+/* Conditioning of the GLOBAL fit's LM steps (handles with S > 1 on a specialised kernel set).  The reference's driver
+ * QR-factors the tall (m S) x q Jacobian (src/solvers/levmar/mod.rs:172-186 + qrfac via :247); the device step works on
+ * J^T J accumulated over the right-hand sides and is exact to ~10 cond(J)^2 eps (measured within that
+ * bound to cond(J) = 3.9e4).  cond_out[b] = the largest estimate of cond(J D^-1) -- J with normalised columns, as the LM
+ * driver sees it -- over the steps of the last vp_fit (ratio of the extreme diagonal entries of the pivoted factor): a
+ * caller who needs the QR-grade step beyond cond ~ 1e5 can tell from it that a fit ran there.  [B] doubles, host or
+ * device pointer like every other array of the handle. */
+int vp_global_fit_condition(vp_batch *h, double *cond_out);
+
 /* same aggregates written to 4 DEVICE doubles, enqueued on the handle's stream without any host
  * synchronisation: the buffer can be handed straight to ncclAllReduce (RCCL) */
 int vp_summary_device(vp_batch *h, double *dev_out4);

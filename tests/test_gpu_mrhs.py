@@ -336,9 +336,11 @@ def test_mrhs_gram_based_lm_step_beyond_cond_1e2():
         rr, tr_ref = ref.fit_trace(max_rows=4)
         bp = vp.BatchProblem(mdl, Y[None], x=x)
         alpha, C, rep, tr = bp.fit_trace(guess, max_rows=4)
+        cond_seen = float(np.asarray(bp.global_fit_condition())[0])  # vp_global_fit_condition: what the device's steps saw
         bp.close()
         dev = np.abs(tr[0, 1, :2] - tr_ref[1, :2]).max() / np.abs(tr_ref[1, :2] - tr_ref[0, :2]).max()
-        rows.append(dict(guess_separation=e, cond_J=float(sv[0] / sv[-1]), cond_Phi=float(cond_phi), first_step_rel_dev=float(dev),
+        rows.append(dict(guess_separation=e, cond_J=float(sv[0] / sv[-1]), cond_J_seen_by_the_device=cond_seen,
+                         cond_Phi=float(cond_phi), first_step_rel_dev=float(dev),
                          objective_rel_dev=float(abs(rep["objective"][0] - rr.objective) / rr.objective),
                          ok_device=bool(rep["termination"][0] > 0), ok_oracle=bool(rr.termination > 0),
                          evals_device=int(rep["n_evals"][0]), evals_oracle=int(rr.n_evals),
@@ -351,6 +353,10 @@ def test_mrhs_gram_based_lm_step_beyond_cond_1e2():
         pass
     assert max(r["cond_J"] for r in rows) >= 1e4          # the sweep does reach the regime the first one could not
     for r in rows:
+        # the regime is DETECTABLE (round 5): the largest estimate over the fit's steps is at least the initial point's
+        # conditioning to within the factor a pivoted-factor diagonal ratio is good for, and it does not cry wolf
+        # (measured: exactly half of cond(J D^-1) at the initial point for e = 1e-2 .. 1e-5 -- 19.8 / 39.5 ... 19 764 / 38 921)
+        assert 0.2 * r["cond_J"] <= r["cond_J_seen_by_the_device"] <= 50.0 * r["cond_J"], r
         if r["cond_Phi"] <= 1e6:
             bound = 10.0 * r["cond_J"] ** 2 * eps + 100.0 * r["cond_J"] * r["cond_Phi"] * eps
             assert r["first_step_rel_dev"] <= max(1e-9, bound), r

@@ -45,7 +45,7 @@ VP_FIT_KERNEL_AUTO, VP_FIT_KERNEL_WAVE, VP_FIT_KERNEL_SLOTS = 0, 1, 2
 ABI_SYMBOLS = [
     "vp_batch_create", "vp_batch_destroy", "vp_set_params", "vp_params", "vp_residuals", "vp_jacobian",
     "vp_linear_coeffs", "vp_weighted_data", "vp_set_observations", "vp_cost", "vp_evaluate", "vp_basis", "vp_lm_opts_default", "vp_fit", "vp_fit_trace",
-    "vp_best_fit", "vp_statistics", "vp_summary", "vp_summary_device", "vp_set_rhs_allreduce", "vp_set_fit_kernel", "vp_set_timing", "vp_last_kernel_ms", "vp_synchronize", "vp_last_error",
+    "vp_best_fit", "vp_statistics", "vp_summary", "vp_summary_device", "vp_global_fit_condition", "vp_set_rhs_allreduce", "vp_set_fit_kernel", "vp_set_timing", "vp_last_kernel_ms", "vp_synchronize", "vp_last_error",
     "vp_last_error_detail", "vp_version", "vp_device_count",
     "vp_batch_create_external", "vp_set_params_with_basis", "vp_jacobian_with_derivatives", "vp_evaluate_with_basis",
     "vp_reduce_cost", "vp_fit_begin", "vp_fit_step_with_basis", "vp_fit_end",
@@ -140,6 +140,7 @@ def load():
     lib.vp_statistics.argtypes = [vp, vp, vp, vp, vp]
     lib.vp_summary.argtypes = [vp, dp]
     lib.vp_summary_device.argtypes = [vp, vp]
+    lib.vp_global_fit_condition.argtypes = [vp, vp]
     lib.vp_reduce_cost.argtypes = [vp, vp, dp]
     lib.vp_set_rhs_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, C.c_int64]
     lib.vp_set_fit_kernel.argtypes = [vp, C.c_int]

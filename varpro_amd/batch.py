@@ -594,6 +594,14 @@ class BatchProblem:
         return np.array(list(out))
 
     @_device_entry
+    def global_fit_condition(self):
+        """(B,) largest estimate of cond(J D^-1) the Gram-based LM steps of the last GLOBAL fit (S > 1) have seen
+        (vp_global_fit_condition): the step is exact to ~10 cond^2 eps -- beyond ~1e5 it is at rounding level"""
+        out = self._empty((self.B,), np.float64)
+        check(self.lib.vp_global_fit_condition(self._h, self._ptr(out)))
+        return out
+
+    @_device_entry
     def summary_device(self, out):
         """the same 4 aggregates into a CUDA float64 tensor of 4 elements, asynchronously on the handle's stream
         (no host synchronisation): ready to be all-reduced over RCCL"""

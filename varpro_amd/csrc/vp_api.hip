@@ -1168,6 +1168,8 @@ static int batch_create_impl(vp_batch **out, const vp_model_desc *model, int dty
         }
         VP_TRY(hipMalloc((void **)&h->mrhs.widx, (size_t)B * sizeof(int32_t)));
         VP_TRY(hipMalloc((void **)&h->mrhs.bidx, (size_t)B * sizeof(int32_t)));
+        VP_TRY(hipMalloc((void **)&h->mrhs.jcond, (size_t)B * sizeof(double)));
+        VP_TRY(hipMemsetAsync(h->mrhs.jcond, 0, (size_t)B * sizeof(double), h->stream));
         h->have_mrhs = true;
     }
 #undef VP_TRY
@@ -1225,6 +1227,7 @@ void vp_batch_destroy(vp_batch *h) {
         (void)hipFree(h->mrhs.stbuf[i]);
     }
     (void)hipFree(h->mrhs.widx);
+    (void)hipFree(h->mrhs.jcond);
     (void)hipFree(h->mrhs.bidx);
     if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
     if (h->mrhs_graph_tail) (void)hipGraphExecDestroy(h->mrhs_graph_tail);
@@ -1855,6 +1858,16 @@ int vp_summary(vp_batch *h, double out[4]) {
     VP_HIP(hipMemcpyAsync(out, h->d_sum4, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     VP_HIP(hipStreamSynchronize(h->stream));
     return VP_ERR_OK;
+}
+
+// cond(J D^-1) as the Gram-based LM step of the last global fit saw it at its worst (MrhsWs::jcond)
+int vp_global_fit_condition(vp_batch *h, double *cond_out) {
+    VP_ENTER(h);
+    if (!cond_out) return fail(VP_ERR_INVALID, "null output");
+    if (!h->have_mrhs || !h->mrhs.jcond || !h->have_report)
+        return fail(VP_ERR_INVALID, "vp_global_fit_condition requires a completed vp_fit on a handle with several right-hand sides "
+                                    "(specialised kernel set)");
+    return copy_out(h, cond_out, h->mrhs.jcond, (size_t)h->B * sizeof(double));
 }
 
 int vp_summary_device(vp_batch *h, double *dev_out4) {

@@ -50,6 +50,10 @@ struct MrhsWs {
     double *costbuf[2];   // [B][S]
     int32_t *stbuf[2];    // [B][S]
     int32_t *widx, *bidx; // [B]
+    // largest conditioning estimate of the column-scaled Jacobian any LM step of the current / last fit has seen (round 5):
+    // the step works on J^T J, exact to ~10 cond(J)^2 eps -- vp_global_fit_condition hands it to the
+    // caller, who can tell a fit that ran beyond the stated bound from one that did not
+    double *jcond; // [B]
 };
 
 // where a captured whole-fit graph finds the CALLER's arrays of this call (device-pointer handles): a pinned, device-mapped
@@ -1181,6 +1185,7 @@ __global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<
             a.ws.done[b] = 0;
             a.ws.widx[b] = 0;
             a.ws.bidx[b] = 0;
+            if (a.ws.jcond) a.ws.jcond[b] = 0.0;
         }
     } else {
 #ifdef VP_MRHS_STEP_CLOCKS
@@ -1288,6 +1293,20 @@ __global__ void __launch_bounds__(64 * W) mrhs_step_kernel(const MrhsFactorArgs<
         }
         double Rd[Q][Q], acd[Q], qd[Q];
         gram_to_qr<double, Q>(A, bv, Rd, acd, s.ipvt, qd);
+        if (a.ws.jcond && gl == 0) {
+            // pivoted factor of the column-NORMALISED Jacobian: |R_kk| / ||J_pivot(k)||; the ratio of the largest to the
+            // smallest is cond(J D^-1) to within a small factor (rank-revealing pivoting); 1e300 for a dropped column
+            double dmx = 0.0, dmn = 1e300;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                const double an = dyn_get_o<Q, true>(acd, s.ipvt[k]);
+                const double d = (an > 0.0) ? fabs(Rd[k][k]) / an : 0.0;
+                dmx = d > dmx ? d : dmx;
+                dmn = d < dmn ? d : dmn;
+            }
+            const double est = (dmn > 0.0) ? dmx / dmn : 1e300;
+            if (est > a.ws.jcond[b]) a.ws.jcond[b] = est;
+        }
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
             s.acnorm[k] = (T)acd[k];
