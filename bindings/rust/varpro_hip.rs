@@ -77,6 +77,7 @@ extern "C" {
     pub fn vp_debug_gram_evaluate(h: *mut vp_batch, alpha: *const c_void, out: *mut f64) -> i32;
     pub fn vp_summary(h: *mut vp_batch, out: *mut f64) -> i32;
     pub fn vp_summary_device(h: *mut vp_batch, dev_out4: *mut f64) -> i32;
+    pub fn vp_global_fit_condition(h: *mut vp_batch, cond_out: *mut f64) -> i32;
     pub fn vp_fit_trace(h: *mut vp_batch, opts: *const vp_lm_opts, alpha_inout: *mut c_void, c_out: *mut c_void,
         rep: *mut vp_report, trace_out: *mut f64, trace_rows: i32) -> i32;
     pub fn vp_statistics(h: *mut vp_batch, cov_out: *mut c_void, chi2_out: *mut f64, sigma_out: *mut c_void,
@@ -220,7 +221,15 @@ extern "C" {
     pub fn vp_evaluate_with_basis(h: *mut vp_batch, alpha: *const c_void, phi: *const c_void, dphi: *const c_void,
                                   r: *mut c_void, j: *mut c_void, c: *mut c_void, cost: *mut f64, status: *mut i32) -> i32;
     pub fn vp_reduce_cost(h: *mut vp_batch, rccl_comm: *mut c_void, out4: *mut f64) -> i32;
+    // round 5: LevMarSolver::fit for a BATCH of caller-evaluated models by reverse communication
+    pub fn vp_fit_begin(h: *mut vp_batch, opts: *const vp_lm_opts, alpha0: *const c_void, flags: i32) -> i32;
+    pub fn vp_fit_step_with_basis(h: *mut vp_batch, phi: *const c_void, dphi: *const c_void, alpha_trial_out: *mut c_void,
+                                  want_out: *mut i32, n_active_out: *mut i64) -> i32;
+    pub fn vp_fit_end(h: *mut vp_batch, alpha_out: *mut c_void, c_out: *mut c_void, rep: *mut vp_report) -> i32;
 }
+pub const VP_FIT_DERIVATIVES_ON_ACCEPT: i32 = 1;
+pub const VP_WANT_BASIS: i32 = 1;
+pub const VP_WANT_DERIVATIVES: i32 = 2;
 
 /// `SeparableProblem<M, Rhs>` for ANY model `M` (src/problem.rs:57-83): the model is evaluated where it lives (host
 /// closures, `src/model/mod.rs:441-512`), everything downstream of `eval()` / `eval_partial_deriv(k)` runs on the device
