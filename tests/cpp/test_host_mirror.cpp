@@ -136,15 +136,131 @@ static void test_gpu() {
     }
 }
 
+// a model the descriptor language cannot express (Gaussian + Lorentzian + offset; n = 3, q = 4, four derivative columns)
+static ClosureModel peaks_model(const std::vector<double> &x) {
+    auto gauss = [](const std::vector<double> &x, const std::vector<double> &p) {
+        std::vector<double> v(x.size());
+        for (size_t i = 0; i < x.size(); ++i) v[i] = std::exp(-0.5 * (x[i] - p[0]) * (x[i] - p[0]) / (p[1] * p[1]));
+        return v;
+    };
+    auto lorentz = [](const std::vector<double> &x, const std::vector<double> &p) {
+        std::vector<double> v(x.size());
+        for (size_t i = 0; i < x.size(); ++i) v[i] = p[1] * p[1] / ((x[i] - p[0]) * (x[i] - p[0]) + p[1] * p[1]);
+        return v;
+    };
+    ClosureModel cm({"mu1", "s1", "mu2", "g2"}, x);
+    cm.function({"mu1", "s1"}, gauss)
+        .partial_deriv("mu1", [gauss](const std::vector<double> &x, const std::vector<double> &p) {
+            auto v = gauss(x, p);
+            for (size_t i = 0; i < x.size(); ++i) v[i] *= (x[i] - p[0]) / (p[1] * p[1]);
+            return v;
+        })
+        .partial_deriv("s1", [gauss](const std::vector<double> &x, const std::vector<double> &p) {
+            auto v = gauss(x, p);
+            for (size_t i = 0; i < x.size(); ++i) v[i] *= (x[i] - p[0]) * (x[i] - p[0]) / (p[1] * p[1] * p[1]);
+            return v;
+        });
+    cm.function({"mu2", "g2"}, lorentz)
+        .partial_deriv("mu2", [](const std::vector<double> &x, const std::vector<double> &p) {
+            std::vector<double> v(x.size());
+            for (size_t i = 0; i < x.size(); ++i) {
+                const double d = x[i] - p[0], den = d * d + p[1] * p[1];
+                v[i] = 2 * p[1] * p[1] * d / (den * den);
+            }
+            return v;
+        })
+        .partial_deriv("g2", [](const std::vector<double> &x, const std::vector<double> &p) {
+            std::vector<double> v(x.size());
+            for (size_t i = 0; i < x.size(); ++i) {
+                const double d = x[i] - p[0], den = d * d + p[1] * p[1];
+                v[i] = 2 * p[1] * d * d / (den * den);
+            }
+            return v;
+        });
+    cm.invariant_function([](const std::vector<double> &x, const std::vector<double> &) { return std::vector<double>(x.size(), 1.0); });
+    return cm;
+}
+
+static void test_closure_errors() {
+    std::vector<double> x = {0, 1, 2, 3};
+    auto id = [](const std::vector<double> &x, const std::vector<double> &) { return x; };
+    EXPECT(variant_of([&] { ClosureModel({}, x); }) == "EmptyParameters");
+    EXPECT(variant_of([&] { ClosureModel({"a", "a"}, x); }) == "DuplicateParameterNames");
+    EXPECT(variant_of([&] { ClosureModel({"a"}, x).validate(); }) == "EmptyModel");
+    EXPECT(variant_of([&] { ClosureModel({"a"}, x).function({"b"}, id); }) == "FunctionParameterNotInModel");
+    EXPECT(variant_of([&] { ClosureModel({"a"}, x).function({"a"}, id).validate(); }) == "MissingDerivative");
+    EXPECT(variant_of([&] { ClosureModel({"a", "b"}, x).function({"a"}, id).partial_deriv("a", id).validate(); }) == "UnusedParameter");
+    EXPECT(variant_of([&] { ClosureModel({"a", "b"}, x).function({"a"}, id).partial_deriv("b", id); }) == "InvalidDerivative");
+    EXPECT(variant_of([&] { ClosureModel({"a"}, x).function({"a"}, id).partial_deriv("a", id).partial_deriv("a", id); }) == "DuplicateDerivative");
+    ClosureModel cm = peaks_model(x);
+    EXPECT(cm.parameter_count() == 4 && cm.base_function_count() == 3 && cm.pairs().size() == 4);
+}
+
+// LevMarSolver::fit for a BATCH of closure models: LM drivers on the device, the model on the host
+static void test_closure_gpu() {
+    const int64_t B = 6, m = 400;
+    std::vector<double> x((size_t)m);
+    for (int64_t i = 0; i < m; ++i) x[(size_t)i] = 10.0 * (double)i / (double)(m - 1);
+    ClosureModel cm = peaks_model(x);
+    std::vector<double> truth((size_t)(B * 4)), guess((size_t)(B * 4)), Y((size_t)(B * m));
+    for (int64_t b = 0; b < B; ++b) {
+        const double t[4] = {2.6 + 0.15 * b, 0.5 + 0.05 * b, 6.1 + 0.1 * b, 0.6 + 0.08 * b};
+        const double f[4] = {1.04, 0.93, 0.97, 1.08};
+        for (int k = 0; k < 4; ++k) truth[(size_t)(b * 4 + k)] = t[k], guess[(size_t)(b * 4 + k)] = t[k] * f[k];
+    }
+    const std::vector<double> Phi = cm.eval_batch(truth, B);
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t i = 0; i < m; ++i)
+            Y[(size_t)(b * m + i)] = (10.0 + b) * Phi[(size_t)((b * 3 + 0) * m + i)] + (20.0 - b) * Phi[(size_t)((b * 3 + 1) * m + i)] + 1.5;
+    ExternalBatchProblem prob(cm, Y, B);
+    // the trait-level evaluation at the truth: zero residual, coefficients recovered
+    auto ev = prob.evaluate(truth);
+    for (int64_t b = 0; b < B; ++b) {
+        EXPECT(ev.status[(size_t)b] == 0 && ev.cost[(size_t)b] < 1e-20);
+        EXPECT(std::fabs(ev.coefficients[(size_t)(b * 3)] - (10.0 + b)) < 1e-9 && std::fabs(ev.coefficients[(size_t)(b * 3 + 2)] - 1.5) < 1e-9);
+    }
+    // Jacobian against central differences of the residual at the truth, where Kaufman's approximation is exact (the
+    // reference's own check, src/solvers/levmar/test.rs:21-40)
+    {
+        auto e0 = prob.evaluate(truth);
+        const double h = 1e-6;
+        for (int k = 0; k < 4; ++k) {
+            std::vector<double> ap = truth, am = truth;
+            for (int64_t b = 0; b < B; ++b) ap[(size_t)(b * 4 + k)] += h, am[(size_t)(b * 4 + k)] -= h;
+            auto rp = prob.evaluate(ap).residuals, rm = prob.evaluate(am).residuals;
+            double worst = 0, scale = 0;
+            for (int64_t b = 0; b < B; ++b)
+                for (int64_t i = 0; i < m; ++i) {
+                    const double fd = (rp[(size_t)(b * m + i)] - rm[(size_t)(b * m + i)]) / (2 * h);
+                    worst = std::fmax(worst, std::fabs(fd - e0.jacobian[(size_t)((b * 4 + k) * m + i)]));
+                    scale = std::fmax(scale, std::fabs(fd));
+                }
+            EXPECT(worst <= 1e-5 * scale);
+        }
+    }
+    for (int lazy = 0; lazy < 2; ++lazy) {
+        auto fit = prob.fit(guess, LevenbergMarquardt(), lazy != 0);
+        for (int64_t b = 0; b < B; ++b) {
+            EXPECT(fit.reports[(size_t)b].termination > 0);
+            for (int k = 0; k < 4; ++k) EXPECT(std::fabs(fit.nonlinear_parameters[(size_t)(b * 4 + k)] - truth[(size_t)(b * 4 + k)]) < 1e-6);
+            EXPECT(std::fabs(fit.linear_coefficients[(size_t)(b * 3 + 1)] - (20.0 - b)) < 1e-5);
+        }
+        std::printf("closure-model batch fit (%s): %d steps, problem 0: %d evaluations, objective %.3e\n",
+                    lazy ? "derivatives on accept" : "eager", fit.steps, fit.reports[0].n_evals, fit.reports[0].objective);
+    }
+}
+
 int main(int argc, char **argv) {
     const std::string mode = argc > 1 ? argv[1] : "errors";
     test_errors();
+    test_closure_errors();
     if (mode == "gpu") {
         if (vp_device_count() <= 0) {
             std::printf("no GPU visible\n");
             return 2;
         }
         test_gpu();
+        test_closure_gpu();
     } else {
         // without a device the product must refuse to compute (no CPU fallback)
         if (vp_device_count() <= 0) {

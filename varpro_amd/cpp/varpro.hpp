@@ -15,8 +15,11 @@
 // std::vector<double> exactly as nalgebra stores them.  Closures are replaced by basis kinds.
 // Link with -lvarpro_hip (varpro_amd/lib).  No CPU fallback: without a gfx950 device every compute call throws.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
+#include <map>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -362,6 +365,197 @@ class BatchProblem {
     // the given HIP stream (ncclAllReduce on RCCL); see include/varpro_hip.h
     void set_rhs_allreduce(vp_allreduce_fn fn, void *user, int64_t global_rhs_count) {
         check(vp_set_rhs_allreduce(h_, fn, user, global_rhs_count));
+    }
+};
+
+// ---- models OUTSIDE the descriptor language: the reference's closure-based `SeparableModel` (src/model/mod.rs:367-517),
+// built as `SeparableModelBuilder::function(params, f).partial_deriv(param, df)` (src/model/builder/mod.rs:338-525) with REAL
+// C++ callables.  f(x, params) -> m values.  The model is evaluated where it lives (the host); everything downstream of
+// eval() / eval_partial_deriv(k) runs on the device (vp_batch_create_external, include/varpro_hip.h).
+class ClosureModel {
+  public:
+    using Fn = std::function<std::vector<double>(const std::vector<double> &x, const std::vector<double> &params)>;
+
+  private:
+    struct Basis_ {
+        std::vector<int> idx;        // model parameter indices of the function's parameter list
+        Fn f;
+        std::map<int, Fn> derivs;    // model parameter index -> d f / d parameter
+    };
+    std::vector<std::string> names_;
+    std::vector<double> x_;
+    std::vector<Basis_> fns_;
+    int find(const std::string &nm) const {
+        for (size_t i = 0; i < names_.size(); ++i)
+            if (names_[i] == nm) return (int)i;
+        return -1;
+    }
+
+  public:
+    ClosureModel(std::vector<std::string> parameter_names, std::vector<double> x) : names_(std::move(parameter_names)), x_(std::move(x)) {
+        if (names_.empty()) throw ModelBuildError("EmptyParameters", "A function or model parameter list is empty!");
+        for (size_t i = 0; i < names_.size(); ++i) {
+            if (names_[i].find(',') != std::string::npos)
+                throw ModelBuildError("CommaInParameterNameNotAllowed", "Parameter names may not contain comma separator");
+            for (size_t j = 0; j < i; ++j)
+                if (names_[i] == names_[j]) throw ModelBuildError("DuplicateParameterNames", "Parameter list contains duplicates!");
+        }
+    }
+    ClosureModel &invariant_function(Fn f) {
+        fns_.push_back(Basis_{{}, std::move(f), {}});
+        return *this;
+    }
+    ClosureModel &function(const std::vector<std::string> &params, Fn f) {
+        if (params.empty()) throw ModelBuildError("EmptyParameters", "A function or model parameter list is empty!");
+        Basis_ b;
+        for (const auto &nm : params) {
+            const int k = find(nm);
+            if (k < 0) throw ModelBuildError("FunctionParameterNotInModel", "Function parameter '" + nm + "' is not part of the model parameters.");
+            for (int kk : b.idx)
+                if (kk == k) throw ModelBuildError("DuplicateParameterNames", "Parameter list contains duplicates!");
+            b.idx.push_back(k);
+        }
+        b.f = std::move(f);
+        fns_.push_back(std::move(b));
+        return *this;
+    }
+    ClosureModel &partial_deriv(const std::string &param, Fn df) {
+        if (fns_.empty() || fns_.back().idx.empty()) throw ModelBuildError("IllegalCallToPartialDeriv", "partial_deriv needs a preceding function");
+        const int k = find(param);
+        Basis_ &b = fns_.back();
+        bool in = false;
+        for (int kk : b.idx) in = in || kk == k;
+        if (k < 0 || !in) throw ModelBuildError("InvalidDerivative", "Parameter '" + param + "' is not in the function's parameter list");
+        if (b.derivs.count(k)) throw ModelBuildError("DuplicateDerivative", "Derivative for parameter '" + param + "' was already provided!");
+        b.derivs[k] = std::move(df);
+        return *this;
+    }
+    // == SeparableModelBuilder::build (src/model/builder/mod.rs:527-553)
+    void validate() const {
+        if (fns_.empty()) throw ModelBuildError("EmptyModel", "Tried to construct model with no functions.");
+        std::vector<bool> used(names_.size(), false);
+        for (const auto &b : fns_)
+            for (int k : b.idx) {
+                used[(size_t)k] = true;
+                if (!b.derivs.count(k)) throw ModelBuildError("MissingDerivative", "missing derivative for parameter '" + names_[(size_t)k] + "'");
+            }
+        for (size_t k = 0; k < used.size(); ++k)
+            if (!used[k]) throw ModelBuildError("UnusedParameter", "Parameter '" + names_[k] + "' is not used by any function of the model");
+    }
+    size_t parameter_count() const { return names_.size(); }
+    size_t base_function_count() const { return fns_.size(); }
+    size_t output_len() const { return x_.size(); }
+    // the (basis j, parameter k) pairs with a non-zero derivative, in the column order of derivs()
+    std::vector<std::pair<int, int>> pairs() const {
+        std::vector<std::pair<int, int>> p;
+        for (size_t j = 0; j < fns_.size(); ++j)
+            for (int k : fns_[j].idx) p.emplace_back((int)j, k);
+        return p;
+    }
+    // == eval() (src/model/mod.rs:441-471) for a batch of parameter sets alpha [B][q]: Phi [B][n][m], UNWEIGHTED
+    std::vector<double> eval_batch(const std::vector<double> &alpha, int64_t B) const {
+        const size_t q = names_.size(), n = fns_.size(), m = x_.size();
+        std::vector<double> out((size_t)B * n * m);
+        for (int64_t b = 0; b < B; ++b)
+            for (size_t j = 0; j < n; ++j) {
+                std::vector<double> pr;
+                for (int k : fns_[j].idx) pr.push_back(alpha[(size_t)b * q + (size_t)k]);
+                const std::vector<double> v = fns_[j].f(x_, pr);
+                std::copy(v.begin(), v.end(), out.begin() + ((size_t)b * n + j) * m);
+            }
+        return out;
+    }
+    // == the non-zero columns of eval_partial_deriv(k) (src/model/mod.rs:473-512) in pair order: dPhi [B][p][m]
+    std::vector<double> derivs_batch(const std::vector<double> &alpha, int64_t B) const {
+        const size_t q = names_.size(), m = x_.size();
+        const auto prs = pairs();
+        std::vector<double> out((size_t)B * prs.size() * m);
+        for (int64_t b = 0; b < B; ++b)
+            for (size_t p = 0; p < prs.size(); ++p) {
+                const Basis_ &bs = fns_[(size_t)prs[p].first];
+                std::vector<double> pr;
+                for (int k : bs.idx) pr.push_back(alpha[(size_t)b * q + (size_t)k]);
+                const std::vector<double> v = bs.derivs.at(prs[p].second)(x_, pr);
+                std::copy(v.begin(), v.end(), out.begin() + ((size_t)b * prs.size() + p) * m);
+            }
+        return out;
+    }
+};
+
+// B problems of one closure model (single right-hand side, fp64, host-pointer mode): trait-level evaluation and the
+// batched LM fit by reverse communication -- LevMarSolver::fit over any SeparableNonlinearModel
+// (src/solvers/levmar/mod.rs:238-254): the LM drivers on the device, the model with the caller
+class ExternalBatchProblem {
+    vp_batch *h_ = nullptr;
+    const ClosureModel *model_ = nullptr;
+
+  public:
+    int64_t m = 0, B = 0;
+    int n = 0, q = 0, np = 0;
+    ExternalBatchProblem(const ClosureModel &model, const std::vector<double> &Y, int64_t B_, const std::vector<double> *weights = nullptr,
+                         double epsilon = -1.0, int device = 0)
+        : model_(&model) {
+        model.validate();
+        m = (int64_t)model.output_len();
+        B = B_;
+        n = (int)model.base_function_count();
+        q = (int)model.parameter_count();
+        const auto prs = model.pairs();
+        np = (int)prs.size();
+        std::vector<int32_t> pb, pp;
+        for (const auto &pr : prs) {
+            pb.push_back(pr.first);
+            pp.push_back(pr.second);
+        }
+        if ((int64_t)Y.size() != B * m) throw std::invalid_argument("Y must hold B*m values");
+        check(vp_batch_create_external(&h_, n, q, np, pb.data(), pp.data(), VP_F64, m, 1, B, Y.data(), weights ? weights->data() : nullptr,
+                                       epsilon, VP_FLAG_OWN_STREAM, device, nullptr));
+    }
+    ExternalBatchProblem(const ExternalBatchProblem &) = delete;
+    ExternalBatchProblem &operator=(const ExternalBatchProblem &) = delete;
+    ~ExternalBatchProblem() {
+        if (h_) vp_batch_destroy(h_);
+    }
+    struct Evaluation {
+        std::vector<double> residuals, jacobian, coefficients, cost; // [B][m], [B][q][m], [B][n], [B]
+        std::vector<int32_t> status;
+    };
+    // set_params + residuals + jacobian of every problem at alpha [B][q] (src/solvers/levmar/mod.rs:42-73, 91-95, 101-201)
+    Evaluation evaluate(const std::vector<double> &alpha) const {
+        const std::vector<double> Phi = model_->eval_batch(alpha, B), dPhi = model_->derivs_batch(alpha, B);
+        Evaluation e;
+        e.residuals.resize((size_t)(B * m));
+        e.jacobian.resize((size_t)(B * q * m));
+        e.coefficients.resize((size_t)(B * n));
+        e.cost.resize((size_t)B);
+        e.status.resize((size_t)B);
+        check(vp_evaluate_with_basis(h_, alpha.data(), Phi.data(), dPhi.data(), e.residuals.data(), e.jacobian.data(),
+                                     e.coefficients.data(), e.cost.data(), e.status.data()));
+        return e;
+    }
+    struct BatchFit {
+        std::vector<double> nonlinear_parameters, linear_coefficients; // [B][q], [B][n]
+        std::vector<vp_report> reports;                                // termination > 0 <=> FitResult Ok (:249-253)
+        int steps = 0;
+    };
+    BatchFit fit(const std::vector<double> &alpha0, const LevenbergMarquardt &solver = LevenbergMarquardt(), bool derivatives_on_accept = false) {
+        check(vp_fit_begin(h_, &solver.o, alpha0.data(), derivatives_on_accept ? VP_FIT_DERIVATIVES_ON_ACCEPT : 0));
+        std::vector<double> trial = alpha0;
+        std::vector<int32_t> want((size_t)B, VP_WANT_BASIS | VP_WANT_DERIVATIVES);
+        int64_t active = B;
+        BatchFit out;
+        const int limit = 2 * (solver.o.patience * (q + 1) + 2);
+        while (active > 0 && out.steps < limit) {
+            // (the columns of every problem are evaluated: a model may skip the problems whose want word is 0)
+            const std::vector<double> Phi = model_->eval_batch(trial, B), dPhi = model_->derivs_batch(trial, B);
+            check(vp_fit_step_with_basis(h_, Phi.data(), dPhi.data(), trial.data(), want.data(), &active));
+            ++out.steps;
+        }
+        out.nonlinear_parameters.resize((size_t)(B * q));
+        out.linear_coefficients.resize((size_t)(B * n));
+        out.reports.resize((size_t)B);
+        check(vp_fit_end(h_, out.nonlinear_parameters.data(), out.linear_coefficients.data(), out.reports.data()));
+        return out;
     }
 };
 
