@@ -491,7 +491,7 @@ def main():
             # predicted efficiency = mean / max of the per-shard step times.
             G = args.emulate_shards
             if G > 1:
-                shard_ms, shard_evals, shard_max = [], [], []
+                shard_ms, shard_evals, shard_max, shard_ms2 = [], [], [], []
                 for g in range(G):
                     fg, cg = vd.shard_range(G * B, g, G)
                     dg = d if g == 0 else synth.double_exp_batch(cg, m=m, first_problem=fg, noise=args.noise)
@@ -503,8 +503,29 @@ def main():
                     ng = bp.report_to_numpy(repg)["n_evals"]
                     shard_evals.append(int(ng.sum()))
                     shard_max.append(int(ng.max()))
-                    del dg
+                    # the same shard the way a rank of the real run steps: TWO batches in flight (handle / stream k mod 2; the
+                    # second handle fits the rank's block of the NEXT G x B problems, as in the timed region above)
+                    dg2 = synth.double_exp_batch(cg, m=m, first_problem=G * B + fg, noise=args.noise)
+                    with torch.cuda.stream(streams[1]):
+                        handles[1].set_observations(torch.from_numpy(dg2["Y"]).to(dev))
+                    gg2 = torch.from_numpy(dg2["tau_guess"]).to(dev)
+                    torch.cuda.synchronize()
+
+                    def two_steps(nsteps):
+                        for k_ in range(nsteps):
+                            with torch.cuda.stream(streams[k_ % 2]):
+                                handles[k_ % 2].fit(gg if k_ % 2 == 0 else gg2, want_coefficients=False)
+                    two_steps(2)
+                    torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                    two_steps(8)
+                    torch.cuda.synchronize()
+                    shard_ms2.append((time.perf_counter() - t0_) * 1e3 / 8)
+                    del dg, dg2
                 bp.set_observations(Y)
+                with torch.cuda.stream(streams[1]):
+                    handles[1].set_observations(Y2)
+                torch.cuda.synchronize()
                 sm, se = np.array(shard_ms), np.array(shard_evals, dtype=np.float64)
                 out["configs3_emulated"] = {
                     "workload": "BASELINE configs[3]: %d problems = %d shards of %d (contiguous split, varpro_amd/distributed.py"
@@ -514,6 +535,12 @@ def main():
                     "predicted_efficiency": float(sm.mean() / sm.max()),
                     "predicted_efficiency_from_evaluation_counts": float(se.mean() / se.max()),
                     "predicted_fits_per_s_at_%d_gpus" % G: float(G * B / (sm.max() * 1e-3)),
+                    "two_batches_in_flight": {
+                        "per_shard_ms_per_step": [float(v) for v in shard_ms2],
+                        "predicted_efficiency": float(np.mean(shard_ms2) / np.max(shard_ms2)),
+                        "predicted_fits_per_s_at_%d_gpus" % G: float(G * B / (np.max(shard_ms2) * 1e-3)),
+                        "note": "every shard stepped the way a rank of the real run steps it (step k on handle / stream k mod 2, wall "
+                                "clock over 8 steps): the tail of a shard's longest fit overlaps the bulk of the rank's next batch"},
                     "note": "kernel time only (HIP events); the real run adds one RCCL all-reduce of 4 doubles per step",
                 }
 
