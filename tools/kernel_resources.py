@@ -1,57 +1,42 @@
-"""Per-kernel code-object metadata (VGPRs, spilled VGPRs / SGPRs, scratch bytes, LDS) of a built object file or of
-the whole library: `python tools/kernel_resources.py varpro_amd/csrc/build/vp_inst_ext_b_f64.o [substring]`
-(llvm-objdump --offloading extracts the gfx950 code object, llvm-readelf --notes prints its metadata).
-`--worst N` lists the N kernels with the most spilled VGPRs over all objects of varpro_amd/csrc/build."""
-import glob
-import os
-import re
-import subprocess
-import sys
-import tempfile
-
+"""VGPRs / spilled VGPRs / scratch / LDS of every kernel in a built object or library (code-object metadata).
+usage: python tools/kernel_resources.py [varpro_amd/lib/libvarpro_hip.so] [--worst N] [--json out.json]"""
+import json, os, re, subprocess, sys, tempfile, shutil
 LLVM = "/opt/rocm/lib/llvm/bin"
-
-
-def kernels_of(obj):
-    out = []
-    with tempfile.TemporaryDirectory() as td:
-        dst = os.path.join(td, os.path.basename(obj))
-        os.symlink(os.path.abspath(obj), dst)
-        subprocess.run([LLVM + "/llvm-objdump", "--offloading", dst], capture_output=True, cwd=td)
-        for co in glob.glob(dst + ".*gfx950*"):
-            txt = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
-            for blk in txt.split("- .agpr_count")[1:]:
-                g = lambda k: (re.search(r"\.%s:\s+(\S+)" % k, blk) or [None, "0"])[1]
-                out.append(dict(name=g("name"), vgpr=int(g("vgpr_count")), vspill=int(g("vgpr_spill_count")),
-                                sspill=int(g("sgpr_spill_count")), scratch=int(g("private_segment_fixed_size")),
-                                lds=int(g("group_segment_fixed_size"))))
-    names = [k["name"] for k in out]
-    if names:
-        dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
-        for k, d in zip(out, dem):
-            k["dem"] = re.sub(r"\(.*", "", d).replace("void vp::", "").replace("vp::", "")
-    return out
-
-
-def main():
-    if sys.argv[1] == "--worst":
-        n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-        allk = []
-        for obj in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "..", "varpro_amd", "csrc", "build", "*.o"))):
-            for k in kernels_of(obj):
-                k["obj"] = os.path.basename(obj)
-                allk.append(k)
-        allk.sort(key=lambda k: -k["vspill"])
-        print("%d kernels; %d with spilled VGPRs, %d with more than 64" % (len(allk), sum(k["vspill"] > 0 for k in allk),
-                                                                          sum(k["vspill"] > 64 for k in allk)))
-        for k in allk[:n]:
-            print("%-26s %-100s vgpr %3d vspill %4d sspill %3d scratch %5d" % (k["obj"], k["dem"][:100], k["vgpr"], k["vspill"], k["sspill"], k["scratch"]))
-        return
-    flt = sys.argv[2] if len(sys.argv) > 2 else ""
-    for k in kernels_of(sys.argv[1]):
-        if flt in k["dem"]:
-            print("%-100s vgpr %3d vspill %4d sspill %3d scratch %5d lds %6d" % (k["dem"][:100], k["vgpr"], k["vspill"], k["sspill"], k["scratch"], k["lds"]))
-
-
-if __name__ == "__main__":
-    main()
+args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] not in ("--worst", "--json")]
+obj = os.path.abspath(args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "varpro_amd", "lib", "libvarpro_hip.so"))
+worst = int(sys.argv[sys.argv.index("--worst") + 1]) if "--worst" in sys.argv else 15
+out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+tmp = tempfile.mkdtemp()
+try:
+    shutil.copy(obj, os.path.join(tmp, "x.o"))
+    subprocess.run([LLVM + "/llvm-objdump", "--offloading", "x.o"], cwd=tmp, capture_output=True)
+    kernels = []
+    for fn in sorted(os.listdir(tmp)):
+        if "amdgcn" not in fn: continue
+        notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", os.path.join(tmp, fn)], capture_output=True, text=True).stdout
+        cur = {}
+        for line in notes.splitlines():
+            m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)$", line)
+            if not m: continue
+            k, v = m.group(1), m.group(2).strip()
+            if k == "name" and cur.get("_in_kernel"):
+                cur["name"] = v
+            if k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size", "sgpr_count"):
+                cur[k] = int(v); cur["_in_kernel"] = True
+            if k == "wavefront_size":
+                if "name" in cur or "symbol" in cur: kernels.append(cur)
+                cur = {}
+            if k == "symbol": cur["symbol"] = v
+    ks = [k for k in kernels if "vgpr_count" in k]
+    def nm(k): return subprocess.run([shutil.which("c++filt") or "cat", k.get("symbol", k.get("name", "?")).replace(".kd", "")], capture_output=True, text=True).stdout.strip()[:150]
+    sp = sorted(ks, key=lambda k: -k.get("vgpr_spill_count", 0))
+    summary = {"object": os.path.relpath(obj), "bytes": os.path.getsize(obj), "kernels": len(ks),
+               "kernels_with_spilled_vgprs": sum(1 for k in ks if k.get("vgpr_spill_count", 0) > 0),
+               "kernels_above_64_spilled_vgprs": sum(1 for k in ks if k.get("vgpr_spill_count", 0) > 64),
+               "worst": [dict(kernel=nm(k), vgprs=k["vgpr_count"], spilled_vgprs=k.get("vgpr_spill_count", 0), spilled_sgprs=k.get("sgpr_spill_count", 0),
+                              scratch_bytes=k.get("private_segment_fixed_size", 0)) for k in sp[:worst]]}
+    print(json.dumps({k: v for k, v in summary.items() if k != "worst"}))
+    for w in summary["worst"]: print("%4d spilled  %3d VGPRs  %5d B scratch  %s" % (w["spilled_vgprs"], w["vgprs"], w["scratch_bytes"], w["kernel"]))
+    if out_json: json.dump(summary, open(out_json, "w"), indent=1)
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)

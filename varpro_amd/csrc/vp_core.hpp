@@ -528,7 +528,10 @@ __device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T 
     T tau[NCX];
     // (opaque: 1 / beta_0 and its square in solve_coeffs are loop invariants of the caller's LM loop -- hoisted, they are two
     // more spilled registers whose reload is a VMEM wait in every evaluation)
-    Rm[0][0] = dyn_opq(h0.beta);
+#ifndef VP_OPAQUE_BETA0
+#define VP_OPAQUE_BETA0 1
+#endif
+    Rm[0][0] = VP_OPAQUE_BETA0 ? dyn_opq(h0.beta) : h0.beta;
 #pragma unroll
     for (int j = 0; j < NCX; ++j) {
         if (YPRE && j == NE) {

@@ -40,7 +40,11 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 // the lane index recomputed on the spot (two instructions) and opaque to the optimiser: a lane-dependent address that is
 // needed once per loop iteration is otherwise kept -- i.e. SPILLED and reloaded -- across the register-critical part of the
 // iteration, and a scratch reload is a VMEM wait (vmcnt) the asynchronous refill of vp_fit2.hpp cannot afford
+#ifndef VP_LANE_FRESH
+#define VP_LANE_FRESH 1
+#endif
 __device__ __forceinline__ int lane_fresh() {
+    if (!VP_LANE_FRESH) return lane_id();
     unsigned z = 0u; // (the count starts from an opaque zero: the mbcnt pair itself must not be hoisted out of the caller's loop)
     asm volatile("" : "+v"(z));
     return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));

@@ -1008,8 +1008,17 @@ __device__ __forceinline__ void jac_qrfac_scaled(T (&Z)[Q][R], T (&rv)[R], const
 template <typename T, int Q> struct ParamPack {
     T v[Q];
 };
-template <typename T, class M, int W>
-inline constexpr bool jac_rescue_v = sizeof(T) == 8 && W == 1 && M::kStatic && M::kConstLast && M::kDiagonalPairs;
+#ifndef VP_JAC_RESCUE
+#define VP_JAC_RESCUE 1
+#endif
+// Where: the kernels of FULL-LENGTH, unweighted problems (PADM == 1: m == 64 R -- the sets every census runs on).  In the
+// kernels compiled for a general length or for weights the call's register constraints reach into the hot loop (the row
+// masks / weight columns are live across everything: 11 -> 37 scratch reloads per evaluation at PADM = 0, 139 -> 224 spilled
+// VGPRs), for an event that takes a decay time through zero within a factor 1e2 of overflow (2 in a million fits): those
+// kernels keep the round-4 behaviour (the fit ends `Numerical`).
+template <typename T, class M, int W, int PADM = 1, bool WEIGHTED = false>
+inline constexpr bool jac_rescue_v = VP_JAC_RESCUE && sizeof(T) == 8 && W == 1 && PADM == 1 && !WEIGHTED && M::kStatic &&
+                                     M::kConstLast && M::kDiagonalPairs;
 
 template <typename T, class M, int R, class Src, bool YPRE>
 __device__ __noinline__ void rescue_jacobian(const ParamPack<T, M::Q> al, const Src src, const T eps, const T h0_beta,
@@ -1381,7 +1390,7 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
 #pragma unroll
                 for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
                 jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
-                if constexpr (CF && jac_rescue_v<T, M, W>) {
+                if constexpr (CF && jac_rescue_v<T, M, W, PADM, WEIGHTED>) {
                     bool bad = false;
 #pragma unroll
                     for (int k = 0; k < Q; ++k) bad = bad || !is_finite(acnorm[k]);

@@ -665,7 +665,7 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
 #pragma unroll
             for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
             jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
-            if constexpr (jac_rescue_v<T, M, 1>) {
+            if constexpr (jac_rescue_v<T, M, 1, PADM>) {
                 bool bad = false;
 #pragma unroll
                 for (int k = 0; k < Q; ++k) bad = bad || !is_finite(acnorm[k]);
@@ -932,7 +932,7 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
 #pragma unroll
                 for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
                 jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
-                if constexpr (jac_rescue_v<T, M, W>) {
+                if constexpr (jac_rescue_v<T, M, W, PADM>) {
                     // a Jacobian that is not finite after a good evaluation is redone after the slot loop (rescue_jacobian)
 #pragma unroll
                     for (int k = 0; k < Q; ++k) jbad = jbad || !is_finite(acnorm[k]);
@@ -965,7 +965,7 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
             }
         }
         group_sync();
-        if constexpr (jac_rescue_v<T, M, W>) {
+        if constexpr (jac_rescue_v<T, M, W, PADM>) {
             if (anybad) { // (rare) out of line, between the phases: only the kernel's own constants are live here
 #pragma nounroll
                 for (int s = 0; s < GS; ++s) {
