@@ -362,3 +362,31 @@ def test_mrhs_gram_based_lm_step_beyond_cond_1e2():
             assert r["first_step_rel_dev"] <= max(1e-9, bound), r
         assert r["ok_device"] == r["ok_oracle"], r
         assert r["objective_rel_dev"] <= 1e-9 and r["alpha_dev"] <= 1e-6, r
+
+
+def test_global_fit_condition_entry_point():
+    """vp_global_fit_condition (round 5): one number per problem after a global fit, refused where it has no meaning (before a
+    fit; on a single-RHS handle), small on a well-conditioned problem, reset by every fit"""
+    rng = np.random.default_rng(11)
+    S, m, B = 6, 300, 3
+    x = 12.5 * np.arange(m) / (m - 1)
+    Cm = rng.uniform(10, 100, (B, S, 3))
+    Y = Cm[..., 0:1] * np.exp(-x / 1.0) + Cm[..., 1:2] * np.exp(-x / 4.0) + Cm[..., 2:3]
+    Y = Y + 1e-3 * np.abs(Y).max() * rng.standard_normal(Y.shape)
+    guess = np.tile([1.3, 3.2], (B, 1))
+    mdl = double_exp_builder_model(x, guess[0])
+    bp = vp.BatchProblem(mdl, Y, x=x)
+    with pytest.raises(vp.VarproHipError):
+        bp.global_fit_condition()  # no fit yet
+    bp.fit(guess)
+    c1 = np.asarray(bp.global_fit_condition())
+    assert c1.shape == (B,) and np.isfinite(c1).all() and (c1 >= 1.0).all() and (c1 < 1e3).all(), c1
+    bp.fit(np.tile([1.0, 4.0], (B, 1)))  # starts at the truth: the estimate is that of this fit, not the maximum over both
+    c2 = np.asarray(bp.global_fit_condition())
+    assert np.isfinite(c2).all() and (c2 < 1e3).all()
+    bp.close()
+    bp1 = vp.BatchProblem(mdl, Y[:, 0], x=x)  # single right-hand side: the Householder kernels factor J itself
+    bp1.fit(guess)
+    with pytest.raises(vp.VarproHipError):
+        bp1.global_fit_condition()
+    bp1.close()
