@@ -14,3 +14,4 @@ a, C, rep, tr = bp.fit_trace(d["tau_guess"], max_rows=160)
 ck = tr[0, 159, :3]
 n = rep["n_evals"][0]
 print("problem 0 evals", n, "clocks vector/scalar/refill", ck, " per evaluation:", ck / max(1, n))
+print("scalar phase sections [load | update+tests | gtest+diag | lmpar | prered+trial | write-back]:", tr[0, 158, :6])

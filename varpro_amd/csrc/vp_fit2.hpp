@@ -85,6 +85,9 @@ template <typename T, typename TO = T> struct SlotConsts {
     int64_t B;
     int trace_rows, scale_diag, max_fev, m;
     T eps;             // (Gram kernel) rank threshold of the linear solve
+#ifdef VP_FIT2_CLOCKS
+    long long sck[6];  // (debug) section clocks of the scalar phase, accumulated by wave 0 of workgroup 0
+#endif
 };
 
 // Fill a slot: y' = H_0 y_w into the slot's LDS column (row order, zero padded); returns (H_0 y_w)[0].
@@ -198,6 +201,18 @@ __device__ __noinline__ void slot_fill(VP_LDS SlotRec<T, N, Q> *rec, VP_LDS T *s
 template <typename T, int N, int Q, int GS, typename TO = T, bool GRAM = false>
 __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *recs, VP_LDS const SlotConsts<T, TO> *k, const bool act = true) {
     const int lane = lane_id();
+#ifdef VP_FIT2_CLOCKS
+    long long sc0_ = __builtin_amdgcn_s_memtime();
+    const bool sck_on_ = blockIdx.x == 0 && (threadIdx.x >> 6) == 0;
+#define VP_SCK(i)                                                                                                      \
+    do {                                                                                                               \
+        const long long c1_ = __builtin_amdgcn_s_memtime();                                                           \
+        if (sck_on_ && lane == 0) const_cast<SlotConsts<T, TO> *>((const SlotConsts<T, TO> *)k)->sck[i] += c1_ - sc0_;   \
+        sc0_ = c1_;                                                                                                    \
+    } while (0)
+#else
+#define VP_SCK(i)
+#endif
     if (!(act && lane < GS && recs[lane].prob >= 0)) return;
     VP_LDS SlotRec<T, N, Q> *s = recs + lane;
     const T ftol = k->ftol, xtol = k->xtol, gtol = k->gtol, stepbound = k->stepbound;
@@ -243,6 +258,7 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
     };
 
     bool need_step = false;
+    VP_SCK(0);
     if (first) {
         first = false;
         nfev = 1;
@@ -268,66 +284,60 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
             accept_c = true;
             status = VP_ST_NONFINITE;
         } else {
-            if (ratio <= T(0.25)) {
-                T temp = !(actred < T(0)) ? T(0.5) : T(0.5) * dirder * frcp(dirder + T(0.5) * actred);
-                if (fnorm1 * T(0.1) >= fnorm || temp < T(0.1)) temp = T(0.1);
-                delta = temp * tmin(delta, pnorm * T(10));
-                par = par * frcp(temp);
-            } else if (par == T(0) || ratio >= T(0.75)) {
-                delta = pnorm * T(2);
-                par = par * T(0.5);
-            }
+            // STRAIGHT-LINE from here (round 5): lane s runs its own problem, so every `if` of the bookkeeping is a divergent
+            // branch -- an exec-mask save / restore and a scalar branch whose latency nothing hides (23 of them in this block,
+            // 31 % of the scalar phase by the section clocks of tools/fit2_clocks.py).  The same expressions, evaluated
+            // unconditionally and SELECTED: identical values wherever the branchy form computed them.
+            const bool lo = ratio <= T(0.25);
+            const bool hi = !lo && (par == T(0) || ratio >= T(0.75));
+            T temp = !(actred < T(0)) ? T(0.5) : T(0.5) * dirder * frcp(dirder + T(0.5) * actred);
+            temp = (fnorm1 * T(0.1) >= fnorm || temp < T(0.1)) ? T(0.1) : temp;
+            const T d_lo = temp * tmin(delta, pnorm * T(10)), p_lo = par * frcp(temp);
+            delta = lo ? d_lo : (hi ? pnorm * T(2) : delta);
+            par = lo ? p_lo : (hi ? par * T(0.5) : par);
             trace_row(ratio);
-            if (good_v) {
+            const bool g = good_v;
 #pragma unroll
-                for (int i = 0; i < Q; ++i) x[i] = xt[i];
-                accept_c = true;
-                T tmpv[Q];
+            for (int i = 0; i < Q; ++i) x[i] = g ? xt[i] : x[i];
+            accept_c = g;
+            T tmpv[Q];
 #pragma unroll
-                for (int i = 0; i < Q; ++i) tmpv[i] = scale_diag ? diag[i] * x[i] : x[i];
-                xnorm = enorm_small<T, Q, false>(tmpv);
-                fnorm = fnorm1;
-                objective = T(0.5) * fnorm1 * fnorm1;
-                if (!is_finite(xnorm)) term = VP_TERM_NUMERICAL;
-            }
-            if (!term) {
-                int tcode = 0;
-                if (fnorm <= num<T>::tiny) tcode = VP_TERM_RESIDUALS_ZERO;
-                if (!tcode) {
-                    const bool ftol_check = tabs(actred) <= ftol && prered <= ftol && ratio * T(0.5) <= T(1);
-                    const bool xtol_check = delta <= xtol * xnorm;
-                    if (ftol_check || xtol_check)
-                        tcode = (ftol_check && xtol_check) ? VP_TERM_CONVERGED_BOTH
-                                                           : (ftol_check ? VP_TERM_CONVERGED_FTOL : VP_TERM_CONVERGED_XTOL);
-                }
-                if (!tcode && nfev >= max_fev) tcode = VP_TERM_LOST_PATIENCE;
-                if (!tcode && tabs(actred) <= num<T>::eps && prered <= num<T>::eps && ratio * T(0.5) <= T(1))
-                    tcode = VP_TERM_NO_IMPROVEMENT;
-                if (!tcode && delta <= num<T>::eps * xnorm) tcode = VP_TERM_NO_IMPROVEMENT;
-                if (!tcode && gnorm <= num<T>::eps) tcode = VP_TERM_NO_IMPROVEMENT;
-                term = tcode;
-                // (a rejected step keeps the old Jacobian factor and only re-solves the trust-region problem)
-                need_step = (tcode == 0);
-            }
+            for (int i = 0; i < Q; ++i) tmpv[i] = scale_diag ? diag[i] * x[i] : x[i];
+            const T xn_new = enorm_small<T, Q, false>(tmpv);
+            xnorm = g ? xn_new : xnorm;
+            fnorm = g ? fnorm1 : fnorm;
+            objective = g ? T(0.5) * fnorm1 * fnorm1 : objective;
+            const bool xbad = g && !is_finite(xnorm);
+            const bool ftol_check = tabs(actred) <= ftol && prered <= ftol && ratio * T(0.5) <= T(1);
+            const bool xtol_check = delta <= xtol * xnorm;
+            const int conv = ftol_check ? (xtol_check ? VP_TERM_CONVERGED_BOTH : VP_TERM_CONVERGED_FTOL)
+                                        : (xtol_check ? VP_TERM_CONVERGED_XTOL : 0);
+            int tcode = (fnorm <= num<T>::tiny) ? VP_TERM_RESIDUALS_ZERO : conv;
+            tcode = (tcode == 0 && nfev >= max_fev) ? VP_TERM_LOST_PATIENCE : tcode;
+            const bool stuck = (tabs(actred) <= num<T>::eps && prered <= num<T>::eps && ratio * T(0.5) <= T(1)) ||
+                               delta <= num<T>::eps * xnorm || gnorm <= num<T>::eps;
+            tcode = (tcode == 0 && stuck) ? VP_TERM_NO_IMPROVEMENT : tcode;
+            term = xbad ? VP_TERM_NUMERICAL : tcode;
+            // (a rejected step keeps the old Jacobian factor and only re-solves the trust-region problem)
+            need_step = (term == 0);
         }
     }
-
+    VP_SCK(1);
     if (need_step && jac_done) {
         // the vector phase refreshed (Rj, qtf, acnorm, ipvt) at the accepted point
         T gmax = T(0);
         bool degenerate = false;
         const T ifn = frcp(fnorm);
 #pragma unroll
-        for (int j = 0; j < Q; ++j) {
+        for (int j = 0; j < Q; ++j) { // (selected, not branched: see above)
             const T an = dyn_get_o<Q, (Q > 3)>(acnorm, ipvt[j]);
-            if (an != T(0)) {
-                T sum = T(0);
+            const bool nz = an != T(0);
+            T sum = T(0);
 #pragma unroll
-                for (int i = 0; i <= j; ++i) sum = tfma(Rj[i][j], qtf[i], sum);
-                const T temp = tabs(sum * frcp(an) * ifn);
-                if (temp != temp) degenerate = true;
-                gmax = tmax(gmax, temp);
-            }
+            for (int i = 0; i <= j; ++i) sum = tfma(Rj[i][j], qtf[i], sum);
+            const T temp = tabs(sum * frcp(an) * ifn);
+            degenerate = degenerate || (nz && temp != temp);
+            gmax = nz ? tmax(gmax, temp) : gmax;
         }
         gnorm = gmax;
         if (degenerate) {
@@ -352,6 +362,7 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
         if (term) need_step = false;
     }
 
+    VP_SCK(2);
     if (need_step) {
         T Rw[Q][Q]; // lmpar scribbles on the strict lower triangle
 #pragma unroll
@@ -360,9 +371,8 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
             for (int j = 0; j < Q; ++j) Rw[i][j] = Rj[i][j];
         if constexpr (GRAM) par = lmpar_chol<T, Q, false, (Q > 3)>(Rj, ipvt, diag, qtf, delta, par, step, pnorm);
         else par = lmpar_any<T, Q, false, (Q > 3)>(Rw, ipvt, diag, qtf, delta, par, step, pnorm);
-        if (!is_finite(pnorm)) {
-            term = VP_TERM_NUMERICAL;
-        } else {
+        VP_SCK(3);
+        {
             T wa[Q];
 #pragma unroll
             for (int i = 0; i < Q; ++i) wa[i] = T(0);
@@ -377,19 +387,19 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
             const T temp1 = t1 * t1;
             const T t2 = (usqrt(par) * pnorm) * ifn;
             const T temp2 = t2 * t2;
-            if (!is_finite(temp1) || !is_finite(temp2)) {
-                term = VP_TERM_NUMERICAL;
-            } else {
-                prered = temp1 + temp2 * T(2);
-                dirder = -(temp1 + temp2);
-                if (first_tr && pnorm < delta) delta = pnorm;
-                first_tr = false;
+            // (a non-finite step length makes both terms non-finite: one test, selected results)
+            const bool bad = !is_finite(pnorm) || !is_finite(temp1) || !is_finite(temp2);
+            term = bad ? VP_TERM_NUMERICAL : term;
+            prered = bad ? prered : temp1 + temp2 * T(2);
+            dirder = bad ? dirder : -(temp1 + temp2);
+            delta = (!bad && first_tr && pnorm < delta) ? pnorm : delta;
+            first_tr = bad ? first_tr : false;
 #pragma unroll
-                for (int i = 0; i < Q; ++i) xt[i] = x[i] - step[i];
-            }
+            for (int i = 0; i < Q; ++i) xt[i] = bad ? xt[i] : x[i] - step[i];
         }
     }
 
+    VP_SCK(4);
     // write the record back
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
@@ -435,6 +445,7 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
             for (int i = 0; i < N; ++i) C_out[prob * N + i] = (TO)s->cbest[i];
         }
     }
+    VP_SCK(5);
 }
 
 template <typename T, int N, int Q, int GS, typename TO = T, bool GRAM = false>
@@ -846,6 +857,9 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
             kc->scale_diag = a.scale_diag;
             kc->max_fev = a.patience * (Q + 1);
             kc->m = a.m;
+#ifdef VP_FIT2_CLOCKS
+            for (int i = 0; i < 6; ++i) kc->sck[i] = 0;
+#endif
         }
     }
     __syncthreads();
@@ -1043,6 +1057,10 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
     if (args.f.trace && blockIdx.x == 0 && threadIdx.x == 0) {
         double *tr = args.f.trace + (size_t)(args.f.trace_rows - 1) * (Q + 4);
         for (int i = 0; i < 3; ++i) tr[i] = (double)ck[i];
+        // (row trace_rows - 2: the scalar phase's sections -- record load | update + termination tests | gradient test, diag |
+        // lmpar | predicted reduction, trial point | write-back, results)
+        double *tr2 = args.f.trace + (size_t)(args.f.trace_rows - 2) * (Q + 4);
+        for (int i = 0; i < 6 && i < Q + 4; ++i) tr2[i] = (double)kc->sck[i];
     }
 #endif
 }
