@@ -609,10 +609,12 @@ def main():
             # (66 FMAs + 11 adds), 5 exponential + 10 derivative multiplies = 158 fp64 flops.  The kernel EXECUTES far
             # fewer: the moment form needs 133 per row, and on a uniform grid with unit weights (this workload) the 55
             # moments that do not depend on y come from a closed form (doubling recurrence over the bits of m), which
-            # leaves 10 multiplies + 11 FMAs + 1 add = 33 per row.  Both fractions are reported; the launch is bound by its
-            # LONGEST fit (evaluations x {moment pass + lane-serial bookkeeping}), not by the fp64 pipe.
+            # left 10 multiplies + 11 FMAs + 1 add = 33 per row through round 4.  Round 5: the 10 y-dependent moments are
+            # polynomials in rho_k = e^{-dt/tau_k} -- Horner over a lane's 4 rows, times the lane's anchor: 43 FMAs + 9
+            # multiplies per 4 rows = 23.75 flops per row (sum y^2 and sum y once per fit).  Both fractions are reported; the
+            # launch is bound by its LONGEST fit (evaluations x {moment pass + lane-serial bookkeeping}), not by the fp64 pipe.
             flops4 = m4 * 158
-            flops4_exec = m4 * 33
+            flops4_exec = m4 * 95 // 4
             tf4 = float(r4["n_evals"].sum()) * flops4 / (ms4 * 1e-3) / 1e12
             out["configs4"] = {
                 "workload": "BASELINE configs[4]: %d fp32 fits, five exponentials + offset (n=6, q=5), m=%d" % (B4, m4),
@@ -627,16 +629,17 @@ def main():
                                        "moments + Cholesky-based LM; per CU one 8-wave workgroup = 7 streaming waves + 1 bookkeeping "
                                        "wave over a pool of 32 problem slots; passes of long fits split over 4 waves)",
                              "bound": "latency (the longest fit's chain of rounds: evaluations x {moment pass + LM bookkeeping})",
-                             "timeline": "tools/cfg4_timeline.py on a -DVP_FITG_TIMELINE=1 build: the first ~1.25 ms every workgroup holds "
-                                         "32..8 live fits and both roles are busy (bookkeeping wave 100 %, 9.4 slots per trip; stream "
-                                         "waves 10.4 us per pass at 2 waves per SIMD) -- a round costs 55-60 us there; the rest is the fits "
-                                         "past ~24 evaluations at the 17 us of a lone round (3 us split pass, 12 us of dependent fp64 "
+                             "timeline": "tools/cfg4_timeline.py on a -DVP_FITG_TIMELINE=1 build (round 5): the first ~1.0 ms every workgroup holds "
+                                         "32..8 live fits and both roles are busy (bookkeeping wave 74 % busy, 6.9 slots per trip of 11.6 us; "
+                                         "stream waves 9.4 us per pass or part at 2 waves per SIMD, 10.6 before the y stream ran 8 chunks "
+                                         "deep) -- a round costs 41-49 us there; 99 % of the fits are done at 1.25 ms, the rest is the fits "
+                                         "past ~32 evaluations at the 22-26 us of a lone round (a split pass, then the dependent fp64 "
                                          "bookkeeping: Cholesky of the 6x6 Gram, pivoted Cholesky of J^T J, lmpar on the Cholesky factor "
-                                         "of R^T R + par D^2 -- lmpar_chol; with qrsolv's Givens sweeps a lone round took 21 us)",
+                                         "of R^T R + par D^2 -- lmpar_chol)",
                              "achieved": tf4 * flops4_exec / flops4, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf4 * flops4_exec / flops4 / FP64_VALU_PEAK_TFLOPS,
                              "flops_executed_per_evaluation": flops4_exec,
-                             "note": "frac = fp64 flops the kernel EXECUTES (33 per row: closed-form y-independent moments) over the "
+                             "note": "frac = fp64 flops the kernel EXECUTES (23.75 per row: closed-form y-independent moments, Horner form of the others) over the "
                                      "fp64 VALU peak; against the 158 flop/row Gram model of round 2 it would read %.2f" % (tf4 / FP64_VALU_PEAK_TFLOPS),
                              "hbm_bytes_per_evaluation": 4 * m4, "y_reread_bytes_per_launch": 4.0 * m4 * float(r4["n_evals"].sum()),
                              "traffic": committed_traffic("fitg2_kernel"), "traffic_source": traffic_source("fitg2_kernel")},

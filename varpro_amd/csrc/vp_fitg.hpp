@@ -68,6 +68,24 @@
 #ifndef VP_FITG_CLOSED
 #define VP_FITG_CLOSED 1       // uniform grid + unit weights: the y-independent moments in closed form
 #endif
+#ifndef VP_FITG_HORNER
+#define VP_FITG_HORNER 1       // ... and the y-dependent ones by Horner's rule in rho_k = e^{-dt / tau_k} (gram_pass)
+#endif
+#ifndef VP_FITG_Y_ONCE
+#define VP_FITG_Y_ONCE 1       // ... with sum y^2, sum y taken once per fit instead of once per pass
+#endif
+#ifndef VP_FITG_RING
+#define VP_FITG_RING 8         // ... and this many 256-row chunks of y in flight per stream wave
+#endif
+#ifndef VP_FITG_UNI_EXP_LANES
+#define VP_FITG_UNI_EXP_LANES 1 // the wave-uniform ratios of the recurrence: one exponential over 2 NE lanes + broadcasts
+#endif
+#ifndef VP_FITG_EXP_HALVES
+#define VP_FITG_EXP_HALVES 1   // closed form: the exponentials of four doubling steps as two per lane over both half-waves
+#endif
+#ifndef VP_FITG_EXP_BATCH
+#define VP_FITG_EXP_BATCH 4    // steps of the closed form's doubling recurrence whose exponentials are evaluated together
+#endif
 
 namespace vp {
 
@@ -352,16 +370,56 @@ __device__ __forceinline__ void gram_load_chunk(GramChunk<UNIFORM, WEIGHTED> &c,
     }
 }
 
+// The y stream alone, 16 B per lane, through a BUFFER resource over the problem's m floats: a row group past the end reads as
+// zeros by the hardware's range check -- no branch around the load, so the compiler counts the loads in flight (vmcnt)
+// instead of waiting for all of them at the first use.  VEC: the rows are 16-byte aligned (one dwordx4), else four dwords.
+template <bool VEC> __device__ __forceinline__ float4 gram_buf_load_y(const __amdgpu_buffer_rsrc_t rs, const int row0) {
+    float4 v;
+    // (the values go through named integers: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+    if constexpr (VEC) {
+        const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, row0 * 4, 0, 0);
+        const unsigned int q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        v.x = __uint_as_float(q0);
+        v.y = __uint_as_float(q1);
+        v.z = __uint_as_float(q2);
+        v.w = __uint_as_float(q3);
+    } else {
+        const unsigned int q0 = __builtin_amdgcn_raw_buffer_load_b32(rs, row0 * 4, 0, 0);
+        const unsigned int q1 = __builtin_amdgcn_raw_buffer_load_b32(rs, row0 * 4 + 4, 0, 0);
+        const unsigned int q2 = __builtin_amdgcn_raw_buffer_load_b32(rs, row0 * 4 + 8, 0, 0);
+        const unsigned int q3 = __builtin_amdgcn_raw_buffer_load_b32(rs, row0 * 4 + 12, 0, 0);
+        v.x = __uint_as_float(q0);
+        v.y = __uint_as_float(q1);
+        v.z = __uint_as_float(q2);
+        v.w = __uint_as_float(q3);
+    }
+    return v;
+}
+
 // The MOMENT PASS of one slot by one wavefront: streams the rows of problem `prob` once and leaves the NVR moments in
 // gram_out (LDS).  rec->xt holds the trial parameters; grid2 = {t_0, dt} of the slot's grid (UNIFORM).
-template <int NE, bool UNIFORM, bool WEIGHTED>
-__device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRec<double, NE + 1, NE> *rec, VP_LDS const double *grid2,
+template <int NE, bool UNIFORM, bool WEIGHTED, bool VEC>
+__device__ __forceinline__ void gram_pass_v(const FitgArgs &a, VP_LDS const SlotRec<double, NE + 1, NE> *rec, VP_LDS const double *grid2,
                                           VP_LDS double *gram_out, const int prob, const int lane, const int m, const int ch0,
-                                          const int nchunk, const bool vec, const bool own_closed = true) {
+                                          const int nchunk, const bool vec, const bool own_closed, VP_LDS double *ymom) {
     // chunks [ch0, nchunk) of 256 rows (a whole pass: ch0 = 0, nchunk = all; a PART of a split pass: its chunk range;
     // own_closed: this pass / part also delivers the moments that do not depend on y -- see below)
     using GI = GramIdx<NE>;
     constexpr int NVR = WEIGHTED ? GI::NV : GI::NV - 1;
+    constexpr bool CLOSED = UNIFORM && !WEIGHTED && (VP_FITG_CLOSED != 0);
+    constexpr bool HORNER = CLOSED && (VP_FITG_HORNER != 0);
+    // The y stream of the Horner form: VP_FITG_RING chunks in flight per wave, the first of them requested BEFORE the
+    // exponentials of the preamble.  With one chunk of prefetch a pass was its 16 memory latencies (a chunk is 0.1 us of
+    // arithmetic; y comes from L2 / HBM): 9.8 us per pass where its instructions issue in 2.5.
+    constexpr int RING = HORNER ? VP_FITG_RING : 1;
+    const float *yp = a.yw + (int64_t)prob * m;
+    float4 ring[RING];
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)yp, 0, m * 4, 0x00020000);
+    if constexpr (HORNER) {
+        // (chunks at or past nchunk -- a part's range ends before the rows do -- are loaded and never used)
+#pragma unroll
+        for (int j = 0; j < RING; ++j) ring[j] = gram_buf_load_y<VEC>(yrs, (ch0 + j) * 256 + 4 * lane);
+    }
     double rt[NE];
 #pragma unroll
     for (int kx = 0; kx < NE; ++kx) rt[kx] = frcp(rec->xt[kx]);
@@ -370,9 +428,29 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
     if constexpr (UNIFORM) {
         t0 = uni_d(grid2[0]);
         dt = uni_d(grid2[1]);
-        // anchor at the lane's first row, ratio per row, ratio per chunk: 3 NE exponentials per evaluation
-        double ax[3 * NE], ex[3 * NE];
+        // anchor at the lane's first row, ratio per row, ratio per chunk: 3 NE exponentials per evaluation -- the 2 NE ratios
+        // are wave-uniform: ONE exponential with a different argument per lane (lane k: per row, lane NE + k: per chunk of
+        // column k) and 2 NE broadcasts instead of 2 NE exponentials that every lane repeats
         const double tl = tfma((double)(ch0 * 256 + 4 * lane), dt, t0);
+#if VP_FITG_UNI_EXP_LANES
+        double ax[NE + 1], ex[NE + 1];
+#pragma unroll
+        for (int kx = 0; kx < NE; ++kx) ax[kx] = -tl * rt[kx];
+        {
+            const int lk = lane < NE ? lane : (lane < 2 * NE ? lane - NE : 0);
+            const double rtl = frcp(rec->xt[lk]);
+            const double sc = lane < NE ? dt : 256.0 * dt;
+            ax[NE] = -sc * rtl;
+        }
+        texp_n<NE + 1>(ax, ex);
+#pragma unroll
+        for (int kx = 0; kx < NE; ++kx) {
+            fa[kx] = ex[kx];
+            q1[kx] = readlane(ex[NE], kx);
+            qc[kx] = readlane(ex[NE], NE + kx);
+        }
+#else
+        double ax[3 * NE], ex[3 * NE];
 #pragma unroll
         for (int kx = 0; kx < NE; ++kx) {
             ax[kx] = -tl * rt[kx];
@@ -386,6 +464,7 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
             q1[kx] = uni_d(ex[NE + kx]);
             qc[kx] = uni_d(ex[2 * NE + kx]);
         }
+#endif
     }
     // ---- uniform grid, unit weights: 55 of the 67 moments do not depend on y and have a closed form ----
     // A0_ik = sum_r e^{-s t_r}, A1_ik = sum_r t_r e^{-s t_r}, A2_ik = sum_r t_r^2 e^{-s t_r} with s = 1/tau_i + 1/tau_k, and
@@ -396,11 +475,18 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
     // at every step).  One lane per value of s (NE (NE + 1) / 2 + NE = 20 lanes for five exponentials), ~13 exponentials
     // each: the row loop below then carries 12 accumulators instead of 67 (B0, B1, YY, SY) -- 28 instead of 86
     // instructions per row.
-    constexpr bool CLOSED = UNIFORM && !WEIGHTED && (VP_FITG_CLOSED != 0);
+    // sum y^2 and sum y do not depend on the parameters: accumulated by the FIRST pass of a fit (never a split one) and kept
+    // in ymom[2] for its later passes
+    const bool y_once = HORNER && (VP_FITG_Y_ONCE != 0) && ymom != nullptr;
+    const bool need_y = !y_once || uni((rec->flags & 1) != 0);
     constexpr int NPAIR = NE * (NE + 1) / 2;
     double G0 = 0.0, G1 = 0.0, G2 = 0.0;
     if constexpr (CLOSED) {
-        if (own_closed && lane < NPAIR + NE) {
+        // The lanes of the upper half-wave mirror the lower one (ls = lane & 31): the rho^n of FOUR steps of the recurrence
+        // are two exponentials per lane -- lane ls takes steps 1 and 3 of the four, lane ls + 32 steps 2 and 4, two half-wave
+        // swaps hand them over -- instead of four.  (The recurrences themselves matter on lanes < NPAIR + NE only.)
+        const int ls = VP_FITG_EXP_HALVES ? (lane & 31) : lane;
+        if (own_closed && ls < NPAIR + NE) {
             // lane -> (i, k): pairs in the row-major upper-triangle order of GramIdx::tri, then the NE single columns
             double sv = 0.0;
             {
@@ -409,17 +495,17 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
                 for (int i = 0; i < NE; ++i)
 #pragma unroll
                     for (int k2 = i; k2 < NE; ++k2) {
-                        sv = (lane == idx) ? rt[i] + rt[k2] : sv;
+                        sv = (ls == idx) ? rt[i] + rt[k2] : sv;
                         ++idx;
                     }
 #pragma unroll
-                for (int k2 = 0; k2 < NE; ++k2) sv = (lane == NPAIR + k2) ? rt[k2] : sv;
+                for (int k2 = 0; k2 < NE; ++k2) sv = (ls == NPAIR + k2) ? rt[k2] : sv;
             }
             const double x1 = -sv * dt; // log rho
             double H0 = 0.0, H1 = 0.0, H2 = 0.0;
             int n = 0;
-            for (int bit = 31 - __builtin_clz((unsigned)m); bit >= 0; --bit) { // (m > 0; uniform over the wave)
-                const double Pn = texp(x1 * (double)n), dn = (double)n;        // rho^n
+            auto step = [&](const int bit, const double Pn) __attribute__((always_inline)) {
+                const double dn = (double)n; // Pn = rho^n
                 H2 = tfma(Pn, tfma(dn * dn, H0, tfma(2.0 * dn, H1, H2)), H2);
                 H1 = tfma(Pn, tfma(dn, H0, H1), H1);
                 H0 = tfma(Pn, H0, H0);
@@ -431,23 +517,95 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
                     H2 = tfma(da * da, Pa, H2);
                     n += 1;
                 }
+            };
+            // (n at the step of `bit` is the binary prefix m >> (bit + 1): the rho^n of several steps are independent of each
+            // other and evaluated together -- interleaved polynomial chains instead of one after the other)
+#if VP_FITG_EXP_HALVES
+            const bool upper = lane >= 32;
+            for (int b0 = 31 - __builtin_clz((unsigned)m); b0 >= 0; b0 -= 4) { // (m > 0; uniform over the wave)
+                auto n_of = [&](const int bit) __attribute__((always_inline)) { return bit >= 0 ? (m >> (bit + 1)) : 0; };
+                double ax[2], pn[2];
+                ax[0] = x1 * (double)(upper ? n_of(b0 - 1) : n_of(b0));
+                ax[1] = x1 * (double)(upper ? n_of(b0 - 3) : n_of(b0 - 2));
+                texp_n<2>(ax, pn);
+                const auto s01 = lane_swap<0>(pn[0], pn[0]); // .a: the lower half's value on every lane, .b: the upper half's
+                const auto s23 = lane_swap<0>(pn[1], pn[1]);
+                step(b0, s01.a);
+                if (b0 >= 1) step(b0 - 1, s01.b);
+                if (b0 >= 2) step(b0 - 2, s23.a);
+                if (b0 >= 3) step(b0 - 3, s23.b);
             }
+#else
+            for (int b0 = 31 - __builtin_clz((unsigned)m); b0 >= 0; b0 -= VP_FITG_EXP_BATCH) { // (m > 0; uniform over the wave)
+                double ax[VP_FITG_EXP_BATCH], pn[VP_FITG_EXP_BATCH];
+#pragma unroll
+                for (int j = 0; j < VP_FITG_EXP_BATCH; ++j) ax[j] = x1 * (double)((b0 - j) >= 0 ? (m >> (b0 - j + 1)) : 0);
+                texp_n<VP_FITG_EXP_BATCH>(ax, pn);
+#pragma unroll
+                for (int j = 0; j < VP_FITG_EXP_BATCH; ++j)
+                    if (b0 - j >= 0) step(b0 - j, pn[j]);
+            }
+#endif
             const double e0 = texp(-sv * t0);
             G0 = e0 * H0;
             G1 = e0 * tfma(dt, H1, t0 * H0);
             G2 = e0 * tfma(dt * dt, H2, tfma(2.0 * t0 * dt, H1, t0 * t0 * H0));
         }
     }
-    const float *yp = a.yw + (int64_t)prob * m;
     const float *tp = a.t + (int64_t)prob * a.t_stride;
     const float *wp = a.w ? a.w + (int64_t)prob * a.w_stride : nullptr;
     double acc[NVR];
 #pragma unroll
     for (int i = 0; i < NVR; ++i) acc[i] = 0.0;
-    GramChunk<UNIFORM, WEIGHTED> nxt;
-    gram_load_chunk(nxt, yp, tp, wp, ch0 * 256 + 4 * lane, m, vec);
+    if constexpr (HORNER) {
+        // B0_k = sum_r e_k(t_r) y_r and B1_k = sum_r e_k(t_r) (t_r y_r) on the lattice are POLYNOMIALS in rho_k = e^{-dt/tau_k}:
+        // a lane's four rows of the chunk by Horner (3 FMAs per moment and exponential), times the lane's anchor
+        // e_k(t_row0) -- 9 instructions per exponential and row group where carrying e_k and u_k = t e_k row by row
+        // took 16.  (Rows past the end were loaded as zeros.)
+        // (two instances of the loop: a predicated block inside it would still issue its instructions when sum y^2 and
+        // sum y are not wanted)
+        auto horner_rows = [&](auto with_y) __attribute__((always_inline)) {
+        constexpr bool WITH_Y = decltype(with_y)::value;
 #pragma nounroll
-    for (int ch = ch0; ch < nchunk; ++ch) {
+        for (int cb = ch0; cb < nchunk; cb += RING) {
+#pragma unroll
+            for (int j = 0; j < RING; ++j) {
+                const int ch = cb + j;
+                if (ch >= nchunk) break; // (uniform)
+                const float4 cur = ring[j];
+                const int row0 = ch * 256 + 4 * lane;
+                ring[j] = gram_buf_load_y<VEC>(yrs, row0 + RING * 256); // (past the part's range or the rows: unused / zeros)
+                const double yd[4] = {(double)cur.x, (double)cur.y, (double)cur.z, (double)cur.w};
+                double ty[4];
+                const double tb = tfma((double)row0, dt, t0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ty[e] = (e == 0 ? tb : tfma((double)e, dt, tb)) * yd[e];
+#pragma unroll
+                for (int kx = 0; kx < NE; ++kx) {
+                    const double r = q1[kx];
+                    const double i0 = tfma(r, tfma(r, tfma(r, yd[3], yd[2]), yd[1]), yd[0]);
+                    const double i1 = tfma(r, tfma(r, tfma(r, ty[3], ty[2]), ty[1]), ty[0]);
+                    acc[GI::B0(kx)] = tfma(fa[kx], i0, acc[GI::B0(kx)]);
+                    acc[GI::B1(kx)] = tfma(fa[kx], i1, acc[GI::B1(kx)]);
+                    fa[kx] *= qc[kx];
+                }
+                if constexpr (WITH_Y) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[GI::YY] = tfma(yd[e], yd[e], acc[GI::YY]);
+                        acc[GI::SY] += yd[e];
+                    }
+                }
+            }
+        }
+        };
+        if (need_y) horner_rows(std::true_type{});
+        else horner_rows(std::false_type{});
+    }
+    GramChunk<UNIFORM, WEIGHTED> nxt;
+    if constexpr (!HORNER) gram_load_chunk(nxt, yp, tp, wp, ch0 * 256 + 4 * lane, m, vec);
+#pragma nounroll
+    for (int ch = ch0; ch < (HORNER ? ch0 : nchunk); ++ch) {
         const GramChunk<UNIFORM, WEIGHTED> cur = nxt;
         const int row0 = ch * 256 + 4 * lane;
         if (ch + 1 < nchunk) gram_load_chunk(nxt, yp, tp, wp, row0 + 256, m, vec);
@@ -545,9 +703,27 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
         for (int i = 0; i < 2 * NE + 1; ++i) ya[i] = acc[GI::B0(0) + i];
         ya[NY - 1] = acc[GI::SY];
         static_assert(GI::B1(0) == GI::B0(0) + NE && GI::YY == GI::B0(0) + 2 * NE && GI::S0(0) == GI::YY + 1, "layout");
-        wave_reduce_store<NY>(ya, gram_out + GI::B0(0));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) gram_out[GI::SY] = gram_out[GI::S0(0)];
+        if (need_y) {
+            wave_reduce_store<NY>(ya, gram_out + GI::B0(0));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                const double sy = gram_out[GI::S0(0)];
+                gram_out[GI::SY] = sy;
+                if (y_once) {
+                    ymom[0] = gram_out[GI::YY];
+                    ymom[1] = sy;
+                }
+            }
+        } else {
+            double yb[2 * NE];
+#pragma unroll
+            for (int i = 0; i < 2 * NE; ++i) yb[i] = ya[i];
+            wave_reduce_store<2 * NE>(yb, gram_out + GI::B0(0));
+            if (lane == 0) { // (the parts of a split pass are summed: one of them carries the values)
+                gram_out[GI::YY] = own_closed ? ymom[0] : 0.0;
+                gram_out[GI::SY] = own_closed ? ymom[1] : 0.0;
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // (a part that does not own the closed-form moments contributes zeros: the parts are summed)
         if (lane < NPAIR) {
@@ -560,6 +736,21 @@ __device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRe
         }
     } else {
         wave_reduce_store<NVR>(acc, gram_out);
+    }
+}
+
+// (dispatch on the alignment of the rows ONCE per pass: each instance has its loads in straight-line code)
+template <int NE, bool UNIFORM, bool WEIGHTED>
+__device__ __forceinline__ void gram_pass(const FitgArgs &a, VP_LDS const SlotRec<double, NE + 1, NE> *rec, VP_LDS const double *grid2,
+                                          VP_LDS double *gram_out, const int prob, const int lane, const int m, const int ch0,
+                                          const int nchunk, const bool vec, const bool own_closed = true,
+                                          VP_LDS double *ymom = nullptr) {
+    constexpr bool HORNER = UNIFORM && !WEIGHTED && (VP_FITG_CLOSED != 0) && (VP_FITG_HORNER != 0);
+    if constexpr (HORNER) {
+        if (vec) gram_pass_v<NE, UNIFORM, WEIGHTED, true>(a, rec, grid2, gram_out, prob, lane, m, ch0, nchunk, vec, own_closed, ymom);
+        else gram_pass_v<NE, UNIFORM, WEIGHTED, false>(a, rec, grid2, gram_out, prob, lane, m, ch0, nchunk, vec, own_closed, ymom);
+    } else {
+        gram_pass_v<NE, UNIFORM, WEIGHTED, false>(a, rec, grid2, gram_out, prob, lane, m, ch0, nchunk, vec, own_closed, ymom);
     }
 }
 
@@ -644,6 +835,7 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES == 8 ? 2 :
     __shared__ __attribute__((aligned(16))) Rec s_recs[NS];
     __shared__ __attribute__((aligned(16))) KC s_kc;
     __shared__ double s_grid[NS][2];
+    __shared__ double s_ymom[NS][2]; // sum y^2, sum y of the slot's problem (gram_pass)
     __shared__ int s_state[NS]; // 0 empty | 1 needs a moment pass | 2 being streamed | 3 moments ready / bookkeeping | 4 split pass, parts unclaimed
     __shared__ int s_live;      // slots that hold a fit
     // split passes (the tail of a launch): the parts' moments, the next unclaimed part, the parts finished
@@ -895,13 +1087,14 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES == 8 ? 2 :
             int ready_slot = -1;
             if (part < 0) {
                 gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0], gram + (size_t)s * GI::NV, prob, lane, m,
-                                                 0, nchunk, vec);
+                                                 0, nchunk, vec, true, (VP_LDS double *)&s_ymom[s][0]);
                 lds_release(); // the moments are in LDS before the slot is handed on
                 ready_slot = s;
             } else {
                 const int c0 = (int)((long)part * nchunk / VP_FITG_PARTS), c1 = (int)((long)(part + 1) * nchunk / VP_FITG_PARTS);
                 gram_pass<NE, UNIFORM, WEIGHTED>(a, recs + s, (VP_LDS const double *)&s_grid[s][0],
-                                                 (VP_LDS double *)&s_pgram[s][part][0], prob, lane, m, c0, c1, vec, part == 0);
+                                                 (VP_LDS double *)&s_pgram[s][part][0], prob, lane, m, c0, c1, vec, part == 0,
+                                                 (VP_LDS double *)&s_ymom[s][0]);
                 lds_release();
                 int d = 0;
                 if (lane == 0) d = __hip_atomic_fetch_add(&s_done[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
