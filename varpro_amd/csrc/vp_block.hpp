@@ -272,8 +272,32 @@ template <typename T, int NC, bool STATIC = true> constexpr int block_rows() {
 // carry and private trailing triangles; the W carries are then stacked through LDS and every wave reduces the stack by the
 // same stacked_qr (TSQR merges carries as easily as blocks), so all waves hold the bit-identical compressed problem and
 // run the LM bookkeeping redundantly -- no LM state is ever exchanged (as in the resident multi-wave groups, Grp<W>).
+// Rows per lane and block of the fit kernel on LONG problems (block_rows_long) and the waves per SIMD a block of RB rows
+// per lane leaves room for (blk_fit_waves).  A block costs N dependent reduction rounds + the trailing update whatever its
+// height -- about half of a 512-row block's instructions (round 5, 16 384 double-exponential fits of 10 000 rows: RB = 4 at
+// three waves per SIMD 16.8 ms, RB = 8 at two 11.3, RB = 12 at one 10.3, RB = 16 at one 8.9: more resident waves hide
+// nothing, the kernel is bound by the instructions of its reductions) -- so problems of at least four such blocks take the
+// tallest block (<= 16 rows per lane) whose columns fit ONE wave per SIMD (512 VGPRs: 208 words of block columns) and
+// whose row ring leaves room for four waves per CU (36 KiB per wave).
+#ifndef VP_BLK_RB_LONG
+#define VP_BLK_RB_LONG 16
+#endif
+template <typename T, class M, bool WEIGHTED> constexpr int block_rows_long() {
+    constexpr int RB = block_rows<T, M::N + 1 + M::P, M::kStatic>();
+    constexpr int words = (M::N + 1 + M::P) * (int)(sizeof(T) / 4);
+    constexpr int ring_per_row = 2 * (WEIGHTED ? 3 : 2) * 64 * (int)sizeof(T);
+    int best = RB;
+    if (M::kStatic)
+        for (int rb = RB + 4; rb <= VP_BLK_RB_LONG; rb += 4)
+            if (words * rb <= 208 && ring_per_row * rb <= 36 * 1024) best = rb;
+    return best;
+}
+template <typename T, class M, int RB> constexpr int blk_fit_waves() {
+    return RB > block_rows<T, M::N + 1 + M::P, M::kStatic>() ? 1 : blk_waves<M>();
+}
+
 template <typename T, class M, int RB, bool WEIGHTED, int W = 1>
-__global__ void __launch_bounds__(64 * W, (blk_waves<M>())) blk_fit_kernel(const FitArgs<T, M> a) {
+__global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_kernel(const FitArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     constexpr int ROWS = 64 * RB;
     constexpr int NTRI = NC * (NC + 1) / 2;
@@ -806,13 +830,28 @@ template <typename T, class M> int launch_fit(const LaunchParams &p) {
     // matters there.  Results do not depend on the choice beyond rounding (a different but equally valid TSQR tree).
     constexpr int WM = 4;
     const bool multi = p.B <= (int64_t)16 * (p.num_cus > 0 ? p.num_cus : 256) && p.m >= VP_BLK_MULTI_MIN_BLOCKS * WM * 64 * RB && WM * (M::N + 1 + M::P) <= 128;
+    // (long problems: taller blocks, one wave per SIMD -- block_rows_long)
+    constexpr int RLU = block_rows_long<T, M, false>(), RLW = block_rows_long<T, M, true>();
+#define VP_BLK_FIT(RB_, WEIGHTED_, W_)                                                                                  \
+    hipLaunchKernelGGL((blk_fit_kernel<T, M, RB_, WEIGHTED_, W_>), dim3((unsigned)a.B), dim3(64 * (W_)), 0, p.stream, a)
     if (multi) {
-        if (p.w) hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, true, WM>), dim3((unsigned)a.B), dim3(64 * WM), 0, p.stream, a);
-        else hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, false, WM>), dim3((unsigned)a.B), dim3(64 * WM), 0, p.stream, a);
+        if (p.w) {
+            if (RLW > RB && p.m >= (int64_t)4 * WM * 64 * RLW) VP_BLK_FIT(RLW, true, WM);
+            else VP_BLK_FIT(RB, true, WM);
+        } else {
+            if (RLU > RB && p.m >= (int64_t)4 * WM * 64 * RLU) VP_BLK_FIT(RLU, false, WM);
+            else VP_BLK_FIT(RB, false, WM);
+        }
     } else {
-        if (p.w) hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, true>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
-        else hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, false>), dim3((unsigned)a.B), dim3(64), 0, p.stream, a);
+        if (p.w) {
+            if (RLW > RB && p.m >= (int64_t)4 * 64 * RLW) VP_BLK_FIT(RLW, true, 1);
+            else VP_BLK_FIT(RB, true, 1);
+        } else {
+            if (RLU > RB && p.m >= (int64_t)4 * 64 * RLU) VP_BLK_FIT(RLU, false, 1);
+            else VP_BLK_FIT(RB, false, 1);
+        }
     }
+#undef VP_BLK_FIT
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 
