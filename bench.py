@@ -864,7 +864,7 @@ def main():
                     "workload": "B=%d double-exp+offset fits, m=%d, fp64 (no resident kernel set is this long)" % (Bs, ms),
                     "fits_per_s": Bs / (mss * 1e-3), "ms_per_step": mss, "mean_evaluations_per_fit": evs / Bs,
                     "fraction_failed": float((rs["termination"] <= 0).mean()),
-                    "roofline": {"kernel": "blk_fit_kernel<double, MultiExpModel<2, true>, 16> (blocks of 1 024 rows, one wave per SIMD; four waves per problem at m = 100 000)", "bound": "fp64_valu",
+                    "roofline": {"kernel": "blk_fit_kernel<double, MultiExpModel<2, true>, 20, false, W, TC> (blocks of 1 280 rows, one wave per SIMD, grid values computed: the LDS ring holds the data alone; four waves per problem at m = 100 000)", "bound": "fp64_valu",
                                  "achieved": evs * fl / (mss * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": evs * fl / (mss * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                  "y_stream_GBps": evs * ms * T / (mss * 1e-3) / 1e9, "algorithmic_bytes_per_launch": evs * ms * T,

@@ -1,7 +1,7 @@
 """streamed fit kernels (vp_block.hpp) of a library build: the bench's m = 10 000 / 100 000 double-exponential legs and the
 O'Leary exp*cos leg (m = 5000), ms per launch + evaluation totals + sum of objectives.
 usage: VARPRO_HIP_LIBRARY=lib.so PYTHONPATH=. python tools/stream_ab_probe.py"""
-import time
+import sys, time
 import numpy as np, torch
 import varpro_amd as vp
 from varpro_amd import synth
@@ -13,13 +13,15 @@ def timed(bp, g, n=3):
         t0 = time.perf_counter(); a, c, rep = bp.fit(g, want_coefficients=False); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     r = bp.report_to_numpy(rep)
     return min(ts) * 1e3, int(r["n_evals"].sum()), float(np.nansum(r["objective"])), int((r["termination"] <= 0).sum())
-for ms, Bs in ((10000, 16384), (100000, 2048), (3000, 32768)):
+FIRST = len(sys.argv) > 1 and sys.argv[1] == "first"  # only the m = 10 000 leg (tools/pmc_blk.sh)
+for ms, Bs in ((10000, 16384), (100000, 2048), (3000, 32768))[:1 if FIRST else 3]:
     ds = synth.double_exp_batch(Bs, m=ms, noise=1e-3)
     mdl = vp.multi_exponential_model(ds["x"], ds["tau_guess"][0])
     bp = vp.BatchProblem(mdl, torch.from_numpy(ds["Y"]).to(dev), x=torch.from_numpy(ds["x"]).to(dev), flags=getattr(vp, "FLAG_STREAM_ROWS", 0) if ms <= 4096 else 0) if False else vp.BatchProblem(mdl, torch.from_numpy(ds["Y"]).to(dev), x=torch.from_numpy(ds["x"]).to(dev))
     t, ev, ob, nf = timed(bp, torch.from_numpy(ds["tau_guess"]).to(dev))
     print("double-exp m=%d B=%d: %.3f ms = %.3f M fits/s  evals %d  sum objective %.9e  failed %d" % (ms, Bs, t, Bs / t / 1e3, ev, ob, nf))
     bp.close()
+if FIRST: sys.exit(0)
 Bg, mg = 4096, 5000
 tg = np.linspace(0.0, 1.5, mg)
 rg = synth.SplitMix64(np.uint64(0x5EED3000) + np.arange(Bg, dtype=np.uint64))

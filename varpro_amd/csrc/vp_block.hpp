@@ -137,9 +137,11 @@ __device__ __forceinline__ void lane_trail_merge(const T (&Tl)[PT][PT], T (&K)[N
 // as in vp_mrhs.hpp: between begin() and the last stage() of a pass the wave must issue nothing else that counts in vmcnt
 // except what the caller declares (`extra` stores per block).  Arrays that do not allow whole 16-byte groups (m not a
 // multiple of 16/sizeof(T), unaligned bases) are staged element-wise through registers, without prefetch.
-template <typename T, int RB, bool WEIGHTED> struct RowRing {
+// NOGRID (unit weights, uniform grid): only the data is staged -- the caller computes the grid values (RowSource TCALC).
+template <typename T, int RB, bool WEIGHTED, bool NOGRID = false> struct RowRing {
+    static_assert(!(NOGRID && WEIGHTED), "the data-only ring serves unit-weight problems");
     static constexpr int ROWS = 64 * RB;
-    static constexpr int NARR = WEIGHTED ? 3 : 2;
+    static constexpr int NARR = WEIGHTED ? 3 : (NOGRID ? 1 : 2);
     static constexpr int EL = 16 / (int)sizeof(T); // elements per lane and DMA instruction
     static constexpr int KA = RB / EL;             // DMA instructions per array and block
     static constexpr int KD = NARR * KA;           // ... per block
@@ -158,7 +160,7 @@ template <typename T, int RB, bool WEIGHTED> struct RowRing {
         m = m_;
         lane = lane_;
         it = 0;
-        dma = (m % EL) == 0 && ((reinterpret_cast<uintptr_t>(tp) | reinterpret_cast<uintptr_t>(yp) |
+        dma = (m % EL) == 0 && (((NOGRID ? 0 : reinterpret_cast<uintptr_t>(tp)) | reinterpret_cast<uintptr_t>(yp) |
                                  (WEIGHTED ? reinterpret_cast<uintptr_t>(wp) : 0)) & 15) == 0;
     }
     __device__ __forceinline__ void issue(const int off, const int slot) {
@@ -167,7 +169,7 @@ template <typename T, int RB, bool WEIGHTED> struct RowRing {
         for (int arr = 0; arr < NARR; ++arr) {
             // (the base must sit in an SGPR pair: made explicitly wave-uniform, or under register pressure the "s" operand
             // below is handed over in VGPRs and the instruction does not assemble)
-            const uint64_t sv = reinterpret_cast<uint64_t>((arr == 0 ? tp : (arr == 1 ? yp : wp)) + off);
+            const uint64_t sv = reinterpret_cast<uint64_t>((NOGRID ? yp : (arr == 0 ? tp : (arr == 1 ? yp : wp))) + off);
             const uint64_t src = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(sv >> 32)) << 32) |
                                  (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(sv & 0xffffffffu));
 #pragma unroll
@@ -203,7 +205,7 @@ template <typename T, int RB, bool WEIGHTED> struct RowRing {
         ++it;
         const int mrem = m - off;
         s_t = ring + (size_t)slot * NARR * ROWS;
-        s_y = s_t + ROWS;
+        s_y = NOGRID ? s_t : s_t + ROWS;
         s_w = s_y + ROWS;
         if (dma) {
             if (next_off >= 0) {
@@ -227,8 +229,10 @@ template <typename T, int RB, bool WEIGHTED> struct RowRing {
             }
         } else {
             T tmp[RB];
-            load_rows<T, RB, 1>(tp + off, mrem, lane, false, tmp);
-            store_rows<T, RB, 1>(s_t, ROWS, lane, true, tmp);
+            if constexpr (!NOGRID) {
+                load_rows<T, RB, 1>(tp + off, mrem, lane, false, tmp);
+                store_rows<T, RB, 1>(s_t, ROWS, lane, true, tmp);
+            }
             load_rows<T, RB, 1>(yp + off, mrem, lane, false, tmp);
             store_rows<T, RB, 1>(s_y, ROWS, lane, true, tmp);
             if constexpr (WEIGHTED) {
@@ -282,21 +286,28 @@ template <typename T, int NC, bool STATIC = true> constexpr int block_rows() {
 #ifndef VP_BLK_RB_LONG
 #define VP_BLK_RB_LONG 16
 #endif
-template <typename T, class M, bool WEIGHTED> constexpr int block_rows_long() {
+#ifndef VP_BLK_RB_LONG_TC
+#define VP_BLK_RB_LONG_TC 32
+#endif
+#ifndef VP_BLK_TC_WORDS
+#define VP_BLK_TC_WORDS 264
+#endif
+// TC: unit weights on a uniform grid -- the grid values are computed, the ring holds the data alone (half the LDS per row)
+template <typename T, class M, bool WEIGHTED, bool TC = false> constexpr int block_rows_long() {
     constexpr int RB = block_rows<T, M::N + 1 + M::P, M::kStatic>();
     constexpr int words = (M::N + 1 + M::P) * (int)(sizeof(T) / 4);
-    constexpr int ring_per_row = 2 * (WEIGHTED ? 3 : 2) * 64 * (int)sizeof(T);
+    constexpr int ring_per_row = 2 * (WEIGHTED ? 3 : (TC ? 1 : 2)) * 64 * (int)sizeof(T);
     int best = RB;
-    if (M::kStatic)
-        for (int rb = RB + 4; rb <= VP_BLK_RB_LONG; rb += 4)
-            if (words * rb <= 208 && ring_per_row * rb <= 36 * 1024) best = rb;
+    if (M::kStatic && !(TC && (WEIGHTED || sizeof(T) != 8)))
+        for (int rb = RB + 4; rb <= (TC ? VP_BLK_RB_LONG_TC : VP_BLK_RB_LONG); rb += 4)
+            if (words * rb <= (TC ? VP_BLK_TC_WORDS : 208) && ring_per_row * rb <= 36 * 1024) best = rb;
     return best;
 }
 template <typename T, class M, int RB> constexpr int blk_fit_waves() {
     return RB > block_rows<T, M::N + 1 + M::P, M::kStatic>() ? 1 : blk_waves<M>();
 }
 
-template <typename T, class M, int RB, bool WEIGHTED, int W = 1>
+template <typename T, class M, int RB, bool WEIGHTED, int W = 1, bool TC = false>
 __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_kernel(const FitArgs<T, M> a) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     constexpr int ROWS = 64 * RB;
@@ -332,7 +343,8 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
     for (int k = 0; k < N; ++k) cbest[k] = T(0);
     int trow = 0;
 
-    using Ring = RowRing<T, RB, WEIGHTED>;
+    static_assert(!TC || (!WEIGHTED && sizeof(T) == 8), "computed grid: unit weights, fp64 (the recurrence's own condition)");
+    using Ring = RowRing<T, RB, WEIGHTED, TC>;
     __shared__ __attribute__((aligned(16))) T ring_mem[W * 2 * Ring::NARR * ROWS];
     __shared__ T s_merge[W > 1 ? 2 * W * NTRI : 1]; // the waves' carries, double-buffered by the evaluation's parity
     __shared__ LmVars<T, N, Q> s_lm[W];             // the parked LM records
@@ -342,6 +354,8 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
     int parity = 0;
     // distance between a lane's consecutive row pairs on a uniform grid (RowSource::set_uniform, from the WHOLE grid)
     const T dpair = (m >= 3) ? (tp[m - 1] - tp[0]) / T(m - 1) * T(128) : T(0);
+    // (TC) the lattice the handle's grid check held the grid to: t_i = t_0 + i dt
+    const T tc_t0 = TC ? tp[0] : T(0), tc_dt = dpair * T(1.0 / 128.0);
 
     while (S.term == 0) {
         // ================= compress the problem at xt: stream the rows, fold every block into the carry =================
@@ -383,24 +397,38 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
         for (int off = wave * ROWS; off < m; off += W * ROWS) {
             T *s_t, *s_y, *s_w;
             ring.stage(off, off + W * ROWS < m ? off + W * ROWS : -1, s_t, s_y, s_w);
-            using Src = RowSource<T, RB, true, WEIGHTED ? 1 : 0, 1, 1, true, 0>;
-            Src src;
-            src.t = s_t;
-            src.w = WEIGHTED ? s_w : nullptr;
-            src.m = m - off;
-            src.lane = lane;
-            src.vec = true;
-            src.uniform = Src::kRecur && a.grid_uniform != 0 && m >= 3;
-            src.delta = dpair;
-            T Cb[NC][RB];
-            load_rows_lds<T, RB, 1>(s_y, lane, Cb[N]);
-            build_columns<T, M, RB, NC, Src>(a.mdl, xt_now, src, Cb);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (kLaneTrail) {
-                if constexpr (NF > 0) stacked_qr<T, NC, NF, RB, G>(K, Cb, grp);
-                lane_trail_update<T, NC, NF, PT, RB>(Tl, Cb);
+            // (TC: a whole block takes the source without row masks, the last, partial one the masked source)
+            auto fold_block = [&](auto padm_c) __attribute__((always_inline)) {
+                constexpr int PADM = decltype(padm_c)::value;
+                using Src = RowSource<T, RB, true, WEIGHTED ? 1 : 0, 1, 1, true, PADM, TC, TC>;
+                Src src;
+                src.t = s_t;
+                src.w = WEIGHTED ? s_w : nullptr;
+                src.m = m - off;
+                src.lane = lane;
+                src.vec = true;
+                src.uniform = Src::kRecur && (TC || a.grid_uniform != 0) && m >= 3;
+                src.delta = dpair;
+                if constexpr (TC) {
+                    src.tl[0] = tfma(T(off + 2 * lane), tc_dt, tc_t0);
+                    src.tl[1] = tfma(T(off + 2 * lane + 1), tc_dt, tc_t0);
+                }
+                T Cb[NC][RB];
+                load_rows_lds<T, RB, 1>(s_y, lane, Cb[N]);
+                build_columns<T, M, RB, NC, Src>(a.mdl, xt_now, src, Cb);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (kLaneTrail) {
+                    if constexpr (NF > 0) stacked_qr<T, NC, NF, RB, G>(K, Cb, grp);
+                    lane_trail_update<T, NC, NF, PT, RB>(Tl, Cb);
+                } else {
+                    stacked_qr<T, NC, NC, RB, G>(K, Cb, grp);
+                }
+            };
+            if constexpr (TC) {
+                if (m - off >= ROWS) fold_block(std::integral_constant<int, 1>{});
+                else fold_block(std::integral_constant<int, 0>{});
             } else {
-                stacked_qr<T, NC, NC, RB, G>(K, Cb, grp);
+                fold_block(std::integral_constant<int, 0>{});
             }
             asm volatile("" ::: "memory");
         }
@@ -831,15 +859,21 @@ template <typename T, class M> int launch_fit(const LaunchParams &p) {
     constexpr int WM = 4;
     const bool multi = p.B <= (int64_t)16 * (p.num_cus > 0 ? p.num_cus : 256) && p.m >= VP_BLK_MULTI_MIN_BLOCKS * WM * 64 * RB && WM * (M::N + 1 + M::P) <= 128;
     // (long problems: taller blocks, one wave per SIMD -- block_rows_long)
-    constexpr int RLU = block_rows_long<T, M, false>(), RLW = block_rows_long<T, M, true>();
+    constexpr int RLU = block_rows_long<T, M, false>(), RLW = block_rows_long<T, M, true>(), RLT = block_rows_long<T, M, false, true>();
 #define VP_BLK_FIT(RB_, WEIGHTED_, W_)                                                                                  \
     hipLaunchKernelGGL((blk_fit_kernel<T, M, RB_, WEIGHTED_, W_>), dim3((unsigned)a.B), dim3(64 * (W_)), 0, p.stream, a)
+#define VP_BLK_FIT_TC(RB_, W_)                                                                                          \
+    hipLaunchKernelGGL((blk_fit_kernel<T, M, RB_, false, W_, true>), dim3((unsigned)a.B), dim3(64 * (W_)), 0, p.stream, a)
+    // unit weights on one shared uniform grid: the grid values are computed and the ring holds the data alone
+    const bool tc = RLT > RLU && !p.w && p.grid_uniform != 0 && p.m >= 3;
     if (multi) {
         if (p.w) {
             if (RLW > RB && p.m >= (int64_t)4 * WM * 64 * RLW) VP_BLK_FIT(RLW, true, WM);
             else VP_BLK_FIT(RB, true, WM);
         } else {
-            if (RLU > RB && p.m >= (int64_t)4 * WM * 64 * RLU) VP_BLK_FIT(RLU, false, WM);
+            if (tc && p.m >= (int64_t)4 * WM * 64 * RLT) {
+                if constexpr (RLT > RLU) VP_BLK_FIT_TC(RLT, WM);
+            } else if (RLU > RB && p.m >= (int64_t)4 * WM * 64 * RLU) VP_BLK_FIT(RLU, false, WM);
             else VP_BLK_FIT(RB, false, WM);
         }
     } else {
@@ -847,11 +881,14 @@ template <typename T, class M> int launch_fit(const LaunchParams &p) {
             if (RLW > RB && p.m >= (int64_t)4 * 64 * RLW) VP_BLK_FIT(RLW, true, 1);
             else VP_BLK_FIT(RB, true, 1);
         } else {
-            if (RLU > RB && p.m >= (int64_t)4 * 64 * RLU) VP_BLK_FIT(RLU, false, 1);
+            if (tc && p.m >= (int64_t)4 * 64 * RLT) {
+                if constexpr (RLT > RLU) VP_BLK_FIT_TC(RLT, 1);
+            } else if (RLU > RB && p.m >= (int64_t)4 * 64 * RLU) VP_BLK_FIT(RLU, false, 1);
             else VP_BLK_FIT(RB, false, 1);
         }
     }
 #undef VP_BLK_FIT
+#undef VP_BLK_FIT_TC
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 

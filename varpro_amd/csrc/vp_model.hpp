@@ -184,7 +184,7 @@ __device__ __forceinline__ void tsincos(float x, float &sn, float &cs) {
 //            (64*(R-2)*W < m < 64*R*W, e.g. m = 1000 in the 1024-row kernel)
 //   UNI    : (with RECUR) the grid IS uniform -- the caller dispatched on the handle's grid check -- so only the recurrence
 //            path of build_columns is compiled: a kernel that carries both paths is register-allocated for the wider one
-//   TCALC  : (UNI, PADDED, unit weights, PADM == 1) the grid values are COMPUTED, t = t(lane's first row pair) + k * delta,
+//   TCALC  : (UNI, PADDED, unit weights) the grid values are COMPUTED, t = t(lane's first row pair) + k * delta,
 //            instead of loaded: 16 loads that the scheduler issues together are 32 live registers; the lattice is within
 //            4 ulp of the stored grid (grid_check_kernel)
 template <typename T, int R, bool PADDED = false, int WMODE = 2, int VMODE = 2, int W = 1, bool RECUR = false,
@@ -211,7 +211,7 @@ struct RowSource {
             uniform = flag && m >= 3;
             if (uniform) delta = (t[m - 1] - t[0]) / T(m - 1) * T(64 * W * L::VW);
             if constexpr (TCALC) {
-                static_assert(PADDED && UNI && WMODE == 0 && PADM == 1 && L::VW == 2, "computed grid: full, unweighted, uniform");
+                static_assert(PADDED && UNI && WMODE == 0 && L::VW == 2, "computed grid: unweighted, uniform");
                 using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
                 const V2 v = (reinterpret_cast<const V2 *>(t) + lane)[0];
                 tl[0] = v.x;
@@ -236,6 +236,11 @@ struct RowSource {
             for (int e = 0; e < 2; ++e) {
                 tt[e] = (r0 == 0) ? tl[e] : tfma(T(r0 / 2), delta, tl[e]);
                 sc[e] = T(1);
+                if constexpr (PADM != 1) { // (a partially filled problem / block: rows >= m are padding)
+                    const bool in = i + e < m;
+                    tt[e] = in ? tt[e] : T(0);
+                    sc[e] = in ? T(1) : T(0);
+                }
             }
             return;
         }
