@@ -1,5 +1,6 @@
-// double exponential + offset, fp32: 8 rows per lane (m <= 512) and 32 rows per lane (m <= 2048: five fp32 columns of 32 rows
-// are 160 VGPRs) -- the fp32 handle had the 128- and the 1024-row set only and ran on the generic kernels above 1024 rows
+// double exponential + offset, fp32: 8 rows per lane (m <= 512) and, for handles with several right-hand sides, 32 rows per lane (m <= 2048);
+// single-RHS handles above 1024 rows run on the streamed kernels (faster than the 32-row resident set at m = 2048, within 11 % at 1500:
+// profiles/r05_prune_probe.json)
 #include "vp_inst.hpp"
 VP_REGISTER_MULTIEXP(float, VP_F32, 2, 1, 8)
-VP_REGISTER_MULTIEXP(float, VP_F32, 2, 1, 32)
+VP_REGISTER_MULTIEXP_MRHS_ONLY(float, VP_F32, 2, 1, 32)
