@@ -88,16 +88,42 @@ def test_census_generic_fallback_bench_leg_oleary_m5000_all_4096_problems():
            .function(["alpha1", "alpha2"], vp.basis.EXP_COS).partial_deriv("alpha1").partial_deriv("alpha2").build())
     bp = vp.BatchProblem(mdl, Yg, x=tg)
     a, _c, rep = bp.fit(gg0)
-    bp.close()
     ao, _co, ro, _s = O.fit_batch(mdl, tg, Yg, gg0, n_threads=min(16, O.max_threads()))
     res = CS.census(rep, a, ro, ao, max_listed=50)
     print(json.dumps({k: v for k, v in res.items() if k != "disagreements"}))
     for dis in res["disagreements"]:
         print("DISAGREEMENT", dis)
     # the largest evaluation count is not compared on this leg: with 4 096 problems it is set by one or two fits that creep
-    # along the flat cos-frequency valley until xtol fires (97 here, 158 in the oracle, same minimum to 1.4e-8 at worst);
-    # the counts agree within 3 on 98.5 % and in their sum to 1 %
-    _assert_fp64_contract(res, max_evals_slack=None)
+    # along the flat cos-frequency valley (the three fitted parameters within 0.5 % of each other: the two basis functions
+    # all but coincide) until a tolerance fires; the counts agree within 3 on 98.5 % and in their sum to 1 %.
+    # WHERE such a fit stops is not a property of the problem: the ORACLE's own result moves by 1e-4 ... 0.3 in the objective
+    # when every datum is moved by at most one ulp (problems 818, 1104, 898 of this batch: 10 %, 64 %, 48 % of 256 such
+    # perturbations end more than 1e-6 away from the unperturbed run -- tools/valley_probe.py, profiles/r05_valley_probe.json).
+    # Contract: 1e-6 on every problem the oracle itself reproduces to 1e-6; a problem beyond it (at most 0.1 % of the batch)
+    # must (i) be one the oracle does NOT reproduce under one-ulp perturbations of its data and (ii) sit within 1e-6 of one
+    # of the oracle's own outcomes.
+    rd = bp.report_to_numpy(rep)
+    bp.close()
+    od, oo = rd["objective"].astype(np.float64), ro["objective"].astype(np.float64)
+    rel = np.abs(od - oo) / oo
+    beyond = [int(i) for i in np.nonzero(rel > 1e-6)[0]]
+    print("beyond 1e-6:", [(i, float(rel[i])) for i in beyond])
+    assert len(beyond) <= 4
+    for i in beyond:
+        n = 256
+        Yp = np.repeat(Yg[i:i + 1], n, 0) * (1 + 2.0 ** -52 * np.random.default_rng(i).choice([-1.0, 0.0, 1.0], (n, mg)))
+        _a, _c2, rp, _s2 = O.fit_batch(mdl, tg, Yp, np.repeat(gg0[i:i + 1], n, 0), n_threads=min(16, O.max_threads()))
+        outcomes = rp["objective"].astype(np.float64)
+        print(i, "oracle outcomes beyond 1e-6 of its unperturbed run:", float((np.abs(outcomes - oo[i]) / oo[i] > 1e-6).mean()),
+              "device to the nearest outcome:", float(np.min(np.abs(outcomes - od[i])) / oo[i]))
+        assert (np.abs(outcomes - oo[i]) / oo[i] > 1e-6).any(), "a well-posed problem beyond 1e-6"
+        assert np.min(np.abs(outcomes - od[i])) / oo[i] <= 1e-6
+    res_wp = dict(res)
+    if beyond:
+        keep = np.ones(Bg, bool)
+        keep[beyond] = False
+        res_wp["objective_rel_diff_max_common_successes"] = float(rel[keep & (rd["termination"] > 0) & (ro["termination"] > 0)].max())
+    _assert_fp64_contract(res_wp, max_evals_slack=None)
 
 
 def test_census_configs3_shard_all_65536_problems():

@@ -351,6 +351,12 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
     // the derivative columns still use the actual t_i.
     constexpr bool kRecur = Src::kRecur;
     T fu[N][VW], qq[N];
+    // run-time-descriptor models: the trigonometric kinds advance by a ROTATION on a uniform grid -- exp(-a t) (cos b t + i sin b t)
+    // of pair k is the value of pair k-1 times the wave-uniform w = exp(-a delta) (cos b delta + i sin b delta): 2 multiplies
+    // + 2 FMAs (+ the clamp of the exponential chain) per element instead of an exponential and a sine / cosine pair;
+    // absolute error <= (R/2) * 2 ulp OF THE MODULUS per component (what a least-squares column is measured by)
+    constexpr bool kTrig = kRecur && !M::kStatic;
+    T fv[kTrig ? N : 1][VW], wr[kTrig ? N : 1], wi[kTrig ? N : 1];
     bool fast = false;
     // static models: the first row pair's exponentials and the ratios of ALL columns in one batched evaluation
     // (texp_n: interleaved Horner chains, polynomial constants live only here)
@@ -383,10 +389,28 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                     qq[j] = T(1);
                     if (kind[j] == VP_BASIS_EXP_DECAY) qq[j] = texp(-div_refined(src.delta, p0[j], rt[j]));
                     else if (kind[j] == VP_BASIS_EXP_RATE) qq[j] = texp(-p0[j] * src.delta);
+                    if constexpr (kTrig) {
+                        wr[j] = T(1);
+                        wi[j] = T(0);
+                        if (kind[j] == VP_BASIS_EXP_COS || kind[j] == VP_BASIS_SIN_PHASE) {
+                            const bool damped = kind[j] == VP_BASIS_EXP_COS;
+                            T sn_, cs_;
+                            tsincos((damped ? p1[j] : p0[j]) * src.delta, sn_, cs_);
+                            const T q_ = damped ? texp(-p0[j] * src.delta) : T(1);
+                            wr[j] = q_ * cs_;
+                            wi[j] = q_ * sn_;
+                        }
+                    }
                 }
             }
         }
     }
+    // (re, im) <- (re, im) * (wr, wi); clamped like the exponential chain: a zero-scaled padding row must not see inf * 0
+    auto rotate = [&](T &re, T &im, const T wr_, const T wi_) __attribute__((always_inline)) {
+        const T a_ = re, b_ = im;
+        re = tmax(tmin(tfma(a_, wr_, -(b_ * wi_)), num<T>::huge), -num<T>::huge);
+        im = tmax(tmin(tfma(a_, wi_, b_ * wr_), num<T>::huge), -num<T>::huge);
+    };
     auto shifted = [&](T v, int j) __attribute__((always_inline)) {
         if constexpr (SHIFT) return tldexp(v, -ks[j]);
         else return v;
@@ -444,16 +468,42 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
                         d0 = -t * shifted(f, j);
                     } else if (kind[j] == VP_BASIS_EXP_COS) {
                         // exp(-a t) cos(b t)   (shared_test_code/src/models.rs:313-314, 349-372)
-                        const T ex = texp(-p0[j] * t) * scl;
-                        T sn_, cs_;
-                        tsincos(p1[j] * t, sn_, cs_);
-                        f = ex * cs_;
-                        d0 = f * (-t);
-                        d1 = -t * ex * sn_;
+                        if constexpr (FAST && kTrig) {
+                            if (r0 == 0) {
+                                const T ex = texp(-p0[j] * t);
+                                T sn_, cs_;
+                                tsincos(p1[j] * t, sn_, cs_);
+                                fu[j][e] = ex * cs_;
+                                fv[j][e] = ex * sn_;
+                            } else {
+                                rotate(fu[j][e], fv[j][e], wr[j], wi[j]);
+                            }
+                            f = fu[j][e] * scl;
+                            d0 = f * (-t);
+                            d1 = -t * (fv[j][e] * scl);
+                        } else {
+                            const T ex = texp(-p0[j] * t) * scl;
+                            T sn_, cs_;
+                            tsincos(p1[j] * t, sn_, cs_);
+                            f = ex * cs_;
+                            d0 = f * (-t);
+                            d1 = -t * ex * sn_;
+                        }
                     } else { // VP_BASIS_SIN_PHASE   (src/test_helpers/mod.rs:28-52)
-                        const T ph = p0[j] * t + p1[j];
                         T sn_, cs_;
-                        tsincos(ph, sn_, cs_);
+                        if constexpr (FAST && kTrig) {
+                            if (r0 == 0) {
+                                tsincos(p0[j] * t + p1[j], sn_, cs_);
+                                fu[j][e] = cs_;
+                                fv[j][e] = sn_;
+                            } else {
+                                rotate(fu[j][e], fv[j][e], wr[j], wi[j]);
+                            }
+                            cs_ = fu[j][e];
+                            sn_ = fv[j][e];
+                        } else {
+                            tsincos(p0[j] * t + p1[j], sn_, cs_);
+                        }
                         const T cs = cs_ * scl;
                         f = sn_ * scl;
                         d0 = t * cs;
