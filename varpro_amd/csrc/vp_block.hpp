@@ -260,7 +260,9 @@ template <typename T, int RB, bool WEIGHTED, bool NOGRID = false> struct RowRing
 #endif
 // (run-time-descriptor models evaluate every basis kind per element and their column build needs about as many registers
 // again as the block itself: their kernels run ONE wave per SIMD -- 512 VGPRs -- like the resident ones, model_waves_for)
-template <class M> constexpr int blk_waves() { return M::kStatic ? VP_BLK_WAVES : 1; }
+// (so do static models of more than ten columns: five exponentials in fp64 -- 12 columns of 4 rows + the carry + the lane-private
+// trailing triangle spilled 176-570 VGPRs at two waves per SIMD)
+template <class M> constexpr int blk_waves() { return (M::kStatic && M::N + 1 + M::P <= 10) ? VP_BLK_WAVES : 1; }
 template <typename T, int NC, bool STATIC = true> constexpr int block_rows() {
 #ifdef VP_BLK_RB
     return VP_BLK_RB;
@@ -298,7 +300,8 @@ template <typename T, class M, bool WEIGHTED, bool TC = false> constexpr int blo
     constexpr int words = (M::N + 1 + M::P) * (int)(sizeof(T) / 4);
     constexpr int ring_per_row = 2 * (WEIGHTED ? 3 : (TC ? 1 : 2)) * 64 * (int)sizeof(T);
     int best = RB;
-    if (M::kStatic && !(TC && (WEIGHTED || sizeof(T) != 8)))
+    // (more than ten columns: the 4-row block already takes one wave per SIMD -- blk_waves -- and taller ones spill 64-150 VGPRs)
+    if (M::kStatic && M::N + 1 + M::P <= 10 && !(TC && (WEIGHTED || sizeof(T) != 8)))
         for (int rb = RB + 4; rb <= (TC ? VP_BLK_RB_LONG_TC : VP_BLK_RB_LONG); rb += 4)
             if (words * rb <= (TC ? VP_BLK_TC_WORDS : 208) && ring_per_row * rb <= 36 * 1024) best = rb;
     return best;
