@@ -354,8 +354,9 @@ void vp_lm_opts_default(vp_lm_opts *opts, int dtype);
  *       (vp_params, vp_linear_coeffs, vp_cost, vp_summary*, vp_reduce_cost); entries that need the MODEL at that point
  *       (vp_residuals, vp_jacobian, vp_best_fit, vp_statistics) first need its columns: vp_set_params_with_basis.
  * Every problem terminates after at most patience*(q+1) evaluations (TerminationReason::LostPatience), so stepping until
- * n_active == 0 always ends.  Covered shapes: single right-hand side, m >= n, the (n, q, pairs, m) of the compiled step
- * kernels (VP_ERR_UNSUPPORTED from vp_fit_begin otherwise).
+ * n_active == 0 always ends.  Covered shapes: single right-hand side, m >= n, the (n, q, pairs) of the compiled step
+ * kernels (VP_ERR_UNSUPPORTED from vp_fit_begin otherwise) at ANY m: register-resident to 4 096 rows, the caller's
+ * columns streamed in row blocks beyond (shapes of up to ten columns n + 1 + pairs).
  */
 enum { VP_FIT_DERIVATIVES_ON_ACCEPT = 1 };
 enum { VP_WANT_BASIS = 1, VP_WANT_DERIVATIVES = 2 };

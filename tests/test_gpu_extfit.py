@@ -72,8 +72,9 @@ def compare_with_oracle(rep, alpha, ref, obj_median=1e-12, obj_max=1e-6, evals_s
                 obj_max=float(rel.max()), failed=int((~ok).sum()))
 
 
-# (m = 3000: four waves per problem, vp_inst_extfit_long_*.hip -- round 5; one wave to 1 024 rows)
-@pytest.mark.parametrize("m", [200, 1000, 3000])
+# (m = 3000: four waves per problem, vp_inst_extfit_long_*.hip -- round 5; one wave to 1 024 rows; m = 5000, 10 001: the rows
+# streamed in blocks, vp_blk_extfit.hpp -- any length; 10 001 is not a multiple of a 16-byte group: element-wise loads)
+@pytest.mark.parametrize("m", [200, 1000, 3000, 5000, 10001])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_stepped_fit_matches_the_oracle_and_both_protocols_agree(m, weighted):
     rng = np.random.default_rng(100 + m)

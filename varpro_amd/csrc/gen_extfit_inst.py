@@ -40,6 +40,17 @@ def emit_long(fname, T, head):
     open(fname, 'w').write('\n'.join(lines) + '\n')
 
 
+def emit_stream(fname, T, head):
+    # end of round 5: any length -- the rows streamed in blocks through the TSQR carry of vp_block.hpp (vp_blk_extfit.hpp); shapes
+    # of up to ten columns (the carry and two resident blocks of the double buffer are the registers of a wave)
+    lines = [head, '#include "vp_blk_extfit.hpp"', '']
+    for n in sorted(shapes):
+        for (P, Q) in shapes[n]:
+            if n + 1 + P <= 10:
+                lines.append('VP_REGISTER_EXTFIT_STREAM(%s, %d, %d, %d)' % (T, n, P, Q))
+    open(fname, 'w').write('\n'.join(lines) + '\n')
+
+
 H = '// batched LM fit of caller-evaluated models (vp_extfit.hpp): evaluation kernels, %s, n = %s: (N, P pair slots, Q parameters, R rows per lane, W waves per problem); written by gen_extfit_inst.py'
 emit('vp_inst_extfit_a_f64.hip', 'double', [1, 2], H % ('f64', '1, 2'))
 emit('vp_inst_extfit_b_f64.hip', 'double', [3], H % ('f64', '3'))
@@ -48,3 +59,5 @@ emit('vp_inst_extfit_a_f32.hip', 'float', [1, 2, 3], H % ('f32', '1, 2, 3'))
 emit('vp_inst_extfit_b_f32.hip', 'float', [4, 5, 6], H % ('f32', '4, 5, 6'))
 emit_long('vp_inst_extfit_long_f64.hip', 'double', '// batched LM fit of caller-evaluated models (vp_extfit.hpp): evaluation kernels for LONG problems, f64 (four / eight waves per problem); written by gen_extfit_inst.py')
 emit_long('vp_inst_extfit_long_f32.hip', 'float', '// batched LM fit of caller-evaluated models (vp_extfit.hpp): evaluation kernels for LONG problems, f32 (four / eight waves per problem); written by gen_extfit_inst.py')
+emit_stream('vp_inst_extfit_stream_f64.hip', 'double', '// batched LM fit of caller-evaluated models at ANY length (vp_blk_extfit.hpp: rows streamed in blocks), f64: (N, P pair slots, Q parameters); written by gen_extfit_inst.py')
+emit_stream('vp_inst_extfit_stream_f32.hip', 'float', '// batched LM fit of caller-evaluated models at ANY length (vp_blk_extfit.hpp: rows streamed in blocks), f32: (N, P pair slots, Q parameters); written by gen_extfit_inst.py')
