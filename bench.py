@@ -872,6 +872,56 @@ def main():
                                  "traffic_source": traffic_source("blk_fit_kernel"),
                                  "note": "y (8 m bytes) is re-read per evaluation through the LDS ring; the grid comes from L2"},
                 }
+                if ms == 10000:
+                    # the same long problems as a CALLER-EVALUATED model fitted by reverse communication: beyond 4 096 rows the
+                    # step streams the caller's columns in row blocks (vp_blk_extfit.hpp); columns by a torch expression on the
+                    # device for every problem and step (the simplest caller)
+                    Bx = 4096
+                    Yx_, gx_ = torch.from_numpy(ds["Y"][:Bx]).to(dev), gs[:Bx].contiguous()
+                    xrow = torch.from_numpy(ds["x"]).to(dev)[None, None, :]
+                    bxs = vp.BatchProblem(vp.ExternalModel(3, 2, [(0, 0), (1, 1)]), Yx_)
+                    phis = torch.ones((Bx, 3, ms), dtype=torch.float64, device=dev)
+                    dphis = torch.empty((Bx, 2, ms), dtype=torch.float64, device=dev)
+
+                    def long_stepped(evts=None):
+                        bxs.fit_begin(gx_)
+                        al_, nact_, st_ = gx_, Bx, 0
+                        while nact_ > 0 and st_ < 400:
+                            a3 = al_[:, :, None]
+                            torch.exp(-xrow / a3, out=phis[:, 0:2])
+                            torch.mul(phis[:, 0:2], xrow / (a3 * a3), out=dphis)
+                            if evts is not None and st_ == 0:
+                                e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                e0_.record()
+                            al_, _w, nact_ = bxs.fit_step_with_basis(phis, dphis)
+                            if evts is not None and st_ == 0:
+                                e1_.record()
+                                evts.append((e0_, e1_))
+                            st_ += 1
+                        return bxs.fit_end(want_coefficients=False) + (st_,)
+
+                    long_stepped()
+                    torch.cuda.synchronize()
+                    evx = []
+                    t0s = time.perf_counter()
+                    _ax, _cx, repx, stx = long_stepped(evx)
+                    torch.cuda.synchronize()
+                    xs_s = time.perf_counter() - t0s
+                    rxs = bxs.report_to_numpy(repx)
+                    okb = (rxs["termination"] > 0) & (rs["termination"][:Bx] > 0)
+                    relx = np.abs(rxs["objective"] - rs["objective"][:Bx])[okb] / rs["objective"][:Bx][okb]
+                    st0 = evx[0][0].elapsed_time(evx[0][1])
+                    byx = Bx * T * ms * 6
+                    legs["m%d" % ms]["as_caller_evaluated_model"] = {
+                        "workload": "vp_fit_begin / vp_fit_step_with_basis / vp_fit_end, B=%d of the same problems, m=%d: columns by a torch expression on the device every step" % (Bx, ms),
+                        "fits_per_s_including_the_callers_columns": Bx / xs_s, "steps": stx, "mean_evaluations_per_fit": float(rxs["n_evals"].mean()),
+                        "vs_vp_fit_of_the_same_problems": {"same_success_class": float(((rxs["termination"] > 0) == (rs["termination"][:Bx] > 0)).mean()),
+                                                           "objective_rel_diff_median": float(np.median(relx)), "objective_rel_diff_max": float(relx.max())},
+                        "roofline": {"kernel": "blk::ext_fit_stream_eval_kernel<double, 3, 2, 2, 4> + ext_fit_lm_kernel<double, 2> (first step: every problem active)", "bound": "hbm",
+                                     "achieved": byx / (st0 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byx / (st0 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "bytes_per_launch": byx, "avg_launch_ms": st0, "traffic": None}}
+                    bxs.close()
+                    del phis, dphis, Yx_
                 bps.close()
                 del ds, gs
             out["streamed_rows"] = legs

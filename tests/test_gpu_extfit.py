@@ -214,9 +214,11 @@ def test_census_4096_hard_starts():
           % (same.mean(), (term <= 0).sum(), (rel <= 1e-6).mean(), (dev <= 3).mean()))
 
 
-def test_three_parameter_basis_weighted_and_fp32():
+# (m = 6000: the streamed step kernels, vp_blk_extfit.hpp -- weighted fp64 and fp32)
+@pytest.mark.parametrize("m", [400, 6000])
+def test_three_parameter_basis_weighted_and_fp32(m):
     rng = np.random.default_rng(31)
-    m, B = 400, 32
+    B = 32
     x = np.linspace(0.0, 10.0, m)
     cm = voigt_model(x)
     mu, wd, eta = rng.uniform(4, 6, B), rng.uniform(0.5, 1.0, B), rng.uniform(0.2, 0.8, B)
@@ -243,6 +245,33 @@ def test_three_parameter_basis_weighted_and_fp32():
     assert (np.abs(rep32["objective"] - ref[3])[ok] <= 2e-3 * ref[3][ok]).all()
     assert (np.abs(a32 - ref[0])[ok] <= 2e-2 * np.abs(ref[0][ok])).all()
     bp32.close()
+
+
+def test_eleven_columns_streamed():
+    """two Gauss peaks + Lorentz peak + offset: n = 4, q = 6, six derivative columns -- 11 columns, beyond the resident step
+    kernels' 4 096 rows: the streamed kernel at one wave per SIMD, two rows per lane and block"""
+    from test_gpu_external import pvoigt_dmu  # noqa: F401  (the module's closures)
+    rng = np.random.default_rng(77)
+    m, B = 4500, 24
+    x = np.linspace(0.0, 10.0, m)
+    cm = (vp.ClosureModel(["mu1", "s1", "mu2", "s2", "mu3", "g3"], x)
+          .function(["mu1", "s1"], gauss).partial_deriv("mu1", gauss_dmu).partial_deriv("s1", gauss_dsg)
+          .function(["mu2", "s2"], gauss).partial_deriv("mu2", gauss_dmu).partial_deriv("s2", gauss_dsg)
+          .function(["mu3", "g3"], lorentz).partial_deriv("mu3", lorentz_dmu).partial_deriv("g3", lorentz_dga)
+          .invariant_function(lambda x: np.ones_like(x)))
+    truth = np.stack([rng.uniform(2.0, 2.6, B), rng.uniform(0.4, 0.6, B), rng.uniform(5.0, 5.6, B), rng.uniform(0.5, 0.8, B),
+                      rng.uniform(7.8, 8.4, B), rng.uniform(0.4, 0.7, B)], 1)
+    Phi = cm.eval_batch(truth)
+    Y = (rng.uniform(5, 20, (B, 4, 1)) * Phi).sum(1)
+    Y = Y + 1e-2 * rng.standard_normal(Y.shape)
+    guess = truth * (1 + rng.uniform(-0.03, 0.03, truth.shape))
+    ref = oracle_fits(cm, Y, guess)
+    bp = vp.BatchProblem(cm.shape(), Y)
+    a, _C, rep, _s = bp.fit_with_model(host_model(cm), guess)
+    compare_with_oracle(rep, a, ref, evals_share=0.8)
+    a2, _C2, rep2, _s2 = bp.fit_with_model(host_model(cm), guess, derivatives_on_accept=True)
+    assert np.array_equal(a, a2) and np.array_equal(rep["objective"], rep2["objective"])
+    bp.close()
 
 
 def test_lm_options_and_failures_follow_the_oracle():

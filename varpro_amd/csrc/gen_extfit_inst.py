@@ -41,13 +41,12 @@ def emit_long(fname, T, head):
 
 
 def emit_stream(fname, T, head):
-    # end of round 5: any length -- the rows streamed in blocks through the TSQR carry of vp_block.hpp (vp_blk_extfit.hpp); shapes
-    # of up to ten columns (the carry and two resident blocks of the double buffer are the registers of a wave)
+    # end of round 5: any length -- the rows streamed in blocks through the TSQR carry of vp_block.hpp (vp_blk_extfit.hpp); every
+    # shape of the resident tables (up to 13 columns: two rows per lane and block, one wave per SIMD)
     lines = [head, '#include "vp_blk_extfit.hpp"', '']
     for n in sorted(shapes):
         for (P, Q) in shapes[n]:
-            if n + 1 + P <= 10:
-                lines.append('VP_REGISTER_EXTFIT_STREAM(%s, %d, %d, %d)' % (T, n, P, Q))
+            lines.append('VP_REGISTER_EXTFIT_STREAM(%s, %d, %d, %d)' % (T, n, P, Q))
     open(fname, 'w').write('\n'.join(lines) + '\n')
 
 

@@ -21,7 +21,7 @@ namespace blk {
 // waves per SIMD: the two resident blocks of the double buffer are 2 NC RB values; beyond 112 register words they leave a
 // second wave no room (eight fp64 columns of four rows spilled 74-158 VGPRs at two waves per SIMD)
 template <typename T, int NC, int RB> constexpr int ext_fit_stream_waves() {
-    return 2 * NC * RB * (int)(sizeof(T) / 4) <= 112 ? 2 : 1;
+    return (2 * NC * RB * (int)(sizeof(T) / 4) <= 112 && (NC <= 10 || sizeof(T) == 4)) ? 2 : 1; // (eleven and more fp64 columns: the carry and the q x q factor)
 }
 
 template <typename T, int N, int P, int Q, int RB>
