@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(64, (ext_fit_stream_waves<T, N + 1 + P, RB>())
     auto load_block = [&](const int off, T (&Cb)[NC][RB]) __attribute__((always_inline)) {
         const int mrem = m - off;
 #pragma unroll
-        for (int j = 0; j < N; ++j) load_rows<T, RB, 1>(ph + (int64_t)j * m + off, mrem, lane, vec, Cb[j]);
+        for (int j = 0; j < N; ++j) load_rows<T, RB, 1>(ph + (int64_t)a.perm[j] * m + off, mrem, lane, vec, Cb[j]);
         load_rows<T, RB, 1>(yp + off, mrem, lane, vec, Cb[N]);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(64, (ext_fit_stream_waves<T, N + 1 + P, RB>())
     if (lane == 0) {
         st[F::C_FN * a.B + b] = usqrt(fn2);
 #pragma unroll
-        for (int k = 0; k < N; ++k) st[(F::C_C + k) * a.B + b] = c[k];
+        for (int k = 0; k < N; ++k) st[(F::C_C + a.perm[k]) * a.B + b] = c[k];
         si[F::C_OK * a.B + b] = ok ? 1 : 0;
         si[F::C_HASJ * a.B + b] = (with_d && ok) ? 1 : 0;
     }

@@ -47,8 +47,21 @@ template <typename T> int ext_fit_step_t(const ExtFitParams &p) {
     a.want = p.want;
     a.nactive = p.nactive;
     a.step = p.step;
+    // sweep order: the invariant basis functions (no derivative pair) first, each group in the model's order (ExtFitArgs::perm)
+    int inv[VP_MAX_BASIS];
+    {
+        bool varies[VP_MAX_BASIS] = {};
+        for (int i = 0; i < p.np; ++i)
+            if (p.pb[i] >= 0 && p.pb[i] < VP_MAX_BASIS) varies[p.pb[i]] = true;
+        int k = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int j = 0; j < p.n && j < VP_MAX_BASIS; ++j)
+                if (varies[j] == (pass == 1)) a.perm[k++] = j;
+        for (; k < VP_MAX_BASIS; ++k) a.perm[k] = k;
+        for (int j = 0; j < VP_MAX_BASIS; ++j) inv[a.perm[j]] = j;
+    }
     for (int i = 0; i < VP_MAX_PAIRS; ++i) {
-        a.pb[i] = i < p.np ? p.pb[i] : 0;
+        a.pb[i] = i < p.np ? inv[p.pb[i]] : 0;
         a.pp[i] = i < p.np ? p.pp[i] : -1;
     }
     a.np = p.np;
