@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
         for (int k = 0; k < Q; ++k) a.alpha[b * Q + k] = S.x[k];
         if (a.C_out) {
 #pragma unroll
-            for (int k = 0; k < N; ++k) a.C_out[b * N + k] = cbest[k];
+            for (int k = 0; k < N; ++k) a.C_out[b * N + a.mdl.out_index(k)] = cbest[k];
         }
     }
 }
@@ -832,6 +832,7 @@ template <typename T, class M> int launch_evaluate(const LaunchParams &p, int (*
 template <typename T, class M> int launch_fit(const LaunchParams &p) {
     FitArgs<T, M> a;
     if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+    sweep_invariant_first(a.mdl); // (run-time-descriptor models: constant columns first in the sweep, vp_model.hpp)
     a.t = (const T *)p.t;
     a.w = (const T *)p.w;
     a.yw = (const T *)p.yw;

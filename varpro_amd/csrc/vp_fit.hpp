@@ -1516,7 +1516,7 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
         for (int k = 0; k < Q; ++k) a.alpha[b * Q + k] = x[k];
         if (a.C_out) {
 #pragma unroll
-            for (int k = 0; k < N; ++k) a.C_out[b * N + k] = cbest[k];
+            for (int k = 0; k < N; ++k) a.C_out[b * N + a.mdl.out_index(k)] = cbest[k];
         }
     }
 }
@@ -1530,6 +1530,7 @@ template <typename T, class M, int R, int W> constexpr size_t fit_lds_bytes(bool
 template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchParams &p) {
     FitArgs<T, M> a;
     if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+    sweep_invariant_first(a.mdl); // (run-time-descriptor models: constant columns first in the sweep, vp_model.hpp)
     a.t = (const T *)p.t;
     a.w = (const T *)p.w;
     a.yw = (const T *)p.yw;

@@ -29,6 +29,7 @@ template <int NEXP, bool OFFSET> struct MultiExpModel {
     __host__ __device__ constexpr int pair_param(int p) const { return p; }
     static constexpr bool kDiagonalPairs = true; // pair p <-> (basis p, param p), P == Q
     static constexpr bool kConstLast = OFFSET;   // the last basis is the constant: see evaluate_core_const_first
+    __host__ __device__ constexpr int out_index(int j) const { return j; }
 };
 
 // ---- runtime model with compile-time sizes: any mix of kinds / shared parameters ---------------
@@ -40,6 +41,8 @@ template <int N_, int Q_, int P_> struct RtModel {
     int32_t kind_[N_];
     int32_t par_[N_][VP_MAX_BASIS_PARAMS];
     int32_t pb_[P_], pa_[P_], pp_[P_];
+    int32_t out_[N_]; // column j is basis function out_[j] of the caller's model (identity unless sweep_invariant_first reordered it)
+    __host__ __device__ int out_index(int j) const { return out_[j]; }
     __host__ __device__ int kind(int j) const { return kind_[j]; }
     __host__ __device__ int param(int j, int a) const { return par_[j][a]; }
     __host__ __device__ int pair_basis(int p) const { return pb_[p]; }
@@ -536,6 +539,7 @@ template <int N_, int Q_, int P_> inline bool make_rt_model(const vp_model_desc 
     int p = 0;
     for (int j = 0; j < N_; ++j) {
         out.kind_[j] = d.kind[j];
+        out.out_[j] = j;
         for (int a = 0; a < VP_MAX_BASIS_PARAMS; ++a) {
             out.par_[j][a] = d.param[j][a];
             if (d.param[j][a] >= 0) {
@@ -548,6 +552,31 @@ template <int N_, int Q_, int P_> inline bool make_rt_model(const vp_model_desc 
         }
     }
     return p == P_;
+}
+
+// FIT kernels of run-time-descriptor models: the invariant (constant) columns FIRST in the sweep, whatever their place in the
+// model.  Their reflectors are then the same in every evaluation of a fit and their rounding cancels in
+// actred = 1 - (||r_trial|| / ||r||)^2, which the ftol test reads at the 30-eps level -- what the static models' implicit
+// constant-first sweep (evaluate_core_const_first) and the external fit's ExtFitArgs::perm do.  Only the coefficients leave a
+// fit kernel per basis function: stored through out_index().  (host side; static models: nothing to do)
+template <class M> inline void sweep_invariant_first(M &mdl) {
+    if constexpr (!M::kStatic) {
+        constexpr int N = M::N, P = M::P;
+        M src = mdl;
+        int pos[N];
+        int k = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int j = 0; j < N; ++j)
+                if ((src.kind_[j] == VP_BASIS_CONST) == (pass == 0)) {
+                    mdl.kind_[k] = src.kind_[j];
+                    mdl.out_[k] = src.out_[j];
+                    for (int a = 0; a < VP_MAX_BASIS_PARAMS; ++a) mdl.par_[k][a] = src.par_[j][a];
+                    pos[j] = k++;
+                }
+        for (int p = 0; p < P; ++p) mdl.pb_[p] = pos[src.pb_[p]];
+    } else {
+        (void)mdl;
+    }
 }
 
 } // namespace vp
