@@ -95,7 +95,7 @@ template <typename T> struct ExtFitArgs {
                                 // Their reflectors are then the same in every evaluation of a fit and their rounding cancels in
                                 // actred = 1 - (||r_trial|| / ||r||)^2, which the ftol test reads at the 30-eps level (the headline
                                 // problems as an external model, constant column last: +0.69 evaluations per fit against the
-                                // oracle, within 3 on 90.8 %; invariant columns first: -0.08, 98.2 % -- what vp_fit's implicit
+                                // reference algorithm on the CPU, within 3 on 90.8 %; invariant columns first: -0.08, 98.2 % -- what vp_fit's implicit
                                 // constant-first sweep has; tools/extfit_headline_probe.py)
     int np;
     int n; // basis functions (the LM kernel is compiled per Q only)
