@@ -9,8 +9,7 @@
 // Q-coordinates, MINPACK's pivoted qrfac on those two-rows-per-lane columns (jac_qrfac) the factor.  The results land in the
 // candidate slot of the problem's LM record (ExtFitLayout C_*), which is all ext_fit_lm_kernel reads: the LM launch, the
 // protocols (eager / VP_FIT_DERIVATIVES_ON_ACCEPT) and the host entry points are those of vp_extfit.hpp unchanged.
-// A step without derivative columns runs the first n + 1 reflectors only; they are the same arithmetic on the same values as
-// the first n + 1 of a step with them, so the residual norm of a point does not depend on the protocol.
+// The residual norm of a point does not depend on the protocol (with or without derivative columns in the step): see `fold`.
 #pragma once
 #include "vp_blk_ext.hpp"
 #include "vp_extfit.hpp"
@@ -82,9 +81,28 @@ __global__ void __launch_bounds__(64, (ext_fit_stream_waves<T, N + 1 + P, RB>())
 #pragma unroll
     for (int j = 0; j < NC; ++j) K[j][0] = K[j][1] = T(0);
     const int nb = (m + ROWS - 1) / ROWS;
+    // the trailing columns [y | dPhi_1 .. dPhi_P] are final after the n wave-wide reflectors of a block: each LANE folds its own
+    // rows of them into a private (p + 1)^2 triangle (lane_trail_update, vp_block.hpp: no reduction, no broadcast) and the 64
+    // triangles are merged once per evaluation -- n reduction rounds per block instead of n + 1 + p.  A step without derivative
+    // columns runs the same code on zero columns: the data column is the first of the trailing ones, its reflectors do not
+    // see the others, so the residual norm of a point is the same number under both protocols.
+    constexpr int PT = P + 1;
+    constexpr bool kLaneTrail = PT <= 5;
+    T Tl[kLaneTrail ? PT : 1][kLaneTrail ? PT : 1];
+    if constexpr (kLaneTrail) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) Tl[i][j] = T(0);
+    }
     auto fold = [&](T (&Cb)[NC][RB]) __attribute__((always_inline)) {
-        if (with_d) stacked_qr<T, NC, NC, RB, G>(K, Cb, grp);
-        else stacked_qr<T, NC, N + 1, RB, G>(K, Cb, grp);
+        if constexpr (kLaneTrail) {
+            stacked_qr<T, NC, N, RB, G>(K, Cb, grp);
+            lane_trail_update<T, NC, N, PT, RB>(Tl, Cb);
+        } else {
+            if (with_d) stacked_qr<T, NC, NC, RB, G>(K, Cb, grp);
+            else stacked_qr<T, NC, N + 1, RB, G>(K, Cb, grp);
+        }
     };
     {
         T Ca[NC][RB], Cc[NC][RB];
@@ -98,6 +116,8 @@ __global__ void __launch_bounds__(64, (ext_fit_stream_waves<T, N + 1 + P, RB>())
             }
         }
     }
+
+    if constexpr (kLaneTrail) lane_trail_merge<T, NC, N, PT, G>(Tl, K, grp);
 
     // ---- set_params on the compressed problem: src/solvers/levmar/mod.rs:42-73 ----
     T Rm[N][N], qty[N];
