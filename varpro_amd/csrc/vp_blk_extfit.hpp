@@ -19,7 +19,18 @@ namespace blk {
 
 // waves per SIMD: the two resident blocks of the double buffer are 2 NC RB values; beyond 112 register words they leave a
 // second wave no room (eight fp64 columns of four rows spilled 74-158 VGPRs at two waves per SIMD)
+// rows per lane and block.  Shapes of up to 14 register words per row (seven fp64 columns): ONE resident block of 8 rows per
+// lane -- the second wave of the SIMD loads while this one folds -- instead of two of 4 (a block's reduction rounds and
+// reflector scalars cost the same whatever its height); wider shapes: the double buffer of ext_block_rows
+#ifndef VP_EXTFIT_STREAM_SINGLE
+#define VP_EXTFIT_STREAM_SINGLE 1
+#endif
+template <typename T, int NC> constexpr bool ext_fit_stream_single() {
+    return VP_EXTFIT_STREAM_SINGLE && NC * (int)(sizeof(T) / 4) > 8 && NC * (int)(sizeof(T) / 4) <= 14;
+}
+template <typename T, int NC> constexpr int ext_fit_stream_rows() { return ext_fit_stream_single<T, NC>() ? 8 : ext_block_rows<T, NC>(); }
 template <typename T, int NC, int RB> constexpr int ext_fit_stream_waves() {
+    if (ext_fit_stream_single<T, NC>()) return 2;
     return (2 * NC * RB * (int)(sizeof(T) / 4) <= 112 && (NC <= 10 || sizeof(T) == 4)) ? 2 : 1; // (eleven and more fp64 columns: the carry and the q x q factor)
 }
 
@@ -104,7 +115,13 @@ __global__ void __launch_bounds__(64, (ext_fit_stream_waves<T, N + 1 + P, RB>())
             else stacked_qr<T, NC, N + 1, RB, G>(K, Cb, grp);
         }
     };
-    {
+    if constexpr (ext_fit_stream_single<T, NC>()) {
+        for (int ib = 0; ib < nb; ++ib) {
+            T Ca[NC][RB];
+            load_block(ib * ROWS, Ca);
+            fold(Ca);
+        }
+    } else {
         T Ca[NC][RB], Cc[NC][RB];
         load_block(0, Ca);
         for (int ib = 0; ib < nb; ib += 2) {
@@ -186,7 +203,7 @@ __global__ void __launch_bounds__(64, (ext_fit_stream_waves<T, N + 1 + P, RB>())
 }
 
 template <typename T, int N, int P, int Q> int launch_fit_stream_eval(const ext::ExtFitArgs<T> &a, hipStream_t stream) {
-    constexpr int RB = ext_block_rows<T, N + 1 + P>();
+    constexpr int RB = ext_fit_stream_rows<T, N + 1 + P>();
     hipLaunchKernelGGL((ext_fit_stream_eval_kernel<T, N, P, Q, RB>), dim3((unsigned)a.B), dim3(64), 0, stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
