@@ -744,7 +744,7 @@ def main():
             long_legs = {}
             for tdt, ml, Bl, kern in ((torch.float32, 4096, 32768, "ext_evaluate_kernel<float, 3, 2, 16, true, 4> (four waves per problem)"),
                                       (torch.float64, 8192, 8192, "ext_evaluate_kernel<double, 3, 2, 16, true, 8> (eight waves per problem)"),
-                                      (torch.float64, 10000, 4096, "blk::ext_stream_evaluate_kernel<double, 3, 2, 4> (rows streamed in blocks, two passes over the caller's columns: 15 column transfers for 9 algorithmic)")):
+                                      (torch.float64, 10000, 4096, "blk::ext_stream_evaluate_kernel<double, 3, 2, 8> (rows streamed in blocks, two passes over the caller's columns: 15 column transfers for 9 algorithmic)")):
                 Tl = 4 if tdt == torch.float32 else 8
                 gl_ = torch.Generator(device=dev)
                 gl_.manual_seed(0x5EED77)

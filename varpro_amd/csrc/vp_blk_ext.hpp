@@ -29,6 +29,16 @@ template <typename T, int NC> constexpr int ext_block_rows() {
     constexpr int words = NC * (int)(sizeof(T) / 4);
     return words <= 8 ? 8 : (words <= 18 ? 4 : 2);
 }
+// the evaluation kernel on shapes of 9 .. 12 register words per row (five / six fp64 columns): ONE resident block of 8 rows per
+// lane -- the SIMD's second wave loads while this one folds -- instead of a double buffer of two of 4 (end of round 5: the
+// batched fit's streamed step went from 0.49 to 0.61 of HBM that way, vp_blk_extfit.hpp)
+#ifndef VP_EXT_STREAM_SINGLE
+#define VP_EXT_STREAM_SINGLE 1
+#endif
+template <typename T, int NC> constexpr bool ext_stream_single() {
+    return VP_EXT_STREAM_SINGLE && NC * (int)(sizeof(T) / 4) > 8 && NC * (int)(sizeof(T) / 4) <= 12;
+}
+template <typename T, int NC> constexpr int ext_stream_rows() { return ext_stream_single<T, NC>() ? 8 : ext_block_rows<T, NC>(); }
 
 template <typename T, int N, int P, int RB>
 __global__ void __launch_bounds__(64, 2) ext_stream_evaluate_kernel(const ext::ExtArgs<T> a) {
@@ -99,7 +109,13 @@ __global__ void __launch_bounds__(64, 2) ext_stream_evaluate_kernel(const ext::E
 #pragma unroll
         for (int r = 0; r < RB; ++r) sq = tfma(Cb[N][r], Cb[N][r], sq);
     };
-    {
+    if constexpr (ext_stream_single<T, NC>()) {
+        for (int ib = 0; ib < nb; ++ib) {
+            T Ca[NC][RB];
+            load_block(ib * ROWS, Ca);
+            fold(Ca, ib);
+        }
+    } else {
         T Ca[NC][RB], Cc[NC][RB];
         load_block(0, Ca);
         for (int ib = 0; ib < nb; ib += 2) {
@@ -180,7 +196,13 @@ __global__ void __launch_bounds__(64, 2) ext_stream_evaluate_kernel(const ext::E
             }
         }
     };
-    {
+    if constexpr (ext_stream_single<T, NC>()) {
+        for (int ib = nb - 1; ib >= 0; --ib) {
+            T Ca[NC][RB];
+            load_block(ib * ROWS, Ca);
+            unfold(Ca, ib);
+        }
+    } else {
         T Ca[NC][RB], Cc[NC][RB];
         load_block((nb - 1) * ROWS, Ca);
         for (int ib = nb - 1; ib >= 0; ib -= 2) {
@@ -200,7 +222,7 @@ template <typename T, int N, int P, int RB> constexpr size_t ext_stream_snap_byt
 }
 
 template <typename T, int N, int P> int launch_ext_stream(const ext::ExtArgs<T> &a, hipStream_t stream) {
-    constexpr int RB = ext_block_rows<T, N + 1 + P>();
+    constexpr int RB = ext_stream_rows<T, N + 1 + P>();
     const bool want_rj = a.r_out != nullptr || a.J_out != nullptr;
     const size_t snap = want_rj ? ext_stream_snap_bytes<T, N, P, RB>(a.m) : 0;
     if (snap > kEvalSnapMax) return VP_ERR_UNSUPPORTED; // (the caller falls back to the generic kernels)
