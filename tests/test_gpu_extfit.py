@@ -272,6 +272,14 @@ def test_eleven_columns_streamed():
     a2, _C2, rep2, _s2 = bp.fit_with_model(host_model(cm), guess, derivatives_on_accept=True)
     assert np.array_equal(a, a2) and np.array_equal(rep["objective"], rep2["objective"])
     bp.close()
+    # fp32 handle (one resident block of 8 rows per lane: ext_fit_stream_single): the same minimum to single precision
+    cm.dtype = np.dtype(np.float32)
+    bp32 = vp.BatchProblem(cm.shape(), Y.astype(np.float32))
+    a32, _C32, rep32, _s32 = bp32.fit_with_model(host_model(cm), guess.astype(np.float32))
+    ok = (ref[1] > 0) & (rep32["termination"] > 0)
+    assert ok.mean() >= 0.9
+    assert (np.abs(rep32["objective"] - ref[3])[ok] <= 5e-3 * ref[3][ok]).all()
+    bp32.close()
 
 
 def test_lm_options_and_failures_follow_the_oracle():
