@@ -346,7 +346,10 @@ void vp_lm_opts_default(vp_lm_opts *opts, int dtype);
  *       VP_FIT_DERIVATIVES_ON_ACCEPT: the driver's own call order -- trial points want Phi only (want = 1, dPhi is not
  *       read and may be NULL); a problem that ACCEPTS its trial point answers want = 3 with the same alpha_trial and
  *       forms its Jacobian from the columns of the next step.  eval_partial_deriv is then evaluated exactly where the
- *       reference evaluates it, at the price of a second pass over Phi per accepted point.
+ *       reference evaluates it, at the price of a second pass over Phi per accepted point.  A problem whose want = 3
+ *       request is answered with dPhi == NULL ends with VP_TERM_USER (the reference: eval_partial_deriv failed ->
+ *       jacobian() == None); a handle WITHOUT dependency pairs (n_pairs == 0: every eval_partial_deriv is zero) never
+ *       reads dPhi and its fits end `Orthogonal` at alpha0 -- the zero Jacobian's scaled gradient is 0 <= gtol.
  *   vp_fit_end(h, alpha_out, C_out, rep)
  *       FitResult::nonlinear_parameters / linear_coefficients (src/fit.rs:113-115) and the MinimizationReport of every
  *       problem (rep[b].termination == VP_TERM_NOT_RUN for a problem the caller stopped stepping before it terminated;

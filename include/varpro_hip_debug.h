@@ -33,6 +33,14 @@ int vp_debug_gram_evaluate(vp_batch *h, const void *alpha, double *out);
 int vp_debug_lmpar_gram(int64_t B, int q, const double *Rj, const int32_t *ipvt, const double *diag, const double *qtb,
                         const double *delta, const double *par_in, double *out);
 
+/*
+ * Diagnostics for the flag-and-refit tests: enabled != 0 (the default) lets vp_fit re-fit, in a second launch with
+ * power-of-two column scaling, the problems whose Jacobian factor is not representable column by column -- the reference
+ * forms D_k c before it projects (src/solvers/levmar/mod.rs:156-171); 0 returns what the fit kernels themselves report for
+ * them (VP_TERM_NUMERICAL, parameters = the initial guess).  Single-right-hand-side descriptor handles only.
+ */
+int vp_debug_set_refit(vp_batch *h, int enabled);
+
 #ifdef __cplusplus
 }
 #endif

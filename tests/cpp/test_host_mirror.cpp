@@ -194,6 +194,27 @@ static void test_closure_errors() {
     EXPECT(variant_of([&] { ClosureModel({"a"}, x).function({"a"}, id).partial_deriv("a", id).partial_deriv("a", id); }) == "DuplicateDerivative");
     ClosureModel cm = peaks_model(x);
     EXPECT(cm.parameter_count() == 4 && cm.base_function_count() == 3 && cm.pairs().size() == 4);
+    // == ModelError::UnexpectedFunctionOutput (src/model/model_basis_function.rs:70): a closure that returns a column of
+    // the wrong length is an error, never a write outside its column (too long) or a silently zero tail (too short)
+    auto too_long = [](const std::vector<double> &x, const std::vector<double> &) { return std::vector<double>(x.size() + 3, 1.0); };
+    auto too_short = [](const std::vector<double> &x, const std::vector<double> &) { return std::vector<double>(x.size() - 1, 1.0); };
+    auto model_error_of = [](const std::function<void()> &f) -> std::string {
+        try {
+            f();
+        } catch (const ModelError &e) {
+            return e.variant + ":" + std::to_string(e.expected_length) + ":" + std::to_string(e.actual_length);
+        }
+        return "";
+    };
+    {
+        ClosureModel bad({"a"}, x);
+        bad.function({"a"}, too_long).partial_deriv("a", id);
+        EXPECT(model_error_of([&] { bad.eval_batch({1.0, 2.0}, 2); }) == "UnexpectedFunctionOutput:4:7");
+        ClosureModel bad2({"a"}, x);
+        bad2.function({"a"}, id).partial_deriv("a", too_short);
+        EXPECT(model_error_of([&] { bad2.eval_batch({1.0}, 1); }) == "");
+        EXPECT(model_error_of([&] { bad2.derivs_batch({1.0}, 1); }) == "UnexpectedDerivativeOutput:4:3");
+    }
 }
 
 // LevMarSolver::fit for a BATCH of closure models: LM drivers on the device, the model on the host

@@ -353,3 +353,96 @@ def test_model_without_any_derivative_column_has_a_zero_jacobian():
     bp.set_params_with_basis(alpha, Phi)
     assert np.array_equal(np.asarray(bp.jacobian()), np.zeros((B, 2, m)))
     bp.close()
+
+
+def test_a_fit_without_derivative_columns_ends_orthogonal():
+    """a handle with q > 0 and NO dependency pair (every eval_partial_deriv is zero) is accepted by
+    vp_batch_create_external and vp_fit_begin; stepping until n_active == 0 must end.  The reference's driver sees J = 0 ->
+    scaled gradient 0 <= gtol -> `Orthogonal` after ONE evaluation (levenberg-marquardt minimize; src/solvers/levmar/mod.rs:247)."""
+    rng = np.random.default_rng(5)
+    m, B = 128, 70  # (more than one wavefront of the lane-per-problem LM kernel)
+    x = np.linspace(0.0, 1.0, m)
+    Phi = np.stack([[np.ones(m), x, x * x]] * B)
+    Y = rng.standard_normal((B, m))
+    bp = vp.BatchProblem(vp.ExternalModel(3, 2, []), Y)
+    alpha0 = rng.random((B, 2))
+    for lazy in (False, True):
+        a, Cm, rep, steps = bp.fit_with_model(lambda al, want: (Phi, None), alpha0, derivatives_on_accept=lazy, max_steps=10)
+        rep = vp.BatchProblem.report_to_numpy(rep)
+        assert steps == 1
+        assert (rep["termination"] == 2).all() and (rep["n_evals"] == 1).all()
+        assert np.array_equal(np.asarray(a), alpha0)
+        for b in range(0, B, 9):
+            c_ref = np.linalg.lstsq(Phi[b].T, Y[b], rcond=None)[0]
+            assert np.abs(Cm[b] - c_ref).max() <= 1e-10 * np.abs(c_ref).max()
+            r = Y[b] - Phi[b].T @ c_ref
+            assert abs(rep["objective"][b] - 0.5 * r @ r) <= 1e-12 * (r @ r)
+    bp.close()
+
+
+def test_withheld_derivative_columns_end_the_fit_instead_of_spinning():
+    """a VP_FIT_DERIVATIVES_ON_ACCEPT caller that answers a want = basis | derivatives request with
+    dPhi == NULL.  The reference: eval_partial_deriv fails -> jacobian() == None -> the driver ends with `User`.  The device
+    must not defer the request for ever (the evaluation count does not advance in that phase)."""
+    rng = np.random.default_rng(6)
+    m, B = 200, 8
+    x = np.linspace(0.0, 10.0, m)
+    cm = peaks_model(x)
+    _t, _c, Y, guess = peaks_data(rng, B, x, noise=1e-2)
+    bp = vp.BatchProblem(cm.shape(), Y)
+    bp.fit_begin(guess, derivatives_on_accept=True)
+    alpha, want, nact = bp.fit_step_with_basis(cm.eval_batch(guess), cm.derivs_batch(guess))
+    steps = 1
+    while nact > 0 and steps < 50:
+        a = np.asarray(alpha).copy()
+        alpha, want, nact = bp.fit_step_with_basis(cm.eval_batch(a), None)  # never any derivative column again
+        steps += 1
+    assert nact == 0 and steps < 50
+    _a, _C, rep = bp.fit_end()
+    rep = vp.BatchProblem.report_to_numpy(rep)
+    # every problem either finished on its own before its first accepted step or ended `User` at the withheld Jacobian
+    assert ((rep["termination"] == -1) | (rep["termination"] > 0)).all()
+    assert (rep["termination"] == -1).sum() >= B // 2
+    bp.close()
+
+
+def test_finished_problems_are_reported_in_every_steps_arrays():
+    """on device-pointer handles the step kernel writes the caller's alpha_trial_out / want_out directly; a
+    caller that ROTATES those arrays between steps must still find want = 0 and the final parameters of the problems that
+    finished in an earlier step (include/varpro_hip.h, vp_fit_step_with_basis)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    m, B = 200, 96
+    x = np.linspace(0.0, 10.0, m)
+    cm = peaks_model(x)
+    _t, _c, Y, guess = peaks_data(rng, B, x, noise=1e-2)
+    model = torch_peaks_model(x, dev)
+    bp = vp.BatchProblem(cm.shape(), torch.as_tensor(Y, device=dev))
+    g = torch.as_tensor(guess, device=dev)
+    bp.fit_begin(g)
+    alpha, nact, steps = g, B, 0
+    finished_at = {}
+    while nact > 0 and steps < 300:
+        Phi, dPhi = model(alpha, None)
+        # fresh, poisoned output arrays every step
+        bp._xf_trial = torch.full((B, 4), float("nan"), dtype=torch.float64, device=dev)
+        bp._xf_want = torch.full((B,), 77, dtype=torch.int32, device=dev)
+        alpha, want, nact = bp.fit_step_with_basis(Phi, dPhi)
+        steps += 1
+        w = want.cpu().numpy()
+        assert set(np.unique(w)) <= {0, 1, 3}, np.unique(w)
+        a = alpha.cpu().numpy()
+        assert np.isfinite(a).all()
+        for b in np.nonzero(w == 0)[0]:
+            if b in finished_at:
+                assert np.array_equal(a[b], finished_at[b]), "a finished problem's parameters changed in a later step"
+            else:
+                finished_at[b] = a[b].copy()
+        alpha = alpha.clone()
+    assert nact == 0 and len(finished_at) == B
+    a_end, _C, rep = bp.fit_end()
+    a_end = a_end.cpu().numpy()
+    for b, v in finished_at.items():
+        assert np.array_equal(a_end[b], v)
+    bp.close()

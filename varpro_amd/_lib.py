@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
 
 
 # test hooks (include/varpro_hip_debug.h): exported by the library, not part of the drop-in boundary
-DEBUG_SYMBOLS = ["vp_debug_gram_evaluate", "vp_debug_lmpar_gram"]
+DEBUG_SYMBOLS = ["vp_debug_gram_evaluate", "vp_debug_lmpar_gram", "vp_debug_set_refit"]
 
 
 class VarproHipUnavailable(ImportError):
@@ -137,6 +137,7 @@ def load():
     lib.vp_best_fit.argtypes = [vp, vp]
     lib.vp_debug_gram_evaluate.argtypes = [vp, vp, vp]
     lib.vp_debug_lmpar_gram.argtypes = [C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.vp_debug_set_refit.argtypes = [vp, C.c_int]
     lib.vp_statistics.argtypes = [vp, vp, vp, vp, vp]
     lib.vp_summary.argtypes = [vp, dp]
     lib.vp_summary_device.argtypes = [vp, vp]

@@ -615,6 +615,12 @@ class BatchProblem:
         code = {"auto": _lib.VP_FIT_KERNEL_AUTO, "wave": _lib.VP_FIT_KERNEL_WAVE, "slots": _lib.VP_FIT_KERNEL_SLOTS}[which]
         check(self.lib.vp_set_fit_kernel(self._h, code))
 
+    def set_refit(self, enable=True):
+        """diagnostics (include/varpro_hip_debug.h:vp_debug_set_refit): False returns what the fit kernels themselves report
+        for a problem whose Jacobian factor is not representable column by column (Numerical, parameters = the guess)
+        instead of re-fitting it with scaled columns in vp_fit's second launch"""
+        check(self.lib.vp_debug_set_refit(self._h, int(enable)))
+
     def set_timing(self, enable=True):
         check(self.lib.vp_set_timing(self._h, int(enable)))
 

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <functional>
 #include <map>
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -50,6 +51,16 @@ inline int arity(Basis k) {
 struct ModelBuildError : std::runtime_error {
     std::string variant;
     ModelBuildError(std::string v, const std::string &msg) : std::runtime_error(v + ": " + msg), variant(std::move(v)) {}
+};
+// == ModelError (src/model/errors.rs): an error of the model AT EVALUATION time; UnexpectedFunctionOutput carries the
+// expected and the actual column length (src/model/model_basis_function.rs:70)
+struct ModelError : std::runtime_error {
+    std::string variant;
+    size_t function_index, expected_length, actual_length;
+    ModelError(std::string v, size_t j, size_t expected, size_t actual)
+        : std::runtime_error(v + ": basis function " + std::to_string(j) + " returned " + std::to_string(actual) + " elements, expected " +
+                             std::to_string(expected)),
+          variant(std::move(v)), function_index(j), expected_length(expected), actual_length(actual) {}
 };
 // == SeparableProblemBuilderError (src/problem/builder.rs:15-46)
 struct SeparableProblemBuilderError : std::runtime_error {
@@ -461,6 +472,9 @@ class ClosureModel {
                 std::vector<double> pr;
                 for (int k : fns_[j].idx) pr.push_back(alpha[(size_t)b * q + (size_t)k]);
                 const std::vector<double> v = fns_[j].f(x_, pr);
+                // == ModelError::UnexpectedFunctionOutput (src/model/model_basis_function.rs:70): a column of the wrong length is
+                // an error of the model, never a write past (or short of) its slot
+                if (v.size() != m) throw ModelError("UnexpectedFunctionOutput", j, m, v.size());
                 std::copy(v.begin(), v.end(), out.begin() + ((size_t)b * n + j) * m);
             }
         return out;
@@ -476,6 +490,7 @@ class ClosureModel {
                 std::vector<double> pr;
                 for (int k : bs.idx) pr.push_back(alpha[(size_t)b * q + (size_t)k]);
                 const std::vector<double> v = bs.derivs.at(prs[p].second)(x_, pr);
+                if (v.size() != m) throw ModelError("UnexpectedDerivativeOutput", (size_t)prs[p].first, m, v.size());
                 std::copy(v.begin(), v.end(), out.begin() + ((size_t)b * prs.size() + p) * m);
             }
         return out;
@@ -487,14 +502,16 @@ class ClosureModel {
 // (src/solvers/levmar/mod.rs:238-254): the LM drivers on the device, the model with the caller
 class ExternalBatchProblem {
     vp_batch *h_ = nullptr;
-    const ClosureModel *model_ = nullptr;
+    // the model is COPIED (closures are shared_ptr-backed std::function objects: cheap): a problem built from a temporary
+    // model must not dangle, and the reference's problem owns its model too (src/problem.rs:55-70)
+    std::shared_ptr<const ClosureModel> model_;
 
   public:
     int64_t m = 0, B = 0;
     int n = 0, q = 0, np = 0;
     ExternalBatchProblem(const ClosureModel &model, const std::vector<double> &Y, int64_t B_, const std::vector<double> *weights = nullptr,
                          double epsilon = -1.0, int device = 0)
-        : model_(&model) {
+        : model_(std::make_shared<const ClosureModel>(model)) {
         model.validate();
         m = (int64_t)model.output_len();
         B = B_;

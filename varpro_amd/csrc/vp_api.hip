@@ -20,6 +20,12 @@
 
 using namespace vp;
 
+// global fit: identical consecutive fits (by their longest problem's evaluation count) before the captured graph drops its
+// spare iteration (mrhs_fit)
+#ifndef VP_MRHS_EXACT_AFTER
+#define VP_MRHS_EXACT_AFTER 8
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -243,6 +249,11 @@ struct vp_batch {
     int xf_flags;
     int64_t xf_steps;
     vp_lm_opts xf_opts;
+    // flag-and-refit of single-RHS fits (vp_fit.hpp jac_not_finite; rescue_refit below)
+    int32_t *d_rescue;      // [2 + B]: two ping-pong counters + the flagged problems of the running fit
+    void *d_rescue_ws;      // kRescueBlocks workspace slots of the generic fit kernel
+    int rescue_slot;        // the counter the NEXT fit appends to
+    bool rescue_off;        // vp_debug / VP_NO_RESCUE=1: fits keep the kernels' own `Numerical` (what rounds 1-4 returned)
 };
 
 namespace {
@@ -730,11 +741,14 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
     // short of it by 4 or more (each idle iteration is two empty launches, ~10 us); the 12-iteration tail graph does not
     // depend on the length and is only re-captured with the options.
     const bool opts_changed = !h->mrhs_graph || std::memcmp(&h->mrhs_graph_opts, &o, sizeof(o)) != 0;
-    // (a handle whose last three fits took the same number of evaluations drops the spare iteration -- two empty launches,
-    // ~10 us of a 0.7 ms fit: want_iters is then exact and the head is re-captured once to that length)
-    const bool exact = h->mrhs_same_count >= 2;
+    // (a handle whose last VP_MRHS_EXACT_AFTER + 1 fits took the same number of evaluations drops the spare iteration -- two
+    // empty launches, ~10 us of a 0.7 ms fit: want_iters is then exact and the head is re-captured ONCE, down to that length.
+    // The exact length only ever SHRINKS the graph: a stream whose longest fit moves by +-1 every few calls (A A A B A A A B)
+    // never reaches the run length, and after a miss the spare-iteration rule above decides alone -- no recapture per
+    // fluctuation.)
+    const bool exact = h->mrhs_same_count >= VP_MRHS_EXACT_AFTER;
     if (want_graph && (opts_changed || want_iters > h->mrhs_graph_len || want_iters + 4 <= h->mrhs_graph_len ||
-                       (exact && want_iters != h->mrhs_graph_len))) {
+                       (exact && want_iters < h->mrhs_graph_len))) {
         if (h->mrhs_graph) (void)hipGraphExecDestroy(h->mrhs_graph);
         h->mrhs_graph = nullptr;
         bool ok = capture(h->mrhs_graph, true, want_iters);
@@ -777,7 +791,7 @@ int mrhs_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out
         const int nfev_max = ((volatile int32_t *)h->h_nactive)[1];
         h->mrhs_same_count = (nfev_max == h->mrhs_prev_nfev) ? h->mrhs_same_count + 1 : 0;
         h->mrhs_prev_nfev = nfev_max;
-        int it_next = nfev_max + (h->mrhs_same_count >= 2 ? 0 : 1);
+        int it_next = nfev_max + (h->mrhs_same_count >= VP_MRHS_EXACT_AFTER ? 0 : 1);
         it_next = it_next < 6 ? 6 : (it_next > 24 ? 24 : it_next);
         h->mrhs_graph_iters = it_next;
     } else {
@@ -1210,6 +1224,8 @@ void vp_batch_destroy(vp_batch *h) {
     (void)hipFree(h->d_xf_trial);
     (void)hipFree(h->d_xf_want);
     (void)hipFree(h->d_xf_nactive);
+    (void)hipFree(h->d_rescue);
+    (void)hipFree(h->d_rescue_ws);
     if (h->h_xf_nactive) (void)hipHostFree(h->h_xf_nactive);
     // (the struct is zero-initialised: freeing unconditionally also covers a create that failed half way)
     (void)hipFree(h->mrhs.qthin);
@@ -1330,13 +1346,12 @@ int vp_fit_begin(vp_batch *h, const vp_lm_opts *opts, const void *alpha0, int fl
     const size_t rec = external_fit_rec_bytes(h->dtype, h->n, h->ext_np, h->q, h->m);
     if (!rec) return fail(VP_ERR_UNSUPPORTED, "no step kernel for this (n, q, pairs, m) of a caller-evaluated model");
     const size_t ts = tsize(h->dtype);
-    if (!h->d_xf_state) {
-        VP_HIP(hipMalloc(&h->d_xf_state, (size_t)h->B * rec + 16));
-        VP_HIP(hipMalloc(&h->d_xf_trial, (size_t)h->B * h->q * ts));
-        VP_HIP(hipMalloc((void **)&h->d_xf_want, (size_t)h->B * sizeof(int32_t)));
-        VP_HIP(hipMalloc((void **)&h->d_xf_nactive, 2 * sizeof(int32_t)));
-        VP_HIP(hipHostMalloc((void **)&h->h_xf_nactive, sizeof(int32_t), hipHostMallocDefault));
-    }
+    // (each buffer guarded on its own: an allocation that fails half way leaves the handle in a state the next call completes)
+    if (!h->d_xf_state) VP_HIP(hipMalloc(&h->d_xf_state, (size_t)h->B * rec + 16));
+    if (!h->d_xf_trial) VP_HIP(hipMalloc(&h->d_xf_trial, (size_t)h->B * h->q * ts));
+    if (!h->d_xf_want) VP_HIP(hipMalloc((void **)&h->d_xf_want, (size_t)h->B * sizeof(int32_t)));
+    if (!h->d_xf_nactive) VP_HIP(hipMalloc((void **)&h->d_xf_nactive, 2 * sizeof(int32_t)));
+    if (!h->h_xf_nactive) VP_HIP(hipHostMalloc((void **)&h->h_xf_nactive, sizeof(int32_t), hipHostMallocDefault));
     if (opts) h->xf_opts = *opts;
     else vp_lm_opts_default(&h->xf_opts, h->dtype);
     VP_HIP(hipMemcpyAsync(h->d_alpha, alpha0, (size_t)h->B * h->q * ts,
@@ -1617,6 +1632,44 @@ int vp_fit(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, 
     return vp_fit_trace(h, opts, alpha_inout, C_out, rep, nullptr, 0);
 }
 
+// ---- flag-and-refit (round 6; vp_fit.hpp jac_not_finite) --------------------------------------------------------------
+// A fit kernel that finds the Jacobian factor of an accepted point non-finite after an evaluation that was ok ends that fit,
+// appends the problem to h->d_rescue and leaves its initial guess in h->d_alpha.  rescue_refit launches the generic fit
+// kernel (any descriptor, any m, weights) over that list with power-of-two column scaling -- the reference's order of
+// operations, D_k c first (src/solvers/levmar/mod.rs:156-171) -- from alpha0; it overwrites every output of those
+// problems.  kRescueBlocks persistent workgroups: a launch with an empty list ends in the time of the launch itself
+// (~3 us on the stream, no host synchronisation anywhere).
+namespace {
+constexpr int kRescueBlocks = 8;
+int rescue_prepare(vp_batch *h, LaunchParams &p) {
+    if (h->rescue_off || h->kern->family == FAMILY_GENERIC || h->kern->gram_fit) return 0; // (the generic kernel scales by itself)
+    if (!h->d_rescue) {
+        VP_HIP(hipMalloc((void **)&h->d_rescue, (size_t)(2 + h->B) * sizeof(int32_t)));
+        VP_HIP(hipMemsetAsync(h->d_rescue, 0, 2 * sizeof(int32_t), h->stream));
+        h->rescue_slot = 0;
+    }
+    if (!h->d_rescue_ws) {
+        const size_t slot = (size_t)(h->n + 1 + h->p + h->q) * (size_t)h->m * tsize(h->dtype);
+        VP_HIP(hipMalloc(&h->d_rescue_ws, (size_t)kRescueBlocks * slot));
+    }
+    p.rescue = h->d_rescue;
+    p.rescue_slot = h->rescue_slot;
+    return 0;
+}
+int rescue_refit(vp_batch *h, const LaunchParams &fit_params) {
+    if (!fit_params.rescue) return 0;
+    LaunchParams p = fit_params;
+    p.rescue = nullptr;
+    p.gen_ws = h->d_rescue_ws;
+    p.gen_blocks = kRescueBlocks;
+    p.gen_list = h->d_rescue;
+    p.gen_list_slot = h->rescue_slot;
+    p.gen_scale_cols = 1;
+    h->rescue_slot ^= 1;
+    return generic_kernels(h->dtype)->fit_single(p);
+}
+} // namespace
+
 int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C_out, vp_report *rep,
                  double *trace_out, int trace_rows) {
     VP_ENTER(h);
@@ -1674,8 +1727,10 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
     // (vp_fit.hpp) by itself for the cases it does not cover (weights, per-problem grids, models without a trailing
     // constant column, batches smaller than the device's resident wave slots).  vp_set_fit_kernel overrides.
     launch_fn fit_fn = h->kern->fit ? h->kern->fit : h->kern->fit_single;
+    if (int rc0 = rescue_prepare(h, p)) return rc0;
     Timer tm(h, VP_KERNEL_FIT);
     int rc = fit_fn(p);
+    if (rc == VP_ERR_OK) rc = rescue_refit(h, p); // (second, tiny launch: the problems the fit kernels flagged)
     tm.stop();
     if (rc != VP_ERR_OK) return fail(rc, "fit kernel launch failed");
     h->have_params = true;
@@ -1685,6 +1740,12 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
     if (int rc2 = copy_out(h, C_out, h->d_C, (size_t)h->B * h->n * ts)) return rc2;
     if (int rc2 = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc2;
     if (int rc2 = tr.finish(h)) return rc2;
+    return VP_ERR_OK;
+}
+
+int vp_debug_set_refit(vp_batch *h, int enabled) {
+    VP_ENTER(h);
+    h->rescue_off = enabled == 0;
     return VP_ERR_OK;
 }
 

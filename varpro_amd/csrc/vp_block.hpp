@@ -341,6 +341,7 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
         for (int k = 0; k < Q; ++k) a0[k] = a.alpha[b * Q + k];
         lm_init<T, N, Q>(S, a0);
     }
+    bool flagged = false; // handed to the re-fit launch (vp_fit.hpp, jac_not_finite)
     T cbest[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) cbest[k] = T(0);
@@ -534,7 +535,8 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
             }
             jac_qrfac<T, 2, Q, N>(Zs, K[N], S.Rj, S.acnorm, S.ipvt, S.qtf, grp);
         }
-        lm_next_step<T, N, Q, true>(S, opt, need);
+        // (a refreshed factor with non-finite column norms: flag and re-fit, vp_fit.hpp jac_not_finite)
+        if (lm_next_step<T, N, Q, true>(S, opt, need)) flagged = a.rescue != nullptr;
     }
 
     if (lane == 0 && wave == 0) {
@@ -545,8 +547,12 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
         a.report[b] = rep;
         if (a.cost_out) a.cost_out[b] = (double)S.objective;
         if (a.status) a.status[b] = S.status;
+        if (flagged) { // alpha[b] keeps the initial guess for the re-fit launch
+            rescue_push(a.rescue, a.rescue_slot, b);
+        } else {
 #pragma unroll
-        for (int k = 0; k < Q; ++k) a.alpha[b * Q + k] = S.x[k];
+            for (int k = 0; k < Q; ++k) a.alpha[b * Q + k] = S.x[k];
+        }
         if (a.C_out) {
 #pragma unroll
             for (int k = 0; k < N; ++k) a.C_out[b * N + a.mdl.out_index(k)] = cbest[k];
@@ -855,6 +861,8 @@ template <typename T, class M> int launch_fit(const LaunchParams &p) {
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
     a.grid_uniform = p.grid_uniform;
+    a.rescue = p.rescue;
+    a.rescue_slot = p.rescue_slot;
     if (a.B <= 0) return VP_ERR_OK;
     constexpr int RB = block_rows<T, M::N + 1 + M::P, M::kStatic>();
     // A launch that does not fill the device several times over ends when its LONGEST fit does (evaluation counts are

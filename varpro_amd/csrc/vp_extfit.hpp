@@ -256,7 +256,14 @@ template <typename T, int Q> __global__ void __launch_bounds__(64) ext_fit_lm_ke
 #pragma unroll
         for (int k = 0; k < VP_MAX_BASIS; ++k) st[(F::CBEST + k) * B + b] = T(0);
     } else {
-        if (si[F::TERM * B + b] != 0) return;
+        if (si[F::TERM * B + b] != 0) {
+            // finished in an earlier step: the caller's arrays of THIS step (they may be other buffers than the last step's)
+            // still get what the header promises -- want = 0 and the final parameters
+            a.want[b] = 0;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) a.alpha_trial[b * Q + k] = st[(F::X + k) * B + b];
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
             s.x[k] = st[(F::X + k) * B + b];
@@ -304,10 +311,29 @@ template <typename T, int Q> __global__ void __launch_bounds__(64) ext_fit_lm_ke
         }
     }
     bool deferred = false;
-    if (s.term == 0 && need_jac && !has_jac) {
-        deferred = true; // accepted without derivative columns at hand (second protocol): ask for them at this very point
+    const bool zero_jac = a.np == 0; // a model without derivative columns: eval_partial_deriv is zero for every parameter
+    if (s.term == 0 && need_jac && !has_jac && !zero_jac) {
+        if (phase == EXTFIT_PH_JAC) {
+            // the derivative columns were asked for at this point in the previous step and did not come (dPhi == NULL):
+            // the model's eval_partial_deriv failed -> jacobian() == None -> the driver ends with `User`
+            // (src/solvers/levmar/mod.rs:101-104).  Deferring again would never end: nfev does not advance here.
+            s.term = VP_TERM_USER;
+            s.status = VP_ST_NONFINITE;
+        } else {
+            deferred = true; // accepted without derivative columns at hand (second protocol): ask for them at this very point
+        }
     } else if (s.term == 0) {
-        if (need_jac) { // the candidate factor becomes the factor of the current point
+        if (need_jac && zero_jac) {
+            // J = 0: R_J = 0, Q_J^T r = 0, column norms 0 -> the scaled gradient is 0 <= gtol: `Orthogonal`, as in the reference
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                s.acnorm[k] = T(0);
+                s.qtf[k] = T(0);
+                s.ipvt[k] = k;
+#pragma unroll
+                for (int j = 0; j < Q; ++j) s.Rj[k][j] = T(0);
+            }
+        } else if (need_jac) { // the candidate factor becomes the factor of the current point
 #pragma unroll
             for (int k = 0; k < Q; ++k) {
                 s.acnorm[k] = st[(F::C_ACN + k) * B + b];

@@ -993,84 +993,26 @@ __device__ __forceinline__ void jac_qrfac_scaled(T (&Z)[Q][R], T (&rv)[R], const
     for (int j = 0; j < Q; ++j) Rj[j][j] = sc[j] * rdiag[j];
 }
 
-// ---- rescue of a Jacobian that is not representable column by column (round 5) ---------------------------------------
+// ---- a Jacobian that is not representable column by column: flag and re-fit (round 6) -------------------------------
 // The fit kernels carry the UNSCALED derivative columns dPhi_k through the sweep and let the coefficient c_k enter the
 // Jacobian QR as a wave-uniform factor (jac_qrfac_scaled).  The reference forms D_k c first and projects afterwards
 // (src/solvers/levmar/mod.rs:156-171), so a trial point at which a basis column is huge and its coefficient tiny -- a decay
 // time stepping through zero: exp(+t/0.035) = 1e153, c = 1e-152 -- is an ordinary evaluation there (D_k c = 1e5), while
-// here the dot product of the 1e153 column with its 1e157 derivative column overflows and the fit would end `Numerical`
-// (one problem in the 524 288 of BASELINE configs[3]).  When a Jacobian comes out non-finite after an evaluation that
-// was itself ok, evaluation and Jacobian are REPEATED out of line with every derivative column scaled by 2^-ks, ks = the
-// binary exponent of its basis column's largest entry, and the coefficient by 2^ks: the basis part (R, c, the residual) is
-// bit for bit the evaluation that was just made, c_k D_k is unchanged, nothing overflows; power-of-two factors are exact, so
-// where the unscaled Jacobian IS representable the two agree to the last bit.  The results go to LDS (the caller's parked
-// LM record): the call sites sit where little is live, and the hot path pays the finiteness test of acnorm only.
-template <typename T, int Q> struct ParamPack {
-    T v[Q];
-};
-#ifndef VP_JAC_RESCUE
-#define VP_JAC_RESCUE 1
-#endif
-// Where: the kernels of FULL-LENGTH, unweighted problems (PADM == 1: m == 64 R -- the sets every census runs on).  In the
-// kernels compiled for a general length or for weights the call's register constraints reach into the hot loop (the row
-// masks / weight columns are live across everything: 11 -> 37 scratch reloads per evaluation at PADM = 0, 139 -> 224 spilled
-// VGPRs), for an event that takes a decay time through zero within a factor 1e2 of overflow (2 in a million fits): those
-// kernels keep the round-4 behaviour (the fit ends `Numerical`).
-template <typename T, class M, int W, int PADM = 1, bool WEIGHTED = false>
-inline constexpr bool jac_rescue_v = VP_JAC_RESCUE && sizeof(T) == 8 && W == 1 && PADM == 1 && !WEIGHTED && M::kStatic &&
-                                     M::kConstLast && M::kDiagonalPairs;
-
-template <typename T, class M, int R, class Src, bool YPRE>
-__device__ __noinline__ void rescue_jacobian(const ParamPack<T, M::Q> al, const Src src, const T eps, const T h0_beta,
-                                             const T h0_u, const T h0_g, const T *s_col, const T qty0, VP_LDS T *Rj_out,
-                                             VP_LDS T *acnorm_out, VP_LDS T *qtf_out, VP_LDS int *ipvt_out) {
-    constexpr int N = M::N, P = M::P, Q = M::Q, NE = N - 1;
-    constexpr int NC = N + P, YC = N - 1, DC = YC + 1;
-    using G = Grp<1>;
-    G grp = G::make(nullptr);
-    const int lane = grp.gl;
-    const M mdl{};
-    ConstReflector<T> h0;
-    h0.beta = h0_beta;
-    h0.u = h0_u;
-    h0.g = h0_g;
-    h0.live = true;
-    T alpha[Q];
+// here the dot product of the 1e153 column with its 1e157 derivative column overflows (one problem in the 524 288 of
+// BASELINE configs[3]).  Round 5 redid such a Jacobian out of line INSIDE the hot kernels (rescue_jacobian: 29 more spilled
+// VGPRs in every wave of the headline kernel for a 2e-6 event, and only in the full-length unweighted static kernels).
+// Round 6: every fit kernel -- any length, weights, run-time descriptors, streamed rows -- only TESTS the column norms of
+// the Jacobian factor it just made; a problem whose factor is not finite after an evaluation that was itself ok ends its
+// fit, appends its index to the handle's rescue list (rescue_push, vp_kernels.hpp) and leaves its initial guess in place.
+// vp_fit then re-fits the listed problems from alpha0 in a second, tiny launch of the generic kernel with every huge basis
+// column and its derivative columns scaled by the same power of two (gen::evaluate, vp_generic.hpp: c_k D_k is unchanged,
+// power-of-two factors are exact, nothing overflows).  A fit is a pure function of its inputs: every problem that is not
+// flagged is bit for bit what it was.
+template <typename T, int Q> __device__ __forceinline__ bool jac_not_finite(const T (&acnorm)[Q]) {
+    bool bad = false;
 #pragma unroll
-    for (int k = 0; k < Q; ++k) alpha[k] = al.v[k];
-    // largest exponent of exp(-t/tau_j) over the grid, from its two ends (grids are sorted; an unsorted one keeps ks = 0 and
-    // with it the unscaled result)
-    const T t_first = src.t[0], t_last = src.t[src.m - 1];
-    int ks[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) ks[j] = 0;
-#pragma unroll
-    for (int j = 0; j < NE; ++j) {
-        const T rt = T(1) / alpha[j];
-        const T e2 = tmax(-t_first * rt, -t_last * rt) * T(1.4426950408889634);
-        ks[j] = uni((e2 > T(64) && e2 < T(1100)) ? (int)e2 : 0);
-    }
-    T C[NC][R];
-    EvalUniform<T, N> u;
-    load_rows_lds<T, R, 1>(s_col, lane, C[YC]);
-    evaluate_core_const_first<T, M, R, NC, Src, G, YPRE, false, true>(mdl, alpha, src, eps, grp, h0, C, u, nullptr, qty0, ks);
-    residual_qcoords<T, R, N>(C[YC], u.e, grp);
-    T zs[Q], Rj[Q][Q], acnorm[Q], qtf[Q];
-    int ipvt[Q];
-#pragma unroll
-    for (int k = 0; k < Q; ++k) zs[k] = -tldexp(u.c[k], ks[k]);
-    jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < Q; ++k) {
-            acnorm_out[k] = acnorm[k];
-            qtf_out[k] = qtf[k];
-            ipvt_out[k] = ipvt[k];
-#pragma unroll
-            for (int j = 0; j < Q; ++j) Rj_out[k * Q + j] = Rj[k][j];
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int k = 0; k < Q; ++k) bad = bad || !is_finite(acnorm[k]);
+    return bad;
 }
 
 template <typename T, class M> struct FitArgs {
@@ -1093,6 +1035,8 @@ template <typename T, class M> struct FitArgs {
     double *trace;  // diagnostics (vp_fit_trace): [B][trace_rows][q+4] or null
     int trace_rows;
     int grid_uniform; // the handle's grids passed grid_check_kernel -> exp recurrence allowed
+    int32_t *rescue;  // flag-and-refit list (LaunchParams::rescue) or null
+    int rescue_slot;
 };
 
 // Wave-uniform LM state.  It is PARKED in LDS while the fused QR sweep runs (lane 0 writes, every
@@ -1189,6 +1133,7 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
     bool first = true, first_tr = true, first_update = true;
     int nfev = 0, term = VP_TERM_NOT_RUN;
     int st_best = VP_ST_NOT_EVALUATED;
+    bool flagged = false; // handed to the re-fit launch (jac_not_finite)
     const int max_fev = a.patience * (Q + 1);
     const int mres = m; // number of residuals (S == 1)
     int trow = 0;
@@ -1390,25 +1335,15 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
 #pragma unroll
                 for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
                 jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
-                if constexpr (CF && jac_rescue_v<T, M, W, PADM, WEIGHTED>) {
-                    bool bad = false;
-#pragma unroll
-                    for (int k = 0; k < Q; ++k) bad = bad || !is_finite(acnorm[k]);
-                    if (uni(bad)) { // (rare: rescue_jacobian; the LM state goes through its LDS record, nothing is live across the call)
-                        park();
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        ParamPack<T, Q> al;
-#pragma unroll
-                        for (int k = 0; k < Q; ++k) al.v[k] = xt[k];
-                        rescue_jacobian<T, M, R, Src, false>(al, src, a.eps, h0.beta, h0.u, h0.g, s_y, T(0), (VP_LDS T *)&st->Rj[0][0],
-                                                             (VP_LDS T *)st->acnorm, (VP_LDS T *)st->qtf, (VP_LDS int *)st->ipvt);
-                        unpark();
-                    }
-                }
             } else {
                 T Zs[Q][R];
                 jacobian_qcoords<T, M, R, NC, G, DC>(a.mdl, C, u.c, Zs, grp);
                 jac_qrfac<T, R, Q, N>(Zs, C[YC], Rj, acnorm, ipvt, qtf, grp);
+            }
+            if (uni(jac_not_finite<T, Q>(acnorm))) { // (rare) flag and re-fit: see jac_not_finite
+                term = VP_TERM_NUMERICAL;
+                flagged = a.rescue != nullptr;
+                break;
             }
             VP_TICK(clk, 5);
             // norm of the scaled gradient
@@ -1512,8 +1447,12 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
     }
     // lane 0 stores the (uniform) results one by one: a lane-indexed gather would turn x[] into a scratch array
     if (lane == 0) {
+        if (flagged) { // alpha[b] keeps the initial guess: the re-fit launch starts from it and overwrites every output
+            rescue_push(a.rescue, a.rescue_slot, b);
+        } else {
 #pragma unroll
-        for (int k = 0; k < Q; ++k) a.alpha[b * Q + k] = x[k];
+            for (int k = 0; k < Q; ++k) a.alpha[b * Q + k] = x[k];
+        }
         if (a.C_out) {
 #pragma unroll
             for (int k = 0; k < N; ++k) a.C_out[b * N + a.mdl.out_index(k)] = cbest[k];
@@ -1553,6 +1492,8 @@ template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchPara
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
     a.grid_uniform = p.grid_uniform;
+    a.rescue = p.rescue;
+    a.rescue_slot = p.rescue_slot;
     if (a.B <= 0) return VP_ERR_OK;
     const size_t lds = fit_lds_bytes<T, M, R, W>(p.w != nullptr);
     if (p.w) hipLaunchKernelGGL((fit_kernel<T, M, R, W, true>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);

@@ -82,6 +82,8 @@ template <typename T, typename TO = T> struct SlotConsts {
     double *trace;     // [B][trace_rows][q+4] or null
     const TO *yw;      // [B][m]
     int *queue;
+    int32_t *rescue;   // flag-and-refit list (vp_fit.hpp jac_not_finite; LaunchParams::rescue) or null
+    int rescue_slot;
     int64_t B;
     int trace_rows, scale_diag, max_fev, m;
     T eps;             // (Gram kernel) rank threshold of the linear solve
@@ -323,10 +325,20 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
         }
     }
     VP_SCK(1);
+    bool flagged = false;
     if (need_step && jac_done) {
         // the vector phase refreshed (Rj, qtf, acnorm, ipvt) at the accepted point
         T gmax = T(0);
+        // (rare) a factor whose column norms are not finite after an evaluation that was ok: the fit ends here and -- Householder
+        // kernels with a rescue list -- is re-fitted by vp_fit's second launch (vp_fit.hpp, jac_not_finite)
         bool degenerate = false;
+        if constexpr (!GRAM) {
+            bool jb = false;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) jb = jb || !is_finite(acnorm[i]);
+            degenerate = jb;
+            flagged = jb;
+        }
         const T ifn = frcp(fnorm);
 #pragma unroll
         for (int j = 0; j < Q; ++j) { // (selected, not branched: see above)
@@ -438,8 +450,13 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
         TO *alpha_out = k->alpha, *C_out = k->C_out;
         if (cost_out) cost_out[prob] = (double)objective;
         if (status_out && !VP_FITG_TIMELINE) status_out[prob] = status;
+        int32_t *rescue = k->rescue;
+        if (flagged && rescue) { // alpha[prob] keeps the initial guess for the re-fit launch
+            rescue_push(rescue, k->rescue_slot, prob);
+        } else {
 #pragma unroll
-        for (int i = 0; i < Q; ++i) alpha_out[prob * Q + i] = (TO)x[i];
+            for (int i = 0; i < Q; ++i) alpha_out[prob * Q + i] = (TO)x[i];
+        }
         if (C_out) {
 #pragma unroll
             for (int i = 0; i < N; ++i) C_out[prob * N + i] = (TO)s->cbest[i];
@@ -500,6 +517,7 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
     T fnorm, delta, par, xnorm, gnorm, pnorm, prered, dirder, objective;
     bool first, first_tr, first_update;
     int nfev, term = VP_TERM_NOT_RUN, st_best = uni(rec->status), trow = uni(rec->trow);
+    bool flagged = false;
     auto trace_row = [&](const T(&xx)[Q], T fn, T ratio) {
         double *trace = kc->trace;
         const int trace_rows = kc->trace_rows;
@@ -676,21 +694,10 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
 #pragma unroll
             for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
             jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
-            if constexpr (jac_rescue_v<T, M, 1, PADM>) {
-                bool bad = false;
-#pragma unroll
-                for (int k = 0; k < Q; ++k) bad = bad || !is_finite(acnorm[k]);
-                if (uni(bad)) { // (rare: rescue_jacobian, vp_fit.hpp; the LM state goes through the slot's record)
-                    park();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    ParamPack<T, Q> al;
-#pragma unroll
-                    for (int k = 0; k < Q; ++k) al.v[k] = xt[k];
-                    rescue_jacobian<T, M, R, Src, true>(al, src, eps, h0.beta, h0.u, h0.g, (const T *)s_col, qty0,
-                                                        (VP_LDS T *)&rec->Rj[0][0], (VP_LDS T *)rec->acnorm,
-                                                        (VP_LDS T *)rec->qtf, (VP_LDS int *)rec->ipvt);
-                    unpark();
-                }
+            if (uni(jac_not_finite<T, Q>(acnorm))) { // (rare) flag and re-fit: vp_fit.hpp, jac_not_finite
+                term = VP_TERM_NUMERICAL;
+                flagged = kc->rescue != nullptr;
+                break;
             }
             T gmax = T(0);
             bool degenerate = false;
@@ -782,8 +789,12 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
         T *alpha_out = kc->alpha, *C_out = kc->C_out;
         if (cost_out) cost_out[prob] = (double)objective;
         if (status_out) status_out[prob] = st_best;
+        if (flagged) {
+            rescue_push(kc->rescue, kc->rescue_slot, prob);
+        } else {
 #pragma unroll
-        for (int k = 0; k < Q; ++k) alpha_out[prob * Q + k] = x[k];
+            for (int k = 0; k < Q; ++k) alpha_out[prob * Q + k] = x[k];
+        }
         if (C_out) {
 #pragma unroll
             for (int k = 0; k < N; ++k) C_out[prob * N + k] = cbest[k];
@@ -845,6 +856,8 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
             kc->gtol = a.gtol;
             kc->stepbound = a.stepbound;
             kc->alpha = a.alpha;
+            kc->rescue = a.rescue;
+            kc->rescue_slot = a.rescue_slot;
             kc->C_out = a.C_out;
             kc->cost_out = a.cost_out;
             kc->status = a.status;
@@ -908,7 +921,6 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
 #endif
     while (nactive > 0) {
         // =============================== VECTOR phase ===============================
-        bool anybad = false;
 #pragma nounroll
         for (int s = 0; s < GS; ++s) {
             Rec *rec = recs + s;
@@ -938,7 +950,6 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
             const bool need_jac = u.ok && (first || good);
             T Rj[Q][Q], acnorm[Q], qtf[Q];
             int ipvt[Q];
-            bool jbad = false;
             if (need_jac) {
                 // z_k = -c_k Q^T D_k: factor the unscaled columns in place, the coefficients enter as column scales
                 residual_qcoords<T, R, N>(C[YC], u.e, grp);
@@ -946,13 +957,6 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
 #pragma unroll
                 for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
                 jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
-                if constexpr (jac_rescue_v<T, M, W, PADM>) {
-                    // a Jacobian that is not finite after a good evaluation is redone after the slot loop (rescue_jacobian)
-#pragma unroll
-                    for (int k = 0; k < Q; ++k) jbad = jbad || !is_finite(acnorm[k]);
-                    jbad = uni(jbad);
-                    anybad = anybad || jbad;
-                }
             }
             if (lane == 0) { // group lane 0
                 rec->fnorm1 = fnorm1;
@@ -974,27 +978,10 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
                     }
                 }
                 if (good) fl |= 32;
-                if (jbad) fl |= 64;
                 rec->flags = fl;
             }
         }
         group_sync();
-        if constexpr (jac_rescue_v<T, M, W, PADM>) {
-            if (anybad) { // (rare) out of line, between the phases: only the kernel's own constants are live here
-#pragma nounroll
-                for (int s = 0; s < GS; ++s) {
-                    Rec *rec = recs + s;
-                    if (uni(rec->prob) < 0 || (uni(rec->flags) & 64) == 0) continue;
-                    ParamPack<T, Q> al;
-#pragma unroll
-                    for (int k = 0; k < Q; ++k) al.v[k] = rec->xt[k];
-                    rescue_jacobian<T, M, R, Src, true>(al, src, eps_, h0.beta, h0.u, h0.g, s_y + (size_t)s * MP, rec->qty0,
-                                                        (VP_LDS T *)&rec->Rj[0][0], (VP_LDS T *)rec->acnorm,
-                                                        (VP_LDS T *)rec->qtf, (VP_LDS int *)rec->ipvt);
-                }
-                group_sync();
-            }
-        }
         VP_CK2(0);
 
         // =============================== SCALAR phase: lane s of wave 0 <-> slot s ===============================
@@ -1110,6 +1097,8 @@ template <typename T, class M, int R, int W = 1> int launch_fit2(const LaunchPar
         a.trace = p.trace;
         a.trace_rows = p.trace_rows;
         a.grid_uniform = p.grid_uniform;
+        a.rescue = p.rescue;
+        a.rescue_slot = p.rescue_slot;
         if (a.B <= 0) return VP_ERR_OK;
         // persistent grid: every resident workgroup slot of the device, or fewer when the batch is smaller
         const int64_t cap_blocks = (int64_t)p.num_cus * BPC;

@@ -861,6 +861,8 @@ __global__ void __launch_bounds__(64 * VP_FITG2_WAVES, VP_FITG2_WAVES == 8 ? 2 :
         k->trace = VP_FITG_TIMELINE ? nullptr : a.trace;
         k->yw = a.yw;
         k->queue = a.queue;
+        k->rescue = nullptr; // (the Gram kernel's failures are conditioning, not representability: no re-fit list)
+        k->rescue_slot = 0;
         k->B = a.B;
         k->trace_rows = a.trace_rows;
         k->scale_diag = a.scale_diag;

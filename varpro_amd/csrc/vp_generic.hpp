@@ -63,6 +63,12 @@ template <typename T> struct GenArgs {
     int ext;
     const T *ext_phi, *ext_dphi;
     int ext_rows;       // rows per column in the caller's arrays (< m only when the handle padded m < n: zero rows)
+    // fit: the problems to fit -- null: all B; else list[2 + i], i < list[list_slot] (the flag-and-refit list the register and
+    // streamed fit kernels append to, vp_kernels.hpp rescue_push); the launch zeroes the OTHER counter for the next fit
+    const int32_t *list;
+    int list_slot;
+    // power-of-two scaling of huge columns (evaluate below): 1 for every fit launched here
+    int scale_cols;
 };
 __host__ __device__ constexpr int gen_nacc(int q) { return 2 + q * q + q; }
 
@@ -111,6 +117,7 @@ template <typename T> struct GenShared {
     T Rm[VP_MAX_BASIS][VP_MAX_BASIS];
     T g[VP_MAX_BASIS], qty[VP_MAX_BASIS], c[VP_MAX_BASIS], e[VP_MAX_BASIS];
     T alpha[VP_MAX_PARAMS];
+    T cscale[VP_MAX_BASIS]; // 2^-e_j applied to basis column j and its derivative columns (1 unless scale_cols found it huge)
     T fn2;
     int ok;
     // Jacobian QR
@@ -136,6 +143,26 @@ template <typename T> __device__ __forceinline__ void multi_reduce(GenShared<T> 
     if (tid < nv) {
         T s = T(0);
         for (int i = 0; i < 8; ++i) s += sh.part[tid][i];
+        sh.red[tid] = s;
+    }
+    __syncthreads();
+}
+
+// the same for maxima of non-negative values (any order gives the same result)
+template <typename T> __device__ __forceinline__ void multi_reduce_max(GenShared<T> &sh, const T *vals, int nv) {
+    const int tid = (int)threadIdx.x;
+    for (int v = 0; v < nv; ++v) sh.part[v][tid] = vals[v];
+    __syncthreads();
+    for (int v = tid >> 3; v < nv; v += TB / 8) {
+        const int sub = tid & 7;
+        T s = T(0);
+        for (int i = sub; i < TB; i += 8) s = (sh.part[v][i] > s || sh.part[v][i] != sh.part[v][i]) ? sh.part[v][i] : s; // (a NaN wins)
+        sh.part[v][sub] = s;
+    }
+    __syncthreads();
+    if (tid < nv) {
+        T s = T(0);
+        for (int i = 0; i < 8; ++i) s = (sh.part[tid][i] > s || sh.part[tid][i] != sh.part[tid][i]) ? sh.part[tid][i] : s;
         sh.red[tid] = s;
     }
     __syncthreads();
@@ -235,6 +262,41 @@ __device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b
         col(n)[i] = yp[i];
     }
     __syncthreads();
+    // ---- huge columns: basis column j and its derivative columns times 2^-e_j (scale_cols) ----
+    // The reference forms D_k c BEFORE it projects (src/solvers/levmar/mod.rs:156-171) and its SVD works on the matrix
+    // scaled by its largest entry: a basis column of 1e153 with a coefficient of 1e-152 is an ordinary evaluation there,
+    // while the raw dot products of this sweep overflow.  With e_j = the binary exponent of the largest entry of column j
+    // and of its derivative columns: Phi' = Phi diag(2^-e), D'_p = D_p 2^-e_j(p) -> c' = diag(2^e) c, and r = y - Phi' c',
+    // J_k = -P_perp sum_p c'_j(p) D'_p are UNCHANGED (power-of-two factors are exact); c = diag(2^-e) c' at the end.
+    // Columns below 2^64 (fp32: 2^16) are left alone, i.e. every ordinary problem is bit for bit what it was.  (The
+    // reference's absolute singular-value threshold then applies to the scaled factor: a stated deviation for problems that
+    // are BOTH rank-deficient and hold a column beyond 2^64.)
+    if (tid < n) sh.cscale[tid] = T(1);
+    if (a.scale_cols) {
+        T vals[MAXV];
+        for (int j = 0; j < n; ++j) vals[j] = T(0);
+        for (int i = tid; i < m; i += TB) {
+            for (int j = 0; j < n; ++j) vals[j] = tmax(vals[j], tabs(col(j)[i]));
+            for (int p = 0; p < P; ++p) vals[a.pb[p]] = tmax(vals[a.pb[p]], tabs(col(n + 1 + p)[i]));
+        }
+        multi_reduce_max(sh, vals, n);
+        if (tid < n) {
+            const T mx = sh.red[tid];
+            int e = 0;
+            if (is_finite(mx) && mx > T(0)) (void)frexp(mx, &e);
+            sh.cscale[tid] = (e > (sizeof(T) == 8 ? 64 : 16)) ? tldexp(T(1), -e) : T(1);
+        }
+        __syncthreads();
+        bool any = false;
+        for (int j = 0; j < n; ++j) any = any || sh.cscale[j] != T(1);
+        if (any) { // (uniform)
+            for (int i = tid; i < m; i += TB) {
+                for (int j = 0; j < n; ++j) col(j)[i] *= sh.cscale[j];
+                for (int p = 0; p < P; ++p) col(n + 1 + p)[i] *= sh.cscale[a.pb[p]];
+            }
+        }
+        __syncthreads();
+    }
     // ---- Householder sweep: H_k = I + g_k v_k v_k^T, v_k = a_k[k:] with v_k[k] = alpha - beta ----
     for (int k = 0; k < n; ++k) {
         T vals[MAXV];
@@ -301,7 +363,11 @@ __device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b
         }
     }
     __syncthreads();
-    if (!want_rj) return;
+    if (!want_rj) {
+        if (tid < n) sh.c[tid] *= sh.cscale[tid]; // c = diag(2^-e) c'
+        __syncthreads();
+        return;
+    }
     // ---- r~ and J~ in Q-coordinates, then back with Q = H_0 ... H_{n-1} ----
     {
         T *y = col(n);
@@ -340,6 +406,8 @@ __device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b
         }
         __syncthreads();
     }
+    if (tid < n) sh.c[tid] *= sh.cscale[tid]; // c = diag(2^-e) c' (the Kaufman columns above used c')
+    __syncthreads();
 }
 
 template <typename T> __global__ void __launch_bounds__(TB) gen_evaluate_kernel(const GenArgs<T> a) {
@@ -536,7 +604,16 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_fit_kernel(const
     __shared__ int s_need_jac, s_term, s_trow;
     const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params;
     T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
-    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+    // (flag-and-refit launch: the problems of the list; the counter the NEXT fit appends to is zeroed here -- that fit starts
+    // after this kernel on the handle's stream, and this launch never reads it)
+    int64_t count = a.B;
+    if (a.list) {
+        count = a.list[a.list_slot];
+        if (count > a.B) count = a.B;
+        if (blockIdx.x == 0 && tid == 0) const_cast<int32_t *>(a.list)[a.list_slot ^ 1] = 0;
+    }
+    for (int64_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
+        const int64_t b = a.list ? (int64_t)a.list[2 + bi] : bi;
         if (tid == 0) {
             T a0[VP_MAX_PARAMS];
             for (int k = 0; k < q; ++k) a0[k] = a.alpha_io[b * q + k];
@@ -1059,6 +1136,9 @@ template <typename T> inline bool fill_args(const LaunchParams &p, GenArgs<T> &a
     }
     a.trace = p.trace;
     a.trace_rows = p.trace_rows;
+    a.list = p.gen_list;
+    a.list_slot = p.gen_list_slot;
+    a.scale_cols = p.gen_scale_cols;
     return true;
 }
 
@@ -1073,6 +1153,7 @@ template <typename T> int launch_fit(const LaunchParams &p) {
     GenArgs<T> a;
     if (!fill_args(p, a) || !p.gen_ws) return VP_ERR_UNSUPPORTED;
     if (a.B <= 0) return VP_ERR_OK;
+    a.scale_cols = 1; // (this kernel never flags a problem for a re-fit: it IS the re-fit)
     hipLaunchKernelGGL((gen_fit_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }

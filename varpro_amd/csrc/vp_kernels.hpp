@@ -87,8 +87,26 @@ struct LaunchParams {
     int ext;                 // 1: external model (the fields above are meaningful)
     int ext_np;              // dependency pairs of the external model
     int ext_rows;            // rows per column in the caller's arrays (== m unless the handle padded m < n)
+    // flag-and-refit (round 6): problems whose Jacobian is not representable column by column are NOT redone inside the fit
+    // kernels; they append their index to this list, keep alpha0 in place and are re-fitted by a second, tiny launch of the
+    // generic kernel with power-of-two column scaling (rescue_push below, gen_fit_kernel; vp_api.hip: rescue_refit)
+    int32_t *rescue;         // [2 + B]: two ping-pong counters, then the problem indices; null: nothing is flagged
+    int rescue_slot;         // the counter this fit appends to (0 / 1); the re-fit launch zeroes the other one
+    const int32_t *gen_list; // generic fit kernel: fit the problems gen_list[2 + i], i < gen_list[gen_list_slot] (null: all B)
+    int gen_list_slot;
+    int gen_scale_cols;      // generic kernels: power-of-two scaling of huge basis columns (and their derivative columns)
     hipStream_t stream;
 };
+
+// One fit whose Jacobian came out non-finite after an evaluation that was itself fine -- the reference forms D_k c BEFORE it
+// projects (src/solvers/levmar/mod.rs:156-171), the register kernels sweep the unscaled derivative columns, so a decay time
+// stepping through zero (exp(+t/0.035) = 1e153 with c = 1e-152) overflows here and not there -- hands itself over: called by
+// ONE lane of the problem; the caller then skips its store of the final parameters, so alpha[b] still holds the initial guess
+// the re-fit starts from.
+__device__ __forceinline__ void rescue_push(int32_t *base, const int slot, const int64_t b) {
+    const int i = atomicAdd(&base[slot], 1);
+    base[2 + i] = (int32_t)b;
+}
 
 // ---- row-distributed loads / stores ------------------------------------------------------------
 // branch-free: rows >= m read element 0 and are zeroed by a select

@@ -131,12 +131,18 @@ __device__ __forceinline__ bool lm_after_eval(LmVars<T, N, Q> &s, const LmOpts<T
     return s.term == 0 && good;
 }
 
+// Returns true when a REFRESHED factor's column norms are not finite (the fit then ends `Numerical`): the one failure a re-fit
+// with scaled columns repairs (vp_fit.hpp, jac_not_finite) -- callers with a rescue list flag the problem, the others ignore it.
 template <typename T, int N, int Q, bool U>
-__device__ __forceinline__ void lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T> &o, const bool jac_refreshed) {
-    if (s.term != 0) return;
+__device__ __forceinline__ bool lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T> &o, const bool jac_refreshed) {
+    if (s.term != 0) return false;
     if (jac_refreshed) {
         T gmax = T(0);
         bool degenerate = false;
+        if (pol<U>(jac_not_finite<T, Q>(s.acnorm))) {
+            s.term = VP_TERM_NUMERICAL;
+            return true;
+        }
         const T ifn = frcp(s.fnorm);
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
@@ -153,11 +159,11 @@ __device__ __forceinline__ void lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T>
         s.gnorm = gmax;
         if (pol<U>(degenerate)) {
             s.term = VP_TERM_NUMERICAL;
-            return;
+            return false;
         }
         if (pol<U>(s.gnorm <= o.gtol)) {
             s.term = VP_TERM_ORTHOGONAL;
-            return;
+            return false;
         }
         if (s.first_update) {
             T tmpv[Q];
@@ -169,7 +175,7 @@ __device__ __forceinline__ void lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T>
             s.xnorm = enorm_small<T, Q, U>(tmpv);
             if (pol<U>(!is_finite(s.xnorm))) {
                 s.term = VP_TERM_NUMERICAL;
-                return;
+                return false;
             }
             s.delta = (s.xnorm == T(0)) ? o.stepbound : o.stepbound * s.xnorm;
             s.first_update = 0;
@@ -187,7 +193,7 @@ __device__ __forceinline__ void lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T>
     s.par = lmpar_any<T, Q, U, true>(Rwork, s.ipvt, s.diag, s.qtf, s.delta, s.par, step, s.pnorm);
     if (pol<U>(!is_finite(s.pnorm))) {
         s.term = VP_TERM_NUMERICAL;
-        return;
+        return false;
     }
     T wa[Q];
 #pragma unroll
@@ -205,7 +211,7 @@ __device__ __forceinline__ void lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T>
     const T temp2 = t2 * t2;
     if (pol<U>(!is_finite(temp1) || !is_finite(temp2))) {
         s.term = VP_TERM_NUMERICAL;
-        return;
+        return false;
     }
     s.prered = temp1 + temp2 * T(2);
     s.dirder = -(temp1 + temp2);
@@ -213,6 +219,7 @@ __device__ __forceinline__ void lm_next_step(LmVars<T, N, Q> &s, const LmOpts<T>
     s.first_tr = 0;
 #pragma unroll
     for (int k = 0; k < Q; ++k) s.xt[k] = s.x[k] - step[k];
+    return false;
 }
 
 // Pivoted Cholesky of the Gram matrix A = J^T J (q x q) -> the quantities MINPACK's qrfac/lmder deliver from a
