@@ -133,7 +133,7 @@ def compact(out, extra_file=None):
     c["value_definition"] = _short(out.get("value_definition"), 120)
     cfg = out.get("config", {})
     c["config"] = _pick(cfg, ("batch_per_gpu", "m", "batches_in_flight", "world_size", "parallelism", "mean_evaluations_per_fit",
-                              "fits_successful", "fits_failed", "per_rank_ms_per_step"))
+                              "fits_successful", "fits_failed", "sum_cost", "collective_backend", "per_rank_ms_per_step"))
     c["config"]["workload"] = _short(cfg.get("workload"), 120)
     if "one_batch_at_a_time" in cfg:
         c["config"]["one_batch_at_a_time"] = _pick(cfg["one_batch_at_a_time"], ("ms_per_step", "fits_per_s", "per_rank_ms_per_step"))
@@ -197,7 +197,11 @@ def compact(out, extra_file=None):
         c["build"] = _pick(out["build"], ("library_bytes", "kernels", "kernels_spilling", "kernels_above_64_spilled", "clean_build_cpu_minutes"))
     if extra_file:
         c["extra_file"] = extra_file
+    precise = {k: c[k] for k in ("value", "ms_per_step") if k in c}
+    precise_cfg = {k: c["config"][k] for k in ("sum_cost", "mean_evaluations_per_fit") if k in c["config"]}
     c = _round_floats(c)
+    c.update(_round_floats(precise, 13))  # (the contract's own numbers and the all-reduced totals keep their digits)
+    c["config"].update(_round_floats(precise_cfg, 13))
     # hard bound: drop the least important blocks until the line fits (never the contract fields)
     for k in ("side", "build", "parity_census", "gpu_over_cpu_single_socket_extrapolated", "value_definition"):
         if len(json.dumps(c, separators=(",", ":"))) < COMPACT_LINE_LIMIT:

@@ -446,3 +446,86 @@ def test_finished_problems_are_reported_in_every_steps_arrays():
     for b, v in finished_at.items():
         assert np.array_equal(a_end[b], v)
     bp.close()
+
+
+# ---- round 6: every shape the header admits, and several right-hand sides (the generic step, vp_gen_extfit.hpp) ----------
+def _many_gauss_model(x, npeaks):
+    """c_1 Gauss(mu_1, s) + ... + c_k Gauss(mu_k, s) + c_0: k + 1 basis functions, k + 1 parameters (a SHARED width), 2 k pairs"""
+    names = ["mu%d" % i for i in range(npeaks)] + ["s"]
+    cm = vp.ClosureModel(names, x)
+    for i in range(npeaks):
+        cm = cm.function(["mu%d" % i, "s"], gauss).partial_deriv("mu%d" % i, gauss_dmu).partial_deriv("s", gauss_dsg)
+    return cm.invariant_function(lambda x: np.ones_like(x))
+
+
+def _many_gauss_data(rng, B, x, npeaks, noise=1e-2):
+    mus = np.stack([rng.uniform(1.0 + 8.0 * i / npeaks, 1.0 + 8.0 * i / npeaks + 0.6, B) for i in range(npeaks)], 1)
+    s = rng.uniform(0.25, 0.4, (B, 1))
+    truth = np.concatenate([mus, s], 1)
+    c = rng.uniform(5, 50, (B, npeaks + 1))
+    Y = c[:, -1:] + sum(c[:, i:i + 1] * gauss(x, mus[:, i:i + 1], s) for i in range(npeaks))
+    Y = Y + noise * np.abs(Y).max(1, keepdims=True) * rng.standard_normal(Y.shape)
+    guess = truth * (1 + rng.uniform(-0.03, 0.03, truth.shape))
+    return truth, Y, guess
+
+
+@pytest.mark.parametrize("npeaks,m", [(6, 300), (7, 1500), (5, 5000)])
+def test_shapes_outside_the_specialised_tables(npeaks, m):
+    """n = 7 / 8 basis functions, q = 7 / 8 parameters, 12 / 14 pairs: round 5 answered VP_ERR_UNSUPPORTED (n <= 6 and a table of
+    (n, pairs, q)); (5, 5000): a shape the resident table has at no streamed length (10 pairs).  == fit over ANY
+    SeparableNonlinearModel (/root/reference/src/solvers/levmar/mod.rs:238-254)"""
+    rng = np.random.default_rng(40 + npeaks)
+    B = 24
+    x = np.linspace(0.0, 10.0, m)
+    cm = _many_gauss_model(x, npeaks)
+    assert cm.shape().n_basis == npeaks + 1 and cm.shape().n_params == npeaks + 1 and len(cm.pairs()) == 2 * npeaks
+    _truth, Y, guess = _many_gauss_data(rng, B, x, npeaks)
+    ref = oracle_fits(cm, Y, guess)
+    bp = vp.BatchProblem(cm.shape(), Y)
+    a1, C1, rep1, _steps = bp.fit_with_model(host_model(cm), guess)
+    compare_with_oracle(rep1, a1, ref, evals_share=0.9)
+    for b in range(0, B, 5):
+        if ref[1][b] > 0:
+            p = oracle_problem(cm, Y[b])
+            p.set_params(a1[b])
+            assert np.abs(C1[b] - p.linear_coefficients()).max() <= 1e-8 * np.abs(C1[b]).max()
+    a2, C2, rep2, _s2 = bp.fit_with_model(host_model(cm), guess, derivatives_on_accept=True)
+    assert np.array_equal(a1, a2) and np.array_equal(rep1["n_evals"], rep2["n_evals"])
+    bp.close()
+
+
+@pytest.mark.parametrize("S,weighted", [(2, False), (3, True), (17, False)])
+def test_several_right_hand_sides(S, weighted):
+    """== LevMarSolver::fit on a SeparableProblem<MRHS> (/root/reference/src/solvers/levmar/mod.rs:172-186,
+    src/problem/builder.rs:194-225) for a caller-evaluated model: the S data columns of a problem share alpha; round 5 refused
+    S > 1.  Checker: the oracle's global fit driven by the same closures."""
+    rng = np.random.default_rng(50 + S)
+    B, m = 12, 400
+    x = np.linspace(0.0, 10.0, m)
+    cm = peaks_model(x)
+    truth, _c, _Y1, guess = peaks_data(rng, B, x, noise=1e-2)
+    # S columns per problem: the same peaks, different amplitudes
+    Phi = cm.eval_batch(truth)                                   # (B, 3, m)
+    Cs = np.stack([rng.uniform(5, 50, (B, S)), rng.uniform(5, 50, (B, S)), rng.uniform(0, 5, (B, S))], 2)  # (B, S, 3)
+    Y = np.einsum("bsn,bnm->bsm", Cs, Phi)
+    Y = Y + 1e-2 * np.abs(Y).max(2, keepdims=True) * rng.standard_normal(Y.shape)
+    w = (0.5 + rng.random(m)) if weighted else None
+    bp = vp.BatchProblem(cm.shape(), Y, weights=w)
+    a1, C1, rep1, _steps = bp.fit_with_model(host_model(cm), guess)
+    rep = vp.BatchProblem.report_to_numpy(rep1)
+    assert np.asarray(C1).shape == (B, S, 3)
+    for b in range(B):
+        p = oracle_problem(cm, Y[b], w=w)
+        p.set_params(guess[b])
+        r = p.fit()
+        assert (rep["termination"][b] > 0) == (r.termination > 0), (b, rep[b], r.termination)
+        if r.termination > 0:
+            assert abs(rep["objective"][b] - r.objective) <= 1e-6 * r.objective, (b, rep["objective"][b], r.objective)
+            assert abs(int(rep["n_evals"][b]) - int(r.n_evals)) <= 4
+            a_ref = p.params()
+            assert np.abs(np.asarray(a1)[b] - a_ref).max() <= 1e-5 * np.abs(a_ref).max()
+            Cr = np.asarray(p.linear_coefficients()).reshape(S, 3)
+            assert np.abs(np.asarray(C1)[b] - Cr).max() <= 1e-5 * np.abs(Cr).max()
+    a2, C2, rep2, _s2 = bp.fit_with_model(host_model(cm), guess, derivatives_on_accept=True)
+    assert np.array_equal(np.asarray(a1), np.asarray(a2)) and np.array_equal(np.asarray(C1), np.asarray(C2))
+    bp.close()

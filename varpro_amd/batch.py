@@ -446,7 +446,7 @@ class BatchProblem:
     def fit_end(self, want_coefficients=True):
         """(alpha, C, report) of the stepped fit (vp_fit_end); report as ``fit`` returns it"""
         a = self._empty((self.B, self.q))
-        Cm = self._empty((self.B, self.n)) if want_coefficients else None
+        Cm = self._empty((self.B, self.n) if self.single_rhs else (self.B, self.S, self.n)) if want_coefficients else None
         if self.device_mode:
             rep = torch.empty((self.B, 16), dtype=torch.uint8, device=self._torch_device())
             check(self.lib.vp_fit_end(self._h, self._ptr(a), self._ptr(Cm), self._ptr(rep)))

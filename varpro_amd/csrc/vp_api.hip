@@ -242,6 +242,7 @@ struct vp_batch {
     void *d_xf_state;       // [B] LM records of the step kernel
     void *d_xf_trial;       // [B][q] trial points of the last step
     int32_t *d_xf_want;     // [B] what every problem wants next
+    void *d_xf_ctrial;      // [B][S][n] coefficients of the trial point (S > 1: generic step)
     int32_t *d_xf_nactive;  // device counter of the last step
     int32_t *h_xf_nactive;  // pinned host copy
     bool xf_running;        // between vp_fit_begin and vp_fit_end
@@ -1224,6 +1225,7 @@ void vp_batch_destroy(vp_batch *h) {
     (void)hipFree(h->d_xf_trial);
     (void)hipFree(h->d_xf_want);
     (void)hipFree(h->d_xf_nactive);
+    (void)hipFree(h->d_xf_ctrial);
     (void)hipFree(h->d_rescue);
     (void)hipFree(h->d_rescue_ws);
     if (h->h_xf_nactive) (void)hipHostFree(h->h_xf_nactive);
@@ -1341,11 +1343,21 @@ int vp_fit_begin(vp_batch *h, const vp_lm_opts *opts, const void *alpha0, int fl
     if (!alpha0) return fail(VP_ERR_INVALID, "null alpha0");
     if (flags & ~VP_FIT_DERIVATIVES_ON_ACCEPT) return fail(VP_ERR_INVALID, "unknown vp_fit_begin flag");
     if (h->q <= 0) return fail(VP_ERR_INVALID, "a fit needs at least one nonlinear parameter");
-    if (h->S != 1) return fail(VP_ERR_UNSUPPORTED, "the batched fit of caller-evaluated models covers single right-hand sides");
     if (h->m_user) return fail(VP_ERR_UNSUPPORTED, "the batched fit of caller-evaluated models needs m >= n");
     const size_t rec = external_fit_rec_bytes(h->dtype, h->n, h->ext_np, h->q, h->m);
-    if (!rec) return fail(VP_ERR_UNSUPPORTED, "no step kernel for this (n, q, pairs, m) of a caller-evaluated model");
+    if (!rec) return fail(VP_ERR_UNSUPPORTED, "no LM step kernel for this number of parameters");
     const size_t ts = tsize(h->dtype);
+    if (external_fit_generic(h->dtype, h->n, h->ext_np, h->q, h->m, h->S)) {
+        // shapes outside the specialised tables / several right-hand sides: the generic step and its workspace
+        if (!h->d_gen_ws) {
+            const size_t slot = (size_t)(h->n + 1 + h->ext_np + h->q) * (size_t)h->m * ts;
+            int64_t blocks = std::min<int64_t>(h->B, 1024);
+            while (blocks > 1 && (size_t)blocks * slot > ((size_t)4 << 30)) blocks /= 2;
+            h->gen_blocks = (int)blocks;
+            VP_HIP(hipMalloc(&h->d_gen_ws, (size_t)blocks * slot));
+        }
+        if (h->S > 1 && !h->d_xf_ctrial) VP_HIP(hipMalloc(&h->d_xf_ctrial, (size_t)h->B * h->S * h->n * ts));
+    }
     // (each buffer guarded on its own: an allocation that fails half way leaves the handle in a state the next call completes)
     if (!h->d_xf_state) VP_HIP(hipMalloc(&h->d_xf_state, (size_t)h->B * rec + 16));
     if (!h->d_xf_trial) VP_HIP(hipMalloc(&h->d_xf_trial, (size_t)h->B * h->q * ts));
@@ -1410,6 +1422,10 @@ int vp_fit_step_with_basis(vp_batch *h, const void *Phi, const void *dPhi, void 
     p.opts = h->xf_opts;
     p.init = h->xf_init ? 1 : 0;
     p.lazy = lazy ? 1 : 0;
+    p.S = h->S;
+    p.gen_ws = h->d_gen_ws;
+    p.gen_blocks = h->gen_blocks;
+    p.C_trial = h->d_xf_ctrial;
     p.stream = h->stream;
     Timer tm(h, VP_KERNEL_FIT);
     const int rc = external_fit_step(p);
@@ -1446,7 +1462,7 @@ int vp_fit_end(vp_batch *h, void *alpha_out, void *C_out, vp_report *rep) {
     h->ext_phi = nullptr;
     h->ext_dphi = nullptr;
     if (int rc = copy_out(h, alpha_out, h->d_alpha, (size_t)h->B * h->q * ts)) return rc;
-    if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->n * ts)) return rc;
+    if (int rc = copy_out(h, C_out, h->d_C, (size_t)h->B * h->S * h->n * ts)) return rc;
     if (int rc = copy_out(h, rep, h->d_report, (size_t)h->B * sizeof(vp_report))) return rc;
     return VP_ERR_OK;
 }

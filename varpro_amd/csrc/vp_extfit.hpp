@@ -66,11 +66,48 @@ template <int Q> struct ExtFitLayout {
     // bytes per problem (+ 8 per handle for the alignment of the 32-bit block: added by the host)
     static constexpr size_t bytes(size_t tsize) { return (size_t)NT * tsize + (size_t)NI * 4; }
 };
+// The same offsets for a RUN-TIME parameter count: the generic step kernel (vp_gen_extfit.hpp: any (n, pairs, q) the header
+// admits, any number of right-hand sides) is compiled once and writes the candidate slot of whichever ExtFitLayout<Q> the LM
+// kernel of the handle's q reads.
+struct ExtFitOffsets {
+    int C_FN, C_C, C_RJ, C_ACN, C_QTF, NT;
+    int TERM, WANT, C_OK, C_HASJ, C_IPVT;
+};
+__host__ __device__ constexpr ExtFitOffsets extfit_offsets(const int Q) {
+    ExtFitOffsets o{};
+    const int SC = 5 * Q + Q * Q, CBEST = SC + 9;
+    o.C_FN = CBEST + VP_MAX_BASIS;
+    o.C_C = o.C_FN + 1;
+    o.C_RJ = o.C_C + VP_MAX_BASIS;
+    o.C_ACN = o.C_RJ + Q * Q;
+    o.C_QTF = o.C_ACN + Q;
+    o.NT = o.C_QTF + Q;
+    const int NFEV = Q + 3;
+    o.TERM = NFEV + 1;
+    o.WANT = o.TERM + 2;
+    o.C_OK = o.WANT + 2;
+    o.C_HASJ = o.C_OK + 1;
+    o.C_IPVT = o.C_HASJ + 1;
+    return o;
+}
+template <int Q> constexpr bool extfit_offsets_match() {
+    using F = ExtFitLayout<Q>;
+    constexpr ExtFitOffsets o = extfit_offsets(Q);
+    return o.C_FN == F::C_FN && o.C_C == F::C_C && o.C_RJ == F::C_RJ && o.C_ACN == F::C_ACN && o.C_QTF == F::C_QTF && o.NT == F::NT &&
+           o.TERM == F::TERM && o.WANT == F::WANT && o.C_OK == F::C_OK && o.C_HASJ == F::C_HASJ && o.C_IPVT == F::C_IPVT;
+}
+static_assert(extfit_offsets_match<1>() && extfit_offsets_match<2>() && extfit_offsets_match<3>() && extfit_offsets_match<4>() &&
+                  extfit_offsets_match<5>() && extfit_offsets_match<6>() && extfit_offsets_match<7>() && extfit_offsets_match<8>(),
+              "extfit_offsets must mirror ExtFitLayout");
+
 // the 32-bit fields start behind the NT * B scalars, 8-byte aligned
-template <typename T, int Q> __host__ __device__ inline int32_t *extfit_ints(void *state, int64_t B) {
-    size_t off = (size_t)ExtFitLayout<Q>::NT * sizeof(T) * (size_t)B;
+template <typename T> __host__ __device__ inline int32_t *extfit_ints_rt(void *state, int64_t B, const int NT) {
+    size_t off = (size_t)NT * sizeof(T) * (size_t)B;
     off = (off + 7) & ~(size_t)7;
     return reinterpret_cast<int32_t *>(reinterpret_cast<char *>(state) + off);
+}
+template <typename T, int Q> __host__ __device__ inline int32_t *extfit_ints(void *state, int64_t B) {
+    return extfit_ints_rt<T>(state, B, ExtFitLayout<Q>::NT);
 }
 
 template <typename T> struct ExtFitArgs {
@@ -107,6 +144,11 @@ template <typename T> struct ExtFitArgs {
     int init; // first step after vp_fit_begin: records are created from alpha0
     int lazy; // VP_FIT_DERIVATIVES_ON_ACCEPT
     int vec;
+    // several right-hand sides (generic step kernel only): the problem's S data columns share alpha; the residual is the
+    // stacked one (m S entries, src/solvers/levmar/mod.rs:91-95, 172-186) and the coefficients are [B][S][n]: the evaluation
+    // writes those of the trial point to C_trial, the LM kernel copies them to C_best when the point is accepted
+    int S;            // 1 on every specialised path
+    const T *C_trial; // [B][S][n] (S > 1) or null
 };
 
 template <typename T, int R, int N, int P, int Q, int W> constexpr int extfit_waves() {
@@ -305,9 +347,14 @@ template <typename T, int Q> __global__ void __launch_bounds__(64) ext_fit_lm_ke
             s.status = VP_ST_NONFINITE;
         }
     } else {
-        need_jac = lm_after_eval<T, 1, Q, false>(s, a.o, fnorm1, ok, (long)a.m);
+        need_jac = lm_after_eval<T, 1, Q, false>(s, a.o, fnorm1, ok, (long)a.m * (long)(a.S > 1 ? a.S : 1));
         if (s.accepted) {
-            for (int k = 0; k < n; ++k) st[(F::CBEST + k) * B + b] = st[(F::C_C + k) * B + b];
+            if (a.S > 1) {
+                const int64_t cn = (int64_t)a.S * n;
+                for (int64_t i = 0; i < cn; ++i) a.C_best[b * cn + i] = a.C_trial[b * cn + i];
+            } else {
+                for (int k = 0; k < n; ++k) st[(F::CBEST + k) * B + b] = st[(F::C_C + k) * B + b];
+            }
         }
     }
     bool deferred = false;
@@ -389,7 +436,8 @@ template <typename T, int Q> __global__ void __launch_bounds__(64) ext_fit_lm_ke
     si[F::WANT * B + b] = want_next;
     si[F::PHASE * B + b] = phase;
     a.want[b] = want_next;
-    for (int k = 0; k < n; ++k) a.C_best[b * n + k] = st[(F::CBEST + k) * B + b];
+    if (a.S <= 1)
+        for (int k = 0; k < n; ++k) a.C_best[b * n + k] = st[(F::CBEST + k) * B + b];
     vp_report rep;
     rep.termination = s.term;
     rep.n_evals = s.nfev;

@@ -28,8 +28,15 @@ struct ExtFitParams {
     double eps;
     vp_lm_opts opts;
     int init, lazy;
+    // the generic step (vp_gen_extfit.hpp): shapes outside the specialised tables and several right-hand sides
+    int64_t S;              // right-hand sides per problem (yw: [B][S][m], C_best: [B][S][n])
+    void *gen_ws;           // gen_blocks workspace slots of (n + 1 + np + q) columns x m
+    int gen_blocks;
+    void *C_trial;          // [B][S][n] scratch (S > 1)
     hipStream_t stream;
 };
+// true: a step of this shape runs on the generic kernel and needs gen_ws (and C_trial when S > 1)
+bool external_fit_generic(int dtype, int n, int np, int q, int64_t m, int64_t S);
 // bytes of one LM record of the step kernel that covers this shape; 0 = no kernel (the caller reports VP_ERR_UNSUPPORTED)
 size_t external_fit_rec_bytes(int dtype, int n, int np, int q, int64_t m);
 int external_fit_step(const ExtFitParams &p);

@@ -1,8 +1,11 @@
 // kernel set of caller-evaluated models (vp_batch_create_external): the resident evaluate kernels of vp_ext.hpp where the
 // shape is in their table, the generic kernels (vp_generic.hpp, reading the caller's columns) everywhere else
+#include <cstring>
+
 #include "vp_ext.hpp"
 #include "vp_extfit.hpp"
 #include "vp_generic.hpp"
+#include "vp_gen_extfit.hpp"
 #include "vp_registry.hpp"
 #include "vp_extfit_api.hpp"
 
@@ -28,10 +31,13 @@ const KernelEntry *external_kernels(int dtype, int n, int q, int np, int64_t m, 
 
 namespace {
 template <typename T> int ext_fit_step_t(const ExtFitParams &p) {
-    const ext::ExtFitEntry<T> *e = ext::find_extfit<T>(p.n, p.np, p.q, p.m);
+    const ext::ExtFitEntry<T> *e = p.S > 1 ? nullptr : ext::find_extfit<T>(p.n, p.np, p.q, p.m);
     const ext::ExtFitLmEntry<T> *l = ext::find_extfit_lm<T>(p.q);
-    if (!e || !l) return VP_ERR_UNSUPPORTED;
+    if (!l) return VP_ERR_UNSUPPORTED;
+    if (!e && (!p.gen_ws || (p.S > 1 && !p.C_trial))) return VP_ERR_INVALID;
     ext::ExtFitArgs<T> a;
+    a.S = (int)(p.S > 1 ? p.S : 1);
+    a.C_trial = (const T *)p.C_trial;
     a.phi = (const T *)p.phi;
     a.dphi = (const T *)p.dphi;
     a.w = (const T *)p.w;
@@ -81,18 +87,60 @@ template <typename T> int ext_fit_step_t(const ExtFitParams &p) {
     a.vec = host_aligned<T>((int)p.m, {p.phi, p.dphi, p.w, p.yw}) ? 1 : 0;
     if (a.B <= 0) return VP_ERR_OK;
     // the evaluation of every active problem (one wavefront each), then the LM drivers (one lane each)
-    if (int rc = e->launch(a, p.stream)) return rc;
+    if (e) {
+        if (int rc = e->launch(a, p.stream)) return rc;
+    } else {
+        // no specialised kernel for this (n, pairs, q, m) or several right-hand sides: the generic step (vp_gen_extfit.hpp)
+        gen::GenExtFitArgs<T> x;
+        std::memset(&x, 0, sizeof(x));
+        x.g.mdl.n_basis = p.n;
+        x.g.mdl.n_params = p.q;
+        x.g.P = p.np;
+        for (int i = 0; i < p.np && i < VP_MAX_PAIRS; ++i) {
+            x.g.pb[i] = p.pb[i];
+            x.g.pa[i] = 0;
+            x.g.pp[i] = p.pp[i];
+        }
+        x.g.ext = 1;
+        x.g.ext_phi = (const T *)p.phi;
+        x.g.ext_dphi = (const T *)p.dphi;
+        x.g.ext_rows = (int)p.m;
+        x.g.w = (const T *)p.w;
+        x.g.yw = (const T *)p.yw;
+        x.g.S = a.S;
+        x.g.ws = (T *)p.gen_ws;
+        x.g.ws_cols = p.n + 1 + p.np + p.q;
+        x.g.m = (int)p.m;
+        x.g.B = p.B;
+        x.g.w_stride = p.w_stride;
+        x.g.eps = (T)p.eps;
+        x.state = p.state;
+        x.C_trial = (T *)p.C_trial;
+        x.init = p.init;
+        x.q = p.q;
+        const int blocks = (int)(p.B < p.gen_blocks ? p.B : p.gen_blocks);
+        hipLaunchKernelGGL((gen::gen_extfit_eval_kernel<T>), dim3((unsigned)blocks), dim3(gen::TB), 0, p.stream, x);
+        if (hipGetLastError() != hipSuccess) return VP_ERR_HIP;
+    }
     return l->launch(a, p.stream);
 }
 } // namespace
 
+// (every admitted shape has a step: the LM kernel of its q, and the generic evaluation where no specialised one exists)
 size_t external_fit_rec_bytes(int dtype, int n, int np, int q, int64_t m) {
+    (void)n;
+    (void)np;
+    (void)m;
     if (dtype == VP_F64) {
         const ext::ExtFitLmEntry<double> *l = ext::find_extfit_lm<double>(q);
-        return (l && ext::find_extfit<double>(n, np, q, m)) ? l->rec_bytes : 0;
+        return l ? l->rec_bytes : 0;
     }
     const ext::ExtFitLmEntry<float> *l = ext::find_extfit_lm<float>(q);
-    return (l && ext::find_extfit<float>(n, np, q, m)) ? l->rec_bytes : 0;
+    return l ? l->rec_bytes : 0;
+}
+bool external_fit_generic(int dtype, int n, int np, int q, int64_t m, int64_t S) {
+    if (S > 1) return true;
+    return dtype == VP_F64 ? ext::find_extfit<double>(n, np, q, m) == nullptr : ext::find_extfit<float>(n, np, q, m) == nullptr;
 }
 
 int external_fit_step(const ExtFitParams &p) {
