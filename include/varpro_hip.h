@@ -357,9 +357,11 @@ void vp_lm_opts_default(vp_lm_opts *opts, int dtype);
  *       (vp_params, vp_linear_coeffs, vp_cost, vp_summary*, vp_reduce_cost); entries that need the MODEL at that point
  *       (vp_residuals, vp_jacobian, vp_best_fit, vp_statistics) first need its columns: vp_set_params_with_basis.
  * Every problem terminates after at most patience*(q+1) evaluations (TerminationReason::LostPatience), so stepping until
- * n_active == 0 always ends.  Covered shapes: single right-hand side, m >= n, the (n, q, pairs) of the compiled step
- * kernels (VP_ERR_UNSUPPORTED from vp_fit_begin otherwise) at ANY m: register-resident to 4 096 rows, the caller's
- * columns streamed in row blocks beyond (shapes of up to ten columns n + 1 + pairs).
+ * n_active == 0 always ends.  Covered: EVERY shape vp_batch_create_external admits -- n <= VP_MAX_BASIS, q <= VP_MAX_PARAMS,
+ * any pair table, any number of right-hand sides S (fit<Rhs>, src/problem/builder.rs:194-225: the S data columns share
+ * alpha, the residual is the stacked one, C_out of vp_fit_end is [B][S][n]) -- at ANY m >= n: the (n, q, pairs) of the
+ * compiled step kernels register-resident to 4 096 rows and streamed in row blocks beyond (shapes of up to ten columns
+ * n + 1 + pairs), every other shape and every S > 1 on the generic step kernel.  m < n: VP_ERR_UNSUPPORTED.
  */
 enum { VP_FIT_DERIVATIVES_ON_ACCEPT = 1 };
 enum { VP_WANT_BASIS = 1, VP_WANT_DERIVATIVES = 2 };

@@ -9,6 +9,7 @@ ftol-terminated fit."""
 import numpy as np
 import pytest
 
+import contracts as K
 import varpro_amd as vp
 from test_gpu_external import (gauss, gauss_dmu, gauss_dsg, lorentz, lorentz_dga, lorentz_dmu, oracle_problem, peaks_data,
                                peaks_model, pvoigt, voigt_model)
@@ -56,7 +57,8 @@ def oracle_fits(cm, Y, guess, w=None, opts=None):
     return alpha, term, nev, obj
 
 
-def compare_with_oracle(rep, alpha, ref, obj_median=1e-12, obj_max=1e-6, evals_share=0.95):
+def compare_with_oracle(rep, alpha, ref, obj_median=K.EXTFIT["objective_rel_median_max"], obj_max=K.EXTFIT["objective_rel_max_max"],
+                        evals_share=K.EXTFIT["share_evals_within_3_min"]):
     a_ref, term, nev, obj = ref
     rep = vp.BatchProblem.report_to_numpy(rep)
     ok = term > 0
