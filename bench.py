@@ -711,7 +711,7 @@ def main():
             bp2.set_timing(False)
             Y2_b = Y2.clone()
             x2_dev = torch.from_numpy(d2["x"]).to(dev)
-            ms2_two = in_flight_ms(lambda: vp.BatchProblem(mdl2, Y2_b, x=x2_dev), lambda h_: h_.fit(g2, want_coefficients=False), 2, 12, 10, threads=True)
+            ms2_two = in_flight_ms(lambda: vp.BatchProblem(mdl2, Y2_b, x=x2_dev), lambda h_: h_.fit(g2, want_coefficients=False), 2, 12, 14, threads=True)
             del Y2_b
             out["configs2"] = {
                 "workload": "BASELINE configs[2]: global fit, 1 alpha shared by %d right-hand sides, m=%d, triple-exp+offset" % (S2, m2),
@@ -934,11 +934,16 @@ def main():
             del r_x, J_x, r_ev, J_ev
             xt_row = x[None, None, :]
 
+            act_idx = torch.empty((B,), dtype=torch.int32, device=dev)
+            act_cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+
             def caller_model(alpha, want, n_active):
                 if want is None or n_active * 4 >= B:
                     bp.basis(alpha, skip_invariant=False, out_phi=phi_x, out_dphi=dphi_x)
-                else:  # the tail: only the problems that asked
-                    idx = (want != 0).nonzero().squeeze(1)
+                else:  # the tail: only the problems still running -- the handle's compacted active set (vp_fit_active_set:
+                    # two asynchronous device copies, no scan of want[] and no host synchronisation)
+                    bpx.fit_active_set(act_idx, act_cnt)
+                    idx = act_idx[:n_active].long()
                     a_ = alpha[idx][:, :, None]
                     e_ = torch.exp(-xt_row / a_)
                     phi_x[idx, 0:2] = e_

@@ -369,6 +369,15 @@ int vp_fit_begin(vp_batch *h, const vp_lm_opts *opts, const void *alpha0, int fl
 int vp_fit_step_with_basis(vp_batch *h, const void *Phi, const void *dPhi, void *alpha_trial_out, int32_t *want_out,
                            int64_t *n_active_out);
 int vp_fit_end(vp_batch *h, void *alpha_out, void *C_out, vp_report *rep);
+/*
+ * The ACTIVE SET of the running fit, compacted: after a step, index_out[0 .. *count_out) are the problems still running
+ * (want != 0), in no particular order; entries beyond the count are valid problem indices of finished problems (stale, never
+ * out of range).  A model that evaluates only these -- instead of scanning want_out [B] -- does work proportional to the
+ * problems left: the tail of a batched fit is a few hundred problems for ~100 steps (the reference's driver runs each of
+ * them alone, src/solvers/levmar/mod.rs:247).  The device's own evaluation launch already covers just this set.  Both
+ * arrays follow the handle's address space (device pointers: two asynchronous copies, no synchronisation; index_out [B]).
+ */
+int vp_fit_active_set(vp_batch *h, int32_t *index_out, int32_t *count_out);
 
 /*
  * == LevMarSolver::fit (src/solvers/levmar/mod.rs:238-254), i.e.

@@ -531,3 +531,53 @@ def test_several_right_hand_sides(S, weighted):
     a2, C2, rep2, _s2 = bp.fit_with_model(host_model(cm), guess, derivatives_on_accept=True)
     assert np.array_equal(np.asarray(a1), np.asarray(a2)) and np.array_equal(np.asarray(C1), np.asarray(C2))
     bp.close()
+
+
+@pytest.mark.parametrize("device_model", [False, True])
+def test_active_set_is_the_set_of_problems_that_still_want_columns(device_model):
+    """vp_fit_active_set (round 6): after every step index[:count] are exactly the problems with want != 0; the device's own
+    evaluation launch covers just that set (results identical to round 5's full launches: the census tests above)."""
+    rng = np.random.default_rng(11)
+    m, B = 200, 300
+    x = np.linspace(0.0, 10.0, m)
+    cm = peaks_model(x)
+    _t, _c, Y, guess = peaks_data(rng, B, x, noise=1e-2)
+    if device_model:
+        import torch
+        dev = torch.device("cuda", 0)
+        model = torch_peaks_model(x, dev)
+        bp = vp.BatchProblem(cm.shape(), torch.as_tensor(Y, device=dev))
+        alpha = torch.as_tensor(guess, device=dev)
+    else:
+        model = host_model(cm)
+        bp = vp.BatchProblem(cm.shape(), Y)
+        alpha = guess
+    bp.fit_begin(alpha)
+    nact, steps = B, 0
+    seen_counts = []
+    while nact > 0 and steps < 400:
+        Phi, dPhi = model(alpha, None)
+        alpha, want, nact = bp.fit_step_with_basis(Phi, dPhi)
+        steps += 1
+        idx, cnt = bp.fit_active_set()
+        w = want.cpu().numpy() if device_model else np.asarray(want)
+        i_ = idx.cpu().numpy() if device_model else np.asarray(idx)
+        c_ = int(cnt.cpu().numpy()[0]) if device_model else int(np.asarray(cnt)[0])
+        assert c_ == nact == int((w != 0).sum())
+        assert sorted(i_[:c_].tolist()) == np.nonzero(w != 0)[0].tolist()
+        assert ((i_ >= 0) & (i_ < B)).all()
+        seen_counts.append(c_)
+        if device_model:
+            alpha = alpha.clone()
+        else:
+            alpha = np.asarray(alpha).copy()
+    assert nact == 0 and seen_counts == sorted(seen_counts, reverse=True)
+    a_end, _C, rep = bp.fit_end()
+    rep = vp.BatchProblem.report_to_numpy(rep)
+    # the same fits as one without any look at the active set and without a count read-back per step
+    a2, _C2, rep2, _s = bp.fit_with_model(model, torch.as_tensor(guess, device=dev) if device_model else guess, check_every=7)
+    rep2 = vp.BatchProblem.report_to_numpy(rep2)
+    a_end = a_end.cpu().numpy() if device_model else np.asarray(a_end)
+    a2 = a2.cpu().numpy() if device_model else np.asarray(a2)
+    assert np.array_equal(a_end, a2) and np.array_equal(rep["n_evals"], rep2["n_evals"]) and np.array_equal(rep["termination"], rep2["termination"])
+    bp.close()

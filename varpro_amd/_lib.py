@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "vp_best_fit", "vp_statistics", "vp_summary", "vp_summary_device", "vp_global_fit_condition", "vp_set_rhs_allreduce", "vp_set_fit_kernel", "vp_set_timing", "vp_last_kernel_ms", "vp_synchronize", "vp_last_error",
     "vp_last_error_detail", "vp_version", "vp_device_count",
     "vp_batch_create_external", "vp_set_params_with_basis", "vp_jacobian_with_derivatives", "vp_evaluate_with_basis",
-    "vp_reduce_cost", "vp_fit_begin", "vp_fit_step_with_basis", "vp_fit_end",
+    "vp_reduce_cost", "vp_fit_begin", "vp_fit_step_with_basis", "vp_fit_end", "vp_fit_active_set",
 ]
 
 
@@ -118,6 +118,7 @@ def load():
     lib.vp_fit_begin.argtypes = [vp, C.POINTER(LmOpts), vp, C.c_int]
     lib.vp_fit_step_with_basis.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int64)]
     lib.vp_fit_end.argtypes = [vp, vp, vp, vp]
+    lib.vp_fit_active_set.argtypes = [vp, vp, vp]
     lib.vp_batch_destroy.argtypes = [vp]
     lib.vp_batch_destroy.restype = None
     lib.vp_set_params.argtypes = [vp, vp]

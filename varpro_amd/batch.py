@@ -443,6 +443,16 @@ class BatchProblem:
         return self._xf_trial, self._xf_want, (int(nact.value) if want_count else None)
 
     @_device_entry
+    def fit_active_set(self, index_out=None, count_out=None):
+        """the compacted active set of the running stepped fit (vp_fit_active_set): ``(index (B,) int32, count (1,) int32)`` --
+        index[:count] are the problems still running; entries beyond are stale but valid indices.  Device-pointer handles:
+        torch tensors filled asynchronously (no synchronisation); pass the previous call's tensors to reuse them."""
+        idx = index_out if index_out is not None else self._empty((self.B,), np.int32)
+        cnt = count_out if count_out is not None else self._empty((1,), np.int32)
+        check(self.lib.vp_fit_active_set(self._h, self._ptr(idx), self._ptr(cnt)))
+        return idx, cnt
+
+    @_device_entry
     def fit_end(self, want_coefficients=True):
         """(alpha, C, report) of the stepped fit (vp_fit_end); report as ``fit`` returns it"""
         a = self._empty((self.B, self.q))

@@ -243,6 +243,8 @@ struct vp_batch {
     void *d_xf_trial;       // [B][q] trial points of the last step
     int32_t *d_xf_want;     // [B] what every problem wants next
     void *d_xf_ctrial;      // [B][S][n] coefficients of the trial point (S > 1: generic step)
+    int32_t *d_xf_active;   // [2][B] compacted indices of the still-active problems, written alternately by the LM kernel
+    int64_t xf_known_active; // the last active count the host read (an upper bound of the current one)
     int32_t *d_xf_nactive;  // device counter of the last step
     int32_t *h_xf_nactive;  // pinned host copy
     bool xf_running;        // between vp_fit_begin and vp_fit_end
@@ -1226,6 +1228,7 @@ void vp_batch_destroy(vp_batch *h) {
     (void)hipFree(h->d_xf_want);
     (void)hipFree(h->d_xf_nactive);
     (void)hipFree(h->d_xf_ctrial);
+    (void)hipFree(h->d_xf_active);
     (void)hipFree(h->d_rescue);
     (void)hipFree(h->d_rescue_ws);
     if (h->h_xf_nactive) (void)hipHostFree(h->h_xf_nactive);
@@ -1364,6 +1367,15 @@ int vp_fit_begin(vp_batch *h, const vp_lm_opts *opts, const void *alpha0, int fl
     if (!h->d_xf_want) VP_HIP(hipMalloc((void **)&h->d_xf_want, (size_t)h->B * sizeof(int32_t)));
     if (!h->d_xf_nactive) VP_HIP(hipMalloc((void **)&h->d_xf_nactive, 2 * sizeof(int32_t)));
     if (!h->h_xf_nactive) VP_HIP(hipHostMalloc((void **)&h->h_xf_nactive, sizeof(int32_t), hipHostMallocDefault));
+    if (!h->d_xf_active) {
+        // both lists start as the identity: an entry beyond a step's count is then always a valid (finished) problem index
+        VP_HIP(hipMalloc((void **)&h->d_xf_active, (size_t)2 * h->B * sizeof(int32_t)));
+        std::vector<int32_t> iota((size_t)2 * h->B);
+        for (int64_t i = 0; i < 2 * h->B; ++i) iota[(size_t)i] = (int32_t)(i % h->B);
+        VP_HIP(hipMemcpyAsync(h->d_xf_active, iota.data(), iota.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        VP_HIP(hipStreamSynchronize(h->stream));
+    }
+    h->xf_known_active = h->B;
     if (opts) h->xf_opts = *opts;
     else vp_lm_opts_default(&h->xf_opts, h->dtype);
     VP_HIP(hipMemcpyAsync(h->d_alpha, alpha0, (size_t)h->B * h->q * ts,
@@ -1426,6 +1438,8 @@ int vp_fit_step_with_basis(vp_batch *h, const void *Phi, const void *dPhi, void 
     p.gen_ws = h->d_gen_ws;
     p.gen_blocks = h->gen_blocks;
     p.C_trial = h->d_xf_ctrial;
+    p.active_lists = h->d_xf_active;
+    p.known_active = h->xf_known_active;
     p.stream = h->stream;
     Timer tm(h, VP_KERNEL_FIT);
     const int rc = external_fit_step(p);
@@ -1443,9 +1457,20 @@ int vp_fit_step_with_basis(vp_batch *h, const void *Phi, const void *dPhi, void 
         VP_HIP(hipMemcpyAsync(h->h_xf_nactive, h->d_xf_nactive + ((h->xf_steps - 1) & 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         VP_HIP(hipStreamSynchronize(h->stream));
         *n_active_out = *h->h_xf_nactive;
+        h->xf_known_active = *h->h_xf_nactive; // the next evaluation launch shrinks to it
     } else if (!direct) {
         VP_HIP(hipStreamSynchronize(h->stream)); // host arrays: the caller reads them (and reuses Phi / dPhi) right away
     }
+    return VP_ERR_OK;
+}
+
+int vp_fit_active_set(vp_batch *h, int32_t *index_out, int32_t *count_out) {
+    VP_ENTER(h);
+    if (!h->external || !h->xf_running) return fail(VP_ERR_INVALID, "vp_fit_active_set without vp_fit_begin");
+    if (h->xf_init) return fail(VP_ERR_INVALID, "vp_fit_active_set before the first vp_fit_step_with_basis");
+    const int slot = (int)((h->xf_steps - 1) & 1); // the list and the counter the last step's LM kernel wrote
+    if (int rc = copy_out(h, index_out, h->d_xf_active + (size_t)slot * h->B, (size_t)h->B * sizeof(int32_t))) return rc;
+    if (int rc = copy_out(h, count_out, h->d_xf_nactive + slot, sizeof(int32_t))) return rc;
     return VP_ERR_OK;
 }
 
@@ -1675,6 +1700,16 @@ int rescue_prepare(vp_batch *h, LaunchParams &p) {
 int rescue_refit(vp_batch *h, const LaunchParams &fit_params) {
     if (!fit_params.rescue) return 0;
     LaunchParams p = fit_params;
+    // the first kFitRescueGrid flagged problems on the set's own wave-per-problem kernel with scaled derivative columns (a
+    // flagged fit at ~4 us per evaluation: it must not outlast the batch it came from); whatever is left -- more problems
+    // than that, weights, per-problem grids, models without that kernel -- on the generic kernel, which also zeroes the
+    // list's other counter
+    p.gen_list_first = 0;
+    if (launch_fn fast = find_fit_rescue(h->kern->fit_single)) {
+        const int rc = fast(p);
+        if (rc == VP_ERR_OK) p.gen_list_first = kFitRescueGrid;
+        else if (rc != VP_ERR_UNSUPPORTED) return rc;
+    }
     p.rescue = nullptr;
     p.gen_ws = h->d_rescue_ws;
     p.gen_blocks = kRescueBlocks;
@@ -2027,6 +2062,10 @@ int vp_synchronize(vp_batch *h) {
 // ---- registry ------------------------------------------------------------------------------------------
 namespace vp {
 
+std::vector<RescueEntry> &rescue_registry() {
+    static std::vector<RescueEntry> r;
+    return r;
+}
 std::vector<KernelEntry> &registry() {
     static std::vector<KernelEntry> r;
     return r;

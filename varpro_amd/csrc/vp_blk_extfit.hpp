@@ -42,8 +42,8 @@ __global__ void __launch_bounds__(64, (ext_fit_stream_waves<T, N + 1 + P, RB>())
     using F = ext::ExtFitLayout<Q>;
     G grp = G::make(nullptr);
     const int lane = grp.gl;
-    const int64_t b = blockIdx.x;
-    if (b >= a.B) return;
+    const int64_t b = ext::extfit_problem_of<T>(a, blockIdx.x);
+    if (b < 0) return;
     const int m = a.m;
     const bool vec = a.vec != 0;
     T *st = reinterpret_cast<T *>(a.state);
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(64, (ext_fit_stream_waves<T, N + 1 + P, RB>())
 
 template <typename T, int N, int P, int Q> int launch_fit_stream_eval(const ext::ExtFitArgs<T> &a, hipStream_t stream) {
     constexpr int RB = ext_fit_stream_rows<T, N + 1 + P>();
-    hipLaunchKernelGGL((ext_fit_stream_eval_kernel<T, N, P, Q, RB>), dim3((unsigned)a.B), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((ext_fit_stream_eval_kernel<T, N, P, Q, RB>), dim3((unsigned)a.grid_problems), dim3(64), 0, stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 

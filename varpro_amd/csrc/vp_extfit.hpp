@@ -149,7 +149,22 @@ template <typename T> struct ExtFitArgs {
     // writes those of the trial point to C_trial, the LM kernel copies them to C_best when the point is accepted
     int S;            // 1 on every specialised path
     const T *C_trial; // [B][S][n] (S > 1) or null
+    // the ACTIVE SET, compacted (round 6): the LM kernel of step k writes the indices of the problems still running to
+    // active_out (their number is nactive[k & 1]); the evaluation launch of step k + 1 covers only those -- workgroup i takes
+    // problem active_in[i], i < *active_count; its grid is the host's last known count (an upper bound: counts never grow).
+    // The first step of a fit has no list (active_in == null: workgroup b <-> problem b).
+    const int32_t *active_in;
+    const int32_t *active_count;
+    int32_t *active_out;
+    int64_t grid_problems; // evaluation launch: workgroups (== B without a list)
 };
+
+// the problem of workgroup `wg` (-1: nothing to do)
+template <typename T> __device__ __forceinline__ int64_t extfit_problem_of(const ExtFitArgs<T> &a, const int64_t wg) {
+    if (!a.active_in) return wg < a.B ? wg : -1;
+    const int cnt = uni(*a.active_count);
+    return wg < cnt ? (int64_t)uni(a.active_in[wg]) : -1;
+}
 
 template <typename T, int R, int N, int P, int Q, int W> constexpr int extfit_waves() {
     // resident: N + 1 + P columns during the sweep, 1 + P + Q afterwards.  Two waves per SIMD (256 VGPRs) whenever the
@@ -174,8 +189,8 @@ __global__ void __launch_bounds__(64 * W, (extfit_waves<T, R, N, P, Q, W>())) ex
     extern __shared__ __attribute__((aligned(16))) unsigned char extfit_smem[];
     G grp = G::make(W > 1 ? extfit_smem : nullptr);
     const int lane = grp.gl;
-    const int64_t b = blockIdx.x;
-    if (b >= a.B) return;
+    const int64_t b = extfit_problem_of<T>(a, blockIdx.x);
+    if (b < 0) return;
     const int m = a.m;
     const bool vec = a.vec != 0;
     T *st = reinterpret_cast<T *>(a.state);
@@ -446,12 +461,20 @@ template <typename T, int Q> __global__ void __launch_bounds__(64) ext_fit_lm_ke
     a.cost[b] = (double)s.objective;
     a.status[b] = s.status;
     // the number of problems still running: one atomic per wavefront (lanes that returned early count as finished)
+    // ... and their indices, compacted (the next step's evaluation launch covers only these; order = arrival of the wavefronts,
+    // which nothing depends on)
     const unsigned long long running = __builtin_amdgcn_ballot_w64(s.term == 0);
-    if (running != 0 && (int)(threadIdx.x & 63u) == __builtin_ctzll(running)) atomicAdd(&a.nactive[a.step & 1], __builtin_popcountll(running));
+    if (running != 0) {
+        const int ln = (int)(threadIdx.x & 63u);
+        int base = 0;
+        if (ln == __builtin_ctzll(running)) base = atomicAdd(&a.nactive[a.step & 1], __builtin_popcountll(running));
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(running));
+        if (s.term == 0 && a.active_out) a.active_out[base + __builtin_popcountll(running & ((1ull << ln) - 1ull))] = (int32_t)b;
+    }
 }
 
 template <typename T, int N, int P, int Q, int R, int W> int launch_fit_eval(const ExtFitArgs<T> &a, hipStream_t stream) {
-    hipLaunchKernelGGL((ext_fit_eval_kernel<T, N, P, Q, R, W>), dim3((unsigned)a.B), dim3(64 * W), group_xch_bytes<W>(), stream, a);
+    hipLaunchKernelGGL((ext_fit_eval_kernel<T, N, P, Q, R, W>), dim3((unsigned)a.grid_problems), dim3(64 * W), group_xch_bytes<W>(), stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 template <typename T, int Q> int launch_fit_lm(const ExtFitArgs<T> &a, hipStream_t stream) {

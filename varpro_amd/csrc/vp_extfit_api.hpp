@@ -33,6 +33,9 @@ struct ExtFitParams {
     void *gen_ws;           // gen_blocks workspace slots of (n + 1 + np + q) columns x m
     int gen_blocks;
     void *C_trial;          // [B][S][n] scratch (S > 1)
+    // compacted active set (ExtFitArgs::active_in / active_out): two lists of B indices, used alternately
+    int32_t *active_lists;  // [2][B]
+    int64_t known_active;   // the host's last known number of active problems (an upper bound; B before the first step)
     hipStream_t stream;
 };
 // true: a step of this shape runs on the generic kernel and needs gen_ws (and C_trial when S > 1)

@@ -1057,9 +1057,19 @@ template <typename T, int N, int Q> struct LmState {
 // PADM (unit weights only): 0 = general m; 1 = m == 64*R*W, no padding rows at all; 2 = only the last register pair
 // can hold padding rows -- the row-validity masks (32 SGPRs of hoisted lane masks, two selects per element) disappear
 // from the column build entirely or from all pairs but the last
-template <typename T, class M, int R, int W, bool WEIGHTED, int PADM = 0>
+// RESCUE (round 6): the launch that re-fits the problems the fit kernels FLAGGED (jac_not_finite above) -- workgroup i takes
+// problem list[2 + i], i < list[slot] -- with every derivative column built as 2^-ks times its value, ks = the binary exponent
+// of its basis column's largest entry (from the two ends of the grid), and the coefficient entering the Jacobian QR as
+// c_k 2^ks: c_k D_k is unchanged, the basis part (R, c, the residual) is bit for bit the unscaled evaluation, nothing
+// overflows.  One wavefront(-group) per problem at the lone-wave rate (~4 us per evaluation): a flagged problem must not
+// outlast the batch it came from.  Models with a trailing constant and diagonal pairs (MultiExpModel<.., true>); every
+// other flagged problem goes to the generic kernel (vp_api.hip rescue_refit).
+template <typename T, class M> inline constexpr bool fit_rescue_v = M::kStatic && M::kConstLast && M::kDiagonalPairs;
+
+template <typename T, class M, int R, int W, bool WEIGHTED, int PADM = 0, bool RESCUE = false>
 __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
     static_assert(!(WEIGHTED && PADM != 0), "PADM is a unit-weight specialisation");
+    static_assert(!RESCUE || fit_rescue_v<T, M>, "the scaled re-fit needs the constant-first sweep and diagonal pairs");
     constexpr int N = M::N, P = M::P, Q = M::Q;
     // CF: the constant column leads the factorisation and is never materialised (evaluate_core_const_first)
     constexpr bool CF = M::kConstLast;
@@ -1077,8 +1087,13 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
     LmState<T, N, Q> *st =
         reinterpret_cast<LmState<T, N, Q> *>(s_after + ((group_xch_bytes<W>() + 15) / 16) * 16) + grp.wave;
     const int lane = grp.gl; // group lane: row ownership; LDS park / result writes use grp.lane / grp.wave
-    const int64_t b = blockIdx.x;
-    if (b >= a.B) return;
+    int64_t b = blockIdx.x;
+    if constexpr (RESCUE) {
+        if (b >= (int64_t)uni(a.rescue[a.rescue_slot])) return;
+        b = (int64_t)uni(a.rescue[2 + b]);
+    } else {
+        if (b >= a.B) return;
+    }
     const int m = a.m;
 
     // stage the problem's grid, weights and weighted data in LDS (row order, padding rows zero)
@@ -1224,7 +1239,21 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
         if constexpr (R >= 2) load_rows_lds<T, R, W>(s_y, lane, C[YC]);
         else load_rows<T, R, W>(s_y, MP, lane, true, C[YC]);
         VP_TICK(clk, 0);
-        if constexpr (CF) evaluate_core_const_first<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, h0, C, u, clk);
+        int ks[N]; // (RESCUE) binary exponents the derivative columns are scaled down by
+#pragma unroll
+        for (int j = 0; j < N; ++j) ks[j] = 0;
+        if constexpr (RESCUE) {
+            // largest exponent of exp(-t/tau_j) over the grid, from its two ends (grids are sorted; an unsorted one keeps ks = 0
+            // and with it the unscaled result)
+            const T t_first = s_t[0], t_last = s_t[m - 1];
+#pragma unroll
+            for (int j = 0; j < N - 1; ++j) {
+                const T rt = T(1) / xt[j];
+                const T e2 = tmax(-t_first * rt, -t_last * rt) * T(1.4426950408889634);
+                ks[j] = uni((e2 > T(64) && e2 < T(1100)) ? (int)e2 : 0);
+            }
+            evaluate_core_const_first<T, M, R, NC, Src, G, false, false, true>(a.mdl, xt, src, a.eps, grp, h0, C, u, clk, T(0), ks);
+        } else if constexpr (CF) evaluate_core_const_first<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, h0, C, u, clk);
         else evaluate_core<T, M, R, NC, Src, G>(a.mdl, xt, src, a.eps, grp, C, u, clk);
         VP_TICK(clk, 3);
 
@@ -1333,7 +1362,7 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
                 // z_k = -c_k Q^T D_k: factor the unscaled columns in place, the coefficients enter as column scales
                 T zs[Q];
 #pragma unroll
-                for (int k = 0; k < Q; ++k) zs[k] = -u.c[k];
+                for (int k = 0; k < Q; ++k) zs[k] = RESCUE ? -tldexp(u.c[k], ks[k]) : -u.c[k];
                 jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
             } else {
                 T Zs[Q][R];
@@ -1342,7 +1371,7 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
             }
             if (uni(jac_not_finite<T, Q>(acnorm))) { // (rare) flag and re-fit: see jac_not_finite
                 term = VP_TERM_NUMERICAL;
-                flagged = a.rescue != nullptr;
+                flagged = !RESCUE && a.rescue != nullptr;
                 break;
             }
             VP_TICK(clk, 5);
@@ -1503,6 +1532,45 @@ template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchPara
         hipLaunchKernelGGL((fit_kernel<T, M, R, W, false, 2>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     else hipLaunchKernelGGL((fit_kernel<T, M, R, W, false>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+// the re-fit launch of the flagged problems (fit_kernel<..., RESCUE>): up to kFitRescueGrid of them, one workgroup each; entries
+// beyond that (and weighted problems, and every model outside fit_rescue_v) are the generic kernel's (vp_api.hip rescue_refit)
+template <typename T, class M, int R, int W = 1> int launch_fit_rescue(const LaunchParams &p) {
+    if constexpr (!fit_rescue_v<T, M>) {
+        return VP_ERR_UNSUPPORTED;
+    } else {
+        if (p.w || p.t_stride != 0 || !p.rescue) return VP_ERR_UNSUPPORTED;
+        FitArgs<T, M> a;
+        if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+        a.t = (const T *)p.t;
+        a.w = nullptr;
+        a.yw = (const T *)p.yw;
+        a.alpha = (T *)p.alpha_out;
+        a.C_out = (T *)p.C_out;
+        a.cost_out = p.cost_out;
+        a.status = p.status;
+        a.report = p.report;
+        a.m = p.m;
+        a.B = p.B;
+        a.t_stride = 0;
+        a.w_stride = 0;
+        a.eps = (T)p.eps;
+        a.ftol = (T)p.opts->ftol;
+        a.xtol = (T)p.opts->xtol;
+        a.gtol = (T)p.opts->gtol;
+        a.stepbound = (T)p.opts->stepbound;
+        a.patience = p.opts->patience;
+        a.scale_diag = p.opts->scale_diag;
+        a.trace = p.trace;
+        a.trace_rows = p.trace_rows;
+        a.grid_uniform = p.grid_uniform;
+        a.rescue = p.rescue;
+        a.rescue_slot = p.rescue_slot;
+        const size_t lds = fit_lds_bytes<T, M, R, W>(false);
+        hipLaunchKernelGGL((fit_kernel<T, M, R, W, false, 0, true>), dim3(kFitRescueGrid), dim3(64 * W), lds, p.stream, a);
+        return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+    }
 }
 
 // == FitResult::best_fit (src/fit.rs:55-59, 87-91): UNWEIGHTED Phi(alpha) * C

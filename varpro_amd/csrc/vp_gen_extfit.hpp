@@ -28,6 +28,8 @@ template <typename T> struct GenExtFitArgs {
     T *C_trial;      // [B][S][n] (S > 1) or null
     int init;        // first step: every problem is evaluated with derivative columns
     int q;
+    const int32_t *active_in;    // the compacted active set of the previous step (ExtFitArgs), or null
+    const int32_t *active_count;
 };
 
 template <typename T> __global__ void __launch_bounds__(TB) gen_extfit_eval_kernel(const GenExtFitArgs<T> xa) {
@@ -43,7 +45,9 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_extfit_eval_kern
     int32_t *si = ext::extfit_ints_rt<T>(xa.state, B, F.NT);
     T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
     auto col = [&](int c) { return ws + (int64_t)c * m; };
-    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const int64_t count = xa.active_in ? (int64_t)*xa.active_count : B;
+    for (int64_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
+        const int64_t b = xa.active_in ? (int64_t)xa.active_in[bi] : bi;
         int want = ext::EXTFIT_WANT_BASIS | ext::EXTFIT_WANT_DERIVS;
         if (!xa.init) {
             if (si[F.TERM * B + b] != 0) continue; // (uniform: finished in an earlier step)

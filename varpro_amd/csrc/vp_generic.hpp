@@ -67,6 +67,7 @@ template <typename T> struct GenArgs {
     // streamed fit kernels append to, vp_kernels.hpp rescue_push); the launch zeroes the OTHER counter for the next fit
     const int32_t *list;
     int list_slot;
+    int list_first;     // first list entry this launch fits
     // power-of-two scaling of huge columns (evaluate below): 1 for every fit launched here
     int scale_cols;
 };
@@ -612,7 +613,7 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_fit_kernel(const
         if (count > a.B) count = a.B;
         if (blockIdx.x == 0 && tid == 0) const_cast<int32_t *>(a.list)[a.list_slot ^ 1] = 0;
     }
-    for (int64_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
+    for (int64_t bi = blockIdx.x + (a.list ? a.list_first : 0); bi < count; bi += gridDim.x) {
         const int64_t b = a.list ? (int64_t)a.list[2 + bi] : bi;
         if (tid == 0) {
             T a0[VP_MAX_PARAMS];
@@ -1138,6 +1139,7 @@ template <typename T> inline bool fill_args(const LaunchParams &p, GenArgs<T> &a
     a.trace_rows = p.trace_rows;
     a.list = p.gen_list;
     a.list_slot = p.gen_list_slot;
+    a.list_first = p.gen_list_first;
     a.scale_cols = p.gen_scale_cols;
     return true;
 }

@@ -38,6 +38,12 @@ template <typename T> int ext_fit_step_t(const ExtFitParams &p) {
     ext::ExtFitArgs<T> a;
     a.S = (int)(p.S > 1 ? p.S : 1);
     a.C_trial = (const T *)p.C_trial;
+    // the evaluation covers the active set the previous step's LM kernel compacted (none before the first step)
+    const bool have_list = !p.init && p.active_lists != nullptr;
+    a.active_in = have_list ? p.active_lists + (size_t)((p.step + 1) & 1) * (size_t)p.B : nullptr;
+    a.active_count = have_list ? p.nactive + ((p.step + 1) & 1) : nullptr;
+    a.active_out = p.active_lists ? p.active_lists + (size_t)(p.step & 1) * (size_t)p.B : nullptr;
+    a.grid_problems = have_list ? (p.known_active < p.B ? (p.known_active > 0 ? p.known_active : 1) : p.B) : p.B;
     a.phi = (const T *)p.phi;
     a.dphi = (const T *)p.dphi;
     a.w = (const T *)p.w;
@@ -118,7 +124,9 @@ template <typename T> int ext_fit_step_t(const ExtFitParams &p) {
         x.C_trial = (T *)p.C_trial;
         x.init = p.init;
         x.q = p.q;
-        const int blocks = (int)(p.B < p.gen_blocks ? p.B : p.gen_blocks);
+        x.active_in = a.active_in;
+        x.active_count = a.active_count;
+        const int blocks = (int)(a.grid_problems < p.gen_blocks ? a.grid_problems : p.gen_blocks);
         hipLaunchKernelGGL((gen::gen_extfit_eval_kernel<T>), dim3((unsigned)blocks), dim3(gen::TB), 0, p.stream, x);
         if (hipGetLastError() != hipSuccess) return VP_ERR_HIP;
     }

@@ -94,9 +94,13 @@ struct LaunchParams {
     int rescue_slot;         // the counter this fit appends to (0 / 1); the re-fit launch zeroes the other one
     const int32_t *gen_list; // generic fit kernel: fit the problems gen_list[2 + i], i < gen_list[gen_list_slot] (null: all B)
     int gen_list_slot;
+    int gen_list_first;      // ... starting at entry gen_list_first (the ones before it were re-fitted by the set's own kernel)
     int gen_scale_cols;      // generic kernels: power-of-two scaling of huge basis columns (and their derivative columns)
     hipStream_t stream;
 };
+
+// workgroups of the fast re-fit launch (fit_kernel<..., RESCUE>, vp_fit.hpp): flagged problems beyond that go to the generic kernel
+constexpr int kFitRescueGrid = 256;
 
 // One fit whose Jacobian came out non-finite after an evaluation that was itself fine -- the reference forms D_k c BEFORE it
 // projects (src/solvers/levmar/mod.rs:156-171), the register kernels sweep the unscaled derivative columns, so a decay time
