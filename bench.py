@@ -449,7 +449,7 @@ def main():
                 h_.close()
             return dt_ * 1e3 / (rounds * depth)
 
-        TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+        TRAFFIC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
         def committed_traffic(key, field="hbm_bytes_per_launch_corrected"):
             """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r0x_pmc_traffic.json; separate
@@ -483,7 +483,7 @@ def main():
 
         def committed_valu_issue(key):
             """VALU issue fraction over the launch from the committed SQ PMC pass (profiles/r0x_fit_kernels_valu_pmc.json)"""
-            for fn in ("r05_fit_kernels_valu_pmc.json", "r04_fit_kernels_valu_pmc.json", "r03_fit_kernels_valu_pmc.json", "r02_fit_kernels_valu_pmc.json"):
+            for fn in ("r06_fit_kernels_valu_pmc.json", "r05_fit_kernels_valu_pmc.json", "r04_fit_kernels_valu_pmc.json", "r03_fit_kernels_valu_pmc.json", "r02_fit_kernels_valu_pmc.json"):
                 try:
                     e = json.load(open(os.path.join(ROOT, "profiles", fn)))[key]
                     # wave-level VALU instructions x 4 issue cycles / (1024 SIMDs x launch duration x 2.4 GHz)
@@ -888,9 +888,9 @@ def main():
             # (ext_evaluate_kernel<.., W>): one pass over the caller's arrays up to 4 096 rows (four waves), 8 192 fp64 /
             # 16 384 fp32 (eight); beyond that the streamed kernel of vp_blk_ext.hpp (any m, two passes over the columns)
             long_legs = {}
-            for tdt, ml, Bl, kern in ((torch.float32, 4096, 32768, "ext_evaluate_kernel<float, 3, 2, 16, true, 4> (four waves per problem)"),
-                                      (torch.float64, 8192, 8192, "ext_evaluate_kernel<double, 3, 2, 16, true, 8> (eight waves per problem)"),
-                                      (torch.float64, 10000, 4096, "blk::ext_stream_evaluate_kernel<double, 3, 2, 8> (rows streamed in blocks, two passes over the caller's columns: 15 column transfers for 9 algorithmic)")):
+            for tdt, ml, Bl, kern, tkey in ((torch.float32, 4096, 32768, "ext_evaluate_kernel<float, 3, 2, 16, true, 4> (four waves per problem)", "ext_evaluate_kernel_w4"),
+                                            (torch.float64, 8192, 8192, "ext_evaluate_kernel<double, 3, 2, 16, true, 8> (eight waves per problem)", "ext_evaluate_kernel_w8"),
+                                            (torch.float64, 10000, 4096, "blk::ext_stream_evaluate_kernel<double, 3, 2, 8> (rows streamed in blocks, two passes over the caller's columns: 15 column transfers for 9 algorithmic)", "ext_stream_evaluate_kernel")):
                 Tl = 4 if tdt == torch.float32 else 8
                 gl_ = torch.Generator(device=dev)
                 gl_.manual_seed(0x5EED77)
@@ -921,7 +921,8 @@ def main():
                     "workload": "vp_evaluate_with_basis, B=%d, m=%d, %s, n=3, q=2, p=2 (Phi, dPhi, y in; r, J out)" % (Bl, ml, "fp32" if Tl == 4 else "fp64"),
                     "ms": xl_ms, "status_ok_share": float((stl == 0).double().mean()),
                     "roofline": {"kernel": kern, "bound": "hbm", "achieved": byl / (xl_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": byl / (xl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": byl, "avg_launch_ms": xl_ms, "traffic": None}}
+                                 "frac": byl / (xl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": byl, "avg_launch_ms": xl_ms,
+                                 "traffic": committed_traffic(tkey), "traffic_source": traffic_source(tkey)}}
                 bpl.close()
                 del phl, dpl, Yl, rl, Jl
             out["external_model"]["long_problems"] = long_legs
@@ -957,7 +958,11 @@ def main():
                     if step_events is not None and steps_ < 3:
                         e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0_.record()
-                    alpha_, want_, nact = bpx.fit_step_with_basis(phi_x, dphi_x)
+                    # the active count is read back (a host synchronisation) every fourth step while many problems run: the
+                    # count only shrinks, a stale one makes the caller evaluate a superset
+                    look_ = (steps_ + 1) % 4 == 0 or nact < 64
+                    alpha_, want_, na_ = bpx.fit_step_with_basis(phi_x, dphi_x, want_count=look_)
+                    nact = na_ if look_ else nact
                     if step_events is not None and steps_ < 3:
                         e1_.record()
                         step_events.append((e0_, e1_, nact))
@@ -1070,7 +1075,8 @@ def main():
                                                            "objective_rel_diff_median": float(np.median(relx)), "objective_rel_diff_max": float(relx.max())},
                         "roofline": {"kernel": "blk::ext_fit_stream_eval_kernel<double, 3, 2, 2, 4> + ext_fit_lm_kernel<double, 2> (first step: every problem active)", "bound": "hbm",
                                      "achieved": byx / (st0 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byx / (st0 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     "bytes_per_launch": byx, "avg_launch_ms": st0, "traffic": None}}
+                                     "bytes_per_launch": byx, "avg_launch_ms": st0, "traffic": committed_traffic("ext_fit_stream_eval_kernel"),
+                                     "traffic_source": traffic_source("ext_fit_stream_eval_kernel")}}
                     bxs.close()
                     del phis, dphis, Yx_
                 bps.close()

@@ -1779,9 +1779,11 @@ int vp_fit_trace(vp_batch *h, const vp_lm_opts *opts, void *alpha_inout, void *C
     // constant column, batches smaller than the device's resident wave slots).  vp_set_fit_kernel overrides.
     launch_fn fit_fn = h->kern->fit ? h->kern->fit : h->kern->fit_single;
     if (int rc0 = rescue_prepare(h, p)) return rc0;
+    int list_used = 0; // (set by the launcher when its kernel may append to the list)
+    p.rescue_used = &list_used;
     Timer tm(h, VP_KERNEL_FIT);
     int rc = fit_fn(p);
-    if (rc == VP_ERR_OK) rc = rescue_refit(h, p); // (second, tiny launch: the problems the fit kernels flagged)
+    if (rc == VP_ERR_OK && list_used) rc = rescue_refit(h, p); // (the problems the fit kernel flagged and did not re-fit itself)
     tm.stop();
     if (rc != VP_ERR_OK) return fail(rc, "fit kernel launch failed");
     h->have_params = true;

@@ -226,6 +226,9 @@ template <typename T, int N, int P> int launch_ext_stream(const ext::ExtArgs<T> 
     const bool want_rj = a.r_out != nullptr || a.J_out != nullptr;
     const size_t snap = want_rj ? ext_stream_snap_bytes<T, N, P, RB>(a.m) : 0;
     if (snap > kEvalSnapMax) return VP_ERR_UNSUPPORTED; // (the caller falls back to the generic kernels)
+    // (round 6, tools/ext_stream_cap_probe.py: capping the resident waves through the LDS footprint so that the backward pass's
+    // re-reads come out of the 256 MB Infinity Cache LOSES -- 1.01 ms at 2 048 resident waves, 1.20 at 1 024, 1.81 at 512, 3.07
+    // at 256 per 4 096 problems of 10 000 rows: a wave is bound by its own chain of reduction rounds per block, not by HBM)
     hipLaunchKernelGGL((ext_stream_evaluate_kernel<T, N, P, RB>), dim3((unsigned)a.nprob), dim3(64), snap, stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }

@@ -864,6 +864,7 @@ template <typename T, class M> int launch_fit(const LaunchParams &p) {
     a.rescue = p.rescue;
     a.rescue_slot = p.rescue_slot;
     if (a.B <= 0) return VP_ERR_OK;
+    if (p.rescue_used) *p.rescue_used = 1;
     constexpr int RB = block_rows<T, M::N + 1 + M::P, M::kStatic>();
     // A launch that does not fill the device several times over ends when its LONGEST fit does (evaluation counts are
     // heavy-tailed: mean ~8, max 100+): four waves per problem then shorten every chain ~3.5x at no cost in throughput that

@@ -1066,8 +1066,16 @@ template <typename T, int N, int Q> struct LmState {
 // other flagged problem goes to the generic kernel (vp_api.hip rescue_refit).
 template <typename T, class M> inline constexpr bool fit_rescue_v = M::kStatic && M::kConstLast && M::kDiagonalPairs;
 
-template <typename T, class M, int R, int W, bool WEIGHTED, int PADM = 0, bool RESCUE = false>
-__global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
+// The fit of ONE problem by one wavefront(-group): the body of fit_kernel, also the exit path of the slot kernel's self-rescue
+// (vp_fit2.hpp: a wave re-fits the problems IT flagged before it ends -- no second launch).  LDS: s_t / s_y / s_w = zero-padded
+// row-order copies of grid, data and weights (MP = 64 R W values each), xch = the group's exchange area, st = this wave's
+// parked LM state.  stage_grid = false: s_t already holds the problem's grid (the slot kernel's shared grid).
+// Returns true when the fit ended on a Jacobian factor that is not finite after an evaluation that was ok (jac_not_finite)
+// and RESCUE is off -- the caller re-fits with RESCUE on (SELF) or the problem is on the handle's list (a.rescue).
+//   SELF: the caller re-fits a flagged problem itself: it is neither pushed to the list nor are its parameters stored
+template <typename T, class M, int R, int W, bool WEIGHTED, int PADM, bool RESCUE, bool SELF>
+__device__ __forceinline__ bool fit_problem(const FitArgs<T, M> &a, const int64_t b, T *s_t, T *s_y, T *s_w, unsigned char *xch,
+                                            LmState<T, M::N, M::Q> *st, const bool stage_grid) {
     static_assert(!(WEIGHTED && PADM != 0), "PADM is a unit-weight specialisation");
     static_assert(!RESCUE || fit_rescue_v<T, M>, "the scaled re-fit needs the constant-first sweep and diagonal pairs");
     constexpr int N = M::N, P = M::P, Q = M::Q;
@@ -1077,31 +1085,19 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
     constexpr int YC = CF ? N - 1 : N;         // data column
     constexpr int DC = YC + 1;                 // first derivative column
     constexpr int MP = 64 * R * W;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *s_t = reinterpret_cast<T *>(smem_raw);
-    T *s_y = s_t + MP;
-    T *s_w = WEIGHTED ? s_y + MP : nullptr;
-    unsigned char *s_after = reinterpret_cast<unsigned char *>(s_y + MP + (WEIGHTED ? MP : 0));
     using G = Grp<W>;
-    G grp = G::make(s_after); // exchange area first (8-byte aligned), then one LmState per wave
-    LmState<T, N, Q> *st =
-        reinterpret_cast<LmState<T, N, Q> *>(s_after + ((group_xch_bytes<W>() + 15) / 16) * 16) + grp.wave;
+    G grp = G::make(xch);
     const int lane = grp.gl; // group lane: row ownership; LDS park / result writes use grp.lane / grp.wave
-    int64_t b = blockIdx.x;
-    if constexpr (RESCUE) {
-        if (b >= (int64_t)uni(a.rescue[a.rescue_slot])) return;
-        b = (int64_t)uni(a.rescue[2 + b]);
-    } else {
-        if (b >= a.B) return;
-    }
     const int m = a.m;
 
     // stage the problem's grid, weights and weighted data in LDS (row order, padding rows zero)
     {
         T tmp[R];
-        const T *tp = a.t + b * a.t_stride;
-        load_rows<T, R, W>(tp, m, lane, vec_aligned<T>(tp, m), tmp);
-        store_rows<T, R, W>(s_t, MP, lane, true, tmp);
+        if (stage_grid) {
+            const T *tp = a.t + b * a.t_stride;
+            load_rows<T, R, W>(tp, m, lane, vec_aligned<T>(tp, m), tmp);
+            store_rows<T, R, W>(s_t, MP, lane, true, tmp);
+        }
         if constexpr (WEIGHTED) {
             const T *wp = a.w + b * a.w_stride;
             load_rows<T, R, W>(wp, m, lane, vec_aligned<T>(wp, m), tmp);
@@ -1111,7 +1107,14 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
         load_rows<T, R, W>(yp, m, lane, vec_aligned<T>(yp, m), tmp);
         store_rows<T, R, W>(s_y, MP, lane, true, tmp);
     }
-    __syncthreads(); // orders the LDS writes before the reads below (every lane re-reads only its own rows)
+    // orders the LDS writes before the reads below (every lane re-reads only its own rows; one wave: no workgroup barrier -- the
+    // slot kernel's other waves are not here)
+    if constexpr (W > 1) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     // the LDS copies are zero-padded to MP rows; valid rows are still i < m (scale 0 beyond)
     using Src = RowSource<T, R, true, WEIGHTED ? 1 : 0, 1, W, true, PADM>;
     Src src;
@@ -1371,7 +1374,7 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
             }
             if (uni(jac_not_finite<T, Q>(acnorm))) { // (rare) flag and re-fit: see jac_not_finite
                 term = VP_TERM_NUMERICAL;
-                flagged = !RESCUE && a.rescue != nullptr;
+                flagged = !RESCUE;
                 break;
             }
             VP_TICK(clk, 5);
@@ -1476,8 +1479,8 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
     }
     // lane 0 stores the (uniform) results one by one: a lane-indexed gather would turn x[] into a scratch array
     if (lane == 0) {
-        if (flagged) { // alpha[b] keeps the initial guess: the re-fit launch starts from it and overwrites every output
-            rescue_push(a.rescue, a.rescue_slot, b);
+        if (flagged && (SELF || a.rescue != nullptr)) { // alpha[b] keeps the initial guess: the re-fit starts from it and overwrites every output
+            if (!SELF) rescue_push(a.rescue, a.rescue_slot, b);
         } else {
 #pragma unroll
             for (int k = 0; k < Q; ++k) a.alpha[b * Q + k] = x[k];
@@ -1487,6 +1490,28 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
             for (int k = 0; k < N; ++k) a.C_out[b * N + a.mdl.out_index(k)] = cbest[k];
         }
     }
+    return flagged;
+}
+
+template <typename T, class M, int R, int W, bool WEIGHTED, int PADM = 0, bool RESCUE = false>
+__global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
+    constexpr int MP = 64 * R * W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *s_t = reinterpret_cast<T *>(smem_raw);
+    T *s_y = s_t + MP;
+    T *s_w = WEIGHTED ? s_y + MP : nullptr;
+    unsigned char *s_after = reinterpret_cast<unsigned char *>(s_y + MP + (WEIGHTED ? MP : 0));
+    // exchange area first (8-byte aligned), then one LmState per wave
+    LmState<T, M::N, M::Q> *st = reinterpret_cast<LmState<T, M::N, M::Q> *>(s_after + ((group_xch_bytes<W>() + 15) / 16) * 16) +
+                                 (W > 1 ? (int)(threadIdx.x >> 6) : 0);
+    int64_t b = blockIdx.x;
+    if constexpr (RESCUE) {
+        if (b >= (int64_t)uni(a.rescue[a.rescue_slot])) return;
+        b = (int64_t)uni(a.rescue[2 + b]);
+    } else {
+        if (b >= a.B) return;
+    }
+    (void)fit_problem<T, M, R, W, WEIGHTED, PADM, RESCUE, false>(a, b, s_t, s_y, s_w, s_after, st, true);
 }
 
 // dynamic LDS of fit_kernel: zero-padded copies of the grid, the data column and (weighted problems) the weights, the group
@@ -1524,6 +1549,7 @@ template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchPara
     a.rescue = p.rescue;
     a.rescue_slot = p.rescue_slot;
     if (a.B <= 0) return VP_ERR_OK;
+    if (p.rescue_used) *p.rescue_used = 1;
     const size_t lds = fit_lds_bytes<T, M, R, W>(p.w != nullptr);
     if (p.w) hipLaunchKernelGGL((fit_kernel<T, M, R, W, true>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     else if (p.m == 64 * R * W)

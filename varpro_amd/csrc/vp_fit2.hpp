@@ -40,6 +40,8 @@ template <typename T, int N, int Q> struct alignas(8) SlotRec {
     int status;
     int prob; // problem index of the slot, -1 = empty
     int trow; // trace rows written so far
+    int pend[2]; // (self-rescue) problems this slot FLAGGED (vp_fit.hpp jac_not_finite), re-fitted by the wave before it ends; -1 = none.
+                 // Not touched by slot_fill: the entries outlive the slot's refills
 };
 
 // Slots per group from the LDS budget: a workgroup holds ONE copy of the grid and NG groups x GS columns of 64*R*W
@@ -84,6 +86,7 @@ template <typename T, typename TO = T> struct SlotConsts {
     int *queue;
     int32_t *rescue;   // flag-and-refit list (vp_fit.hpp jac_not_finite; LaunchParams::rescue) or null
     int rescue_slot;
+    int self_rescue;   // 1: flagged problems are parked in the slot's record (SlotRec::pend) and re-fitted by this wave at its end
     int64_t B;
     int trace_rows, scale_diag, max_fev, m;
     T eps;             // (Gram kernel) rank threshold of the linear solve
@@ -451,7 +454,10 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
         if (cost_out) cost_out[prob] = (double)objective;
         if (status_out && !VP_FITG_TIMELINE) status_out[prob] = status;
         int32_t *rescue = k->rescue;
-        if (flagged && rescue) { // alpha[prob] keeps the initial guess for the re-fit launch
+        const int pslot = (s->pend[0] < 0) ? 0 : ((s->pend[1] < 0) ? 1 : -1);
+        if (flagged && k->self_rescue != 0 && pslot >= 0) { // alpha[prob] keeps the initial guess; this wave re-fits it before it ends
+            s->pend[pslot] = (int)prob;
+        } else if (flagged && k->self_rescue == 0 && rescue) { // ... or the re-fit launch does
             rescue_push(rescue, k->rescue_slot, prob);
         } else {
 #pragma unroll
@@ -696,7 +702,7 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
             jac_qrfac_scaled<T, R, Q, N>(reinterpret_cast<T(&)[Q][R]>(C[DC]), C[YC], zs, Rj, acnorm, ipvt, qtf, grp);
             if (uni(jac_not_finite<T, Q>(acnorm))) { // (rare) flag and re-fit: vp_fit.hpp, jac_not_finite
                 term = VP_TERM_NUMERICAL;
-                flagged = kc->rescue != nullptr;
+                flagged = true;
                 break;
             }
             T gmax = T(0);
@@ -789,7 +795,10 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
         T *alpha_out = kc->alpha, *C_out = kc->C_out;
         if (cost_out) cost_out[prob] = (double)objective;
         if (status_out) status_out[prob] = st_best;
-        if (flagged) {
+        const int pslot = (rec->pend[0] < 0) ? 0 : ((rec->pend[1] < 0) ? 1 : -1);
+        if (flagged && kc->self_rescue != 0 && pslot >= 0) {
+            rec->pend[pslot] = (int)prob;
+        } else if (flagged && kc->self_rescue == 0 && kc->rescue) {
             rescue_push(kc->rescue, kc->rescue_slot, prob);
         } else {
 #pragma unroll
@@ -801,6 +810,19 @@ __device__ VP_LONE_TAIL_LINKAGE void fit2_lone_tail(VP_LDS SlotRec<T, M::N, M::Q
         }
         rec->term = term;
     }
+}
+
+#ifndef VP_SELF_RESCUE
+#define VP_SELF_RESCUE 1 // (A/B switch: 0 = flagged problems go to the handle's list and the re-fit launches behind the fit)
+#endif
+template <typename T, class M, int W> inline constexpr bool fit2_self_rescue_v = VP_SELF_RESCUE && W == 1 && fit_rescue_v<T, M>;
+
+// the scaled re-fit of one flagged problem by the wave that flagged it (fit2_kernel's exit path).  OUT OF LINE: inlined, its
+// 160-register column array and spill slots became part of the slot kernel's own frame and the hot loop ran 2 % slower
+// (113 instead of 42 spilled VGPRs in the kernel's metadata, 2.10 instead of 2.065 ms per step with two batches in flight)
+template <typename T, class M, int R>
+__device__ __noinline__ void fit2_refit_flagged(const FitArgs<T, M> *a, const int64_t b, T *s_t, T *s_y, LmState<T, M::N, M::Q> *st) {
+    (void)fit_problem<T, M, R, 1, false, 0, true, false>(*a, b, s_t, s_y, nullptr, nullptr, st, false);
 }
 
 // A workgroup = NG groups of W waves (W = 1: NG = 4 independent waves; W > 1: ONE group, whose reductions use
@@ -858,6 +880,7 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
             kc->alpha = a.alpha;
             kc->rescue = a.rescue;
             kc->rescue_slot = a.rescue_slot;
+            kc->self_rescue = (fit2_self_rescue_v<T, M, W> && a.rescue != nullptr) ? 1 : 0; // (a.rescue == null: re-fits are switched off)
             kc->C_out = a.C_out;
             kc->cost_out = a.cost_out;
             kc->status = a.status;
@@ -895,6 +918,10 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
         if constexpr (W > 1) grp.phase = 0; // slot_fill leaves the exchange buffers quiescent (barrier at its end)
     };
 
+    if (lane == 0) {
+#pragma nounroll
+        for (int s = 0; s < GS; ++s) recs[s].pend[0] = recs[s].pend[1] = -1;
+    }
     // ---- initial, static assignment: group gw takes problems gw*GS .. gw*GS+GS-1 ----
     int nactive = 0;
     bool queue_dry = false;
@@ -1040,6 +1067,28 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
         }
     }
 #endif
+    // SELF-RESCUE (round 6): the problems this wave flagged -- a Jacobian factor that is not finite after an evaluation that
+    // was ok, vp_fit.hpp jac_not_finite -- are re-fitted HERE, from their initial guesses, with scaled derivative columns
+    // (fit_problem<..., RESCUE>): no second launch behind the fit (two mostly empty launches cost the pipelined headline 2 %:
+    // tools/refit_cost_probe.py), and as the kernel's exit path nothing of the slot loop is live across it.  The slot's data
+    // column and records are free by now: they hold the re-fit's data copy and parked LM state.
+    if constexpr (fit2_self_rescue_v<T, M, W>) {
+        group_sync();
+        int pend[2 * GS];
+#pragma unroll
+        for (int s = 0; s < GS; ++s) {
+            pend[2 * s] = uni(recs[s].pend[0]);
+            pend[2 * s + 1] = uni(recs[s].pend[1]);
+        }
+        group_sync();
+        static_assert(sizeof(LmState<T, N, Q>) <= sizeof(Rec) * GS, "the parked LM state of the re-fit lives in the group's records");
+#pragma nounroll
+        for (int i = 0; i < 2 * GS; ++i) {
+            const int pb_ = dyn_get<2 * GS>(pend, i);
+            if (pb_ < 0) continue;
+            fit2_refit_flagged<T, M, R>(&args.f, (int64_t)pb_, s_t, s_y, reinterpret_cast<LmState<T, N, Q> *>(recs));
+        }
+    }
 #ifdef VP_FIT2_CLOCKS
     if (args.f.trace && blockIdx.x == 0 && threadIdx.x == 0) {
         double *tr = args.f.trace + (size_t)(args.f.trace_rows - 1) * (Q + 4);
@@ -1100,6 +1149,8 @@ template <typename T, class M, int R, int W = 1> int launch_fit2(const LaunchPar
         a.rescue = p.rescue;
         a.rescue_slot = p.rescue_slot;
         if (a.B <= 0) return VP_ERR_OK;
+        // (W == 1 slot kernels of fit_rescue_v models re-fit what they flag themselves: no list, no second launch)
+        if (p.rescue_used && !fit2_self_rescue_v<T, M, W>) *p.rescue_used = 1;
         // persistent grid: every resident workgroup slot of the device, or fewer when the batch is smaller
         const int64_t cap_blocks = (int64_t)p.num_cus * BPC;
         const int64_t need_blocks = (a.B + (int64_t)GS * NG - 1) / ((int64_t)GS * NG);

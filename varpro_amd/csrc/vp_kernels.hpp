@@ -92,6 +92,8 @@ struct LaunchParams {
     // generic kernel with power-of-two column scaling (rescue_push below, gen_fit_kernel; vp_api.hip: rescue_refit)
     int32_t *rescue;         // [2 + B]: two ping-pong counters, then the problem indices; null: nothing is flagged
     int rescue_slot;         // the counter this fit appends to (0 / 1); the re-fit launch zeroes the other one
+    int *rescue_used;        // (host) set to 1 by a launcher whose kernel may append to the list (the slot kernels of models
+                             // with the scaled re-fit built in re-fit what they flag themselves: nothing to launch afterwards)
     const int32_t *gen_list; // generic fit kernel: fit the problems gen_list[2 + i], i < gen_list[gen_list_slot] (null: all B)
     int gen_list_slot;
     int gen_list_first;      // ... starting at entry gen_list_first (the ones before it were re-fitted by the set's own kernel)
