@@ -43,7 +43,8 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_extfit_eval_kern
     const ext::ExtFitOffsets F = ext::extfit_offsets(q);
     T *st = reinterpret_cast<T *>(xa.state);
     int32_t *si = ext::extfit_ints_rt<T>(xa.state, B, F.NT);
-    T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gen_dyn_lds[];
+    T *ws = gen_workspace<T>(a, gen_dyn_lds);
     auto col = [&](int c) { return ws + (int64_t)c * m; };
     const int64_t count = xa.active_in ? (int64_t)*xa.active_count : B;
     for (int64_t bi = blockIdx.x; bi < count; bi += gridDim.x) {
@@ -98,16 +99,15 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_extfit_eval_kern
                 }
                 __syncthreads();
                 for (int k = 0; k < q; ++k) {
-                    T vals[MAXV];
                     const int nv = q - k + 1; // z_k . z_l (l >= k), z_k . r
-                    for (int v = 0; v < nv; ++v) vals[v] = T(0);
-                    const T *zk = col(NCQ + k), *y = col(n);
-                    for (int i = n + tid; i < m; i += TB) {
-                        const T x = zk[i];
-                        for (int l = k; l < q; ++l) vals[l - k] = tfma(x, col(NCQ + l)[i], vals[l - k]);
-                        vals[nv - 1] = tfma(x, y[i], vals[nv - 1]);
+                    const T *zk = col(NCQ + k);
+                    for (int v = 0; v < nv; ++v) {
+                        const T *cv = (v == nv - 1) ? col(n) : col(NCQ + k + v);
+                        T acc = T(0);
+                        for (int i = n + tid; i < m; i += TB) acc = tfma(zk[i], cv[i], acc);
+                        reduce_put(sh, v, acc);
                     }
-                    multi_reduce(sh, vals, nv);
+                    reduce_finish(sh, nv);
                     if (tid == 0) {
                         for (int l = k; l < q; ++l) s_acc[1 + k * q + l] += (double)sh.red[l - k];
                         s_acc[1 + q * q + k] += (double)sh.red[nv - 1];

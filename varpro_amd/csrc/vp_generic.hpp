@@ -17,6 +17,8 @@
 #pragma once
 #include <cstring>
 
+#include <mutex>
+
 #include "vp_lm_core.hpp"
 
 namespace vp {
@@ -70,7 +72,18 @@ template <typename T> struct GenArgs {
     int list_first;     // first list entry this launch fits
     // power-of-two scaling of huge columns (evaluate below): 1 for every fit launched here
     int scale_cols;
+    // 1: the workgroup's column workspace lives in its dynamic LDS (it fits: ws_cols * m scalars <= kGenLdsMax) instead of the
+    // global-memory slot -- every pass over the columns then costs an LDS round trip instead of an L2 / HBM one (round 6)
+    int ws_lds;
 };
+// dynamic LDS a generic kernel may take for its columns: the CU's 160 KiB less the static records (GenShared, the LM state)
+#ifndef VP_GEN_LDS_KB
+#define VP_GEN_LDS_KB 150 // (A/B switch: 0 = columns always in the global-memory workspace, round 5's layout)
+#endif
+constexpr size_t kGenLdsMax = (size_t)VP_GEN_LDS_KB * 1024;
+template <typename T> __device__ __forceinline__ T *gen_workspace(const GenArgs<T> &a, unsigned char *dyn_lds) {
+    return a.ws_lds ? reinterpret_cast<T *>(dyn_lds) : a.ws + (int64_t)blockIdx.x * a.ws_cols * a.m;
+}
 __host__ __device__ constexpr int gen_nacc(int q) { return 2 + q * q + q; }
 
 template <typename T> __device__ __forceinline__ T g_exp(T x);
@@ -112,7 +125,10 @@ __device__ __forceinline__ void basis_eval(int kind, T t, T p0, T p1, T &f, T &d
 }
 
 template <typename T> struct GenShared {
-    T part[MAXV][TB];   // multi-dot partials
+    T part[MAXV][TB / 64]; // multi-dot partials: one per wavefront (round 6: a wave-level reduction first -- the 51 KB of one partial
+                           // per THREAD left no room for the problem's columns in LDS)
+    unsigned long long mx[VP_MAX_BASIS]; // bit patterns of the column maxima (multi_reduce_max)
+    T sw[VP_MAX_BASIS][VP_MAX_BASIS], sv[VP_MAX_BASIS][VP_MAX_BASIS]; // svd_solve's work arrays (thread 0; LDS, not scratch)
     T red[MAXV];        // reduced values
     T f[MAXV];          // per-column update factors of the current reflector
     T Rm[VP_MAX_BASIS][VP_MAX_BASIS];
@@ -128,43 +144,56 @@ template <typename T> struct GenShared {
     int flag;
 };
 
-// nv dot-type sums at once: every thread holds vals[0..nv), afterwards sh.red[0..nv) holds the totals (all threads)
+// nv dot-type sums at once: every thread holds vals[0..nv), afterwards sh.red[0..nv) holds the totals (all threads).  Per value a
+// wave-level all-reduce (DPP / permlane, vp_device.hpp), then the TB / 64 wave totals added in a fixed order: deterministic.
 template <typename T> __device__ __forceinline__ void multi_reduce(GenShared<T> &sh, const T *vals, int nv) {
-    const int tid = (int)threadIdx.x;
-    for (int v = 0; v < nv; ++v) sh.part[v][tid] = vals[v];
-    __syncthreads();
-    // 8 threads per value, then a short serial tail: fixed order, deterministic
-    for (int v = tid >> 3; v < nv; v += TB / 8) {
-        const int sub = tid & 7;
-        T s = T(0);
-        for (int i = sub; i < TB; i += 8) s += sh.part[v][i];
-        sh.part[v][sub] = s; // (the sub-th partial slot is only read by this group after its own loop)
+    const int tid = (int)threadIdx.x, wave = tid >> 6, ln = tid & 63;
+    for (int v = 0; v < nv; ++v) {
+        const T s = wave_sum(vals[v]);
+        if (ln == 0) sh.part[v][wave] = s;
     }
     __syncthreads();
     if (tid < nv) {
-        T s = T(0);
-        for (int i = 0; i < 8; ++i) s += sh.part[tid][i];
+        T s = sh.part[tid][0];
+        for (int w = 1; w < TB / 64; ++w) s += sh.part[tid][w];
         sh.red[tid] = s;
     }
     __syncthreads();
 }
 
-// the same for maxima of non-negative values (any order gives the same result)
-template <typename T> __device__ __forceinline__ void multi_reduce_max(GenShared<T> &sh, const T *vals, int nv) {
+// One value at a time (round 6): run-time-indexed per-thread arrays (`vals[v]`, v < nv) live in SCRATCH -- every multiply-add of
+// a dot pass was a scratch load + store, ~0.5 us of latency each.  The passes below keep ONE accumulator in a register per
+// value and walk the rows once per value (the pivot column is re-read from LDS / L2, which is cheap): reduce_put hands the
+// thread's partial of value v to the wave reduction, reduce_finish adds the wave totals (same order as multi_reduce).
+template <typename T> __device__ __forceinline__ void reduce_put(GenShared<T> &sh, const int v, const T acc) {
+    const T s = wave_sum(acc);
+    if ((threadIdx.x & 63u) == 0) sh.part[v][threadIdx.x >> 6] = s;
+}
+template <typename T> __device__ __forceinline__ void reduce_finish(GenShared<T> &sh, const int nv) {
     const int tid = (int)threadIdx.x;
-    for (int v = 0; v < nv; ++v) sh.part[v][tid] = vals[v];
-    __syncthreads();
-    for (int v = tid >> 3; v < nv; v += TB / 8) {
-        const int sub = tid & 7;
-        T s = T(0);
-        for (int i = sub; i < TB; i += 8) s = (sh.part[v][i] > s || sh.part[v][i] != sh.part[v][i]) ? sh.part[v][i] : s; // (a NaN wins)
-        sh.part[v][sub] = s;
-    }
     __syncthreads();
     if (tid < nv) {
-        T s = T(0);
-        for (int i = 0; i < 8; ++i) s = (sh.part[tid][i] > s || sh.part[tid][i] != sh.part[tid][i]) ? sh.part[tid][i] : s;
+        T s = sh.part[tid][0];
+        for (int w = 1; w < TB / 64; ++w) s += sh.part[tid][w];
         sh.red[tid] = s;
+    }
+    __syncthreads();
+}
+
+// the same for maxima of non-negative values: non-negative IEEE numbers order like their bit patterns, and a NaN's pattern
+// lies above infinity's (a NaN wins) -- one LDS atomic per thread and value
+template <typename T> __device__ __forceinline__ void max_put(GenShared<T> &sh, const int v, const T val) { // (sh.mx zeroed + barrier before)
+    unsigned long long bits;
+    if constexpr (sizeof(T) == 8) bits = (unsigned long long)__double_as_longlong((double)val);
+    else bits = (unsigned long long)__float_as_uint((float)val);
+    atomicMax(&sh.mx[v], bits);
+}
+template <typename T> __device__ __forceinline__ void max_finish(GenShared<T> &sh, const int nv) {
+    const int tid = (int)threadIdx.x;
+    __syncthreads();
+    if (tid < nv) {
+        if constexpr (sizeof(T) == 8) sh.red[tid] = (T)__longlong_as_double((long long)sh.mx[tid]);
+        else sh.red[tid] = (T)__uint_as_float((unsigned)sh.mx[tid]);
     }
     __syncthreads();
 }
@@ -172,7 +201,36 @@ template <typename T> __device__ __forceinline__ void multi_reduce_max(GenShared
 // one-sided Jacobi SVD solve of the n x n upper-triangular Rm: minimum-norm c with the reference's absolute
 // singular-value threshold, e = qty - Rm c (thread 0 only; run-time n)
 template <typename T> __device__ void svd_solve(GenShared<T> &sh, int n, T eps) {
-    T W[VP_MAX_BASIS][VP_MAX_BASIS], V[VP_MAX_BASIS][VP_MAX_BASIS]; // [col][row]
+    // FAST PATH (round 6; the rule of the register kernels, vp_core.hpp solve_coeffs): sigma_min(R) >= 1 / ||R^-1||_F > eps
+    // certifies that no singular value is truncated -> plain back-substitution, e = 0.  The Jacobi sweeps below ran for
+    // EVERY evaluation before: tens of thousands of dependent single-lane instructions on scratch-resident arrays
+    // (six exponentials + offset: 1.2 ms per evaluation, tools/gen_probe.py).
+    {
+        T(&Ri)[VP_MAX_BASIS][VP_MAX_BASIS] = sh.sw;
+        bool zero_diag = false;
+        for (int i = 0; i < n; ++i) zero_diag = zero_diag || (sh.Rm[i][i] == T(0));
+        if (!zero_diag) {
+            T inv_f2 = T(0);
+            for (int j = 0; j < n; ++j)
+                for (int i = j; i >= 0; --i) {
+                    T acc = (i == j) ? T(1) : T(0);
+                    for (int l = i + 1; l <= j; ++l) acc = tfma(-sh.Rm[i][l], Ri[l][j], acc);
+                    Ri[i][j] = acc / sh.Rm[i][i];
+                    inv_f2 = tfma(Ri[i][j], Ri[i][j], inv_f2);
+                }
+            if (inv_f2 * eps * eps < T(1)) {
+                for (int i = n - 1; i >= 0; --i) {
+                    T acc = sh.qty[i];
+                    for (int j = i + 1; j < n; ++j) acc = tfma(-sh.Rm[i][j], sh.c[j], acc);
+                    sh.c[i] = acc / sh.Rm[i][i];
+                    sh.e[i] = T(0);
+                }
+                return;
+            }
+        }
+    }
+    T(&W)[VP_MAX_BASIS][VP_MAX_BASIS] = sh.sw;
+    T(&V)[VP_MAX_BASIS][VP_MAX_BASIS] = sh.sv; // [col][row]
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < n; ++i) {
             W[j][i] = (i <= j) ? sh.Rm[i][j] : T(0);
@@ -274,13 +332,18 @@ __device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b
     // are BOTH rank-deficient and hold a column beyond 2^64.)
     if (tid < n) sh.cscale[tid] = T(1);
     if (a.scale_cols) {
-        T vals[MAXV];
-        for (int j = 0; j < n; ++j) vals[j] = T(0);
-        for (int i = tid; i < m; i += TB) {
-            for (int j = 0; j < n; ++j) vals[j] = tmax(vals[j], tabs(col(j)[i]));
-            for (int p = 0; p < P; ++p) vals[a.pb[p]] = tmax(vals[a.pb[p]], tabs(col(n + 1 + p)[i]));
+        if (tid < n) sh.mx[tid] = 0ull;
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            T mxj = T(0);
+            for (int i = tid; i < m; i += TB) {
+                mxj = tmax(mxj, tabs(col(j)[i]));
+                for (int p = 0; p < P; ++p)
+                    if (a.pb[p] == j) mxj = tmax(mxj, tabs(col(n + 1 + p)[i]));
+            }
+            max_put(sh, j, mxj);
         }
-        multi_reduce_max(sh, vals, n);
+        max_finish(sh, n);
         if (tid < n) {
             const T mx = sh.red[tid];
             int e = 0;
@@ -300,15 +363,15 @@ __device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b
     }
     // ---- Householder sweep: H_k = I + g_k v_k v_k^T, v_k = a_k[k:] with v_k[k] = alpha - beta ----
     for (int k = 0; k < n; ++k) {
-        T vals[MAXV];
         const int nv = NCQ - k;
-        for (int v = 0; v < nv; ++v) vals[v] = T(0);
         const T *ak = col(k);
-        for (int i = k + tid; i < m; i += TB) {
-            const T x = ak[i];
-            for (int v = 0; v < nv; ++v) vals[v] = tfma(x, col(k + v)[i], vals[v]);
+        for (int v = 0; v < nv; ++v) {
+            const T *cv = col(k + v);
+            T acc = T(0);
+            for (int i = k + tid; i < m; i += TB) acc = tfma(ak[i], cv[i], acc);
+            reduce_put(sh, v, acc);
         }
-        multi_reduce(sh, vals, nv);
+        reduce_finish(sh, nv);
         if (tid == 0) {
             const T alpha = ak[k], nrm2 = sh.red[0];
             const bool live = nrm2 > num<T>::norm2_min && is_finite(nrm2);
@@ -352,10 +415,11 @@ __device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b
         sh.ok = ok ? 1 : 0;
     }
     {
-        T vals[1] = {T(0)};
+        T acc = T(0);
         const T *y = col(n);
-        for (int i = n + tid; i < m; i += TB) vals[0] = tfma(y[i], y[i], vals[0]);
-        multi_reduce(sh, vals, 1);
+        for (int i = n + tid; i < m; i += TB) acc = tfma(y[i], y[i], acc);
+        reduce_put(sh, 0, acc);
+        reduce_finish(sh, 1);
         if (tid == 0) {
             T fn2 = sh.red[0];
             for (int k = 0; k < n; ++k) fn2 = tfma(sh.e[k], sh.e[k], fn2);
@@ -386,16 +450,15 @@ __device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b
     }
     __syncthreads();
     for (int k = n - 1; k >= 0; --k) {
-        T vals[MAXV];
         const int nv = 1 + q;
-        for (int v = 0; v < nv; ++v) vals[v] = T(0);
         const T *vk = col(k);
-        for (int i = k + tid; i < m; i += TB) {
-            const T x = vk[i];
-            vals[0] = tfma(x, col(n)[i], vals[0]);
-            for (int v = 1; v < nv; ++v) vals[v] = tfma(x, col(NCQ + v - 1)[i], vals[v]);
+        for (int v = 0; v < nv; ++v) {
+            const T *cv = (v == 0) ? col(n) : col(NCQ + v - 1);
+            T acc = T(0);
+            for (int i = k + tid; i < m; i += TB) acc = tfma(vk[i], cv[i], acc);
+            reduce_put(sh, v, acc);
         }
-        multi_reduce(sh, vals, nv);
+        reduce_finish(sh, nv);
         const T gk = sh.g[k];
         for (int i = k + tid; i < m; i += TB) {
             const T x = vk[i];
@@ -414,7 +477,8 @@ __device__ void evaluate(const GenArgs<T> &a, GenShared<T> &sh, T *ws, int64_t b
 template <typename T> __global__ void __launch_bounds__(TB) gen_evaluate_kernel(const GenArgs<T> a) {
     __shared__ GenShared<T> sh;
     const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params, S = a.S;
-    T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gen_dyn_lds[];
+    T *ws = gen_workspace<T>(a, gen_dyn_lds);
     const bool want_rj = a.r_out || a.J_out;
     for (int64_t prob = blockIdx.x; prob < a.B * S; prob += gridDim.x) { // prob = b*S + s: every RHS on its own
         const int64_t b = prob / S;
@@ -445,14 +509,13 @@ template <typename T> __device__ void jac_qrfac(const GenArgs<T> &a, GenShared<T
     auto colp = [&](int c) { return ws + (int64_t)c * m; };
     T *rv = colp(n);
     {
-        T vals[MAXV];
-        for (int k = 0; k < q; ++k) vals[k] = T(0);
-        for (int i = tid; i < m; i += TB)
-            for (int k = 0; k < q; ++k) {
-                const T x = colp(J0 + k)[i];
-                vals[k] = tfma(x, x, vals[k]);
-            }
-        multi_reduce(sh, vals, q);
+        for (int k = 0; k < q; ++k) {
+            const T *ck = colp(J0 + k);
+            T acc = T(0);
+            for (int i = tid; i < m; i += TB) acc = tfma(ck[i], ck[i], acc);
+            reduce_put(sh, k, acc);
+        }
+        reduce_finish(sh, q);
         if (tid == 0)
             for (int k = 0; k < q; ++k) {
                 sh.acnorm[k] = tsqrt(sh.red[k]);
@@ -489,15 +552,14 @@ template <typename T> __device__ void jac_qrfac(const GenArgs<T> &a, GenShared<T
         __syncthreads();
         T *aj = colp(sh.col[j]);
         // raw dots of the pivot column (rows >= j) with itself, the remaining columns and the residual
-        T vals[MAXV];
         const int nv = (q - j) + 1;
-        for (int v = 0; v < nv; ++v) vals[v] = T(0);
-        for (int i = j + tid; i < m; i += TB) {
-            const T x = aj[i];
-            for (int k = j; k < q; ++k) vals[k - j] = tfma(x, colp(sh.col[k])[i], vals[k - j]);
-            vals[nv - 1] = tfma(x, rv[i], vals[nv - 1]);
+        for (int v = 0; v < nv; ++v) {
+            const T *cv = (v == nv - 1) ? rv : colp(sh.col[j + v]);
+            T acc = T(0);
+            for (int i = j + tid; i < m; i += TB) acc = tfma(aj[i], cv[i], acc);
+            reduce_put(sh, v, acc);
         }
-        multi_reduce(sh, vals, nv);
+        reduce_finish(sh, nv);
         if (tid == 0) {
             T ajnorm = tsqrt(sh.red[0]);
             if (ajnorm == T(0)) {
@@ -554,10 +616,11 @@ template <typename T> __device__ void jac_qrfac(const GenArgs<T> &a, GenShared<T
                     redo = T(0.05) * (r * r) <= num<T>::eps;
                 }
                 if (redo) { // uniform: decided from shared values
-                    T v1[1] = {T(0)};
+                    T acc1 = T(0);
                     const T *ak = colp(sh.col[k]);
-                    for (int i = j + 1 + tid; i < m; i += TB) v1[0] = tfma(ak[i], ak[i], v1[0]);
-                    multi_reduce(sh, v1, 1);
+                    for (int i = j + 1 + tid; i < m; i += TB) acc1 = tfma(ak[i], ak[i], acc1);
+                    reduce_put(sh, 0, acc1);
+                    reduce_finish(sh, 1);
                     if (tid == 0) {
                         sh.rdiag[k] = tsqrt(sh.red[0]);
                         sh.wa[k] = sh.rdiag[k];
@@ -604,7 +667,8 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_fit_kernel(const
     __shared__ LmAny<T> lm;
     __shared__ int s_need_jac, s_term, s_trow;
     const int tid = (int)threadIdx.x, m = a.m, n = a.mdl.n_basis, q = a.mdl.n_params;
-    T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gen_dyn_lds[];
+    T *ws = gen_workspace<T>(a, gen_dyn_lds);
     // (flag-and-refit launch: the problems of the list; the counter the NEXT fit appends to is zeroed here -- that fit starts
     // after this kernel on the handle's stream, and this launch never reads it)
     int64_t count = a.B;
@@ -713,7 +777,8 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_mrhs_fit_kernel(
     const int NCQ = n + 1 + P;
     const int phase = a.phase;
     const long mres = (long)m * (long)(a.S_global > 0 ? a.S_global : NS);
-    T *ws = a.ws + (int64_t)blockIdx.x * a.ws_cols * m;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gen_dyn_lds[];
+    T *ws = gen_workspace<T>(a, gen_dyn_lds);
     auto col = [&](int c) { return ws + (int64_t)c * m; };
     LmAny<T> *gstate = reinterpret_cast<LmAny<T> *>(a.lm_state);
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -762,16 +827,15 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_mrhs_fit_kernel(
                     }
                     __syncthreads();
                     for (int k = 0; k < q; ++k) {
-                        T vals[MAXV];
                         const int nv = q - k + 1; // z_k . z_l (l >= k), z_k . r
-                        for (int v = 0; v < nv; ++v) vals[v] = T(0);
-                        const T *zk = col(NCQ + k), *y = col(n);
-                        for (int i = n + tid; i < m; i += TB) {
-                            const T x = zk[i];
-                            for (int l = k; l < q; ++l) vals[l - k] = tfma(x, col(NCQ + l)[i], vals[l - k]);
-                            vals[nv - 1] = tfma(x, y[i], vals[nv - 1]);
+                        const T *zk = col(NCQ + k);
+                        for (int v = 0; v < nv; ++v) {
+                            const T *cv = (v == nv - 1) ? col(n) : col(NCQ + k + v);
+                            T acc = T(0);
+                            for (int i = n + tid; i < m; i += TB) acc = tfma(zk[i], cv[i], acc);
+                            reduce_put(sh, v, acc);
                         }
-                        multi_reduce(sh, vals, nv);
+                        reduce_finish(sh, nv);
                         if (tid == 0) {
                             for (int l = k; l < q; ++l) s_acc[1 + k * q + l] += (double)sh.red[l - k];
                             s_acc[1 + q * q + k] += (double)sh.red[nv - 1];
@@ -995,15 +1059,15 @@ template <typename T> __global__ void __launch_bounds__(TB) gen_stats_kernel(con
         build(true);
         // Householder QR of the K columns (R only)
         for (int k = 0; k < K; ++k) {
-            T vals[MAXV];
             const int nv = K - k;
-            for (int v = 0; v < nv; ++v) vals[v] = T(0);
             const T *ak = col(k);
-            for (int i = k + tid; i < m; i += TB) {
-                const T x = ak[i];
-                for (int v = 0; v < nv; ++v) vals[v] = tfma(x, col(k + v)[i], vals[v]);
+            for (int v = 0; v < nv; ++v) {
+                const T *cv = col(k + v);
+                T acc = T(0);
+                for (int i = k + tid; i < m; i += TB) acc = tfma(ak[i], cv[i], acc);
+                reduce_put(sh, v, acc);
             }
-            multi_reduce(sh, vals, nv);
+            reduce_finish(sh, nv);
             if (tid == 0) {
                 const T alpha = ak[k], nrm2 = sh.red[0];
                 const bool live = nrm2 > num<T>::norm2_min && is_finite(nrm2);
@@ -1144,11 +1208,43 @@ template <typename T> inline bool fill_args(const LaunchParams &p, GenArgs<T> &a
     return true;
 }
 
+// dynamic LDS of a launch: the columns of one problem when they fit (GenArgs::ws_lds), else 0
+template <typename T, class K> inline size_t gen_lds_for(GenArgs<T> &a, K kernel) {
+    const size_t need = (size_t)a.ws_cols * (size_t)a.m * sizeof(T);
+    a.ws_lds = 0;
+    if (need == 0 || need > kGenLdsMax) return 0;
+    // (the attribute is set once per kernel: a small table of the kernels seen -- the pointer TYPE is the same for all of them,
+    // a function-local static would be shared)
+    static const void *seen[16];
+    static bool seen_ok[16];
+    static int nseen = 0;
+    static std::mutex mtx; // (handles may be driven from several host threads)
+    std::lock_guard<std::mutex> lock(mtx);
+    bool attr_ok = false, found = false;
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i] == (const void *)kernel) {
+            attr_ok = seen_ok[i];
+            found = true;
+        }
+    if (!found) {
+        attr_ok = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGenLdsMax) == hipSuccess;
+        if (!attr_ok) (void)hipGetLastError();
+        if (nseen < 16) {
+            seen[nseen] = (const void *)kernel;
+            seen_ok[nseen] = attr_ok;
+            ++nseen;
+        }
+    }
+    if (!attr_ok && need > 48 * 1024) return 0;
+    a.ws_lds = 1;
+    return need;
+}
 template <typename T> int launch_evaluate(const LaunchParams &p) {
     GenArgs<T> a;
     if (!fill_args(p, a) || !p.gen_ws) return VP_ERR_UNSUPPORTED;
     if (a.B <= 0) return VP_ERR_OK;
-    hipLaunchKernelGGL((gen_evaluate_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, a);
+    const size_t lds = gen_lds_for<T>(a, &gen_evaluate_kernel<T>);
+    hipLaunchKernelGGL((gen_evaluate_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), lds, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 template <typename T> int launch_fit(const LaunchParams &p) {
@@ -1156,7 +1252,8 @@ template <typename T> int launch_fit(const LaunchParams &p) {
     if (!fill_args(p, a) || !p.gen_ws) return VP_ERR_UNSUPPORTED;
     if (a.B <= 0) return VP_ERR_OK;
     a.scale_cols = 1; // (this kernel never flags a problem for a re-fit: it IS the re-fit)
-    hipLaunchKernelGGL((gen_fit_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, a);
+    const size_t lds = gen_lds_for<T>(a, &gen_fit_kernel<T>);
+    hipLaunchKernelGGL((gen_fit_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), lds, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 template <typename T> size_t mrhs_lm_state_bytes() { return sizeof(LmAny<T>); }
@@ -1170,7 +1267,8 @@ template <typename T> int launch_mrhs_fit(const LaunchParams &p) {
     a.nactive = p.gen_nactive;
     a.S_global = p.mrhs_S_global;
     if (a.phase != 0 && (!a.lm_state || !a.acc || !a.nactive)) return VP_ERR_INVALID;
-    hipLaunchKernelGGL((gen_mrhs_fit_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), 0, p.stream, a);
+    const size_t lds = gen_lds_for<T>(a, &gen_mrhs_fit_kernel<T>);
+    hipLaunchKernelGGL((gen_mrhs_fit_kernel<T>), dim3((unsigned)p.gen_blocks), dim3(TB), lds, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
 }
 template <typename T> int launch_basis(const LaunchParams &p) {

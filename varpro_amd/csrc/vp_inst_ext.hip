@@ -127,7 +127,8 @@ template <typename T> int ext_fit_step_t(const ExtFitParams &p) {
         x.active_in = a.active_in;
         x.active_count = a.active_count;
         const int blocks = (int)(a.grid_problems < p.gen_blocks ? a.grid_problems : p.gen_blocks);
-        hipLaunchKernelGGL((gen::gen_extfit_eval_kernel<T>), dim3((unsigned)blocks), dim3(gen::TB), 0, p.stream, x);
+        const size_t lds = gen::gen_lds_for<T>(x.g, &gen::gen_extfit_eval_kernel<T>);
+        hipLaunchKernelGGL((gen::gen_extfit_eval_kernel<T>), dim3((unsigned)blocks), dim3(gen::TB), lds, p.stream, x);
         if (hipGetLastError() != hipSuccess) return VP_ERR_HIP;
     }
     return l->launch(a, p.stream);
