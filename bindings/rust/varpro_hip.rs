@@ -226,6 +226,7 @@ extern "C" {
     pub fn vp_fit_step_with_basis(h: *mut vp_batch, phi: *const c_void, dphi: *const c_void, alpha_trial_out: *mut c_void,
                                   want_out: *mut i32, n_active_out: *mut i64) -> i32;
     pub fn vp_fit_end(h: *mut vp_batch, alpha_out: *mut c_void, c_out: *mut c_void, rep: *mut vp_report) -> i32;
+    pub fn vp_fit_active_set(h: *mut vp_batch, index_out: *mut i32, count_out: *mut i32) -> i32;
 }
 pub const VP_FIT_DERIVATIVES_ON_ACCEPT: i32 = 1;
 pub const VP_WANT_BASIS: i32 = 1;
