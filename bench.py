@@ -130,11 +130,11 @@ def compact(out, extra_file=None):
     leg with its prose -- goes to the side file named by `extra_file`."""
     c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                              "vs_baseline", "dtype", "data", "schema") if k in out}
-    c["value_definition"] = _short(out.get("value_definition"), 120)
+    c["value_definition"] = _short(out.get("value_definition"), 56)
     cfg = out.get("config", {})
     c["config"] = _pick(cfg, ("batch_per_gpu", "m", "batches_in_flight", "world_size", "parallelism", "mean_evaluations_per_fit",
                               "fits_successful", "fits_failed", "sum_cost", "collective_backend", "per_rank_ms_per_step"))
-    c["config"]["workload"] = _short(cfg.get("workload"), 120)
+    c["config"]["workload"] = _short(cfg.get("workload"), 100)
     if "one_batch_at_a_time" in cfg:
         c["config"]["one_batch_at_a_time"] = _pick(cfg["one_batch_at_a_time"], ("ms_per_step", "fits_per_s", "per_rank_ms_per_step"))
     r = out.get("roofline")
@@ -148,7 +148,7 @@ def compact(out, extra_file=None):
     if cb:
         c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "cpu_model", "single_thread_fits_per_s", "parallel_efficiency",
                                        "cores_x_single_thread_fits_per_s", "extrapolated_single_socket_fits_per_s"))
-        c["cpu_baseline"]["sample"] = _short(cb.get("sample"), 140)
+        c["cpu_baseline"]["sample"] = _short(cb.get("sample"), 96)
     for k in ("gpu_over_cpu", "gpu_over_cores_x_single_thread", "gpu_over_cpu_single_socket_extrapolated"):
         if k in out:
             c[k] = out[k]
@@ -164,9 +164,9 @@ def compact(out, extra_file=None):
             e = _pick(d, keys)
             rr = d.get(roof)
             if isinstance(rr, dict) and "frac" in rr:
-                e["frac"], e["bound"] = rr["frac"], _short(str(rr.get("bound", "")).split(" (")[0], 12)
+                e["frac"], e["bound"] = rr["frac"], _short(str(rr.get("bound", "")).split(" (")[0].replace("fp64_valu", "f64v"), 7)
                 if rr.get("traffic") is not None and rr.get("bytes_per_launch"):
-                    e["traffic_over_algorithmic"] = rr["traffic"] / rr["bytes_per_launch"]
+                    e["traffic_x"] = rr["traffic"] / rr["bytes_per_launch"]  # HBM traffic (PMC) over the algorithmic bytes
             if e:
                 side[name] = e
 
@@ -174,14 +174,14 @@ def compact(out, extra_file=None):
     leg("configs1", out.get("configs1"), ("fits_per_s", "ms_per_step"))
     leg("configs2", out.get("configs2"), ("global_fit_ms", "global_fit_event_ms", "evaluations", "trait_evaluation_ms"), "roofline_fit")
     if isinstance(out.get("configs2"), dict) and isinstance(out["configs2"].get("two_fits_in_flight"), dict):
-        side["configs2"]["two_in_flight_ms_per_fit"] = out["configs2"]["two_fits_in_flight"].get("ms_per_fit")
-        side["configs2"]["four_in_flight_ms_per_fit"] = (out["configs2"].get("four_fits_in_flight") or {}).get("ms_per_fit")
+        side["configs2"]["ms_per_fit_2_in_flight"] = out["configs2"]["two_fits_in_flight"].get("ms_per_fit")
+        side["configs2"]["ms_per_fit_4_in_flight"] = (out["configs2"].get("four_fits_in_flight") or {}).get("ms_per_fit")
     leg("configs4", out.get("configs4"), ("fits_per_s", "ms_per_step", "fraction_failed"))
     c3 = out.get("configs3_emulated")
     if isinstance(c3, dict):
         side["configs3_emulated"] = _pick(c3, ("shards", "predicted_efficiency"))
         if isinstance(c3.get("two_batches_in_flight"), dict):
-            side["configs3_emulated"]["predicted_efficiency_two_in_flight"] = c3["two_batches_in_flight"].get("predicted_efficiency")
+            side["configs3_emulated"]["predicted_efficiency_2_in_flight"] = c3["two_batches_in_flight"].get("predicted_efficiency")
     leg("evaluate_boundary", out.get("evaluate_boundary"), ("ms",))
     leg("external_model", out.get("external_model"), ("ms_phi_dphi_in_r_J_out",))
     for k, v in (out.get("external_model", {}).get("long_problems", {}) or {}).items():
@@ -190,7 +190,7 @@ def compact(out, extra_file=None):
     for k, v in (out.get("streamed_rows") or {}).items():
         leg("streamed_" + k, v, ("fits_per_s", "ms_per_step"))
         if isinstance(v, dict) and "as_caller_evaluated_model" in v:
-            leg("streamed_" + k + "_external_fit", v["as_caller_evaluated_model"], ("fits_per_s_including_the_callers_columns",))
+            leg("streamed_" + k + "_extfit", v["as_caller_evaluated_model"], ())
     leg("generic_fallback", out.get("generic_fallback"), ("fits_per_s", "ms_per_step"))
     if side:
         c["side"] = side
@@ -203,12 +203,23 @@ def compact(out, extra_file=None):
     c = _round_floats(c)
     c.update(_round_floats(precise, 13))  # (the contract's own numbers and the all-reduced totals keep their digits)
     c["config"].update(_round_floats(precise_cfg, 13))
-    # hard bound: drop the least important blocks until the line fits (never the contract fields)
-    for k in ("side", "build", "parity_census", "gpu_over_cpu_single_socket_extrapolated", "value_definition"):
-        if len(json.dumps(c, separators=(",", ":"))) < COMPACT_LINE_LIMIT:
+    # hard bound, with a margin for longer host strings on another box: shed the least important parts until the line fits
+    # (never the contract fields, `roofline`, `cpu_baseline`)
+    limit = COMPACT_LINE_LIMIT - 256
+
+    def fits():
+        return len(json.dumps(c, separators=(",", ":"))) < limit
+    if not fits():
+        c.pop("value_definition", None)
+    side_ = c.get("side", {})
+    while not fits() and side_:
+        side_.pop(next(reversed(side_)))  # side legs from the end
+        c["dropped_for_length"] = c.get("dropped_for_length", 0) + 1
+    for k in ("side", "build", "parity_census", "gpu_over_cpu_single_socket_extrapolated", "roofline_fit"):
+        if fits():
             break
         c.pop(k, None)
-        c["dropped_for_length"] = c.get("dropped_for_length", []) + [k]
+        c["dropped_for_length"] = c.get("dropped_for_length", 0) + 1
     return c
 
 

@@ -9,4 +9,6 @@ VP_REGISTER_EXT0_W(double, 4, 16, 8)
 VP_REGISTER_EXT_W(double, 1, 2, 16, 8)
 VP_REGISTER_EXT_W(double, 1, 4, 16, 8)
 VP_REGISTER_EXT_W(double, 2, 2, 16, 8)
+// (round 6, measured: sixteen waves x 8 rows per lane instead of eight x 16 -- 128 VGPRs per lane, 116 spilled -- 1.60 ms against
+// 1.09-1.13 ms per 8 192 problems of 8 192 rows)
 VP_REGISTER_EXT_W(double, 3, 2, 16, 8)
