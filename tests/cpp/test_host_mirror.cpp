@@ -269,6 +269,30 @@ static void test_closure_gpu() {
         std::printf("closure-model batch fit (%s): %d steps, problem 0: %d evaluations, objective %.3e\n",
                     lazy ? "derivatives on accept" : "eager", fit.steps, fit.reports[0].n_evals, fit.reports[0].objective);
     }
+    // S = 2 right-hand sides per problem sharing the nonlinear parameters (SeparableProblemBuilder::mrhs,
+    // src/problem/builder.rs:194-225; round 6: the batched fit of caller-evaluated models takes them): exact data -> the
+    // global fit recovers the parameters, and each column its own coefficients
+    {
+        const int64_t S = 2;
+        std::vector<double> Y2((size_t)(B * S * m));
+        for (int64_t b = 0; b < B; ++b)
+            for (int64_t sidx = 0; sidx < S; ++sidx)
+                for (int64_t i = 0; i < m; ++i)
+                    Y2[(size_t)((b * S + sidx) * m + i)] = (10.0 + b + 3.0 * sidx) * Phi[(size_t)((b * 3 + 0) * m + i)] +
+                                                          (20.0 - b - 2.0 * sidx) * Phi[(size_t)((b * 3 + 1) * m + i)] + 1.5 + sidx;
+        ExternalBatchProblem prob2(cm, Y2, B, nullptr, -1.0, 0, S);
+        auto fit = prob2.fit(guess);
+        for (int64_t b = 0; b < B; ++b) {
+            EXPECT(fit.reports[(size_t)b].termination > 0);
+            for (int k = 0; k < 4; ++k) EXPECT(std::fabs(fit.nonlinear_parameters[(size_t)(b * 4 + k)] - truth[(size_t)(b * 4 + k)]) < 1e-6);
+            for (int64_t sidx = 0; sidx < S; ++sidx) {
+                EXPECT(std::fabs(fit.linear_coefficients[(size_t)((b * S + sidx) * 3 + 0)] - (10.0 + b + 3.0 * sidx)) < 1e-5);
+                EXPECT(std::fabs(fit.linear_coefficients[(size_t)((b * S + sidx) * 3 + 2)] - (1.5 + sidx)) < 1e-5);
+            }
+        }
+        std::printf("closure-model GLOBAL fit (S = 2): %d steps, problem 0: %d evaluations, objective %.3e\n", fit.steps,
+                    fit.reports[0].n_evals, fit.reports[0].objective);
+    }
 }
 
 int main(int argc, char **argv) {

@@ -507,14 +507,17 @@ class ExternalBatchProblem {
     std::shared_ptr<const ClosureModel> model_;
 
   public:
-    int64_t m = 0, B = 0;
+    int64_t m = 0, B = 0, S = 1;
     int n = 0, q = 0, np = 0;
+    // Y: [B][S][m] -- S right-hand sides per problem share the nonlinear parameters (SeparableProblemBuilder::mrhs,
+    // src/problem/builder.rs:194-225); S = 1: the single-right-hand-side problem
     ExternalBatchProblem(const ClosureModel &model, const std::vector<double> &Y, int64_t B_, const std::vector<double> *weights = nullptr,
-                         double epsilon = -1.0, int device = 0)
+                         double epsilon = -1.0, int device = 0, int64_t S_ = 1)
         : model_(std::make_shared<const ClosureModel>(model)) {
         model.validate();
         m = (int64_t)model.output_len();
         B = B_;
+        S = S_;
         n = (int)model.base_function_count();
         q = (int)model.parameter_count();
         const auto prs = model.pairs();
@@ -524,8 +527,8 @@ class ExternalBatchProblem {
             pb.push_back(pr.first);
             pp.push_back(pr.second);
         }
-        if ((int64_t)Y.size() != B * m) throw std::invalid_argument("Y must hold B*m values");
-        check(vp_batch_create_external(&h_, n, q, np, pb.data(), pp.data(), VP_F64, m, 1, B, Y.data(), weights ? weights->data() : nullptr,
+        if ((int64_t)Y.size() != B * S * m) throw std::invalid_argument("Y must hold B*S*m values");
+        check(vp_batch_create_external(&h_, n, q, np, pb.data(), pp.data(), VP_F64, m, S, B, Y.data(), weights ? weights->data() : nullptr,
                                        epsilon, VP_FLAG_OWN_STREAM, device, nullptr));
     }
     ExternalBatchProblem(const ExternalBatchProblem &) = delete;
@@ -541,11 +544,11 @@ class ExternalBatchProblem {
     Evaluation evaluate(const std::vector<double> &alpha) const {
         const std::vector<double> Phi = model_->eval_batch(alpha, B), dPhi = model_->derivs_batch(alpha, B);
         Evaluation e;
-        e.residuals.resize((size_t)(B * m));
-        e.jacobian.resize((size_t)(B * q * m));
-        e.coefficients.resize((size_t)(B * n));
-        e.cost.resize((size_t)B);
-        e.status.resize((size_t)B);
+        e.residuals.resize((size_t)(B * S * m));      // [B][S][m]
+        e.jacobian.resize((size_t)(B * q * S * m));   // [B][q][S][m]
+        e.coefficients.resize((size_t)(B * S * n));   // [B][S][n]
+        e.cost.resize((size_t)(B * S));
+        e.status.resize((size_t)(B * S));
         check(vp_evaluate_with_basis(h_, alpha.data(), Phi.data(), dPhi.data(), e.residuals.data(), e.jacobian.data(),
                                      e.coefficients.data(), e.cost.data(), e.status.data()));
         return e;
@@ -569,7 +572,7 @@ class ExternalBatchProblem {
             ++out.steps;
         }
         out.nonlinear_parameters.resize((size_t)(B * q));
-        out.linear_coefficients.resize((size_t)(B * n));
+        out.linear_coefficients.resize((size_t)(B * S * n)); // [B][S][n]
         out.reports.resize((size_t)B);
         check(vp_fit_end(h_, out.nonlinear_parameters.data(), out.linear_coefficients.data(), out.reports.data()));
         return out;
