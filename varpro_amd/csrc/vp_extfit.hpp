@@ -312,6 +312,10 @@ template <typename T, int Q> __global__ void __launch_bounds__(64) ext_fit_lm_ke
         lm_init<T, 1, Q>(s, a.alpha0 + b * Q);
 #pragma unroll
         for (int k = 0; k < VP_MAX_BASIS; ++k) st[(F::CBEST + k) * B + b] = T(0);
+        if (a.S > 1) { // (several right-hand sides: the coefficients live in C_best itself; a fit that never accepts a point reports zeros)
+            const int64_t cn = (int64_t)a.S * n;
+            for (int64_t i = 0; i < cn; ++i) a.C_best[b * cn + i] = T(0);
+        }
     } else {
         if (si[F::TERM * B + b] != 0) {
             // finished in an earlier step: the caller's arrays of THIS step (they may be other buffers than the last step's)
