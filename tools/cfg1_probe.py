@@ -1,3 +1,4 @@
+import sys; sys.path.insert(0, ".")
 import numpy as np, torch, varpro_amd as vp
 from varpro_amd import synth
 dev=torch.device("cuda:0")
