@@ -310,18 +310,23 @@ template <typename T, class M, int RB> constexpr int blk_fit_waves() {
     return RB > block_rows<T, M::N + 1 + M::P, M::kStatic>() ? 1 : blk_waves<M>();
 }
 
-template <typename T, class M, int RB, bool WEIGHTED, int W = 1, bool TC = false>
-__global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_kernel(const FitArgs<T, M> a) {
+// The streamed fit of ONE problem by the W waves of a workgroup: the body of blk_fit_kernel.  RESCUE (round 6): the re-fit of a
+// problem whose Jacobian factor came out non-finite (vp_fit.hpp jac_not_finite) with every derivative column built as 2^-ks
+// times its value and the coefficient entering the Kaufman columns as c 2^ks -- run by the same workgroup at its exit
+// (blk_refit_flagged), for the models of fit_rescue_v; SELF: the caller re-fits, the problem is not pushed to the list.
+// Returns true when the problem was flagged (and the handle has re-fits switched on).
+template <typename T, class M, int RB, bool WEIGHTED, int W, bool TC, bool RESCUE, bool SELF>
+__device__ __forceinline__ bool blk_fit_problem(const FitArgs<T, M> &a, const int64_t b, T *ring_mem, T *s_merge, LmVars<T, M::N, M::Q> *s_lm,
+                                                T (*s_cb)[M::N]) {
     constexpr int N = M::N, P = M::P, Q = M::Q, NC = N + 1 + P;
     constexpr int ROWS = 64 * RB;
     constexpr int NTRI = NC * (NC + 1) / 2;
     static_assert(W * NC <= 128, "the stacked carries must fit two rows per lane");
+    static_assert(!RESCUE || fit_rescue_v<T, M>, "the scaled re-fit needs diagonal pairs");
     using G = Grp<1>; // (reductions are per wave: each wave owns its blocks and, after the merge, a full copy of the problem)
     G grp = G::make(nullptr);
     const int lane = grp.gl;
     const int wave = (W > 1) ? (int)(threadIdx.x >> 6) : 0;
-    const int64_t b = blockIdx.x;
-    if (b >= a.B) return;
     const int m = a.m;
     const T *tp = a.t + b * a.t_stride;
     const T *wp = WEIGHTED ? a.w + b * a.w_stride : nullptr;
@@ -349,10 +354,6 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
 
     static_assert(!TC || (!WEIGHTED && sizeof(T) == 8), "computed grid: unit weights, fp64 (the recurrence's own condition)");
     using Ring = RowRing<T, RB, WEIGHTED, TC>;
-    __shared__ __attribute__((aligned(16))) T ring_mem[W * 2 * Ring::NARR * ROWS];
-    __shared__ T s_merge[W > 1 ? 2 * W * NTRI : 1]; // the waves' carries, double-buffered by the evaluation's parity
-    __shared__ LmVars<T, N, Q> s_lm[W];             // the parked LM records
-    __shared__ T s_cb[W][N];
     Ring ring;
     ring.init(ring_mem + (size_t)wave * 2 * Ring::NARR * ROWS, tp, yp, wp, m, lane);
     int parity = 0;
@@ -389,6 +390,19 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
         T xt_now[Q];
 #pragma unroll
         for (int k = 0; k < Q; ++k) xt_now[k] = S.xt[k];
+        int ks[N]; // (RESCUE) binary exponents the derivative columns are scaled down by: the largest exponent of exp(-t/tau_j)
+                   // over the grid, from its two ends
+#pragma unroll
+        for (int j = 0; j < N; ++j) ks[j] = 0;
+        if constexpr (RESCUE) {
+            const T t_first = tp[0], t_last = tp[m - 1];
+#pragma unroll
+            for (int j = 0; j < N - 1; ++j) {
+                const T rt = T(1) / xt_now[j];
+                const T e2 = tmax(-t_first * rt, -t_last * rt) * T(1.4426950408889634);
+                ks[j] = uni((e2 > T(64) && e2 < T(1100)) ? (int)e2 : 0);
+            }
+        }
         if constexpr (kPark) {
             if (lane == 0) {
                 s_lm[wave] = S;
@@ -419,7 +433,7 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
                 }
                 T Cb[NC][RB];
                 load_rows_lds<T, RB, 1>(s_y, lane, Cb[N]);
-                build_columns<T, M, RB, NC, Src>(a.mdl, xt_now, src, Cb);
+                build_columns<T, M, RB, NC, Src, M::N + 1, false, true, true, -1, RESCUE>(a.mdl, xt_now, src, Cb, ks);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (kLaneTrail) {
                     if constexpr (NF > 0) stacked_qr<T, NC, NF, RB, G>(K, Cb, grp);
@@ -527,7 +541,10 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
             T Zs[Q][2];
             if constexpr (M::kDiagonalPairs) {
                 T Zd[1][2];
-                jacobian_qcoords<T, M, 2, NC, G, N + 1>(a.mdl, K, c, Zd, grp); // in place: z_k = K[N + 1 + k]
+                T cj[N]; // (RESCUE: c_k 2^ks against the derivative column's 2^-ks)
+#pragma unroll
+                for (int k = 0; k < N; ++k) cj[k] = RESCUE ? tldexp(c[k], ks[k]) : c[k];
+                jacobian_qcoords<T, M, 2, NC, G, N + 1>(a.mdl, K, cj, Zd, grp); // in place: z_k = K[N + 1 + k]
 #pragma unroll
                 for (int k = 0; k < Q; ++k) Zs[k][0] = K[N + 1 + k][0], Zs[k][1] = K[N + 1 + k][1];
             } else {
@@ -536,7 +553,7 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
             jac_qrfac<T, 2, Q, N>(Zs, K[N], S.Rj, S.acnorm, S.ipvt, S.qtf, grp);
         }
         // (a refreshed factor with non-finite column norms: flag and re-fit, vp_fit.hpp jac_not_finite)
-        if (lm_next_step<T, N, Q, true>(S, opt, need)) flagged = a.rescue != nullptr;
+        if (lm_next_step<T, N, Q, true>(S, opt, need)) flagged = !RESCUE && a.rescue != nullptr;
     }
 
     if (lane == 0 && wave == 0) {
@@ -547,8 +564,8 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
         a.report[b] = rep;
         if (a.cost_out) a.cost_out[b] = (double)S.objective;
         if (a.status) a.status[b] = S.status;
-        if (flagged) { // alpha[b] keeps the initial guess for the re-fit launch
-            rescue_push(a.rescue, a.rescue_slot, b);
+        if (flagged) { // alpha[b] keeps the initial guess for the re-fit
+            if (!SELF) rescue_push(a.rescue, a.rescue_slot, b);
         } else {
 #pragma unroll
             for (int k = 0; k < Q; ++k) a.alpha[b * Q + k] = S.x[k];
@@ -556,6 +573,37 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
         if (a.C_out) {
 #pragma unroll
             for (int k = 0; k < N; ++k) a.C_out[b * N + a.mdl.out_index(k)] = cbest[k];
+        }
+    }
+    return flagged;
+}
+
+// the scaled re-fit of a flagged problem by the workgroup that flagged it (out of line: see vp_fit.hpp fit_refit_flagged)
+template <typename T, class M, int RB, bool WEIGHTED, int W, bool TC>
+__device__ __noinline__ void blk_refit_flagged(const FitArgs<T, M> *a, const int64_t b, T *ring_mem, T *s_merge, LmVars<T, M::N, M::Q> *s_lm,
+                                               T (*s_cb)[M::N]) {
+    (void)blk_fit_problem<T, M, RB, WEIGHTED, W, TC, true, false>(*a, b, ring_mem, s_merge, s_lm, s_cb);
+}
+
+template <typename T, class M, int RB, bool WEIGHTED, int W = 1, bool TC = false>
+__global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_kernel(const FitArgs<T, M> a) {
+    constexpr int N = M::N, Q = M::Q, NC = N + 1 + M::P;
+    constexpr int ROWS = 64 * RB;
+    constexpr int NTRI = NC * (NC + 1) / 2;
+    using Ring = RowRing<T, RB, WEIGHTED, TC>;
+    __shared__ __attribute__((aligned(16))) T ring_mem[W * 2 * Ring::NARR * ROWS];
+    __shared__ T s_merge[W > 1 ? 2 * W * NTRI : 1]; // the waves' carries, double-buffered by the evaluation's parity
+    __shared__ LmVars<T, N, Q> s_lm[W];             // the parked LM records
+    __shared__ T s_cb[W][N];
+    const int64_t b = blockIdx.x;
+    if (b >= a.B) return;
+    // models with the scaled re-fit (fit_rescue_v): the workgroup re-fits the problem it flagged itself, else the handle's list
+    constexpr bool SELF = fit_rescue_v<T, M>;
+    const bool again = blk_fit_problem<T, M, RB, WEIGHTED, W, TC, false, SELF>(a, b, ring_mem, s_merge, s_lm, s_cb);
+    if constexpr (SELF) {
+        if (again) {
+            if constexpr (W > 1) __syncthreads(); // (every wave is done with the shared records of the first fit)
+            blk_refit_flagged<T, M, RB, WEIGHTED, W, TC>(&a, b, ring_mem, s_merge, s_lm, s_cb);
         }
     }
 }
@@ -864,7 +912,7 @@ template <typename T, class M> int launch_fit(const LaunchParams &p) {
     a.rescue = p.rescue;
     a.rescue_slot = p.rescue_slot;
     if (a.B <= 0) return VP_ERR_OK;
-    if (p.rescue_used) *p.rescue_used = 1;
+    if (p.rescue_used && !fit_rescue_v<T, M>) *p.rescue_used = 1; // (fit_rescue_v kernels re-fit what they flag themselves)
     constexpr int RB = block_rows<T, M::N + 1 + M::P, M::kStatic>();
     // A launch that does not fill the device several times over ends when its LONGEST fit does (evaluation counts are
     // heavy-tailed: mean ~8, max 100+): four waves per problem then shorten every chain ~3.5x at no cost in throughput that
