@@ -905,7 +905,7 @@ def main():
             long_legs = {}
             for tdt, ml, Bl, kern, tkey in ((torch.float32, 4096, 32768, "ext_evaluate_kernel<float, 3, 2, 16, true, 4> (four waves per problem)", "ext_evaluate_kernel_w4"),
                                             (torch.float64, 8192, 8192, "ext_evaluate_kernel<double, 3, 2, 16, true, 8> (eight waves per problem)", "ext_evaluate_kernel_w8"),
-                                            (torch.float64, 10000, 4096, "blk::ext_stream_evaluate_kernel<double, 3, 2, 8> (rows streamed in blocks, two passes over the caller's columns: 15 column transfers for 9 algorithmic)", "ext_stream_evaluate_kernel")):
+                                            (torch.float64, 10000, 4096, "blk::ext_stream_evaluate_kernel<double, 3, 2, 8> (rows streamed in blocks, two passes over the caller's columns: 15 column transfers for 9 algorithmic; round 6: lane-private pass 1 + row-local pass 2 for well-conditioned problems)", "ext_stream_evaluate_kernel")):
                 Tl = 4 if tdt == torch.float32 else 8
                 gl_ = torch.Generator(device=dev)
                 gl_.manual_seed(0x5EED77)
