@@ -278,6 +278,29 @@ def test_long_problems_fp64(m, weighted):
     _check_against_oracle(cm, Y, tau * (1 + rng.uniform(-0.2, 0.2, tau.shape)), w=w)
 
 
+@pytest.mark.parametrize("m", [10000, 12345])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_streamed_evaluation_keeps_the_householder_route_for_badly_scaled_columns(m, weighted):
+    """round 6: beyond 8 192 rows a WELL-conditioned problem takes the direct route of the streamed kernel (lane-private pass 1,
+    row-local pass 2, vp_blk_ext.hpp); a problem whose factor's diagonal spreads over more than 1e4 keeps the two exact
+    Householder passes.  A basis function scaled by 1e-7 (its coefficient by 1e7: r and J are invariant, and so is the
+    reference's result, src/solvers/levmar/mod.rs:42-73, 101-201) forces that route: same 1e-10 against the oracle."""
+    rng = np.random.default_rng(300 + m)
+    B = 3
+    x = np.linspace(0.0, 12.5, m)
+    sc = 1e-7
+    cm = (vp.ClosureModel(["t1", "t2"], x)
+          .function(["t1"], lambda x, t: sc * np.exp(-x / t)).partial_deriv("t1", lambda x, t: sc * np.exp(-x / t) * x / t ** 2)
+          .function(["t2"], lambda x, t: np.exp(-x / t)).partial_deriv("t2", lambda x, t: np.exp(-x / t) * x / t ** 2)
+          .invariant_function(lambda x: np.ones_like(x)))
+    tau = np.stack([rng.uniform(0.5, 2.0, B), rng.uniform(2.5, 8.0, B)], 1)
+    c = rng.uniform(1.0, 100.0, (B, 3))
+    Y = c[:, 0:1] * np.exp(-x / tau[:, 0:1]) + c[:, 1:2] * np.exp(-x / tau[:, 1:2]) + c[:, 2:3]
+    Y = Y + 1e-3 * np.abs(Y).max(1, keepdims=True) * rng.standard_normal(Y.shape)
+    w = (0.5 + rng.random(m)) if weighted else None
+    _check_against_oracle(cm, Y, tau * (1 + rng.uniform(-0.2, 0.2, tau.shape)), w=w)
+
+
 # fp32 handles had no resident kernels before round 5 (generic kernels at every shape): one wave to 1 024 rows, four to
 # 4 096, eight to 16 384.  Checked against the fp64 oracle of the converted inputs at fp32 resolution x cond(Phi)
 @pytest.mark.parametrize("m", [200, 1000, 4096, 5000, 16384, 20000])
