@@ -195,7 +195,7 @@ def compact(out, extra_file=None):
     if side:
         c["side"] = side
     if "build" in out:
-        c["build"] = _pick(out["build"], ("library_bytes", "kernels", "kernels_spilling", "kernels_above_64_spilled", "clean_build_cpu_minutes"))
+        c["build"] = _pick(out["build"], ("library_bytes", "kernels", "kernels_above_64_spilled_vgprs", "full_build_cpu_minutes", "full_build_wall_s"))
     if extra_file:
         c["extra_file"] = extra_file
     precise = {k: c[k] for k in ("value", "ms_per_step") if k in c}
