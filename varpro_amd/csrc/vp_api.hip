@@ -1700,10 +1700,16 @@ int rescue_prepare(vp_batch *h, LaunchParams &p) {
 int rescue_refit(vp_batch *h, const LaunchParams &fit_params) {
     if (!fit_params.rescue) return 0;
     LaunchParams p = fit_params;
-    // (the Householder fit kernels of models with a trailing constant and diagonal pairs -- fit_rescue_v, every multi-exponential
-    // + offset set -- re-fit what they flag themselves and never get here; this launch serves run-time descriptors, models
-    // without an offset and the streamed kernels)
+    // the first kFitRescueGrid flagged problems on the set's own wave-per-problem kernel with scaled derivative columns (a
+    // flagged fit at ~4 us per evaluation: it must not outlast the batch it came from); whatever is left -- more problems
+    // than that, weights, per-problem grids, models without that kernel -- on the generic kernel, which also zeroes the
+    // list's other counter
     p.gen_list_first = 0;
+    if (launch_fn fast = find_fit_rescue(h->kern->fit_single)) {
+        const int rc = fast(p);
+        if (rc == VP_ERR_OK) p.gen_list_first = kFitRescueGrid;
+        else if (rc != VP_ERR_UNSUPPORTED) return rc;
+    }
     p.rescue = nullptr;
     p.gen_ws = h->d_rescue_ws;
     p.gen_blocks = kRescueBlocks;
@@ -2058,6 +2064,10 @@ int vp_synchronize(vp_batch *h) {
 // ---- registry ------------------------------------------------------------------------------------------
 namespace vp {
 
+std::vector<RescueEntry> &rescue_registry() {
+    static std::vector<RescueEntry> r;
+    return r;
+}
 std::vector<KernelEntry> &registry() {
     static std::vector<KernelEntry> r;
     return r;

@@ -312,8 +312,8 @@ template <typename T, class M, int RB> constexpr int blk_fit_waves() {
 
 // The streamed fit of ONE problem by the W waves of a workgroup: the body of blk_fit_kernel.  RESCUE (round 6): the re-fit of a
 // problem whose Jacobian factor came out non-finite (vp_fit.hpp jac_not_finite) with every derivative column built as 2^-ks
-// times its value and the coefficient entering the Kaufman columns as c 2^ks -- run by the same workgroup at its exit
-// (blk_refit_flagged), for the models of fit_rescue_v; SELF: the caller re-fits, the problem is not pushed to the list.
+// times its value and the coefficient entering the Kaufman columns as c 2^ks -- run by blk_fit_kernel<..., RESCUE> over the
+// handle's list (launch_fit_rescue), for the models of fit_rescue_v; SELF: the caller re-fits, the problem is not pushed.
 // Returns true when the problem was flagged (and the handle has re-fits switched on).
 template <typename T, class M, int RB, bool WEIGHTED, int W, bool TC, bool RESCUE, bool SELF>
 __device__ __forceinline__ bool blk_fit_problem(const FitArgs<T, M> &a, const int64_t b, T *ring_mem, T *s_merge, LmVars<T, M::N, M::Q> *s_lm,
@@ -578,14 +578,12 @@ __device__ __forceinline__ bool blk_fit_problem(const FitArgs<T, M> &a, const in
     return flagged;
 }
 
-// the scaled re-fit of a flagged problem by the workgroup that flagged it (out of line: see vp_fit.hpp fit_refit_flagged)
-template <typename T, class M, int RB, bool WEIGHTED, int W, bool TC>
-__device__ __noinline__ void blk_refit_flagged(const FitArgs<T, M> *a, const int64_t b, T *ring_mem, T *s_merge, LmVars<T, M::N, M::Q> *s_lm,
-                                               T (*s_cb)[M::N]) {
-    (void)blk_fit_problem<T, M, RB, WEIGHTED, W, TC, true, false>(*a, b, ring_mem, s_merge, s_lm, s_cb);
-}
-
-template <typename T, class M, int RB, bool WEIGHTED, int W = 1, bool TC = false>
+// RESCUE = true: the launch that re-fits the problems the streamed kernels FLAGGED (jac_not_finite) -- workgroup i takes problem
+// list[2 + i], i < list[slot] -- with scaled derivative columns (blk_fit_problem<..., RESCUE>).  A separate, list-driven launch
+// and not an exit path of the fit kernel: the out-of-line call at the kernel's end cost the streamed fit 2.2 % (8.12 -> 8.30 ms
+// per 16 384 fits of 10 000 rows, stack frame + reserved registers) where two small launches cost 0.15 %; the slot kernel of
+// the resident sets, whose waves are persistent, keeps its exit path (vp_fit2.hpp).
+template <typename T, class M, int RB, bool WEIGHTED, int W = 1, bool TC = false, bool RESCUE = false>
 __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_kernel(const FitArgs<T, M> a) {
     constexpr int N = M::N, Q = M::Q, NC = N + 1 + M::P;
     constexpr int ROWS = 64 * RB;
@@ -595,17 +593,14 @@ __global__ void __launch_bounds__(64 * W, (blk_fit_waves<T, M, RB>())) blk_fit_k
     __shared__ T s_merge[W > 1 ? 2 * W * NTRI : 1]; // the waves' carries, double-buffered by the evaluation's parity
     __shared__ LmVars<T, N, Q> s_lm[W];             // the parked LM records
     __shared__ T s_cb[W][N];
-    const int64_t b = blockIdx.x;
-    if (b >= a.B) return;
-    // models with the scaled re-fit (fit_rescue_v): the workgroup re-fits the problem it flagged itself, else the handle's list
-    constexpr bool SELF = fit_rescue_v<T, M>;
-    const bool again = blk_fit_problem<T, M, RB, WEIGHTED, W, TC, false, SELF>(a, b, ring_mem, s_merge, s_lm, s_cb);
-    if constexpr (SELF) {
-        if (again) {
-            if constexpr (W > 1) __syncthreads(); // (every wave is done with the shared records of the first fit)
-            blk_refit_flagged<T, M, RB, WEIGHTED, W, TC>(&a, b, ring_mem, s_merge, s_lm, s_cb);
-        }
+    int64_t b = blockIdx.x;
+    if constexpr (RESCUE) {
+        if (b >= (int64_t)uni(a.rescue[a.rescue_slot])) return;
+        b = (int64_t)uni(a.rescue[2 + b]);
+    } else {
+        if (b >= a.B) return;
     }
+    (void)blk_fit_problem<T, M, RB, WEIGHTED, W, TC, RESCUE, false>(a, b, ring_mem, s_merge, s_lm, s_cb);
 }
 
 // ---- trait-level evaluation at any m: set_params (+ residuals + Jacobian), src/solvers/levmar/mod.rs:42-73, 91-95, 101-201 ----
@@ -912,7 +907,7 @@ template <typename T, class M> int launch_fit(const LaunchParams &p) {
     a.rescue = p.rescue;
     a.rescue_slot = p.rescue_slot;
     if (a.B <= 0) return VP_ERR_OK;
-    if (p.rescue_used && !fit_rescue_v<T, M>) *p.rescue_used = 1; // (fit_rescue_v kernels re-fit what they flag themselves)
+    if (p.rescue_used) *p.rescue_used = 1;
     constexpr int RB = block_rows<T, M::N + 1 + M::P, M::kStatic>();
     // A launch that does not fill the device several times over ends when its LONGEST fit does (evaluation counts are
     // heavy-tailed: mean ~8, max 100+): four waves per problem then shorten every chain ~3.5x at no cost in throughput that
@@ -951,6 +946,55 @@ template <typename T, class M> int launch_fit(const LaunchParams &p) {
 #undef VP_BLK_FIT
 #undef VP_BLK_FIT_TC
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+// the re-fit launch of the streamed kernels' flagged problems: one wave per problem at the base block height (any m, grid values
+// from memory), up to kFitRescueGrid of them; weights / per-problem grids, models outside fit_rescue_v and whatever is left go
+// to the generic kernel (vp_api.hip rescue_refit)
+template <typename T, class M> int launch_fit_rescue(const LaunchParams &p) {
+    if constexpr (!fit_rescue_v<T, M>) {
+        return VP_ERR_UNSUPPORTED;
+    } else {
+        if (p.w || p.t_stride != 0 || !p.rescue) return VP_ERR_UNSUPPORTED;
+        FitArgs<T, M> a;
+        if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+        a.t = (const T *)p.t;
+        a.w = nullptr;
+        a.yw = (const T *)p.yw;
+        a.alpha = (T *)p.alpha_out;
+        a.C_out = (T *)p.C_out;
+        a.cost_out = p.cost_out;
+        a.status = p.status;
+        a.report = p.report;
+        a.m = p.m;
+        a.B = p.B;
+        a.t_stride = 0;
+        a.w_stride = 0;
+        a.eps = (T)p.eps;
+        a.ftol = (T)p.opts->ftol;
+        a.xtol = (T)p.opts->xtol;
+        a.gtol = (T)p.opts->gtol;
+        a.stepbound = (T)p.opts->stepbound;
+        a.patience = p.opts->patience;
+        a.scale_diag = p.opts->scale_diag;
+        a.trace = p.trace;
+        a.trace_rows = p.trace_rows;
+        a.grid_uniform = p.grid_uniform;
+        a.rescue = p.rescue;
+        a.rescue_slot = p.rescue_slot;
+        constexpr int RB = block_rows<T, M::N + 1 + M::P, M::kStatic>();
+        // (a flagged fit is a chain of ~70 evaluations nothing overlaps: four waves per problem shorten it ~3.5x where the
+        // problem has the blocks for them -- 4.0 -> 1.2 ms behind a batch of 16 384 problems of 10 000 rows)
+        constexpr int WM = 4;
+        if constexpr (WM * (M::N + 1 + M::P) <= 128) {
+            if (p.m >= VP_BLK_MULTI_MIN_BLOCKS * WM * 64 * RB) {
+                hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, false, WM, false, true>), dim3(kFitRescueGrid), dim3(64 * WM), 0, p.stream, a);
+                return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+            }
+        }
+        hipLaunchKernelGGL((blk_fit_kernel<T, M, RB, false, 1, false, true>), dim3(kFitRescueGrid), dim3(64), 0, p.stream, a);
+        return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+    }
 }
 
 } // namespace blk

@@ -1057,14 +1057,13 @@ template <typename T, int N, int Q> struct LmState {
 // PADM (unit weights only): 0 = general m; 1 = m == 64*R*W, no padding rows at all; 2 = only the last register pair
 // can hold padding rows -- the row-validity masks (32 SGPRs of hoisted lane masks, two selects per element) disappear
 // from the column build entirely or from all pairs but the last
-// RESCUE (round 6; a template flag of fit_problem below): the re-fit of a problem a fit kernel FLAGGED (jac_not_finite above),
-// with every derivative column built as 2^-ks times its value, ks = the binary exponent of its basis column's largest entry
-// (from the two ends of the grid), and the coefficient entering the Jacobian QR as c_k 2^ks: c_k D_k is unchanged, the basis
-// part (R, c, the residual) is bit for bit the unscaled evaluation, nothing overflows.  Run by the wavefront(-group) that
-// flagged the problem, at its exit (fit_refit_flagged / fit2_refit_flagged), at the lone-wave rate (~4 us per evaluation): a
-// flagged problem must not outlast the batch it came from, and no launch follows the fit.  Models with a trailing constant
-// and diagonal pairs (MultiExpModel<.., true>); every other flagged problem goes to the generic kernel through the handle's
-// list (vp_api.hip rescue_refit).
+// RESCUE (round 6): the launch that re-fits the problems the fit kernels FLAGGED (jac_not_finite above) -- workgroup i takes
+// problem list[2 + i], i < list[slot] -- with every derivative column built as 2^-ks times its value, ks = the binary exponent
+// of its basis column's largest entry (from the two ends of the grid), and the coefficient entering the Jacobian QR as
+// c_k 2^ks: c_k D_k is unchanged, the basis part (R, c, the residual) is bit for bit the unscaled evaluation, nothing
+// overflows.  One wavefront(-group) per problem at the lone-wave rate (~4 us per evaluation): a flagged problem must not
+// outlast the batch it came from.  Models with a trailing constant and diagonal pairs (MultiExpModel<.., true>); every
+// other flagged problem goes to the generic kernel (vp_api.hip rescue_refit).
 template <typename T, class M> inline constexpr bool fit_rescue_v = M::kStatic && M::kConstLast && M::kDiagonalPairs;
 
 // The fit of ONE problem by one wavefront(-group): the body of fit_kernel, also the exit path of the slot kernel's self-rescue
@@ -1480,7 +1479,7 @@ __device__ __forceinline__ bool fit_problem(const FitArgs<T, M> &a, const int64_
     }
     // lane 0 stores the (uniform) results one by one: a lane-indexed gather would turn x[] into a scratch array
     if (lane == 0) {
-        if (flagged && a.rescue != nullptr) { // alpha[b] keeps the initial guess: the re-fit starts from it and overwrites every output
+        if (flagged && (SELF || a.rescue != nullptr)) { // alpha[b] keeps the initial guess: the re-fit starts from it and overwrites every output
             if (!SELF) rescue_push(a.rescue, a.rescue_slot, b);
         } else {
 #pragma unroll
@@ -1491,18 +1490,10 @@ __device__ __forceinline__ bool fit_problem(const FitArgs<T, M> &a, const int64_
             for (int k = 0; k < N; ++k) a.C_out[b * N + a.mdl.out_index(k)] = cbest[k];
         }
     }
-    return flagged && a.rescue != nullptr;
+    return flagged;
 }
 
-// the scaled re-fit of a flagged problem by the wavefront(-group) that flagged it, at the kernel's exit.  OUT OF LINE: inlined,
-// its column array and spill slots become part of the kernel's own frame (the slot kernel ran 2 % slower that way, vp_fit2.hpp)
-template <typename T, class M, int R, int W, bool WEIGHTED>
-__device__ __noinline__ void fit_refit_flagged(const FitArgs<T, M> *a, const int64_t b, T *s_t, T *s_y, T *s_w, unsigned char *xch,
-                                               LmState<T, M::N, M::Q> *st) {
-    (void)fit_problem<T, M, R, W, WEIGHTED, 0, true, false>(*a, b, s_t, s_y, s_w, xch, st, false);
-}
-
-template <typename T, class M, int R, int W, bool WEIGHTED, int PADM = 0>
+template <typename T, class M, int R, int W, bool WEIGHTED, int PADM = 0, bool RESCUE = false>
 __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M::P>())) fit_kernel(const FitArgs<T, M> a) {
     constexpr int MP = 64 * R * W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1513,15 +1504,14 @@ __global__ void __launch_bounds__(64 * W, (model_waves_for<T, M, R, M::N + 1 + M
     // exchange area first (8-byte aligned), then one LmState per wave
     LmState<T, M::N, M::Q> *st = reinterpret_cast<LmState<T, M::N, M::Q> *>(s_after + ((group_xch_bytes<W>() + 15) / 16) * 16) +
                                  (W > 1 ? (int)(threadIdx.x >> 6) : 0);
-    const int64_t b = blockIdx.x;
-    if (b >= a.B) return;
-    // models with the scaled re-fit (fit_rescue_v): the wavefront(-group) re-fits the problem it flagged itself -- no list, no
-    // second launch; every other model appends to the handle's list (generic kernel, vp_api.hip rescue_refit)
-    constexpr bool SELF = fit_rescue_v<T, M>;
-    const bool again = fit_problem<T, M, R, W, WEIGHTED, PADM, false, SELF>(a, b, s_t, s_y, s_w, s_after, st, true);
-    if constexpr (SELF) {
-        if (again) fit_refit_flagged<T, M, R, W, WEIGHTED>(&a, b, s_t, s_y, s_w, s_after, st);
+    int64_t b = blockIdx.x;
+    if constexpr (RESCUE) {
+        if (b >= (int64_t)uni(a.rescue[a.rescue_slot])) return;
+        b = (int64_t)uni(a.rescue[2 + b]);
+    } else {
+        if (b >= a.B) return;
     }
+    (void)fit_problem<T, M, R, W, WEIGHTED, PADM, RESCUE, false>(a, b, s_t, s_y, s_w, s_after, st, true);
 }
 
 // dynamic LDS of fit_kernel: zero-padded copies of the grid, the data column and (weighted problems) the weights, the group
@@ -1559,7 +1549,7 @@ template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchPara
     a.rescue = p.rescue;
     a.rescue_slot = p.rescue_slot;
     if (a.B <= 0) return VP_ERR_OK;
-    if (p.rescue_used && !fit_rescue_v<T, M>) *p.rescue_used = 1; // (fit_rescue_v kernels re-fit what they flag themselves)
+    if (p.rescue_used) *p.rescue_used = 1;
     const size_t lds = fit_lds_bytes<T, M, R, W>(p.w != nullptr);
     if (p.w) hipLaunchKernelGGL((fit_kernel<T, M, R, W, true>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     else if (p.m == 64 * R * W)
@@ -1568,6 +1558,45 @@ template <typename T, class M, int R, int W = 1> int launch_fit(const LaunchPara
         hipLaunchKernelGGL((fit_kernel<T, M, R, W, false, 2>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     else hipLaunchKernelGGL((fit_kernel<T, M, R, W, false>), dim3((unsigned)a.B), dim3(64 * W), lds, p.stream, a);
     return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+}
+
+// the re-fit launch of the flagged problems (fit_kernel<..., RESCUE>): up to kFitRescueGrid of them, one workgroup each; entries
+// beyond that (and weighted problems, and every model outside fit_rescue_v) are the generic kernel's (vp_api.hip rescue_refit)
+template <typename T, class M, int R, int W = 1> int launch_fit_rescue(const LaunchParams &p) {
+    if constexpr (!fit_rescue_v<T, M>) {
+        return VP_ERR_UNSUPPORTED;
+    } else {
+        if (p.w || p.t_stride != 0 || !p.rescue) return VP_ERR_UNSUPPORTED;
+        FitArgs<T, M> a;
+        if (!bind_model(*p.model, a.mdl)) return VP_ERR_UNSUPPORTED;
+        a.t = (const T *)p.t;
+        a.w = nullptr;
+        a.yw = (const T *)p.yw;
+        a.alpha = (T *)p.alpha_out;
+        a.C_out = (T *)p.C_out;
+        a.cost_out = p.cost_out;
+        a.status = p.status;
+        a.report = p.report;
+        a.m = p.m;
+        a.B = p.B;
+        a.t_stride = 0;
+        a.w_stride = 0;
+        a.eps = (T)p.eps;
+        a.ftol = (T)p.opts->ftol;
+        a.xtol = (T)p.opts->xtol;
+        a.gtol = (T)p.opts->gtol;
+        a.stepbound = (T)p.opts->stepbound;
+        a.patience = p.opts->patience;
+        a.scale_diag = p.opts->scale_diag;
+        a.trace = p.trace;
+        a.trace_rows = p.trace_rows;
+        a.grid_uniform = p.grid_uniform;
+        a.rescue = p.rescue;
+        a.rescue_slot = p.rescue_slot;
+        const size_t lds = fit_lds_bytes<T, M, R, W>(false);
+        hipLaunchKernelGGL((fit_kernel<T, M, R, W, false, 0, true>), dim3(kFitRescueGrid), dim3(64 * W), lds, p.stream, a);
+        return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
+    }
 }
 
 // == FitResult::best_fit (src/fit.rs:55-59, 87-91): UNWEIGHTED Phi(alpha) * C

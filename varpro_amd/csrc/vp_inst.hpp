@@ -22,7 +22,16 @@
         &::vp::launch_mrhs_lm<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                          \
         &::vp::launch_mrhs_finish<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>,                                      \
         ::vp::mrhs_state_bytes<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>>(),                                          \
-        &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>, nullptr, 0, ::vp::mrhs_gx_cap<T, RR>()});
+        &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR>, nullptr, 0, ::vp::mrhs_gx_cap<T, RR>()});            \
+    VP_REGISTER_FIT_RESCUE(T, NEXP, OFF, RR, 1)
+
+// the scaled re-fit kernel of the set's flagged problems (models with an offset: fit_rescue_v)
+#define VP_REGISTER_FIT_RESCUE(T, NEXP, OFF, RR, WW)                                                                   \
+    static ::vp::RescueRegistrar VP_CAT(vp_resc_, __COUNTER__)(                                                       \
+        &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                          \
+        ::vp::fit_rescue_v<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>>                                                  \
+            ? &::vp::launch_fit_rescue<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>                              \
+            : nullptr);
 
 #define VP_REGISTER_RT(T, DT, NN, QQ, PP, RR)                                                                          \
     static ::vp::Registrar VP_CAT(vp_reg_, __COUNTER__)(::vp::KernelEntry{                                            \
@@ -58,7 +67,8 @@
         &::vp::launch_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>,                                          \
         &::vp::launch_best_fit<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, nullptr, nullptr, nullptr, 0, \
         &::vp::launch_stats<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>, nullptr, 0, 0,                         \
-        ::vp::fit_lds_bytes<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>(true)});
+        ::vp::fit_lds_bytes<T, ::vp::MultiExpModel<NEXP, (OFF) != 0>, RR, WW>(true)});                                \
+    VP_REGISTER_FIT_RESCUE(T, NEXP, OFF, RR, WW)
 
 // fp32, many columns x many rows: the FIT runs on the fp64 Gram matrix (vp_fitg.hpp: any grid, any weights; there is
 // no fp32 Householder fit kernel for these shapes -- it lost 15 % of the fits and spilled 230-250 VGPRs);

@@ -21,7 +21,10 @@ template <typename T, class M> int launch_evaluate_entry(const LaunchParams &p) 
         &::vp::blk::launch_fit<T, MODEL>, &::vp::gen::launch_best_fit<T>, nullptr, nullptr, nullptr, nullptr,          \
         ::vp::gen::mrhs_lm_state_bytes<T>(), &::vp::gen::launch_stats<T>, &::vp::gen::launch_mrhs_fit<T>, 0, 0, 0, 1});
 #define VP_REGISTER_BLOCKED_MULTIEXP(T, DT, NEXP, OFF)                                                                 \
-    VP_BLK_ENTRY(T, DT, ::vp::FAMILY_MULTIEXP, NEXP, OFF, 0, VP_BLK_ME(NEXP, OFF))
+    VP_BLK_ENTRY(T, DT, ::vp::FAMILY_MULTIEXP, NEXP, OFF, 0, VP_BLK_ME(NEXP, OFF))                                     \
+    static ::vp::RescueRegistrar VP_BLK_CAT(vp_blk_resc_, __COUNTER__)(                                               \
+        &::vp::blk::launch_fit<T, VP_BLK_ME(NEXP, OFF)>,                                                              \
+        ::vp::fit_rescue_v<T, VP_BLK_ME(NEXP, OFF)> ? &::vp::blk::launch_fit_rescue<T, VP_BLK_ME(NEXP, OFF)> : nullptr);
 #define VP_BLK_ME(NEXP, OFF) ::vp::MultiExpModel<NEXP, (OFF) != 0>
 #define VP_REGISTER_BLOCKED_RT(T, DT, NN, QQ, PP) VP_BLK_ENTRY(T, DT, ::vp::FAMILY_RT, NN, QQ, PP, VP_BLK_RT(NN, QQ, PP))
 #define VP_BLK_RT(NN, QQ, PP) ::vp::RtModel<NN, QQ, PP>

@@ -101,6 +101,9 @@ struct LaunchParams {
     hipStream_t stream;
 };
 
+// workgroups of the fast re-fit launch (fit_kernel<..., RESCUE>, vp_fit.hpp): flagged problems beyond that go to the generic kernel
+constexpr int kFitRescueGrid = 256;
+
 // One fit whose Jacobian came out non-finite after an evaluation that was itself fine -- the reference forms D_k c BEFORE it
 // projects (src/solvers/levmar/mod.rs:156-171), the register kernels sweep the unscaled derivative columns, so a decay time
 // stepping through zero (exp(+t/0.035) = 1e153 with c = 1e-152) overflows here and not there -- hands itself over: called by

@@ -39,6 +39,21 @@ struct Registrar {
     explicit Registrar(const KernelEntry &e) { registry().push_back(e); }
 };
 
+// the fast re-fit launch of a set's flagged problems (fit_kernel<..., RESCUE>, vp_fit.hpp), keyed by the set's fit_single
+// launcher (a side table: KernelEntry initialisers stay as they are)
+struct RescueEntry {
+    launch_fn fit_single, rescue;
+};
+std::vector<RescueEntry> &rescue_registry();
+struct RescueRegistrar {
+    RescueRegistrar(launch_fn fit_single, launch_fn rescue) { rescue_registry().push_back(RescueEntry{fit_single, rescue}); }
+};
+inline launch_fn find_fit_rescue(launch_fn fit_single) {
+    for (const RescueEntry &e : rescue_registry())
+        if (e.fit_single == fit_single) return e.rescue;
+    return nullptr;
+}
+
 // classify a public descriptor; returns family and its key (a,b,c); p_out = number of dependency pairs
 int classify_model(const vp_model_desc &d, int &a, int &b, int &c, int &p_out);
 
