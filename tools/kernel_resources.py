@@ -9,7 +9,24 @@ out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else N
 tmp = tempfile.mkdtemp()
 try:
     shutil.copy(obj, os.path.join(tmp, "x.o"))
-    subprocess.run([LLVM + "/llvm-objdump", "--offloading", "x.o"], cwd=tmp, capture_output=True)
+    blob = open(obj, "rb").read()
+    if blob.find(b"CCOB") >= 0:
+        # compressed offload bundles (--offload-compress): llvm-objdump --offloading mis-extracts a library that holds several
+        # of them; cut each "CCOB" blob out (header: magic, u16 version, u16 method, u64 blob size, ...) and let
+        # clang-offload-bundler decompress + unbundle it
+        import struct
+        i, n = blob.find(b"CCOB"), 0
+        while i >= 0:
+            version = struct.unpack_from("<H", blob, i + 4)[0]
+            size = struct.unpack_from("<Q", blob, i + 8)[0] if version >= 3 else struct.unpack_from("<I", blob, i + 8)[0]
+            open(os.path.join(tmp, "blob"), "wb").write(blob[i:i + size])
+            subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            "--input=" + os.path.join(tmp, "blob"), "--output=" + os.path.join(tmp, "x.%d.amdgcn.co" % n)], capture_output=True)
+            n += 1
+            i = blob.find(b"CCOB", i + max(size, 4))
+        os.remove(os.path.join(tmp, "blob"))
+    else:
+        subprocess.run([LLVM + "/llvm-objdump", "--offloading", "x.o"], cwd=tmp, capture_output=True)
     kernels = []
     for fn in sorted(os.listdir(tmp)):
         if "amdgcn" not in fn: continue
@@ -30,7 +47,8 @@ try:
     ks = [k for k in kernels if "vgpr_count" in k]
     def nm(k): return subprocess.run([shutil.which("c++filt") or "cat", k.get("symbol", k.get("name", "?")).replace(".kd", "")], capture_output=True, text=True).stdout.strip()[:150]
     sp = sorted(ks, key=lambda k: -k.get("vgpr_spill_count", 0))
-    summary = {"object": os.path.relpath(obj), "bytes": os.path.getsize(obj), "kernels": len(ks),
+    summary = {"object": os.path.relpath(obj), "bytes": os.path.getsize(obj), "compressed_bundles": blob.find(b"CCOB") >= 0,
+               "code_object_bytes": sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp) if "amdgcn" in f), "kernels": len(ks),
                "kernels_with_spilled_vgprs": sum(1 for k in ks if k.get("vgpr_spill_count", 0) > 0),
                "kernels_above_64_spilled_vgprs": sum(1 for k in ks if k.get("vgpr_spill_count", 0) > 64),
                "worst": [dict(kernel=nm(k), vgprs=k["vgpr_count"], spilled_vgprs=k.get("vgpr_spill_count", 0), spilled_sgprs=k.get("sgpr_spill_count", 0),

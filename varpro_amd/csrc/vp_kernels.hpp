@@ -219,7 +219,7 @@ template <typename T, class M> struct EvalArgs {
     int grid_uniform;
 };
 
-// MODE 0: coefficients/cost/status only; 1: + residuals; 2: + residuals + Jacobian
+// MODE 1: coefficients / cost / status + residuals (without a residual pointer: set_params alone); 2: + Jacobian
 // ALIGNED: m even and every array 16-byte aligned (checked on the host) -> 2-element accesses only
 // WEIGHTED: weights present (decided on the host)
 // UNIFORM (MODE 2 only): the handle's grid check found a uniform grid -- the exponentials by recurrence, and ONLY that path
@@ -326,7 +326,10 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
         T g1[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) g1[j] = u.g[1 + j];
-        if constexpr (MODE == 0) return; // (phase 1 alone is the set_params of a full-length problem: 3 register columns)
+        // (phase 1 alone is the set_params of a full-length problem: 3 register columns.  A set_params call is the MODE 1
+        // kernel without a residual pointer: one kernel per set instead of two, the branch is uniform over the launch)
+        if constexpr (MODE == 0) return;
+        if (MODE == 1 && !a.r_out) return;
         // r = Q r~ = H_0 H_1 .. H_NE r~
         residual_qcoords<T, R, N>(C[NE], u.e, grp);
         apply_q_cols<T, R, NE, NCX, NE, NCX>(C, g1, grp);
@@ -437,6 +440,7 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
     if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(u.c, lane);
 
     if constexpr (MODE >= 1) {
+        if (MODE == 1 && !a.r_out) return; // set_params alone (launch_evaluate has no MODE 0 kernels any more)
         residual_qcoords<T, R, N>(C[N], u.e, grp);
         T *rp = a.r_out ? a.r_out + prob * (int64_t)m : nullptr;
         if constexpr (MODE == 1) {
@@ -674,12 +678,11 @@ template <typename T, class M, int R, int W = 1> int launch_evaluate(const Launc
     if constexpr (eval2_split<T, M, R, W, 1, true, true>()) {
         // set_params (+ residuals) of a full-length, unweighted problem on a uniform grid: phase 1 of the split kernel
         if (mode < 2 && aligned && p.grid_uniform != 0 && !p.w && p.m == 64 * R * W) {
-            if (mode == 1) hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 1, true, false, true, true>), grid, block, 0, p.stream, a);
-            else hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 0, true, false, true, true>), grid, block, 0, p.stream, a);
+            hipLaunchKernelGGL((evaluate_kernel<T, M, R, W, 1, true, false, true, true>), grid, block, 0, p.stream, a);
             return hipGetLastError() == hipSuccess ? VP_ERR_OK : VP_ERR_HIP;
         }
     }
-    const int variant = mode * 4 + (aligned ? 2 : 0) + (p.w ? 1 : 0);
+    const int variant = (mode == 0 ? 1 : mode) * 4 + (aligned ? 2 : 0) + (p.w ? 1 : 0);
 #define VP_EV(MODE_, AL_, W_)                                                                                          \
     case (MODE_) * 4 + (AL_) * 2 + (W_):                                                                               \
         if constexpr (M::kStatic || (AL_) == 0)                                                                        \
@@ -687,7 +690,6 @@ template <typename T, class M, int R, int W = 1> int launch_evaluate(const Launc
                                a);                                                                                     \
         break;
     switch (variant) {
-        VP_EV(0, 0, 0) VP_EV(0, 0, 1) VP_EV(0, 1, 0) VP_EV(0, 1, 1)
         VP_EV(1, 0, 0) VP_EV(1, 0, 1) VP_EV(1, 1, 0) VP_EV(1, 1, 1)
         VP_EV(2, 0, 0) VP_EV(2, 0, 1) VP_EV(2, 1, 0) VP_EV(2, 1, 1)
     }
