@@ -262,6 +262,15 @@ template <typename T, int RB, bool WEIGHTED, bool NOGRID = false> struct RowRing
 // again as the block itself: their kernels run ONE wave per SIMD -- 512 VGPRs -- like the resident ones, model_waves_for)
 // (so do static models of more than ten columns: five exponentials in fp64 -- 12 columns of 4 rows + the carry + the lane-private
 // trailing triangle spilled 176-570 VGPRs at two waves per SIMD)
+#ifndef VP_BLK_PREDICT
+#define VP_BLK_PREDICT 0 /* fold y - Phi(alpha) c_prev instead of y (c_prev = the coefficients of the last evaluation; see
+   blk_fit_problem).  Built in round 6 to take the noise out of VP_BLK_LANE_ALL's residual norm, and it does: 16 384 fits of
+   10 000 rows take 171 613 evaluations lane-private, 142 617 lane-private + predicted, 142 988 as shipped.  But the lane-private
+   fold is no longer the faster one -- the wave-wide kernel moved to 20-row blocks on a computed grid since round 5 (8.04 ms);
+   lane-private needs 512 VGPRs + 37 spilled there and takes 10.6 ms, 9.35 at 12 / 16 rows -- and on the shipped fold the
+   prediction costs 1 % (N more fma per row) for 0.5 % fewer evaluations, with 3 more failed fits in 32 768 at m = 3 000 (a
+   prediction from a far-away trial point is a LARGER data column: cancellation).  Both off (tools/stream_ab_probe.py). */
+#endif
 template <class M> constexpr int blk_waves() { return (M::kStatic && M::N + 1 + M::P <= 10) ? VP_BLK_WAVES : 1; }
 template <typename T, int NC, bool STATIC = true> constexpr int block_rows() {
 #ifdef VP_BLK_RB
@@ -351,6 +360,13 @@ __device__ __forceinline__ bool blk_fit_problem(const FitArgs<T, M> &a, const in
 #pragma unroll
     for (int k = 0; k < N; ++k) cbest[k] = T(0);
     int trow = 0;
+    // (VP_BLK_PREDICT) the data column is folded as  y' = y_w - Phi_w(alpha) c_prev : the same projection residual, the same
+    // R factor, coefficients c = c_prev + dc -- but every carry entry of the data column is O(|y'|) ~ O(||r||) near the minimum
+    // instead of O(||y||), so the rounding of the sequential updates (eps * entry per fold) no longer shows in ||r||^2
+    T cprev[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) cprev[k] = T(0);
+    [[maybe_unused]] bool shifted = false;
 
     static_assert(!TC || (!WEIGHTED && sizeof(T) == 8), "computed grid: unit weights, fp64 (the recurrence's own condition)");
     using Ring = RowRing<T, RB, WEIGHTED, TC>;
@@ -434,6 +450,15 @@ __device__ __forceinline__ bool blk_fit_problem(const FitArgs<T, M> &a, const in
                 T Cb[NC][RB];
                 load_rows_lds<T, RB, 1>(s_y, lane, Cb[N]);
                 build_columns<T, M, RB, NC, Src, M::N + 1, false, true, true, -1, RESCUE>(a.mdl, xt_now, src, Cb, ks);
+                if constexpr (VP_BLK_PREDICT != 0) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        T acc = Cb[N][r];
+#pragma unroll
+                        for (int j = 0; j < N; ++j) acc = tfma(-cprev[j], Cb[j][r], acc);
+                        Cb[N][r] = acc;
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (kLaneTrail) {
                     if constexpr (NF > 0) stacked_qr<T, NC, NF, RB, G>(K, Cb, grp);
@@ -502,6 +527,18 @@ __device__ __forceinline__ bool blk_fit_problem(const FitArgs<T, M> &a, const in
         T c[N], e[N];
         bool truncated;
         solve_coeffs<T, N>(Rm, qty, a.eps, c, e, truncated);
+        if constexpr (VP_BLK_PREDICT != 0) {
+            // a truncated solve returns the minimum-norm coefficients of WHAT IT WAS GIVEN: redo the evaluation on y itself
+            // (the reference's minimum-norm c, src/solvers/levmar/mod.rs:51-59) -- rank-deficient trial points are rare
+            if (uni(truncated) && shifted) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) cprev[k] = T(0);
+                shifted = false;
+                continue;
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) c[k] += cprev[k];
+        }
         // ||r||^2 = ||e||^2 + sum over the carry rows >= N of (T_y)^2   (only row N is non-zero)
         T sq = T(0);
 #pragma unroll
@@ -516,6 +553,11 @@ __device__ __forceinline__ bool blk_fit_problem(const FitArgs<T, M> &a, const in
 #pragma unroll
         for (int k = 0; k < N; ++k) ok = ok && is_finite(c[k]) && is_finite(Rm[k][k]);
         ok = uni(ok);
+        if constexpr (VP_BLK_PREDICT != 0) {
+            shifted = ok && !uni(truncated);
+#pragma unroll
+            for (int k = 0; k < N; ++k) cprev[k] = shifted ? c[k] : T(0);
+        }
 
         const T fnorm1 = usqrt(fn2);
         const bool need = lm_after_eval<T, N, Q, true>(S, opt, fnorm1, ok, (long)m);
