@@ -492,17 +492,18 @@ __device__ __forceinline__ void apply_qt(const T (&V)[NC][R], const T (&g)[N], T
 //   NOD:  no derivative columns (NCX = N: exponentials + data) -- phase 1 of the split evaluate kernel
 //   SHIFT: the derivative column of exponential j carries the factor 2^-ks[j] (build_columns); everything the basis
 //          columns produce (R, c, the residual) is the unshifted evaluation's bit for bit
-template <typename T, class M, int R, int NCX, class Src, class G, bool YPRE = false, bool NOD = false, bool SHIFT = false>
+//   PRE:  1 / alpha_i and the recurrence ratios of the trial point come from the caller (build_columns)
+template <typename T, class M, int R, int NCX, class Src, class G, bool YPRE = false, bool NOD = false, bool SHIFT = false, bool PRE = false>
 __device__ __forceinline__ void evaluate_core_const_first(const M &mdl, const T (&alpha)[M::Q], const Src &src, T eps,
                                                           G &grp, const ConstReflector<T> &h0, T (&C)[NCX][R],
                                                           EvalUniform<T, M::N> &u, SectionClock *clk = nullptr,
-                                                          const T qty0 = T(0), const int *ks = nullptr) {
+                                                          const T qty0 = T(0), const int *ks = nullptr, const T *pre = nullptr) {
     constexpr int N = M::N, NE = M::N - 1;
     static_assert(M::kConstLast && NCX == M::N + (NOD ? 0 : M::P), "const-first sweep: N-1 exponentials + data + P derivatives");
     using L = Layout<R, G::W>;
     constexpr int VW = L::VW;
     const int lane = grp.gl;
-    build_columns<T, M, R, NCX, Src, NE + 1, true, true, !NOD, -1, SHIFT>(mdl, alpha, src, C, ks);
+    build_columns<T, M, R, NCX, Src, NE + 1, true, true, !NOD, -1, SHIFT, PRE>(mdl, alpha, src, C, ks, pre);
     VP_TICK(clk, 1);
     __builtin_amdgcn_sched_barrier(0);
     // ---- reflector 0: the implicit scale column ----

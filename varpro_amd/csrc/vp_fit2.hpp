@@ -33,6 +33,11 @@ template <typename T, int N, int Q> struct alignas(8) SlotRec {
     T fnorm, delta, par, xnorm, gnorm, pnorm, prered, dirder, objective;
     T fnorm1, actred, ratio; // outputs of the latest evaluation
     T qty0;                  // (H_0 y_w)[0]: first entry of Q^T y_w, fixed for the whole fit
+    // wave-uniform scalars of the trial point xt, computed where xt is (scalar phase: ONE lane per slot; slot_fill): 1 / xt_i,
+    // exp(-delta / xt_i) (the ratio of the uniform-grid recurrence), then 1 / fnorm and 1 / prered -- the vector phase used to
+    // compute them on all 64 lanes once per slot and evaluation (two reciprocals, two refined quotients and two exponentials
+    // per exponential column).  Same functions, same inputs: bit-identical (build_columns PRE)
+    T pre[2 * Q + 2];
     int ipvt[Q];
     int flags; // bit0 first, bit1 first_tr, bit2 first_update, bit3 eval ok, bit4 jacobian refreshed, bit5 good
     int nfev;
@@ -47,6 +52,9 @@ template <typename T, int N, int Q> struct alignas(8) SlotRec {
 // Slots per group from the LDS budget: a workgroup holds ONE copy of the grid and NG groups x GS columns of 64*R*W
 // scalars; `blocks_per_cu` workgroups are resident per CU (160 KiB of LDS).  Capped at 8 (lanes 0..GS-1 of ONE wave
 // run the scalar phase; beyond 8 the divergent branches of lmpar eat the gain).
+#ifndef VP_FIT2_PRE
+#define VP_FIT2_PRE 1 /* the trial point's wave-uniform scalars come from the scalar phase (SlotRec::pre): bit-identical, 1 606 -> 1 582 VALU instructions per evaluation, 36 -> 32 spilled VGPRs, and NO time (2.0825 -> 2.079 ms per step: the moved instructions run for two lanes on the scalar phase's dependent chain) */
+#endif
 #ifndef VP_SLOT_CAP
 #define VP_SLOT_CAP 8
 #endif
@@ -90,6 +98,7 @@ template <typename T, typename TO = T> struct SlotConsts {
     int64_t B;
     int trace_rows, scale_diag, max_fev, m;
     T eps;             // (Gram kernel) rank threshold of the linear solve
+    T pre_delta;       // grid distance between a lane's consecutive row pairs (RowSource::delta) on a uniform grid, else 0
 #ifdef VP_FIT2_CLOCKS
     long long sck[6];  // (debug) section clocks of the scalar phase, accumulated by wave 0 of workgroup 0
 #endif
@@ -187,6 +196,16 @@ __device__ __noinline__ void slot_fill(VP_LDS SlotRec<T, N, Q> *rec, VP_LDS T *s
         rec->objective = T(0) / T(0);
         rec->fnorm1 = rec->actred = rec->ratio = T(0);
         rec->qty0 = qty0;
+        if constexpr (VP_FIT2_PRE != 0) {
+            const T pd = k->pre_delta;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                const T rti = frcp(a0[i]);
+                rec->pre[2 * i] = rti;
+                rec->pre[2 * i + 1] = texp(-div_refined(pd, a0[i], rti));
+            }
+            rec->pre[2 * Q] = rec->pre[2 * Q + 1] = T(0); // (first evaluation: no ratio test)
+        }
         rec->flags = 1 | 2 | 4;
         rec->nfev = 0;
         rec->term = VP_TERM_NOT_RUN;
@@ -425,6 +444,17 @@ __device__ __forceinline__ void slot_scalar_phase_inl(VP_LDS SlotRec<T, N, Q> *r
     if (accept_c) {
 #pragma unroll
         for (int i = 0; i < N; ++i) s->cbest[i] = s->cnew[i];
+    }
+    if constexpr (!GRAM && VP_FIT2_PRE != 0) {
+        const T pd = k->pre_delta;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const T rti = frcp(xt[i]);
+            s->pre[2 * i] = rti;
+            s->pre[2 * i + 1] = texp(-div_refined(pd, xt[i], rti));
+        }
+        s->pre[2 * Q] = frcp(fnorm);
+        s->pre[2 * Q + 1] = frcp(prered);
     }
     s->fnorm = fnorm;
     s->delta = delta;
@@ -910,6 +940,8 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
     src.set_uniform(uniform_ != 0);
     const ConstReflector<T> h0 = make_const_reflector<T, R, Src, G>(src, grp);
     const M mdl = args.f.mdl;
+    if (threadIdx.x == 0) kc->pre_delta = src.uniform ? src.delta : T(0);
+    __syncthreads();
 
     auto fill = [&](int s, int prob) __attribute__((always_inline)) {
         slot_fill<T, N, Q, R, W, PADM>((VP_LDS Rec *)(recs + s), (VP_LDS T *)(s_y + (size_t)s * MP), (VP_LDS const T *)s_t,
@@ -959,19 +991,21 @@ __global__ void __launch_bounds__(64 * W * NG, (WPS * W * NG) / 4 > 0 ? (WPS * W
             const bool first = (fl_in & 1) != 0;
             const T qty0 = rec->qty0;
             const T fnorm = rec->fnorm, prered = rec->prered;
+            constexpr bool kPre = VP_FIT2_PRE != 0 && M::kStatic && sizeof(T) == 8;
 
             T C[NC][R];
             EvalUniform<T, N> u;
             load_rows_lds<T, R, W>(s_y + (size_t)s * MP, W == 1 ? lane_fresh() : lane, C[YC]);
-            evaluate_core_const_first<T, M, R, NC, Src, G, true>(mdl, alpha, src, eps_, grp, h0, C, u, nullptr, qty0);
+            evaluate_core_const_first<T, M, R, NC, Src, G, true, false, false, kPre>(mdl, alpha, src, eps_, grp, h0, C, u, nullptr, qty0, nullptr,
+                                                                                      rec->pre); // (read from LDS where they are used)
 
             const T fnorm1 = usqrt(u.fn2);
             T actred = T(0), ratio = T(0);
             bool good = false;
             if (!first) {
-                const T q1 = fnorm1 * frcp(fnorm);
+                const T q1 = fnorm1 * (kPre ? rec->pre[2 * Q] : frcp(fnorm));
                 actred = (fnorm1 * T(0.1) < fnorm) ? T(1) - q1 * q1 : T(-1);
-                ratio = (prered == T(0)) ? T(0) : actred * frcp(prered);
+                ratio = (prered == T(0)) ? T(0) : actred * (kPre ? rec->pre[2 * Q + 1] : frcp(prered));
                 good = uni(ratio >= T(1.0e-4));
             }
             const bool need_jac = u.ok && (first || good);

@@ -314,10 +314,14 @@ struct RowSource {
 //            applied to the exponential before t / tau^2 multiplies it; the basis columns are untouched (rescue_jacobian,
 //            vp_fit.hpp: a basis column within a few decades of overflow whose derivative column, or whose dot product with
 //            it, is not representable)
+//   PRE:     (static models, round 6) the wave-uniform scalars of the trial point come from the caller: pre[2 i] = 1 / alpha_i
+//            (frcp) and pre[2 i + 1] = exp(-delta / alpha_i) (the recurrence ratio) -- the slot kernel computes them ONCE per
+//            scalar phase, one lane per slot, instead of once per slot and evaluation on all 64 lanes (vp_fit2.hpp); the same
+//            functions on the same inputs: bit-identical columns
 template <typename T, class M, int R, int NC, class Src, int DOFF = M::N + 1, bool SKIP_CONST = false, bool WF = true,
-          bool WD = true, int JSEL = -1, bool SHIFT = false>
+          bool WD = true, int JSEL = -1, bool SHIFT = false, bool PRE = false>
 __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::Q], const Src &src, T (&C)[NC][R],
-                                              const int *ks = nullptr) {
+                                              const int *ks = nullptr, const T *pre = nullptr) {
     constexpr int N = M::N, P = M::P, Q = M::Q;
     constexpr int VW = Layout<R>::VW;
     static_assert(!WD || JSEL >= 0 || NC >= DOFF + P, "column array too small");
@@ -343,7 +347,8 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
         // 1/tau by the Newton-refined v_rcp (1-2 ulp): the quotient t/tau is re-rounded by div_refined, and the
         // derivative scale 1/tau^2 = (1/tau)^2 carries ~2 ulp -- two IEEE division expansions (~13 VALU each, per
         // column and evaluation) less
-        rt[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? frcp(p0[j]) : T(0);
+        if constexpr (PRE) rt[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? pre[2 * mdl.param(j, 0)] : T(0);
+        else rt[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? frcp(p0[j]) : T(0);
         rt2[j] = rt[j] * rt[j];
     }
     // UNIFORM-GRID RECURRENCE (fp64, R > 2): on a grid t_i = t_0 + i*dt a lane's row pairs are delta = 64*W*2*dt
@@ -367,7 +372,26 @@ __device__ __forceinline__ void build_columns(const M &mdl, const T (&alpha)[M::
     if constexpr (kRecur) {
         fast = src.uniform;
         if (fast) {
-            if constexpr (kBatchExp) {
+            if constexpr (kBatchExp && PRE) {
+                static_assert(!PRE || M::kStatic, "precomputed trial-point scalars: static (multi-exponential) models");
+                T tt0[2], sc0[2];
+                src.get(0, tt0, sc0);
+                T ax[N * VW], ex[N * VW];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const bool decay = kind[j] == VP_BASIS_EXP_DECAY, rate = kind[j] == VP_BASIS_EXP_RATE;
+#pragma unroll
+                    for (int e = 0; e < VW; ++e)
+                        ax[j * VW + e] = decay ? -div_refined(tt0[e], p0[j], rt[j]) : (rate ? -p0[j] * tt0[e] : T(0));
+                }
+                texp_n(ax, ex);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) fu[j][e] = ex[j * VW + e];
+                    qq[j] = (kind[j] == VP_BASIS_EXP_DECAY) ? pre[2 * mdl.param(j, 0) + 1] : T(1);
+                }
+            } else if constexpr (kBatchExp) {
                 T tt0[2], sc0[2];
                 src.get(0, tt0, sc0);
                 T ax[N * (VW + 1)], ex[N * (VW + 1)];
