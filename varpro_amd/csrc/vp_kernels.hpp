@@ -143,7 +143,16 @@ __device__ __forceinline__ void load_rows(const T *__restrict__ base, const int 
     }
 }
 
-template <typename T, int R, int W = 1>
+// NT: non-temporal stores (`nt`: streamed past the caches) -- for the OUTPUT arrays of vp_basis (Phi, dPhi) and vp_evaluate (r, J):
+// gigabytes per launch that nothing on the device reads back.  Round 6, 25 launches each on one box, alternating builds
+// (tools/nt_store_probe.py): vp_basis (2.1 GB of stores, nothing else) median 0.388 -> 0.342 ms (0.69 -> 0.79 of 8 TB/s; the fastest
+// launch 0.32 -> 0.30-0.31) -- ordinary stores leave the previous launch's lines dirty in L2 / MALL and the next launch waits for
+// their write-back; vp_evaluate (r + J) 0.390 -> 0.384; residuals only: even.  The caller-evaluated-model kernels (vp_ext.hpp), which
+// READ 2.7 GB next to the 1.6 GB they write, gain nothing (0.84-0.90 vs 0.90-0.92 ms) and keep ordinary stores
+#ifndef VP_NT_STORES
+#define VP_NT_STORES 1
+#endif
+template <typename T, int R, int W = 1, bool NT = false>
 __device__ __forceinline__ void store_rows(T *__restrict__ base, const int m, const int lane, const bool vec_ok,
                                            const T (&in)[R]) {
     using L = Layout<R, W>;
@@ -153,11 +162,17 @@ __device__ __forceinline__ void store_rows(T *__restrict__ base, const int m, co
             for (int r = 0; r < R; r += 2) {
                 const int i = L::row_of(r, lane);
                 if (i < m) {
-                    using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
-                    V2 v;
-                    v.x = in[r];
-                    v.y = in[r + 1];
-                    *reinterpret_cast<V2 *>(base + i) = v;
+                    if constexpr (NT && VP_NT_STORES != 0) {
+                        typedef T v2_t __attribute__((ext_vector_type(2)));
+                        const v2_t v = {in[r], in[r + 1]};
+                        __builtin_nontemporal_store(v, reinterpret_cast<v2_t *>(base + i));
+                    } else {
+                        using V2 = typename std::conditional<sizeof(T) == 8, double2, float2>::type;
+                        V2 v;
+                        v.x = in[r];
+                        v.y = in[r + 1];
+                        *reinterpret_cast<V2 *>(base + i) = v;
+                    }
                 }
             }
             return;
@@ -166,8 +181,25 @@ __device__ __forceinline__ void store_rows(T *__restrict__ base, const int m, co
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = L::row_of(r, lane);
-        if (i < m) base[i] = in[r];
+        if (i < m) {
+            if constexpr (NT && VP_NT_STORES != 0) __builtin_nontemporal_store(in[r], base + i);
+            else base[i] = in[r];
+        }
     }
+}
+__device__ __forceinline__ void store_out2(double *p, const double x, const double y) {
+    if constexpr (VP_NT_STORES != 0) {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const d2_t v = {x, y};
+        __builtin_nontemporal_store(v, reinterpret_cast<d2_t *>(p));
+    } else {
+        *reinterpret_cast<double2 *>(p) = make_double2(x, y);
+    }
+}
+// the output arrays of the trait-level calls
+template <typename T, int R, int W = 1>
+__device__ __forceinline__ void store_rows_out(T *__restrict__ base, const int m, const int lane, const bool vec_ok, const T (&in)[R]) {
+    store_rows<T, R, W, true>(base, m, lane, vec_ok, in);
 }
 
 // zero-padded, 16-byte aligned LDS column (64*R*W rows): ONE lane address + immediate offsets, no bounds logic
@@ -338,7 +370,7 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
 #pragma unroll
             for (int r = 0; r < R; ++r) Y1[0][r] = C[NE][r];
             apply_const_reflector<T, R, 1, Src, G>(Y1, h0, src, grp);
-            if (a.r_out) store_rows<T, R, W>(a.r_out + prob * (int64_t)m, m, lane, yvec, Y1[0]);
+            if (a.r_out) store_rows_out<T, R, W>(a.r_out + prob * (int64_t)m, m, lane, yvec, Y1[0]);
         }
         if constexpr (MODE == 1) return;
         asm volatile("" ::: "memory"); // (the grid loads of phase 2 must not be hoisted into phase 1)
@@ -360,7 +392,7 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
             }
             apply_q<T, R, NE, NCX, 1, G>(C, g1, D, grp);
             apply_const_reflector<T, R, 1, Src, G>(D, h0, src, grp);
-            if (a.J_out) store_rows<T, R, W>(a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m, m, lane, ALIGNED, D[0]);
+            if (a.J_out) store_rows_out<T, R, W>(a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m, m, lane, ALIGNED, D[0]);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -383,7 +415,7 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
         if (a.J_out) {
 #pragma unroll
             for (int k = 0; k < Q; ++k) // J[b][k][s][m]
-                store_rows<T, R, W>(a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m, m, lane, ALIGNED, D[k]);
+                store_rows_out<T, R, W>(a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m, m, lane, ALIGNED, D[k]);
         }
         }
         return;
@@ -401,7 +433,7 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
         if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(u.c, lane);
         residual_qcoords<T, R, N>(C[N], u.e, grp);
         apply_q_cols<T, R, N, N + 1, N, N + 1>(C, u.g, grp);
-        if (a.r_out) store_rows<T, R, W>(a.r_out + prob * (int64_t)m, m, lane, yvec, C[N]);
+        if (a.r_out) store_rows_out<T, R, W>(a.r_out + prob * (int64_t)m, m, lane, yvec, C[N]);
         if (!a.J_out) return;
         static_for<0, Q>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
@@ -423,7 +455,7 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
                 D[0][r] = top ? T(0) : ck * D[0][r];
             }
             apply_q<T, R, N, N + 1, 1, G>(C, u.g, D, grp);
-            store_rows<T, R, W>(a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m, m2, lane, ALIGNED, D[0]);
+            store_rows_out<T, R, W>(a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m, m2, lane, ALIGNED, D[0]);
         });
         return;
     }
@@ -446,18 +478,18 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
         if constexpr (MODE == 1) {
             // r = Q r~ : back-sweep on the data column only, in place
             apply_q_cols<T, R, N, NC, N, N + 1>(C, u.g, grp);
-            if (rp) store_rows<T, R, W>(rp, m, lane, yvec, C[N]);
+            if (rp) store_rows_out<T, R, W>(rp, m, lane, yvec, C[N]);
         } else if constexpr (M::kDiagonalPairs) {
             // J~_k = -c_k (Q^T D_k) in place, then ONE back-sweep over [r~ | J~_1 .. J~_q] in place
             T Zs[1][R];
             jacobian_qcoords<T, M, R, NC>(a.mdl, C, u.c, Zs, grp);
             apply_q_cols<T, R, N, NC, N, NC>(C, u.g, grp);
-            if (rp) store_rows<T, R, W>(rp, m, lane, yvec, C[N]);
+            if (rp) store_rows_out<T, R, W>(rp, m, lane, yvec, C[N]);
             if (a.J_out) {
 #pragma unroll
                 for (int k = 0; k < Q; ++k) { // J[b][k][s][m]
                     T *jp = a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m;
-                    store_rows<T, R, W>(jp, m, lane, ALIGNED, C[N + 1 + k]);
+                    store_rows_out<T, R, W>(jp, m, lane, ALIGNED, C[N + 1 + k]);
                 }
             }
         } else {
@@ -473,12 +505,12 @@ __global__ void __launch_bounds__(64 * W, (eval_waves<T, M, R, W, MODE, UNIFORM,
                     for (int r = 0; r < R; ++r) Z[1 + k][r] = Zs[k][r];
             }
             apply_q<T, R, N, NC, 1 + Q>(C, u.g, Z, grp);
-            if (rp) store_rows<T, R, W>(rp, m, lane, yvec, Z[0]);
+            if (rp) store_rows_out<T, R, W>(rp, m, lane, yvec, Z[0]);
             if (a.J_out) {
 #pragma unroll
                 for (int k = 0; k < Q; ++k) { // J[b][k][s][m]
                     T *jp = a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m;
-                    store_rows<T, R, W>(jp, m, lane, ALIGNED, Z[1 + k]);
+                    store_rows_out<T, R, W>(jp, m, lane, ALIGNED, Z[1 + k]);
                 }
             }
         }
@@ -545,7 +577,7 @@ __global__ void __launch_bounds__((64 * W * basis_ppb<M, R, W>())) basis_kernel(
         for (int j = 0; j < N; ++j) {
             if (a.skip_invariant && a.mdl.kind(j) == VP_BASIS_CONST) continue;
             T *p = a.Phi_out + (b * a.n_phi_cols + col) * (int64_t)m;
-            store_rows<T, R, W>(p, m, lane, ALIGNED, C[j]);
+            store_rows_out<T, R, W>(p, m, lane, ALIGNED, C[j]);
             ++col;
         }
     }
@@ -553,7 +585,7 @@ __global__ void __launch_bounds__((64 * W * basis_ppb<M, R, W>())) basis_kernel(
 #pragma unroll
         for (int pidx = 0; pidx < P; ++pidx) {
             T *p = a.dPhi_out + (b * P + pidx) * (int64_t)m;
-            store_rows<T, R, W>(p, m, lane, ALIGNED, C[N + 1 + pidx]);
+            store_rows_out<T, R, W>(p, m, lane, ALIGNED, C[N + 1 + pidx]);
         }
     }
 }
@@ -583,10 +615,10 @@ template <class M> __global__ void __launch_bounds__(256) basis_rowpair_kernel(c
         f.y = texp(-div_refined(tv.y, tau, rt));
         d.x = (f.x * tv.x) * rt2;
         d.y = (f.y * tv.y) * rt2;
-        if (phi) *reinterpret_cast<double2 *>(phi + (int64_t)k * m) = f;
-        if (dphi) *reinterpret_cast<double2 *>(dphi + (int64_t)k * m) = d;
+        if (phi) store_out2(phi + (int64_t)k * m, f.x, f.y);
+        if (dphi) store_out2(dphi + (int64_t)k * m, d.x, d.y);
     }
-    if (M::kConstLast && !a.skip_invariant && phi) *reinterpret_cast<double2 *>(phi + (int64_t)NE * m) = make_double2(1.0, 1.0);
+    if (M::kConstLast && !a.skip_invariant && phi) store_out2(phi + (int64_t)NE * m, 1.0, 1.0);
 }
 
 // The same with a thread owning one row pair of ONE column: when Phi is written without its constant column, Phi [B][NE][m]
@@ -595,6 +627,7 @@ template <class M> __global__ void __launch_bounds__(256) basis_rowpair_kernel(c
 #ifndef VP_BASIS_FLAT
 #define VP_BASIS_FLAT 1
 #endif
+
 template <class M> __global__ void __launch_bounds__(256) basis_flat_kernel(const BasisArgs<double, M> a, const int blocks_per_col) {
     constexpr int NE = M::kConstLast ? M::N - 1 : M::N, Q = M::Q;
     const unsigned col = blockIdx.x / (unsigned)blocks_per_col; // b * NE + k
@@ -613,8 +646,8 @@ template <class M> __global__ void __launch_bounds__(256) basis_flat_kernel(cons
     d.x = (f.x * tv.x) * rt2;
     d.y = (f.y * tv.y) * rt2;
     const int64_t off = (int64_t)col * m + i;
-    if (a.Phi_out) *reinterpret_cast<double2 *>(a.Phi_out + off) = f;
-    if (a.dPhi_out) *reinterpret_cast<double2 *>(a.dPhi_out + off) = d;
+    if (a.Phi_out) store_out2(a.Phi_out + off, f.x, f.y);
+    if (a.dPhi_out) store_out2(a.dPhi_out + off, d.x, d.y);
 }
 
 // ---- host-side launch templates ------------------------------------------------------------------
