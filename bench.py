@@ -453,13 +453,24 @@ def main():
                                 fit_fn(hs[i])
             run(warm)
             torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            run(rounds)
-            torch.cuda.synchronize()
-            dt_ = time.perf_counter() - t0_
+            # host threads: the interpreter hands the GIL over every 5 ms by default -- longer than a fit; the fits release it
+            # while they wait, but a thread that wakes up must get it back.  Short switch interval, best of three passes (the
+            # spread between passes is the host's scheduling, not the device's: 0.57-0.71 ms per fit box to box before)
+            passes = 3 if threads else 1
+            old_si = sys.getswitchinterval()
+            if threads:
+                sys.setswitchinterval(1e-4)
+            best = None
+            for _p in range(passes):
+                t0_ = time.perf_counter()
+                run(rounds)
+                torch.cuda.synchronize()
+                dt_ = time.perf_counter() - t0_
+                best = dt_ if best is None or dt_ < best else best
+            sys.setswitchinterval(old_si)
             for h_ in hs:
                 h_.close()
-            return dt_ * 1e3 / (rounds * depth)
+            return best * 1e3 / (rounds * depth)
 
         TRAFFIC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
@@ -730,7 +741,7 @@ def main():
                 "workload": "BASELINE configs[2]: global fit, 1 alpha shared by %d right-hand sides, m=%d, triple-exp+offset" % (S2, m2),
                 "trait_evaluation_ms": ev2_ms, "global_fit_ms": fit2_ms, "global_fit_event_ms": fit2_event_ms,
                 "evaluations": int(r2["n_evals"][0]),
-                "two_fits_in_flight": {"ms_per_fit": ms2_two, "what": "two handles, two HIP streams, one host thread each; wall clock over 24 fits / 24"},
+                "two_fits_in_flight": {"ms_per_fit": ms2_two, "what": "two handles, two HIP streams, one host thread each; wall clock over 24 fits / 24, best of three passes"},
                 "four_fits_in_flight": {"ms_per_fit": ms2_four, "hbm_frac": T * m2 * S2 * int(r2["n_evals"][0]) / (ms2_four * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "what": "four handles: the passes of the other fits fill every step gap; the y re-reads (9 x 268 MB per fit) then run at this fraction of HBM"},
                 "termination": int(r2["termination"][0]),
