@@ -24,6 +24,9 @@
 // 2 (n + p + 1) + 1 + q column transfers against the n + p + 2 + q of the resident kernels -- the price of not holding m rows
 // on chip.  Blocks are double-buffered in registers (the loads of block i + 1 are in flight while block i is folded).
 #pragma once
+#ifndef VP_BLKEXT_NT
+#define VP_BLKEXT_NT 1 /* non-temporal stores of r and J: they leave the forward pass's blocks in the caches for the backward pass (round 6: 1-6 % on two boxes at m = 10 000, B = 4 096; tools/ext_probe.py) */
+#endif
 #include "vp_block.hpp"
 #include "vp_ext.hpp"
 
@@ -232,7 +235,7 @@ __global__ void __launch_bounds__(64, 2) ext_stream_evaluate_kernel(const ext::E
                         for (int j = 0; j < N; ++j) acc = tfma(-cd[j], Ca[j][r], acc);
                         v[r] = acc;
                     }
-                    store_rows<T, RB, 1>(a.r_out + prob * (int64_t)m + off, m - off, lane, vec, v);
+                    store_rows<T, RB, 1, VP_BLKEXT_NT != 0>(a.r_out + prob * (int64_t)m + off, m - off, lane, vec, v);
                 }
                 if (want_j) {
 #pragma unroll
@@ -257,7 +260,7 @@ __global__ void __launch_bounds__(64, 2) ext_stream_evaluate_kernel(const ext::E
                             v[r] = acc;
                         }
                         T *jp = a.J_out + ((b * a.q + k) * (int64_t)a.S + s) * (int64_t)m + off;
-                        store_rows<T, RB, 1>(jp, m - off, lane, vec, v);
+                        store_rows<T, RB, 1, VP_BLKEXT_NT != 0>(jp, m - off, lane, vec, v);
                     }
                 }
             }
@@ -352,7 +355,7 @@ __global__ void __launch_bounds__(64, 2) ext_stream_evaluate_kernel(const ext::E
 #pragma unroll
             for (int r = 0; r < RB; ++r) Wb[z][r] = Cb[N + z][r];
         stacked_apply_q<T, NC, N, NW, RB, G>(Cb, u, g, Wc, Wb, grp);
-        if (a.r_out) store_rows<T, RB, 1>(a.r_out + prob * (int64_t)m + off, m - off, lane, vec, Wb[0]);
+        if (a.r_out) store_rows<T, RB, 1, VP_BLKEXT_NT != 0>(a.r_out + prob * (int64_t)m + off, m - off, lane, vec, Wb[0]);
         if (want_j) {
             for (int k = 0; k < a.q; ++k) { // J[b][k][s][m]
                 T cj[P > 0 ? P : 1];
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(64, 2) ext_stream_evaluate_kernel(const ext::E
                     v[r] = acc;
                 }
                 T *jp = a.J_out + ((b * a.q + k) * (int64_t)a.S + s) * (int64_t)m + off;
-                store_rows<T, RB, 1>(jp, m - off, lane, vec, v);
+                store_rows<T, RB, 1, VP_BLKEXT_NT != 0>(jp, m - off, lane, vec, v);
             }
         }
     };

@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(64 * VP_MRHS_WAVES) mrhs_stream_kernel(const M
                 if (a.status_bs) a.status_bs[prob] = ok ? VP_ST_OK : (stA != VP_ST_OK ? stA : VP_ST_NONFINITE);
             }
             if (a.C_out && lane < N) a.C_out[prob * N + lane] = dyn_get<N>(c, lane);
-            if (a.r_out) store_rows<T, R>(a.r_out + prob * (int64_t)m, m, lane, yvec, y);
+            if (a.r_out) store_rows_out<T, R>(a.r_out + prob * (int64_t)m, m, lane, yvec, y);
             if (a.J_out) {
                 for (int k = 0; k < a.q; ++k) {
                     T jk[R];
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(64 * VP_MRHS_WAVES) mrhs_stream_kernel(const M
                         }
                     }
                     T *jp = a.J_out + ((b * a.q + k) * (int64_t)a.S + s) * (int64_t)m;
-                    store_rows<T, R>(jp, m, lane, vec_aligned<T>(jp, m), jk);
+                    store_rows_out<T, R>(jp, m, lane, vec_aligned<T>(jp, m), jk);
                 }
             }
         }
@@ -1080,7 +1080,12 @@ __global__ void __launch_bounds__(64 * NW, WPE) mrhs_coop_out_kernel(const MrhsS
                 for (int j2 = 0; j2 < N; ++j2)
                     if (lane == j2) a.C_out[prob * N + j2] = cc[j2];
             }
-            if (a.r_out) store_rows<T, RW, NW>(a.r_out + prob * (int64_t)m, m, gl, true, y[c]);
+// (non-temporal stores, vp_kernels.hpp store_rows<..., NT>: configs[2]'s trait evaluation -- 1.34 GB of R and J out -- 0.268 -> 0.222 ms,
+// 0.63 -> 0.76 of 8 TB/s, 25 launches per build on one box, alternating: tools/mrhs_trait_probe.py)
+#ifndef VP_MRHS_NT
+#define VP_MRHS_NT 1
+#endif
+            if (a.r_out) store_rows<T, RW, NW, VP_MRHS_NT != 0>(a.r_out + prob * (int64_t)m, m, gl, true, y[c]);
             if (a.J_out) {
                 T cp[P > 0 ? P : 1];
 #pragma unroll
@@ -1101,7 +1106,7 @@ __global__ void __launch_bounds__(64 * NW, WPE) mrhs_coop_out_kernel(const MrhsS
                             for (int r = 0; r < RW; ++r) jk[r] = tfma(cp[p], g[p][r], jk[r]);
                         }
                     }
-                    store_rows<T, RW, NW>(a.J_out + ((b * a.q + k2) * (int64_t)S + s) * (int64_t)m, m, gl, true, jk);
+                    store_rows<T, RW, NW, VP_MRHS_NT != 0>(a.J_out + ((b * a.q + k2) * (int64_t)S + s) * (int64_t)m, m, gl, true, jk);
                 }
             }
         }
