@@ -22,6 +22,9 @@
 // lane i/2): NC * 2 VGPR pairs, whatever m is.  y (and the grid / weights) are re-read per evaluation, 16 bytes per lane:
 // T*m bytes per evaluation from L2 / HBM, the price of not holding m rows on chip.
 #pragma once
+#ifndef VP_BLKEVAL_NT
+#define VP_BLKEVAL_NT 1 /* non-temporal stores of r and J in blk_evaluate_kernel (round 6: 0.953 -> 0.918 ms per 8 192 evaluations of 10 000 rows, tools/blk_eval_probe.py) */
+#endif
 #include "vp_lm_core.hpp"
 
 namespace vp {
@@ -875,12 +878,12 @@ __global__ void __launch_bounds__(64, (blk_waves<M>())) blk_evaluate_kernel(cons
             }
         }
         stacked_apply_q<T, NC, N, NW, RB, G>(Cb, u, g, Wc, Wb, grp);
-        if (a.r_out) store_rows<T, RB, 1>(a.r_out + prob * (int64_t)m + off, m - off, lane, vec_r, Wb[0]);
+        if (a.r_out) store_rows<T, RB, 1, VP_BLKEVAL_NT != 0>(a.r_out + prob * (int64_t)m + off, m - off, lane, vec_r, Wb[0]);
         if (a.J_out) {
 #pragma unroll
             for (int k = 0; k < Q; ++k) { // J[b][k][s][m]
                 T *jp = a.J_out + ((b * Q + k) * (int64_t)a.S + s) * (int64_t)m + off;
-                store_rows<T, RB, 1>(jp, m - off, lane, vec_j && ((m & 1) == 0), Wb[1 + k]);
+                store_rows<T, RB, 1, VP_BLKEVAL_NT != 0>(jp, m - off, lane, vec_j && ((m & 1) == 0), Wb[1 + k]);
             }
         }
         asm volatile("" ::: "memory");
